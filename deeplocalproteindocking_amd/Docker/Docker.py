@@ -1,0 +1,343 @@
+"""Exhaustive rotation x translation search driver -- drop-in for the reference's ``Docker``
+class (/root/reference/src/Docker/Docker.py:17-238): same constructor, ``new_log``, ``cleanup``,
+``update_top``, ``write_conformations``, ``load_batch``, ``dockE3``, ``dockSE3`` and attributes
+(``top_list``, ``rot.R``, ``box_size``, ``resolution``, ``box_length``, ``max_conf``, ``log``).
+
+What differs underneath:
+  * the hot loop (Docker.py:211-236) runs in libdlpd.so with no host synchronisation: rotations
+    are processed ``batch_size`` (any number, odd tails included) at a time, the clash mask, the
+    filter MLP and the mask multiply are fused into the inverse FFT, and the top list lives on the
+    device until the pair is finished;
+  * ``dock_volumes`` is the volume-level entry (a superset): it takes representation volumes
+    directly, which is what the synthetic BASELINE configs use;
+  * rotations can be sharded over ranks (``rank``/``world_size``): rank r scores rotations
+    r, r+W, r+2W, ... and one all-gather of the per-rank top lists + a deterministic merge by
+    (score, rotation, pick) reproduces the single-process list;
+  * PDB parsing / atom typing / density projection (TorchProteinLibrary) are not part of this
+    build (SURVEY.md 8f rows 1,3): ``dockSE3``/``dockE3``/``load_batch`` need a
+    ``coords_backend`` object providing them and raise otherwise.
+"""
+import atexit
+import os
+
+import numpy as np
+import torch
+
+from deeplocalproteindocking_amd.engine import DeviceTopList, DockingEngine
+from deeplocalproteindocking_amd._lib import get_lib
+from deeplocalproteindocking_amd.Utils.Rotations import Rotations, euler_to_matrices
+
+
+class _FixedRotations(object):
+    def __init__(self, R):
+        self.R = torch.as_tensor(np.asarray(R, dtype=np.float64)).reshape(-1, 3, 3)
+        self.source = "explicit"
+
+
+def random_rotation(generator=None):
+    """Uniform random rotation (1,3,3) float64 -- stand-in for TPL getRandomRotation(1)
+    (Docker.py:44); the TPL RNG stream cannot be matched (source absent)."""
+    u = torch.rand(3, generator=generator, dtype=torch.float64).numpy()
+    phi, psi = 2 * np.pi * u[0] - np.pi, 2 * np.pi * u[2] - np.pi
+    theta = np.arccos(1.0 - 2.0 * u[1])
+    return torch.from_numpy(euler_to_matrices(phi, theta, psi)).reshape(1, 3, 3)
+
+
+class Docker:
+    def __init__(self, docking_model, angle_inc=15.0, box_size=80, resolution=1.25, max_conf=1000,
+                 randomize_rot=False, rotations=None, device="cuda", coords_backend=None,
+                 rank=0, world_size=1, process_group=None, lib=None):
+        self.docking_model = docking_model
+        self.log = None
+
+        self.box_size = box_size
+        self.resolution = resolution
+        self.box_length = box_size * resolution
+
+        self.max_conf = max_conf
+        self.rot = Rotations(angle_inc=angle_inc) if rotations is None else _FixedRotations(rotations)
+
+        self.box_center = torch.zeros(1, 3, dtype=torch.double, device='cpu')
+        self.box_center.fill_(self.box_length / 2.0)
+
+        self.randomize_rot = randomize_rot
+        if self.randomize_rot:
+            self.randR = random_rotation()
+            print("Adding random rotation to the receptor:", self.randR)
+
+        self.device = torch.device(device)
+        self.coords_backend = coords_backend
+        self.rank, self.world_size, self.process_group = int(rank), int(world_size), process_group
+        self._lib = lib
+        self._top = None            # DeviceTopList behind update_top()
+        self.top_list = []
+        self.engine = None
+        atexit.register(self.cleanup)
+
+    # ------------------------------------------------------------------ logging (Docker.py:63-84)
+    def new_log(self, log_file_name, rewrite=True):
+        if not self.log is None:
+            self.log.close()
+        if os.path.exists(log_file_name) and (not rewrite):
+            lines = []
+            with open(log_file_name, 'r') as fin:
+                for line in fin:
+                    if len(line.split()) > 0:
+                        lines.append(line)
+            if len(lines) > 1:
+                self.log = None
+                return False
+            else:
+                self.log = open(log_file_name, "w")
+                return True
+        else:
+            self.log = open(log_file_name, "w")
+            return True
+
+    def cleanup(self):
+        if not self.log is None:
+            self.log.close()
+            self.log = None
+
+    # ------------------------------------------------------------------ top list (Docker.py:86-105)
+    def _library(self):
+        if self._lib is None:
+            self._lib = get_lib()
+        return self._lib
+
+    def update_top(self, V, rotation_index):
+        """V (N,N,N) float32 device tensor.  Same observable behaviour as Docker.py:86-105: the
+        max_conf picks are appended to ``self.top_list`` (stable sort, truncate) and the picked
+        voxels of V are set to 0.0 in place.  The list is kept on the device; ``self.top_list``
+        is refreshed from it."""
+        if self._top is None or self._top.K != self.max_conf or self._top.device != V.device:
+            self._top = DeviceTopList(self.max_conf, 1, V.device, self._library())
+            self._top.reset()
+        elif len(self.top_list) == 0:
+            self._top.reset()                      # caller cleared top_list: a new pair starts
+        Vc = V.contiguous()
+        _, idx = self._top.select(Vc.reshape(1, -1), 1)
+        self._top.merge(torch.tensor([rotation_index], dtype=torch.int32, device=V.device), 1)
+        Vc.view(-1)[idx[0].long()] = 0.0           # Docker.py:98, V is mutated in place
+        if Vc.data_ptr() != V.data_ptr():
+            V.copy_(Vc)
+        self.top_list = DeviceTopList.to_top_list(self._top.entries(), V.shape[0])
+
+    # ------------------------------------------------------------------ output (Docker.py:107-133)
+    def write_conformations(self):
+        if not self.log is None:
+            for i, x, y, z, score in self.top_list:
+                r = self.rot.R[i, :, :]
+                t = torch.zeros(3, device='cpu', dtype=torch.double)
+                t[0] = x
+                t[1] = y
+                t[2] = z
+                if x >= self.box_size:
+                    t[0] = -(2 * self.box_size - x)
+                if y >= self.box_size:
+                    t[1] = -(2 * self.box_size - y)
+                if z >= self.box_size:
+                    t[2] = -(2 * self.box_size - z)
+                t = t * self.resolution
+                if self.randomize_rot:
+                    randRT = torch.transpose(self.randR.squeeze(), 0, 1)
+                    t = torch.matmul(randRT, t)
+                    r = torch.matmul(randRT, r)
+                self.log.write("%f\t%f\t%f\t" % (r[0, 0].item(), r[0, 1].item(), r[0, 2].item()))
+                self.log.write("%f\t%f\t%f\t" % (r[1, 0].item(), r[1, 1].item(), r[1, 2].item()))
+                self.log.write("%f\t%f\t%f\t" % (r[2, 0].item(), r[2, 1].item(), r[2, 2].item()))
+                self.log.write("%f\t%f\t%f\t" % (t[0], t[1], t[2]))
+                self.log.write("%f\n" % (score))
+            self.log.flush()
+
+    # ------------------------------------------------------------------ the search on volumes
+    def shard(self, nrot):
+        """Rotation indices of this rank: interleaved, ascending."""
+        return np.arange(self.rank, nrot, self.world_size, dtype=np.int64)
+
+    def dock_volumes(self, receptor_volumes, ligand_volumes, receptor_forbidden=None, ligand_forbidden=None,
+                     batch_size=8, rot_indices=None, write=True):
+        """Search all rotations for one pair given its representation volumes.
+
+        receptor_volumes / ligand_volumes: lists of (1,C_i,L_i,L_i,L_i) (or (C_i,L_i,..)) tensors
+        as returned by ``docking_model.representation``; *_forbidden: (L,L,L)-shaped clash
+        densities (``None`` -> no clash exclusion).  The ligand forbidden volume is rotated with
+        the same trilinear kernel as the representation (stand-in for the reference's per-rotation
+        atom re-projection, Docker.py:221-224)."""
+        model = self.docking_model
+        model.eval() if hasattr(model, "eval") else None
+        rec = [torch.as_tensor(v, dtype=torch.float32) for v in receptor_volumes]
+        lig = [torch.as_tensor(v, dtype=torch.float32) for v in ligand_volumes]
+        rec = [v.reshape((-1,) + tuple(v.shape[-3:])) for v in rec]
+        lig = [v.reshape((-1,) + tuple(v.shape[-3:])) for v in lig]
+        L = rec[0].shape[-1]
+        if L != self.box_size:
+            raise Exception("Volume size does not match box_size", L, self.box_size)
+        has_clash = receptor_forbidden is not None
+        R_all = self.rot.R
+        ids = self.shard(R_all.shape[0]) if rot_indices is None else np.asarray(rot_indices, dtype=np.int64)
+        if len(rec) == 1:
+            W1, b1, W2, b2 = model.filter.parameters_tuple()
+            eng = DockingEngine(L, rec[0].shape[0], W1.cpu(), b1.cpu(), W2.cpu(), b2.cpu(),
+                                clip=getattr(model, "clip", 5.0), threshold_clash=model.threshold_clash,
+                                has_clash=has_clash, max_conf=self.max_conf, batch=batch_size, device=self.device,
+                                lib=self._lib)
+            eng.set_receptor(rec[0], receptor_forbidden)
+            eng.set_ligand(lig[0], ligand_forbidden)
+            eng.reset_top()
+            eng.search(R_all[ids], rot_ids=ids)
+            self.engine = eng
+            entries = eng.top.entries()
+        else:
+            entries = self._dock_volumes_multires(rec, lig, receptor_forbidden, ligand_forbidden, batch_size, ids)
+        entries = self._gather(entries)
+        self.top_list = DeviceTopList.to_top_list(entries, 2 * L)
+        if write:
+            self.write_conformations()
+        return self.top_list
+
+    def _dock_volumes_multires(self, rec, lig, rec_forb, lig_forb, batch_size, ids):
+        """Reference-shaped loop on the stand-alone ops (any number of resolutions): rotate,
+        clash correlation, model forward, mask multiply, device top-K."""
+        from deeplocalproteindocking_amd.ops import VolumeConvolution, VolumeRotation, filter_volumes
+        dev = self.device
+        model = self.docking_model
+        rotate, conv_noclip = VolumeRotation(), VolumeConvolution()
+        rec_d = [v.to(dev) for v in rec]
+        lig_d = [v.to(dev) for v in lig]
+        L = rec[0].shape[-1]
+        top = DeviceTopList(self.max_conf, batch_size, dev, self._library())
+        top.reset()
+        has_clash = rec_forb is not None
+        if has_clash:
+            rf = torch.as_tensor(rec_forb, dtype=torch.float32).reshape(1, 1, L, L, L).to(dev)
+            lf = torch.as_tensor(lig_forb, dtype=torch.float32).reshape(1, 1, L, L, L).to(dev)
+        R_all = self.rot.R
+        W1, b1, W2, b2 = model.filter.parameters_tuple()
+        for beg in range(0, len(ids), batch_size):
+            bid = ids[beg:beg + batch_size]
+            nb = len(bid)
+            Rb = R_all[bid].to(device=dev, dtype=torch.float32).contiguous()
+            lig_rot = [rotate(v.unsqueeze(0).expand(nb, -1, -1, -1, -1).contiguous(), Rb) for v in lig_d]
+            rec_b = [v.unsqueeze(0).expand(nb, -1, -1, -1, -1).contiguous() for v in rec_d]
+            convolved = [model.convolve(r, l) for r, l in zip(rec_b, lig_rot)]
+            norm = None
+            if has_clash:
+                norm = conv_noclip(rf.expand(nb, -1, -1, -1, -1).contiguous(),
+                                   rotate(lf.expand(nb, -1, -1, -1, -1).contiguous(), Rb)).squeeze(1).contiguous()
+            V = filter_volumes(convolved, W1, b1, W2, float(b2.reshape(-1)[0]), mask_norm=norm,
+                               threshold=model.threshold_clash)
+            top.select(V.reshape(nb, -1), nb)
+            top.merge(torch.as_tensor(bid, dtype=torch.int32).to(dev), nb)
+        return top.entries()
+
+    def _gather(self, entries):
+        """One all-gather of the fixed-size per-rank lists + deterministic merge (every rank)."""
+        if self.world_size <= 1:
+            return entries
+        import torch.distributed as dist
+        K = self.max_conf
+        pack = torch.zeros(4, K + 1, dtype=torch.float64)
+        n = len(entries[0])
+        pack[0, 0] = n
+        pack[0, 1:1 + n] = torch.from_numpy(np.asarray(entries[0], dtype=np.float64))
+        pack[1, 1:1 + n] = torch.from_numpy(np.asarray(entries[1], dtype=np.float64))
+        score_bits = np.ascontiguousarray(entries[2], dtype=np.float32).view(np.uint32)
+        pack[2, 1:1 + n] = torch.from_numpy(score_bits.astype(np.float64))   # exact score bits
+        pack[3, 1:1 + n] = torch.from_numpy(np.asarray(entries[3], dtype=np.float64))
+        backend = dist.get_backend(self.process_group)
+        buf = pack.to(self.device) if backend == "nccl" else pack
+        out = [torch.empty_like(buf) for _ in range(self.world_size)]
+        dist.all_gather(out, buf, group=self.process_group)
+        parts = []
+        for o in out:
+            o = o.cpu().numpy()
+            m = int(o[0, 0])
+            parts.append((o[0, 1:1 + m].astype(np.int64), o[1, 1:1 + m].astype(np.int64),
+                          o[2, 1:1 + m].astype(np.uint32).view(np.float32), o[3, 1:1 + m].astype(np.int64)))
+        return DeviceTopList.merge_entries(parts, K)
+
+    # ------------------------------------------------------------------ PDB-level entries
+    def _need_backend(self):
+        if self.coords_backend is None:
+            raise Exception("PDB parsing, atom typing and density projection (TorchProteinLibrary "
+                            "PDB2CoordsUnordered / Coords2TypedCoords / TypedCoords2Volume, Docker.py:37-38,31) "
+                            "are not part of this build; pass coords_backend=... or call dock_volumes()")
+        return self.coords_backend
+
+    def load_batch(self, filenames, bbox_center=True):
+        """Docker.py:49-61 through the coords backend."""
+        be = self._need_backend()
+        coords, chains, resnames, resnums, atomnames, num_atoms = be.pdb2coords(filenames)
+        coords, num_atoms_of_type, offsets = be.assign_types(coords, resnames, atomnames, num_atoms)
+        a, b = be.get_bbox(coords, num_atoms)
+        if bbox_center:
+            translation = -(a + b) * 0.5 + self.box_length / 2.0
+        else:
+            translation = -(a + b) * 0.5
+        coords = be.translate(coords, translation, num_atoms)
+        return coords, num_atoms_of_type, offsets, translation, num_atoms
+
+    def dockSE3(self, ureceptor, uligand, batch_size):
+        """Docker.py:184-238: representations computed once, ligand volumes rotated on the GPU."""
+        be = self._need_backend()
+        self.top_list = []
+        self.docking_model.eval()
+        rcoords, rnat, roff, rT, rnatoms = self.load_batch([ureceptor], bbox_center=False)
+        lcoords, lnat, loff, lT, lnatoms = self.load_batch([uligand], bbox_center=False)
+        if self.randomize_rot:
+            rcoords = be.rotate(rcoords, self.randR, rnatoms)
+        rcoords = be.translate(rcoords, self.box_center, rnatoms)
+        lcoords_trans = be.translate(lcoords, self.box_center, lnatoms)
+        with torch.no_grad():
+            receptor = be.project(rcoords, rnat, roff, self.box_size, self.resolution, self.device)
+            receptor_volumes = self.docking_model.representation(receptor)
+            receptor_forbidden = receptor.sum(dim=1)[0]
+            ligand = be.project(lcoords_trans, lnat, loff, self.box_size, self.resolution, self.device)
+            ligand_volumes = self.docking_model.representation(ligand)
+            ligand_forbidden = ligand.sum(dim=1)[0]
+            self.dock_volumes(receptor_volumes, ligand_volumes, receptor_forbidden, ligand_forbidden,
+                              batch_size=batch_size)
+
+    def dockE3(self, ureceptor, uligand, batch_size):
+        """Docker.py:135-182: the ligand is rotated in coordinate space and re-projected and
+        re-represented every batch (the plugin's cost), then scored by the same kernels."""
+        be = self._need_backend()
+        from deeplocalproteindocking_amd.ops import VolumeConvolution, filter_volumes
+        self.top_list = []
+        model = self.docking_model
+        model.eval()
+        dev = self.device
+        rcoords, rnat, roff, rT, rnatoms = self.load_batch([ureceptor], bbox_center=False)
+        lcoords, lnat, loff, lT, lnatoms = self.load_batch([uligand], bbox_center=False)
+        if self.randomize_rot:
+            rcoords = be.rotate(rcoords, self.randR, rnatoms)
+        rcoords = be.translate(rcoords, self.box_center, rnatoms)
+        conv_noclip = VolumeConvolution()
+        top = DeviceTopList(self.max_conf, batch_size, dev, self._library())
+        top.reset()
+        W1, b1, W2, b2 = model.filter.parameters_tuple()
+        ids = self.shard(self.rot.R.shape[0])
+        with torch.no_grad():
+            receptor = be.project(rcoords, rnat, roff, self.box_size, self.resolution, dev)
+            receptor_volumes = model.representation(receptor)
+            receptor_forbidden = receptor.sum(dim=1).unsqueeze(dim=1).contiguous()
+            for beg in range(0, len(ids), batch_size):
+                bid = ids[beg:beg + batch_size]
+                nb = len(bid)
+                r_batch = self.rot.R[bid]
+                lrot = be.rotate(lcoords.expand(nb, -1), r_batch, lnatoms.expand(nb))
+                lrot = be.translate(lrot, self.box_center.expand(nb, -1), lnatoms.expand(nb))
+                ligand = be.project(lrot, lnat.expand(nb, -1), loff.expand(nb, -1), self.box_size, self.resolution, dev)
+                ligand_volumes = model.representation(ligand)
+                ligand_forbidden = ligand.sum(dim=1).unsqueeze(dim=1).contiguous()
+                norm = conv_noclip(receptor_forbidden.expand(nb, -1, -1, -1, -1).contiguous(), ligand_forbidden)
+                rec_b = [v.expand(nb, -1, -1, -1, -1).contiguous() for v in receptor_volumes]
+                convolved = [model.convolve(r, l) for r, l in zip(rec_b, ligand_volumes)]
+                V = filter_volumes(convolved, W1, b1, W2, float(b2.reshape(-1)[0]),
+                                   mask_norm=norm.squeeze(1).contiguous(), threshold=model.threshold_clash)
+                top.select(V.reshape(nb, -1), nb)
+                top.merge(torch.as_tensor(bid, dtype=torch.int32).to(dev), nb)
+        entries = self._gather(top.entries())
+        self.top_list = DeviceTopList.to_top_list(entries, 2 * self.box_size)
+        self.write_conformations()

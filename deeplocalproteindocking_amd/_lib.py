@@ -1,0 +1,74 @@
+"""ctypes binding of the C-ABI library (include/dlpd.h).
+
+The product path has NO fallback: if ``csrc/libdlpd.so`` is missing or an entry point is absent
+the import of the ops fails loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_PATH = os.path.join(_HERE, "csrc", "libdlpd.so")
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+_ll = ctypes.c_longlong
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/dlpd.h exactly
+SIGNATURES = {
+    "dlpd_version": (_i, []),
+    "dlpd_grid_supported": (_i, [_i]),
+    "dlpd_hidden_pad": (_i, [_i]),
+    "dlpd_rotate_trilinear": (_i, [_p, _p, _p, _i, _i, _i, _ll, _f, _p]),
+    "dlpd_zfft": (_i, [_p, _p, _p, _i, _i, _i, _ll, _i, _f, _p]),
+    "dlpd_rfft3d_padded": (_i, [_p, _p, _p, _i, _i, _f, _p]),
+    "dlpd_xy_correlate": (_i, [_p, _p, _p, _i, _i, _i, _ll, _p]),
+    "dlpd_zifft_real": (_i, [_p, _p, _i, _i, _i, _i, _f, _p]),
+    "dlpd_zifft_filter": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _i, _f, _f, _p]),
+    "dlpd_score_rotations": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _f, _i, _i, _f, _f,
+                                  _p, _p, _p, _p]),
+    "dlpd_filter_mask": (_i, [_p, _i, _i, _p, _i, _i, _p, _f, _i, _p, _p, _p, _f, _i, _p, _i, _p]),
+    "dlpd_topk_workspace_bytes": (_sz, [_i, _i]),
+    "dlpd_topk_select": (_i, [_p, _i, _ll, _i, _p, _p, _p, _p]),
+    "dlpd_topk_glist_bytes": (_sz, [_i]),
+    "dlpd_topk_glist_reset": (_i, [_p, _i, _p]),
+    "dlpd_topk_merge": (_i, [_p, _p, _p, _i, _i, _p, _p]),
+}
+
+ERRORS = {1: "DLPD_ERR_ARG (bad pointer/size)", 2: "DLPD_ERR_UNSUPPORTED (size not compiled)",
+          3: "DLPD_ERR_LAUNCH (HIP launch error)"}
+
+
+class DlpdLib:
+    def __init__(self, path=None):
+        path = path or DEFAULT_PATH
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "dlpd: native library %s not found -- build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+                "There is no CPU fallback." % path)
+        self.path = path
+        self._dll = ctypes.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(self._dll, name)          # AttributeError if a symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, "_" + name, fn)
+
+    def call(self, name, *args):
+        rc = getattr(self, "_" + name)(*args)
+        if SIGNATURES[name][0] is _i and name not in ("dlpd_version", "dlpd_grid_supported",
+                                                      "dlpd_hidden_pad") and rc != 0:
+            raise RuntimeError("dlpd: %s failed: %s" % (name, ERRORS.get(rc, rc)))
+        return rc
+
+
+_LIB = None
+
+
+def get_lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = DlpdLib()
+    return _LIB

@@ -1,0 +1,591 @@
+// Rotation x translation correlation search: the FFT pipeline kernels (gfx950 / CDNA4).
+//
+// Reference path being replaced (file:line in /root/reference):
+//   src/Docker/Docker.py:218            VolumeRotation of the ligand representation volumes
+//   src/Docker/Docker.py:225-226        clash correlation + threshold
+//   src/Models/DockingModels.py:70-83   per-channel VolumeConvolution, concat, SimpleFilter MLP
+//   src/Docker/Docker.py:232            mask multiply
+//
+// Pipeline per rotation (volumes (CT,L,L,L), N = 2L, NZ = N/2+1):
+//   K1 k_rotate_zfft   trilinear rotation fused with the z-axis R2C FFT (two real rows per
+//                      complex pencil)                           -> A  [b][c][kz][x][y]   (L x L)
+//   K2 k_xy_corr       per (c,kz): zero-padded 2-D forward FFT over (x,y) in LDS, multiply by
+//                      the receptor spectrum (conj), 2-D inverse  -> Bw [b][c][kz][x'][y'] (N x N)
+//   K3 k_zifft_filter  per (x', y'-tile): z-axis C2R for all channels, clip, per-voxel MLP,
+//                      clash mask                                 -> V  [b][x'][y'][z']
+// The rotated volumes, the ligand spectrum and the 48 real correlation volumes never exist in
+// HBM; only A (0.25x of a spectrum) and Bw (one spectrum) do.
+#include <dlpd_platform.h>
+#include "dlpd_fft.h"
+#include "dlpd_internal.h"
+
+template <int N> DLPD_D void init_twiddles(cplx* tw, int tid, int nthreads) {
+  for (int k = tid; k < N; k += nthreads) {
+    double s, c;
+    sincospi(-2.0 * (double)k / (double)N, &s, &c);
+    tw[k] = c_make((float)c, (float)s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// trilinear sample of a (L,L,L) volume at position (px,py,pz), zeros outside
+// ------------------------------------------------------------------------------------------
+DLPD_D float trilinear_fetch(const float* __restrict__ v, int L, float px, float py, float pz) {
+  const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+  const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+  const float ax = px - fx, ay = py - fy, az = pz - fz;
+  float acc = 0.f;
+#pragma unroll
+  for (int dx = 0; dx < 2; dx++) {
+    const int x = ix + dx;
+    const float wx = dx ? ax : 1.f - ax;
+    if (x < 0 || x >= L) continue;
+#pragma unroll
+    for (int dy = 0; dy < 2; dy++) {
+      const int y = iy + dy;
+      const float wy = dy ? ay : 1.f - ay;
+      if (y < 0 || y >= L) continue;
+      const float* row = v + ((size_t)x * L + y) * L;
+      const float wxy = wx * wy;
+      if (iz >= 0 && iz < L) acc += row[iz] * (wxy * (1.f - az));
+      if (iz + 1 >= 0 && iz + 1 < L) acc += row[iz + 1] * (wxy * az);
+    }
+  }
+  return acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// Standalone rotation (TPL VolumeRotation equivalent, Docker.py:218): out[b,c] = rot(vol[b,c])
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_rotate(const float* __restrict__ vol, const float* __restrict__ R,
+                                                float* __restrict__ out, int B, int C, int L,
+                                                long long vol_bstride, float c0) {
+  const size_t L3 = (size_t)L * L * L;
+  const size_t total = (size_t)B * C * L3;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int z = (int)(i % L), y = (int)((i / L) % L), x = (int)((i / ((size_t)L * L)) % L);
+    const int c = (int)((i / L3) % C), b = (int)(i / (L3 * C));
+    const float* r = R + (size_t)b * 9;
+    const float dx = x - c0, dy = y - c0, dz = z - c0;
+    const float px = c0 + (r[0] * dx + r[3] * dy + r[6] * dz);
+    const float py = c0 + (r[1] * dx + r[4] * dy + r[7] * dz);
+    const float pz = c0 + (r[2] * dx + r[5] * dy + r[8] * dz);
+    out[i] = trilinear_fetch(vol + (size_t)b * vol_bstride + (size_t)c * L3, L, px, py, pz);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: (optional) rotation + z-axis R2C.  grid (L [x], CT, nb), block (L/2)*T threads.
+//   vol   (.., CT, L,L,L), batch stride vol_bstride (0: one ligand shared by every rotation)
+//   R     (nb, 9) row-major rotation matrices (ignored when do_rotate == 0)
+//   A     (nb, CT, NZ, L, L) complex, [kz][x][y]
+// ------------------------------------------------------------------------------------------
+template <int N> __global__ void __launch_bounds__((N / 4) * FftPlan<N>::T)
+k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* __restrict__ A,
+              int CT, long long vol_bstride, int do_rotate, float c0) {
+  constexpr int L = N / 2, NZ = N / 2 + 1, RS = N + 1, NP = L / 2;
+  constexpr int T = FftPlan<N>::T, R1 = FftPlan<N>::R1, R2 = FftPlan<N>::R2;
+  constexpr int NT = NP * T;
+  __shared__ cplx S[NP * RS + N];
+  cplx* tw = S + NP * RS;
+  const int tid = threadIdx.x;
+  const int x = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
+  init_twiddles<N>(tw, tid, NT);
+  const float* v = vol + (size_t)b * vol_bstride + (size_t)c * L * L * L;
+  float* Sf = reinterpret_cast<float*>(S);
+  if (do_rotate) {
+    const float* r = R + (size_t)b * 9;
+    const float r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6], r7 = r[7], r8 = r[8];
+    const float dx = x - c0;
+    for (int s = tid; s < L * L; s += NT) {
+      const int y = s / L, z = s % L;
+      const float dy = y - c0, dz = z - c0;
+      const float px = c0 + (r0 * dx + r3 * dy + r6 * dz);
+      const float py = c0 + (r1 * dx + r4 * dy + r7 * dz);
+      const float pz = c0 + (r2 * dx + r5 * dy + r8 * dz);
+      Sf[((y >> 1) * RS + z) * 2 + (y & 1)] = trilinear_fetch(v, L, px, py, pz);
+    }
+  } else {
+    const float* plane = v + (size_t)x * L * L;
+    for (int s = tid; s < L * L; s += NT) {
+      const int y = s / L, z = s % L;
+      Sf[((y >> 1) * RS + z) * 2 + (y & 1)] = plane[s];
+    }
+  }
+  __syncthreads();
+  const int p = tid % NP, t = tid / NP;
+  {
+    FftPass<N, R1, 1, -1, T, L> ps;
+    ps.load(S + p * RS, 1, t, tw);
+    __syncthreads();
+    ps.store(S + p * RS, 1, t);
+    __syncthreads();
+  }
+  {
+    FftPass<N, R2, R1, -1, T> ps;
+    ps.load(S + p * RS, 1, t, tw);
+    __syncthreads();
+    ps.store(S + p * RS, 1, t);
+    __syncthreads();
+  }
+  // untangle the two real rows packed in each complex pencil; write [kz][x][y]
+  cplx* a = A + ((size_t)b * CT + c) * NZ * L * L + (size_t)x * L;
+  for (int s = tid; s < NP * NZ; s += NT) {
+    const int m = s % NP, k = s / NP;
+    const cplx zk = S[m * RS + k];
+    const cplx zn = S[m * RS + ((N - k) % N)];
+    // even row: (Z[k] + conj(Z[N-k]))/2 ; odd row: (Z[k] - conj(Z[N-k]))/(2i)
+    float4 o;
+    o.x = 0.5f * (zk.x + zn.x);
+    o.y = 0.5f * (zk.y - zn.y);
+    o.z = 0.5f * (zk.y + zn.y);
+    o.w = 0.5f * (zn.x - zk.x);
+    *reinterpret_cast<float4*>(a + (size_t)k * L * L + 2 * m) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: per (b, c, kz) slab.  grid (nb, NZ, CT), block N*T threads, dynamic LDS (N*RS+N)*8 B.
+//   MODE 0: forward only -> out[(b*CT+c)][kz][kx][ky] = scale * FFT2(pad(A))     (receptor prep)
+//   MODE 1: correlate    -> out = IFFT2( rec * conj(FFT2(pad(A))) )  (unnormalised inverse;
+//                           the 1/N^3 lives in rec)
+//   rec_bstride: element stride between batch entries of rec (0: shared receptor)
+// ------------------------------------------------------------------------------------------
+template <int N, int MODE> __global__ void __launch_bounds__(N * FftPlan<N>::T)
+k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __restrict__ out,
+          int CT, long long rec_bstride, float scale) {
+  constexpr int L = N / 2, NZ = N / 2 + 1, RS = N + 1;
+  constexpr int T = FftPlan<N>::T, R1 = FftPlan<N>::R1, R2 = FftPlan<N>::R2;
+  constexpr int NT = N * T;
+  DLPD_DYN_SHARED(cplx, S);
+  cplx* tw = S + N * RS;
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x, kz = blockIdx.y, c = blockIdx.z;
+  init_twiddles<N>(tw, tid, NT);
+  {
+    const float4* a = reinterpret_cast<const float4*>(A + (((size_t)b * CT + c) * NZ + kz) * L * L);
+    for (int i = tid; i < L * L / 2; i += NT) {
+      const float4 q = a[i];
+      const int e = 2 * i, x = e / L, y = e % L;
+      S[x * RS + y] = c_make(q.x, q.y);
+      S[x * RS + y + 1] = c_make(q.z, q.w);
+    }
+  }
+  __syncthreads();
+  const int p = tid % N, t = tid / N;
+  // forward along y on the L non-zero rows
+  {
+    FftPass<N, R1, 1, -1, T, L> ps;
+    if (p < L) ps.load(S + p * RS, 1, t, tw);
+    __syncthreads();
+    if (p < L) ps.store(S + p * RS, 1, t);
+    __syncthreads();
+  }
+  {
+    FftPass<N, R2, R1, -1, T> ps;
+    if (p < L) ps.load(S + p * RS, 1, t, tw);
+    __syncthreads();
+    if (p < L) ps.store(S + p * RS, 1, t);
+    __syncthreads();
+  }
+  // forward along x on all N columns (rows >= L are implicit zeros)
+  {
+    FftPass<N, R1, 1, -1, T, L> ps;
+    ps.load(S + p, RS, t, tw);
+    __syncthreads();
+    ps.store(S + p, RS, t);
+    __syncthreads();
+  }
+  {
+    FftPass<N, R2, R1, -1, T> ps;
+    ps.load(S + p, RS, t, tw);
+    __syncthreads();
+    if (MODE == 1) {
+      const cplx* r = rec + (size_t)b * rec_bstride + ((size_t)c * NZ + kz) * N * N + p;
+#pragma unroll
+      for (int i = 0; i < ps.PER; i++) {
+#pragma unroll
+        for (int q = 0; q < R2; q++) {
+          const int kx = ps.out_index(i, q, t);
+          ps.v[i][q] = c_mulc(r[(size_t)kx * N], ps.v[i][q]);
+        }
+      }
+    }
+    ps.store(S + p, RS, t);
+    __syncthreads();
+  }
+  if (MODE == 1) {
+    // inverse along x (columns), then along y (rows)
+    {
+      FftPass<N, R1, 1, +1, T> ps;
+      ps.load(S + p, RS, t, tw);
+      __syncthreads();
+      ps.store(S + p, RS, t);
+      __syncthreads();
+    }
+    {
+      FftPass<N, R2, R1, +1, T> ps;
+      ps.load(S + p, RS, t, tw);
+      __syncthreads();
+      ps.store(S + p, RS, t);
+      __syncthreads();
+    }
+    {
+      FftPass<N, R1, 1, +1, T> ps;
+      ps.load(S + p * RS, 1, t, tw);
+      __syncthreads();
+      ps.store(S + p * RS, 1, t);
+      __syncthreads();
+    }
+    {
+      FftPass<N, R2, R1, +1, T> ps;
+      ps.load(S + p * RS, 1, t, tw);
+      __syncthreads();
+      ps.store(S + p * RS, 1, t);
+      __syncthreads();
+    }
+  }
+  {
+    float4* o = reinterpret_cast<float4*>(out + (((size_t)b * CT + c) * NZ + kz) * N * N);
+    const float sc = (MODE == 0) ? scale : 1.0f;
+    for (int i = tid; i < N * N / 2; i += NT) {
+      const int e = 2 * i, x = e / N, y = e % N;
+      const cplx u = S[x * RS + y], w = S[x * RS + y + 1];
+      o[i] = make_float4(u.x * sc, u.y * sc, w.x * sc, w.y * sc);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: z-axis C2R + (MODE 1) filter MLP + clash mask, or (MODE 0) plain real output.
+//   grid (N/TY, N [x'], nb), block 512 threads, dynamic LDS (64*RS + N)*8 B.
+//   Bw   (nb, CT, NZ, N, N) complex [kz][x'][y']
+//   MODE 0: out (nb, CT, N,N,N) real, optionally clamped to +-clip
+//   MODE 1: V   (nb, N,N,N) = mask * (W2 . relu(W1 . clamp(corr) + b1) + b2)
+//           score channels [0,C), clash channel C if has_clash (mask = corr_C < thr)
+//   W1t  (C, HP) transposed + zero padded, b1 (HP), W2 (HP)
+// ------------------------------------------------------------------------------------------
+#define DLPD_K3_THREADS 512
+#define DLPD_K3_TY 16
+template <int N, int HP, int MODE> __global__ void __launch_bounds__(DLPD_K3_THREADS)
+k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int C, int has_clash, int G,
+               const float* __restrict__ W1t, const float* __restrict__ b1, const float* __restrict__ W2,
+               float b2, int has_clip, float clip, float thr) {
+  constexpr int NZ = N / 2 + 1, RS = N + 1, TY = DLPD_K3_TY, NPAIR = TY / 2;
+  constexpr int T = FftPlan<N>::T, R1 = FftPlan<N>::R1, R2 = FftPlan<N>::R2;
+  constexpr int NT = DLPD_K3_THREADS;
+  constexpr int MAXP = NT / T;                 // pencils per group (G * NPAIR <= MAXP)
+  constexpr int EPT = (NPAIR * N) / NT > 0 ? (NPAIR * N) / NT : 1;   // complex outputs per thread per channel
+  constexpr int MSTEP = NT / N;                // pair stride between a thread's outputs
+  static_assert((NPAIR * N) % NT == 0 || NPAIR * N < NT, "tile/thread mismatch");
+  DLPD_DYN_SHARED(cplx, S);
+  cplx* tw = S + MAXP * RS;
+  const int tid = threadIdx.x;
+  const int y0 = blockIdx.x * TY, xo = blockIdx.y, b = blockIdx.z;
+  init_twiddles<N>(tw, tid, NT);
+
+  float h[EPT * 2][HP > 0 ? HP : 1];
+  float nrm[EPT * 2];
+  if (MODE == 1) {
+#pragma unroll
+    for (int e = 0; e < EPT * 2; e++) {
+      nrm[e] = 0.f;
+#pragma unroll
+      for (int j = 0; j < HP; j++) h[e][j] = b1[j];
+    }
+  }
+  const int zz = tid % N, m0 = tid / N;        // output ownership
+  const bool owner = (NPAIR * N >= NT) || (m0 < NPAIR);
+  const int p = tid % MAXP, t = tid / MAXP;    // FFT pencil ownership
+
+  for (int cbase = 0; cbase < CT; cbase += G) {
+    const int gn = (CT - cbase) < G ? (CT - cbase) : G;
+    __syncthreads();                           // previous group's reads done
+    // load: thread <-> (g, k, m): two complex (rows 2m, 2m+1) at frequency k
+    for (int s = tid; s < gn * NZ * NPAIR; s += NT) {
+      const int m = s % NPAIR, k = (s / NPAIR) % NZ, g = s / (NPAIR * NZ);
+      const float4 q = *reinterpret_cast<const float4*>(
+          Bw + ((((size_t)b * CT + cbase + g) * NZ + k) * N + xo) * N + y0 + 2 * m);
+      cplx* P = S + (g * NPAIR + m) * RS;
+      if (k == 0 || k == N / 2) {
+        P[k] = c_make(q.x, q.z);               // purely real bins of both rows
+      } else {
+        P[k] = c_make(q.x - q.w, q.y + q.z);   // A + i B
+        P[N - k] = c_make(q.x + q.w, q.z - q.y);   // conj(A) + i conj(B)
+      }
+    }
+    __syncthreads();
+    const bool act = p < gn * NPAIR;
+    {
+      FftPass<N, R1, 1, +1, T> ps;
+      if (act) ps.load(S + p * RS, 1, t, tw);
+      __syncthreads();
+      if (act) ps.store(S + p * RS, 1, t);
+      __syncthreads();
+    }
+    {
+      FftPass<N, R2, R1, +1, T> ps;
+      if (act) ps.load(S + p * RS, 1, t, tw);
+      __syncthreads();
+      if (act) ps.store(S + p * RS, 1, t);
+      __syncthreads();
+    }
+    if (owner) {
+      for (int g = 0; g < gn; g++) {
+        const int c = cbase + g;
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+          const int m = m0 + e * MSTEP;
+          const cplx val = S[(g * NPAIR + m) * RS + zz];
+          float v0 = val.x, v1 = val.y;
+          if (MODE == 0) {
+            if (has_clip) { v0 = fminf(fmaxf(v0, -clip), clip); v1 = fminf(fmaxf(v1, -clip), clip); }
+            float* o = out + ((((size_t)b * CT + c) * N + xo) * N + y0 + 2 * m) * N + zz;
+            o[0] = v0;
+            o[N] = v1;
+          } else {
+            if (has_clash && c == C) {
+              nrm[2 * e] = v0; nrm[2 * e + 1] = v1;
+            } else {
+              if (has_clip) { v0 = fminf(fmaxf(v0, -clip), clip); v1 = fminf(fmaxf(v1, -clip), clip); }
+              const float* w = W1t + (size_t)c * HP;
+#pragma unroll
+              for (int j = 0; j < HP; j++) {
+                const float wj = w[j];
+                h[2 * e][j] = fmaf(wj, v0, h[2 * e][j]);
+                h[2 * e + 1][j] = fmaf(wj, v1, h[2 * e + 1][j]);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  if (MODE == 1 && owner) {
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+      const int m = m0 + e * MSTEP;
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        float acc = b2;
+#pragma unroll
+        for (int j = 0; j < HP; j++) acc = fmaf(W2[j], fmaxf(h[2 * e + u][j], 0.f), acc);
+        if (has_clash) acc = acc * ((nrm[2 * e + u] < thr) ? 1.0f : 0.0f);
+        out[(((size_t)b * N + xo) * N + y0 + 2 * m + u) * N + zz] = acc;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Generic filter over already materialised correlation volumes (multi-resolution path:
+// DockingModels.py:74-83).  conv_k (nb, C_k, N_k^3); nearest upsample index = i / (N/N_k).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_filter_generic(const float* __restrict__ conv0, int C0, int N0, const float* __restrict__ conv1, int C1, int N1,
+                 const float* __restrict__ mask_norm, float thr, int has_clash,
+                 const float* __restrict__ W1t, const float* __restrict__ b1, const float* __restrict__ W2, float b2,
+                 int H, float* __restrict__ V, int nb) {
+  const int N = N0;
+  const size_t N3 = (size_t)N * N * N;
+  const size_t total = (size_t)nb * N3;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / N3);
+    const size_t r = i % N3;
+    const int z = (int)(r % N), y = (int)((r / N) % N), x = (int)(r / ((size_t)N * N));
+    float hid[DLPD_MAX_HIDDEN];
+    for (int j = 0; j < H; j++) hid[j] = b1[j];
+    for (int c = 0; c < C0; c++) {
+      const float v = conv0[((size_t)b * C0 + c) * N3 + r];
+      for (int j = 0; j < H; j++) hid[j] = fmaf(W1t[(size_t)c * H + j], v, hid[j]);
+    }
+    if (C1 > 0) {
+      const int s = N / N1;
+      const size_t r1 = ((size_t)(x / s) * N1 + (y / s)) * N1 + (z / s);
+      const size_t N13 = (size_t)N1 * N1 * N1;
+      for (int c = 0; c < C1; c++) {
+        const float v = conv1[((size_t)b * C1 + c) * N13 + r1];
+        for (int j = 0; j < H; j++) hid[j] = fmaf(W1t[(size_t)(C0 + c) * H + j], v, hid[j]);
+      }
+    }
+    float acc = b2;
+    for (int j = 0; j < H; j++) acc = fmaf(W2[j], fmaxf(hid[j], 0.f), acc);
+    if (has_clash) acc = acc * ((mask_norm[i] < thr) ? 1.0f : 0.0f);
+    V[i] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side launchers
+// ------------------------------------------------------------------------------------------
+template <int N> static int launch_k1(const float* vol, const float* R, cplx* A, int CT, int nb, long long vbs,
+                                      int do_rotate, float c0, hipStream_t st) {
+  constexpr int L = N / 2;
+  dim3 grid(L, CT, nb), block((N / 4) * FftPlan<N>::T);
+  DLPD_LAUNCH((k_rotate_zfft<N>), grid, block, 0, st, vol, R, A, CT, vbs, do_rotate, c0);
+  return dlpd_check_launch();
+}
+
+template <int N, int MODE> static int launch_k2(const cplx* A, const cplx* rec, cplx* out, int CT, int nb,
+                                                long long rbs, float scale, hipStream_t st) {
+  constexpr int NZ = N / 2 + 1, RS = N + 1;
+  const size_t shmem = (size_t)(N * RS + N) * sizeof(cplx);
+  int rc = dlpd_set_max_dyn_shared((const void*)k_xy_corr<N, MODE>, shmem);
+  if (rc) return rc;
+  dim3 grid(nb, NZ, CT), block(N * FftPlan<N>::T);
+  DLPD_LAUNCH((k_xy_corr<N, MODE>), grid, block, shmem, st, A, rec, out, CT, rbs, scale);
+  return dlpd_check_launch();
+}
+
+static int k3_group(int CT, int maxg) {
+  int ng = (CT + maxg - 1) / maxg;
+  return (CT + ng - 1) / ng;
+}
+
+template <int N, int HP, int MODE> static int launch_k3(const cplx* Bw, float* out, int CT, int C, int has_clash,
+                                                        int nb, const float* W1t, const float* b1, const float* W2,
+                                                        float b2, int has_clip, float clip, float thr,
+                                                        hipStream_t st) {
+  constexpr int RS = N + 1, MAXP = DLPD_K3_THREADS / FftPlan<N>::T;
+  const size_t shmem = (size_t)(MAXP * RS + N) * sizeof(cplx);
+  int rc = dlpd_set_max_dyn_shared((const void*)k_zifft_filter<N, HP, MODE>, shmem);
+  if (rc) return rc;
+  const int G = k3_group(CT, MAXP / (DLPD_K3_TY / 2));
+  dim3 grid(N / DLPD_K3_TY, N, nb), block(DLPD_K3_THREADS);
+  DLPD_LAUNCH((k_zifft_filter<N, HP, MODE>), grid, block, shmem, st, Bw, out, CT, C, has_clash, G, W1t, b1, W2, b2,
+              has_clip, clip, thr);
+  return dlpd_check_launch();
+}
+
+template <int N> static int k3_filter_dispatch(int HP, const cplx* Bw, float* V, int CT, int C, int has_clash, int nb,
+                                               const float* W1t, const float* b1, const float* W2, float b2,
+                                               int has_clip, float clip, float thr, hipStream_t st) {
+  switch (HP) {
+    case 2: return launch_k3<N, 2, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st);
+    case 4: return launch_k3<N, 4, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st);
+    case 8: return launch_k3<N, 8, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st);
+    case 16: return launch_k3<N, 16, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st);
+    case 24: return launch_k3<N, 24, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st);
+    case 32: return launch_k3<N, 32, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st);
+    default: return DLPD_ERR_UNSUPPORTED;
+  }
+}
+
+extern "C" {
+
+int dlpd_version(void) { return 100; }
+
+int dlpd_hidden_pad(int H) {
+  const int opts[6] = {2, 4, 8, 16, 24, 32};
+  for (int i = 0; i < 6; i++)
+    if (H <= opts[i]) return opts[i];
+  return -1;
+}
+
+int dlpd_grid_supported(int L) { return (L == 32 || L == 64) ? 1 : 0; }
+
+int dlpd_rotate_trilinear(const float* vol, const float* R, float* out, int B, int C, int L, long long vol_bstride,
+                          float center, void* stream) {
+  if (!vol || !R || !out || B <= 0 || C <= 0 || L <= 0) return DLPD_ERR_ARG;
+  const size_t total = (size_t)B * C * L * L * L;
+  size_t nblk = (total + 255) / 256;
+  if (nblk > 8192) nblk = 8192;
+  DLPD_LAUNCH(k_rotate, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, vol, R, out, B, C, L, vol_bstride,
+              center);
+  return dlpd_check_launch();
+}
+
+// vol (nb*CT volumes as (nb, CT, L^3), or one (CT, L^3) set with vol_bstride = 0) -> wsA
+int dlpd_zfft(const float* vol, const float* R, void* wsA, int nb, int CT, int L, long long vol_bstride,
+              int do_rotate, float center, void* stream) {
+  if (!vol || !wsA || nb <= 0 || CT <= 0) return DLPD_ERR_ARG;
+  if (do_rotate && !R) return DLPD_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  switch (L) {
+    case 32: return launch_k1<64>(vol, R, (cplx*)wsA, CT, nb, vol_bstride, do_rotate, center, st);
+    case 64: return launch_k1<128>(vol, R, (cplx*)wsA, CT, nb, vol_bstride, do_rotate, center, st);
+    default: return DLPD_ERR_UNSUPPORTED;
+  }
+}
+
+// Padded 3-D R2C spectrum of nvol real (L^3) volumes: spec (nvol, NZ, N, N) [kz][kx][ky], times scale.
+int dlpd_rfft3d_padded(const float* vol, void* spec, void* wsA, int nvol, int L, float scale, void* stream) {
+  if (!vol || !spec || !wsA || nvol <= 0) return DLPD_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = dlpd_zfft(vol, nullptr, wsA, 1, nvol, L, 0, 0, 0.f, stream);
+  if (rc) return rc;
+  switch (L) {
+    case 32: return launch_k2<64, 0>((const cplx*)wsA, nullptr, (cplx*)spec, nvol, 1, 0, scale, st);
+    case 64: return launch_k2<128, 0>((const cplx*)wsA, nullptr, (cplx*)spec, nvol, 1, 0, scale, st);
+    default: return DLPD_ERR_UNSUPPORTED;
+  }
+}
+
+// wsA (nb, CT, NZ, L, L) x rec (CT or nb*CT spectra) -> wsB (nb, CT, NZ, N, N)
+int dlpd_xy_correlate(const void* wsA, const void* rec, void* wsB, int nb, int CT, int L, long long rec_bstride,
+                      void* stream) {
+  if (!wsA || !rec || !wsB || nb <= 0 || CT <= 0) return DLPD_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  switch (L) {
+    case 32: return launch_k2<64, 1>((const cplx*)wsA, (const cplx*)rec, (cplx*)wsB, CT, nb, rec_bstride, 1.f, st);
+    case 64: return launch_k2<128, 1>((const cplx*)wsA, (const cplx*)rec, (cplx*)wsB, CT, nb, rec_bstride, 1.f, st);
+    default: return DLPD_ERR_UNSUPPORTED;
+  }
+}
+
+// wsB -> real correlation volumes out (nb, CT, N^3), optional clamp
+int dlpd_zifft_real(const void* wsB, float* out, int nb, int CT, int L, int has_clip, float clip, void* stream) {
+  if (!wsB || !out || nb <= 0 || CT <= 0) return DLPD_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  switch (L) {
+    case 32: return launch_k3<64, 0, 0>((const cplx*)wsB, out, CT, CT, 0, nb, nullptr, nullptr, nullptr, 0.f, has_clip, clip, 0.f, st);
+    case 64: return launch_k3<128, 0, 0>((const cplx*)wsB, out, CT, CT, 0, nb, nullptr, nullptr, nullptr, 0.f, has_clip, clip, 0.f, st);
+    default: return DLPD_ERR_UNSUPPORTED;
+  }
+}
+
+// wsB -> V (nb, N^3): z C2R + clip + MLP + clash mask
+int dlpd_zifft_filter(const void* wsB, float* V, int nb, int C, int has_clash, int L, const float* W1t,
+                      const float* b1, const float* W2, float b2, int HP, int has_clip, float clip, float thr,
+                      void* stream) {
+  if (!wsB || !V || !W1t || !b1 || !W2 || nb <= 0 || C <= 0) return DLPD_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int CT = C + (has_clash ? 1 : 0);
+  switch (L) {
+    case 32: return k3_filter_dispatch<64>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st);
+    case 64: return k3_filter_dispatch<128>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st);
+    default: return DLPD_ERR_UNSUPPORTED;
+  }
+}
+
+// Fused driver for one batch of rotations (single-resolution model):
+//   lig (CT, L^3) [score channels then, if has_clash, the ligand forbidden volume]
+//   recF (CT, NZ, N, N) from dlpd_rfft3d_padded(receptor, scale = 1/N^3)
+//   R (nb, 9) -> V (nb, N^3).  wsA: nb*CT*NZ*L*L cplx, wsB: nb*CT*NZ*N*N cplx.
+int dlpd_score_rotations(const float* lig, const void* recF, const float* R, int nb, int C, int has_clash, int L,
+                         float center, const float* W1t, const float* b1, const float* W2, float b2, int HP,
+                         int has_clip, float clip, float thr, void* wsA, void* wsB, float* V, void* stream) {
+  const int CT = C + (has_clash ? 1 : 0);
+  int rc = dlpd_zfft(lig, R, wsA, nb, CT, L, 0, 1, center, stream);
+  if (rc) return rc;
+  rc = dlpd_xy_correlate(wsA, recF, wsB, nb, CT, L, 0, stream);
+  if (rc) return rc;
+  return dlpd_zifft_filter(wsB, V, nb, C, has_clash, L, W1t, b1, W2, b2, HP, has_clip, clip, thr, stream);
+}
+
+// Generic per-voxel filter over real correlation volumes (multi-resolution model).
+int dlpd_filter_mask(const float* conv0, int C0, int N0, const float* conv1, int C1, int N1, const float* mask_norm,
+                     float thr, int has_clash, const float* W1t, const float* b1, const float* W2, float b2, int H,
+                     float* V, int nb, void* stream) {
+  if (!conv0 || !V || !W1t || !b1 || !W2 || nb <= 0 || H <= 0 || H > DLPD_MAX_HIDDEN) return DLPD_ERR_ARG;
+  if (C1 > 0 && (!conv1 || N1 <= 0 || N0 % N1 != 0)) return DLPD_ERR_ARG;
+  if (has_clash && !mask_norm) return DLPD_ERR_ARG;
+  const size_t total = (size_t)nb * N0 * N0 * N0;
+  size_t nblk = (total + 255) / 256;
+  if (nblk > 16384) nblk = 16384;
+  DLPD_LAUNCH(k_filter_generic, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, conv0, C0, N0, conv1, C1, N1,
+              mask_norm, thr, has_clash, W1t, b1, W2, b2, H, V, nb);
+  return dlpd_check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,212 @@
+// In-register mixed-radix Stockham FFT passes for LDS-resident pencils (gfx950).
+//
+// A length-N transform is a short list of passes (N=64: 8x8, N=128: 16x8, N=80: 8x10,
+// N=160: 16x10).  T threads cooperate on one pencil; in a pass of radix R each thread
+// loads R strided elements per butterfly into registers, applies the Stockham twiddle,
+// does the radix-R DFT in registers (load()), and after a barrier scatters the results back
+// to the SAME pencil storage at the autosort positions (store()).  Because every read of a
+// pass happens before the barrier and every write after it, the transform is in place.
+//
+// Built-in zero-padding pruning: NNZ < N declares that only the first NNZ inputs of the first
+// pass are non-zero (the docking grids are 2L-padded L-boxes), so those loads are skipped.
+#pragma once
+#include <dlpd_platform.h>
+
+typedef float2 cplx;
+
+DLPD_HD cplx c_make(float a, float b) { cplx r; r.x = a; r.y = b; return r; }
+DLPD_HD cplx c_add(cplx a, cplx b) { return c_make(a.x + b.x, a.y + b.y); }
+DLPD_HD cplx c_sub(cplx a, cplx b) { return c_make(a.x - b.x, a.y - b.y); }
+DLPD_HD cplx c_mul(cplx a, cplx b) { return c_make(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// a * conj(b)
+DLPD_HD cplx c_mulc(cplx a, cplx b) { return c_make(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
+DLPD_HD cplx c_conj(cplx a) { return c_make(a.x, -a.y); }
+DLPD_HD cplx c_scale(cplx a, float s) { return c_make(a.x * s, a.y * s); }
+
+// multiply by exp(DIR * i * pi/2):  DIR=-1 (forward) -> -i*a ; DIR=+1 (inverse) -> +i*a
+template <int DIR> DLPD_HD cplx c_rot90(cplx a) {
+  return DIR < 0 ? c_make(a.y, -a.x) : c_make(-a.y, a.x);
+}
+// multiply by (c + DIR*i*s) i.e. exp(DIR*i*phi) with c=cos(phi), s=sin(phi)
+template <int DIR> DLPD_HD cplx c_rotcs(cplx a, float c, float s) {
+  return DIR < 0 ? c_make(a.x * c + a.y * s, a.y * c - a.x * s)
+                 : c_make(a.x * c - a.y * s, a.y * c + a.x * s);
+}
+
+#define DLPD_SQRT1_2 0.70710678118654752440f
+#define DLPD_COS_PI_8 0.92387953251128675613f
+#define DLPD_SIN_PI_8 0.38268343236508977173f
+#define DLPD_COS_2PI_5 0.30901699437494742410f
+#define DLPD_COS_4PI_5 (-0.80901699437494742410f)
+#define DLPD_SIN_2PI_5 0.95105651629515357212f
+#define DLPD_SIN_4PI_5 0.58778525229247312917f
+#define DLPD_COS_PI_5 0.80901699437494742410f
+#define DLPD_SIN_PI_5 0.58778525229247312917f
+
+// ---- small DFTs in registers: v[k] <- sum_n v[n] exp(DIR*2*pi*i*n*k/R), natural order ----
+template <int DIR> DLPD_HD void dft2(cplx& a, cplx& b) {
+  cplx t = c_sub(a, b);
+  a = c_add(a, b);
+  b = t;
+}
+template <int DIR> DLPD_HD void dft4(cplx& a0, cplx& a1, cplx& a2, cplx& a3) {
+  cplx t0 = c_add(a0, a2), t1 = c_sub(a0, a2);
+  cplx t2 = c_add(a1, a3), t3 = c_rot90<DIR>(c_sub(a1, a3));
+  a0 = c_add(t0, t2);
+  a1 = c_add(t1, t3);
+  a2 = c_sub(t0, t2);
+  a3 = c_sub(t1, t3);
+}
+template <int DIR> DLPD_HD void dft5(cplx& a0, cplx& a1, cplx& a2, cplx& a3, cplx& a4) {
+  cplx s1 = c_add(a1, a4), d1 = c_sub(a1, a4);
+  cplx s2 = c_add(a2, a3), d2 = c_sub(a2, a3);
+  cplx x0 = c_add(a0, c_add(s1, s2));
+  cplx p1 = c_make(a0.x + DLPD_COS_2PI_5 * s1.x + DLPD_COS_4PI_5 * s2.x,
+                   a0.y + DLPD_COS_2PI_5 * s1.y + DLPD_COS_4PI_5 * s2.y);
+  cplx p2 = c_make(a0.x + DLPD_COS_4PI_5 * s1.x + DLPD_COS_2PI_5 * s2.x,
+                   a0.y + DLPD_COS_4PI_5 * s1.y + DLPD_COS_2PI_5 * s2.y);
+  // q1 = i*DIR*(s1*d1 + s2*d2), q2 = i*DIR*(s2*d1 - s1*d2) with s1=sin(2pi/5), s2=sin(4pi/5)
+  cplx u1 = c_make(DLPD_SIN_2PI_5 * d1.x + DLPD_SIN_4PI_5 * d2.x,
+                   DLPD_SIN_2PI_5 * d1.y + DLPD_SIN_4PI_5 * d2.y);
+  cplx u2 = c_make(DLPD_SIN_4PI_5 * d1.x - DLPD_SIN_2PI_5 * d2.x,
+                   DLPD_SIN_4PI_5 * d1.y - DLPD_SIN_2PI_5 * d2.y);
+  cplx q1 = c_rot90<DIR>(u1), q2 = c_rot90<DIR>(u2);
+  a0 = x0;
+  a1 = c_add(p1, q1);
+  a4 = c_sub(p1, q1);
+  a2 = c_add(p2, q2);
+  a3 = c_sub(p2, q2);
+}
+
+template <int R, int DIR> struct SmallDft;
+template <int DIR> struct SmallDft<2, DIR> {
+  DLPD_HD static void run(cplx* v) { dft2<DIR>(v[0], v[1]); }
+};
+template <int DIR> struct SmallDft<4, DIR> {
+  DLPD_HD static void run(cplx* v) { dft4<DIR>(v[0], v[1], v[2], v[3]); }
+};
+template <int DIR> struct SmallDft<5, DIR> {
+  DLPD_HD static void run(cplx* v) { dft5<DIR>(v[0], v[1], v[2], v[3], v[4]); }
+};
+template <int DIR> struct SmallDft<8, DIR> {
+  DLPD_HD static void run(cplx* v) {
+    // even / odd split
+    cplx e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    cplx o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    dft4<DIR>(e0, e1, e2, e3);
+    dft4<DIR>(o0, o1, o2, o3);
+    o1 = c_rotcs<DIR>(o1, DLPD_SQRT1_2, DLPD_SQRT1_2);
+    o2 = c_rot90<DIR>(o2);
+    o3 = c_rotcs<DIR>(o3, -DLPD_SQRT1_2, DLPD_SQRT1_2);
+    v[0] = c_add(e0, o0); v[4] = c_sub(e0, o0);
+    v[1] = c_add(e1, o1); v[5] = c_sub(e1, o1);
+    v[2] = c_add(e2, o2); v[6] = c_sub(e2, o2);
+    v[3] = c_add(e3, o3); v[7] = c_sub(e3, o3);
+  }
+};
+template <int DIR> struct SmallDft<16, DIR> {
+  DLPD_HD static void run(cplx* v) {
+    // n = 4*n1 + n2 ; k = k1 + 4*k2.  Step 1: DFT4 over n1 for each n2.
+    cplx y[4][4];
+#pragma unroll
+    for (int n2 = 0; n2 < 4; n2++) {
+      y[n2][0] = v[n2]; y[n2][1] = v[n2 + 4]; y[n2][2] = v[n2 + 8]; y[n2][3] = v[n2 + 12];
+      dft4<DIR>(y[n2][0], y[n2][1], y[n2][2], y[n2][3]);
+    }
+    // twiddle W16^(n2*k1)
+    const float c1 = DLPD_COS_PI_8, s1 = DLPD_SIN_PI_8, h = DLPD_SQRT1_2;
+    y[1][1] = c_rotcs<DIR>(y[1][1], c1, s1);
+    y[1][2] = c_rotcs<DIR>(y[1][2], h, h);
+    y[1][3] = c_rotcs<DIR>(y[1][3], s1, c1);
+    y[2][1] = c_rotcs<DIR>(y[2][1], h, h);
+    y[2][2] = c_rot90<DIR>(y[2][2]);
+    y[2][3] = c_rotcs<DIR>(y[2][3], -h, h);
+    y[3][1] = c_rotcs<DIR>(y[3][1], s1, c1);
+    y[3][2] = c_rotcs<DIR>(y[3][2], -h, h);
+    y[3][3] = c_rotcs<DIR>(y[3][3], -c1, -s1);
+    // Step 2: DFT4 over n2 for each k1 -> X[k1 + 4*k2]
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++) {
+      dft4<DIR>(y[0][k1], y[1][k1], y[2][k1], y[3][k1]);
+      v[k1] = y[0][k1]; v[k1 + 4] = y[1][k1]; v[k1 + 8] = y[2][k1]; v[k1 + 12] = y[3][k1];
+    }
+  }
+};
+template <int DIR> struct SmallDft<10, DIR> {
+  DLPD_HD static void run(cplx* v) {
+    // n = 2*n1 + n2 (n1<5, n2<2) ; k = k1 + 5*k2
+    cplx e[5] = {v[0], v[2], v[4], v[6], v[8]};
+    cplx o[5] = {v[1], v[3], v[5], v[7], v[9]};
+    dft5<DIR>(e[0], e[1], e[2], e[3], e[4]);
+    dft5<DIR>(o[0], o[1], o[2], o[3], o[4]);
+    // W10^k1 on odd branch: angle k1*pi/5
+    o[1] = c_rotcs<DIR>(o[1], DLPD_COS_PI_5, DLPD_SIN_PI_5);
+    o[2] = c_rotcs<DIR>(o[2], DLPD_COS_2PI_5, DLPD_SIN_2PI_5);
+    o[3] = c_rotcs<DIR>(o[3], -DLPD_COS_2PI_5, DLPD_SIN_2PI_5);
+    o[4] = c_rotcs<DIR>(o[4], -DLPD_COS_PI_5, DLPD_SIN_PI_5);
+#pragma unroll
+    for (int k1 = 0; k1 < 5; k1++) {
+      v[k1] = c_add(e[k1], o[k1]);
+      v[k1 + 5] = c_sub(e[k1], o[k1]);
+    }
+  }
+};
+
+// ---- one Stockham pass over one pencil, register-resident between load() and store() ----
+//  N   transform length            R   radix of this pass
+//  NS  product of earlier radices  DIR -1 forward / +1 inverse (unnormalised)
+//  T   threads cooperating on the pencil
+//  NNZ only inputs [0,NNZ) are non-zero (pruned loads); NNZ % (N/R) == 0
+template <int N, int R, int NS, int DIR, int T, int NNZ = N> struct FftPass {
+  static constexpr int NBF = N / R;
+  static constexpr int PER = (NBF + T - 1) / T;
+  static constexpr int RNZ = NNZ / NBF;   // radix inputs r < RNZ are non-zero
+  static_assert(N % R == 0, "radix must divide N");
+  static_assert(NNZ % NBF == 0, "NNZ must be a multiple of N/R");
+  cplx v[PER][R];
+
+  // P: pencil base, es: element stride (in cplx), t: thread index within the pencil [0,T),
+  // tw: table of exp(-2*pi*i*k/N), k in [0,N)
+  DLPD_HD void load(const cplx* P, int es, int t, const cplx* tw) {
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+      const int j = t + i * T;
+      if ((NBF % T == 0) || j < NBF) {
+#pragma unroll
+        for (int r = 0; r < R; r++) v[i][r] = (r < RNZ) ? P[(j + r * NBF) * es] : c_make(0.f, 0.f);
+        if (NS > 1) {
+          const int k = (j % NS) * (N / (NS * R));
+#pragma unroll
+          for (int r = 1; r < R; r++) {
+            if (r < RNZ) {
+              cplx w = tw[k * r];
+              v[i][r] = DIR < 0 ? c_mul(v[i][r], w) : c_mulc(v[i][r], w);
+            }
+          }
+        }
+        SmallDft<R, DIR>::run(v[i]);
+      }
+    }
+  }
+  DLPD_HD int out_index(int i, int r, int t) const {
+    const int j = t + i * T;
+    return (j / NS) * NS * R + (j % NS) + r * NS;
+  }
+  DLPD_HD bool active(int i, int t) const { return (NBF % T == 0) || (t + i * T) < NBF; }
+  DLPD_HD void store(cplx* P, int es, int t) const {
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+      if (active(i, t)) {
+#pragma unroll
+        for (int r = 0; r < R; r++) P[out_index(i, r, t) * es] = v[i][r];
+      }
+    }
+  }
+};
+
+// Pass plans: radices R1 (first, NS=1) and R2 (second, NS=R1); T threads per pencil.
+template <int N> struct FftPlan;
+template <> struct FftPlan<64> { static constexpr int R1 = 8, R2 = 8, T = 8; };
+template <> struct FftPlan<128> { static constexpr int R1 = 16, R2 = 8, T = 8; };
+template <> struct FftPlan<80> { static constexpr int R1 = 8, R2 = 10, T = 10; };
+template <> struct FftPlan<160> { static constexpr int R1 = 16, R2 = 10, T = 10; };

@@ -1,0 +1,351 @@
+// Top-K (minimum) selection over the translation grid and the running global merge.
+//
+// Reference being replaced: Docker.update_top, /root/reference/src/Docker/Docker.py:86-105 --
+// max_conf x { min over z, y, x ; record (x,y,z,V) ; V[x,y,z] = 0 }, append to top_list,
+// stable sort by score, truncate.  Equivalent closed form implemented here:
+//   * per rotation the picks are the strictly negative voxels among the K smallest, ordered by
+//     (value, flat index) [-0.0 == +0.0]; every picked voxel is zeroed, so once the negatives
+//     run out the minimum is the first zero in flat order among {original zeros} U {picked
+//     voxels} and it is picked again and again with score 0.0 (with no zero at all, the
+//     smallest positive once, then that voxel with 0.0) -- the reference's zero-fill quirk,
+//     pinned by tests/golden/g3_update_top.npz;
+//   * the global list is the K smallest entries ordered by (score, rotation, pick order).
+//
+// Selection = exact radix select on unique 64-bit keys (order-preserving float key << 32 | idx):
+// 3 value digits + 2 index digits with early exit, multi-block histograms, then a compaction
+// and a one-block bitonic sort of the K survivors.  No host synchronisation anywhere.
+#include <dlpd_platform.h>
+#include "dlpd_internal.h"
+
+typedef unsigned long long u64;
+
+#define TOPK_BINS 2048
+#define TOPK_HIST_BLOCKS 64
+#define TOPK_HIST_THREADS 256
+#define TOPK_MAXK 2048
+
+struct TopkState {           // one per rotation in the batch
+  u64 kth;                   // decided high bits of the K-th key, finally the K-th key itself
+  unsigned krem;             // rank still to resolve inside the current prefix
+  int done;
+  unsigned ncand;
+  unsigned pad;
+  unsigned hist[TOPK_BINS];
+};
+
+DLPD_HD unsigned f2key(float v) {
+  v = v + 0.0f;                                   // -0.0 -> +0.0
+  unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+DLPD_HD float key2f(unsigned k) {
+  unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(u);
+}
+
+__device__ const int kShift[5] = {53, 42, 32, 11, 0};
+__device__ const int kBits[5] = {11, 11, 10, 11, 11};
+
+__global__ void __launch_bounds__(256) k_topk_init(TopkState* st, int nb, unsigned K) {
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < TOPK_BINS; i += blockDim.x) st[b].hist[i] = 0;
+  if (threadIdx.x == 0) { st[b].kth = 0; st[b].krem = K; st[b].done = 0; st[b].ncand = 0; }
+}
+
+__global__ void __launch_bounds__(TOPK_HIST_THREADS)
+k_topk_hist(const float* __restrict__ V, long long nvox, TopkState* st, int pass) {
+  const int b = blockIdx.y;
+  if (st[b].done) return;
+  __shared__ unsigned lh[TOPK_BINS];
+  for (int i = threadIdx.x; i < TOPK_BINS; i += blockDim.x) lh[i] = 0;
+  __syncthreads();
+  const int shift = kShift[pass], bits = kBits[pass];
+  const unsigned mask = (1u << bits) - 1u;
+  const u64 kth = st[b].kth;
+  const int hs = shift + bits;
+  const float* v = V + (size_t)b * nvox;
+  const long long per = (nvox + gridDim.x - 1) / gridDim.x;
+  const long long beg = (long long)blockIdx.x * per;
+  const long long end = beg + per < nvox ? beg + per : nvox;
+  for (long long i = beg + threadIdx.x; i < end; i += blockDim.x) {
+    const u64 key = ((u64)f2key(v[i]) << 32) | (u64)i;
+    if (pass == 0 || (key >> hs) == (kth >> hs)) atomicAdd(&lh[(unsigned)(key >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < TOPK_BINS; i += blockDim.x)
+    if (lh[i]) atomicAdd(&st[b].hist[i], lh[i]);
+}
+
+__global__ void __launch_bounds__(256) k_topk_scan(TopkState* st, int pass) {
+  const int b = blockIdx.x;
+  if (st[b].done) return;
+  __shared__ unsigned part[256];
+  __shared__ unsigned sel[3];
+  const int tid = threadIdx.x;
+  constexpr int PER = TOPK_BINS / 256;
+  unsigned s = 0;
+  for (int i = 0; i < PER; i++) s += st[b].hist[tid * PER + i];
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned krem = st[b].krem;
+    unsigned cum = 0;
+    int chunk = 0;
+    for (; chunk < 256; chunk++) {
+      if (cum + part[chunk] >= krem) break;
+      cum += part[chunk];
+    }
+    if (chunk == 256) chunk = 255;   // cannot happen when K <= nvox
+    int bin = chunk * PER;
+    unsigned cnt = 0;
+    for (; bin < chunk * PER + PER; bin++) {
+      cnt = st[b].hist[bin];
+      if (cum + cnt >= krem) break;
+      cum += cnt;
+    }
+    if (bin == chunk * PER + PER) bin--;
+    const int shift = kShift[pass];
+    u64 kth = st[b].kth | ((u64)bin << shift);
+    if (cum + cnt == krem || pass == 4) {
+      // everything in this bin (and below) is selected: close the key with all-ones below
+      if (pass != 4) kth |= ((u64)1 << shift) - 1;
+      st[b].done = 1;
+    } else {
+      st[b].krem = krem - cum;
+    }
+    st[b].kth = kth;
+  }
+  __syncthreads();
+  for (int i = tid; i < TOPK_BINS; i += 256) st[b].hist[i] = 0;
+  (void)sel;
+}
+
+__global__ void __launch_bounds__(TOPK_HIST_THREADS)
+k_topk_collect(const float* __restrict__ V, long long nvox, TopkState* st, u64* __restrict__ cand, int K) {
+  const int b = blockIdx.y;
+  const u64 kth = st[b].kth;
+  const float* v = V + (size_t)b * nvox;
+  const long long per = (nvox + gridDim.x - 1) / gridDim.x;
+  const long long beg = (long long)blockIdx.x * per;
+  const long long end = beg + per < nvox ? beg + per : nvox;
+  for (long long i = beg + threadIdx.x; i < end; i += blockDim.x) {
+    const u64 key = ((u64)f2key(v[i]) << 32) | (u64)i;
+    if (key <= kth) {
+      const unsigned slot = atomicAdd(&st[b].ncand, 1u);
+      if (slot < (unsigned)K) cand[(size_t)b * K + slot] = key;
+    }
+  }
+}
+
+// in-LDS bitonic sort of n (power of two) 64-bit keys, ascending; all threads of the block call
+DLPD_D void bitonic_sort_u64(u64* a, int n, int tid, int nt) {
+  for (int k = 2; k <= n; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (int i = tid; i < n; i += nt) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const u64 x = a[i], y = a[ixj];
+          const bool up = ((i & k) == 0);
+          if ((x > y) == up) { a[i] = y; a[ixj] = x; }
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// one block per rotation: sort the K survivors, apply the zero-fill quirk, write (score, idx)
+__global__ void __launch_bounds__(1024)
+k_topk_sort(const float* __restrict__ V, long long nvox, const TopkState* st, const u64* __restrict__ cand, int K,
+            float* __restrict__ out_score, int* __restrict__ out_idx) {
+  __shared__ u64 keys[TOPK_MAXK];
+  __shared__ int nneg_s;
+  __shared__ unsigned pmin_s;
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  int KP = 1;
+  while (KP < K) KP <<= 1;
+  for (int i = tid; i < KP; i += nt) keys[i] = (i < K) ? cand[(size_t)b * K + i] : ~(u64)0;
+  if (tid == 0) { nneg_s = 0; pmin_s = 0xffffffffu; }
+  bitonic_sort_u64(keys, KP, tid, nt);
+  // number of strictly negative entries (canonical key < key(+0.0)) and their smallest index
+  int local = 0;
+  unsigned lmin = 0xffffffffu;
+  for (int i = tid; i < K; i += nt)
+    if ((unsigned)(keys[i] >> 32) < 0x80000000u) {
+      local++;
+      const unsigned id = (unsigned)(keys[i] & 0xffffffffu);
+      lmin = id < lmin ? id : lmin;
+    }
+  if (local) { atomicAdd(&nneg_s, local); atomicMin(&pmin_s, lmin); }
+  __syncthreads();
+  const int q = nneg_s;
+  // zero-fill: picked voxels were set to 0.0, so after the negatives the minimum is the first
+  // zero in flat order among {original zeros} U {picked voxels}; with no zero at all the
+  // smallest positive is picked once and then repeats with 0.0.
+  int fill_idx = 0;
+  bool first_stored = false;      // position q reports the stored value of an unpicked voxel
+  if (q < K) {
+    const unsigned kq = (unsigned)(keys[q] >> 32), iq = (unsigned)(keys[q] & 0xffffffffu);
+    const bool orig_zero = (kq == 0x80000000u);
+    if (orig_zero && (q == 0 || iq < pmin_s)) { fill_idx = (int)iq; first_stored = true; }
+    else if (q > 0) { fill_idx = (int)pmin_s; }
+    else { fill_idx = (int)iq; first_stored = true; }
+  }
+  for (int i = tid; i < K; i += nt) {
+    float sc;
+    int idx;
+    if (i < q) {
+      sc = key2f((unsigned)(keys[i] >> 32));
+      idx = (int)(keys[i] & 0xffffffffu);
+    } else {
+      idx = fill_idx;
+      sc = (i == q && first_stored) ? V[(size_t)b * nvox + idx] : 0.0f;   // stored (maybe -0.0), then +0.0
+    }
+    out_score[(size_t)b * K + i] = sc;
+    out_idx[(size_t)b * K + i] = idx;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// running global list.  glist: u64 header[2] {count, unused}, u64 hi[K], u64 lo[K]
+//   hi = canonical score key << 32 | rotation ; lo = pick << 32 | negzero << 31 | flat idx
+// ------------------------------------------------------------------------------------------
+DLPD_D bool pair_gt(u64 ah, u64 al, u64 bh, u64 bl) { return ah > bh || (ah == bh && al > bl); }
+
+DLPD_D void bitonic_sort_pairs(u64* hi, u64* lo, int n, int tid, int nt) {
+  for (int k = 2; k <= n; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (int i = tid; i < n; i += nt) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const u64 xh = hi[i], xl = lo[i], yh = hi[ixj], yl = lo[ixj];
+          const bool up = ((i & k) == 0);
+          if (pair_gt(xh, xl, yh, yl) == up) { hi[i] = yh; lo[i] = yl; hi[ixj] = xh; lo[ixj] = xl; }
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(1024)
+k_topk_merge(const float* __restrict__ cs, const int* __restrict__ ci, const int* __restrict__ rot_ids, int nb, int K,
+             u64* __restrict__ glist) {
+  DLPD_DYN_SHARED(u64, sm);
+  const int tid = threadIdx.x, nt = blockDim.x;
+  int KP = 1;
+  while (KP < K) KP <<= 1;
+  const int CAP = 2 * KP;
+  u64* hi = sm;
+  u64* lo = sm + CAP;
+  __shared__ int s_cnt, s_new;
+  u64* ghi = glist + 2;
+  u64* glo = glist + 2 + K;
+  int count = (int)glist[0];
+  for (int i = tid; i < CAP; i += nt) {
+    hi[i] = (i < count) ? ghi[i] : ~(u64)0;
+    lo[i] = (i < count) ? glo[i] : ~(u64)0;
+  }
+  if (tid == 0) { s_cnt = 0; s_new = 0; }
+  __syncthreads();
+  int nnew = 0;                                           // appended, not yet merged (uniform)
+  u64 tau = (count == K) ? (hi[K - 1] >> 32) : ~(u64)0;  // score key of the current K-th
+  for (int r = 0; r < nb; r++) {
+    const u64 rot = (u64)(unsigned)rot_ids[r];
+    for (int attempt = 0; attempt < 2; attempt++) {
+      // count survivors of this rotation against tau
+      int local = 0;
+      for (int i = tid; i < K; i += nt) {
+        const u64 sk = f2key(cs[(size_t)r * K + i]);
+        if (sk < tau) local++;
+      }
+      if (local) atomicAdd(&s_cnt, local);
+      __syncthreads();
+      const int nsurv = s_cnt;
+      __syncthreads();
+      if (tid == 0) s_cnt = 0;
+      if (nnew + nsurv <= CAP - KP || attempt == 1) break;
+      // flush: merge what is pending so the new rotation fits
+      bitonic_sort_pairs(hi, lo, CAP, tid, nt);
+      count = (count + nnew < K) ? count + nnew : K;
+      nnew = 0;
+      for (int i = KP + tid; i < CAP; i += nt) { hi[i] = ~(u64)0; lo[i] = ~(u64)0; }
+      for (int i = count + tid; i < KP; i += nt) { hi[i] = ~(u64)0; lo[i] = ~(u64)0; }
+      __syncthreads();
+      tau = (count == K) ? (hi[K - 1] >> 32) : ~(u64)0;
+      if (tid == 0) s_new = 0;
+      __syncthreads();
+    }
+    for (int i = tid; i < K; i += nt) {
+      const float s = cs[(size_t)r * K + i];
+      const u64 sk = f2key(s);
+      if (sk < tau) {
+        const int slot = KP + atomicAdd(&s_new, 1);
+        const u64 negzero = (__float_as_uint(s) == 0x80000000u) ? 1 : 0;
+        hi[slot] = (sk << 32) | rot;
+        lo[slot] = ((u64)i << 32) | (negzero << 31) | (u64)(unsigned)ci[(size_t)r * K + i];
+      }
+    }
+    __syncthreads();
+    nnew = s_new;
+    __syncthreads();
+  }
+  if (nnew > 0) {
+    bitonic_sort_pairs(hi, lo, CAP, tid, nt);
+    count = (count + nnew < K) ? count + nnew : K;
+  }
+  __syncthreads();
+  for (int i = tid; i < count; i += nt) { ghi[i] = hi[i]; glo[i] = lo[i]; }
+  if (tid == 0) glist[0] = (u64)count;
+}
+
+extern "C" {
+
+size_t dlpd_topk_workspace_bytes(int nb, int K) {
+  return (size_t)nb * sizeof(TopkState) + (size_t)nb * (size_t)K * sizeof(u64) + 256;
+}
+size_t dlpd_topk_glist_bytes(int K) { return (size_t)(2 + 2 * (size_t)K) * sizeof(u64); }
+
+int dlpd_topk_glist_reset(void* glist, int K, void* stream) {
+  if (!glist || K <= 0) return DLPD_ERR_ARG;
+  return hipMemsetAsync(glist, 0, dlpd_topk_glist_bytes(K), (hipStream_t)stream) == hipSuccess ? DLPD_OK
+                                                                                                : DLPD_ERR_LAUNCH;
+}
+
+// V (nb, nvox) -> per rotation the reference's K picks in pick order: out_score/out_idx (nb, K)
+int dlpd_topk_select(const float* V, int nb, long long nvox, int K, float* out_score, int* out_idx, void* ws,
+                     void* stream) {
+  if (!V || !out_score || !out_idx || !ws || nb <= 0 || nvox <= 0 || K <= 0) return DLPD_ERR_ARG;
+  if (K > TOPK_MAXK || (long long)K > nvox || nvox > (1ll << 22)) return DLPD_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  TopkState* state = (TopkState*)ws;
+  u64* cand = (u64*)((char*)ws + (((size_t)nb * sizeof(TopkState) + 255) / 256) * 256);
+  DLPD_LAUNCH(k_topk_init, dim3(nb), dim3(256), 0, st, state, nb, (unsigned)K);
+  for (int pass = 0; pass < 5; pass++) {
+    DLPD_LAUNCH(k_topk_hist, dim3(TOPK_HIST_BLOCKS, nb), dim3(TOPK_HIST_THREADS), 0, st, V, nvox, state, pass);
+    DLPD_LAUNCH(k_topk_scan, dim3(nb), dim3(256), 0, st, state, pass);
+  }
+  DLPD_LAUNCH(k_topk_collect, dim3(TOPK_HIST_BLOCKS, nb), dim3(TOPK_HIST_THREADS), 0, st, V, nvox, state, cand, K);
+  DLPD_LAUNCH(k_topk_sort, dim3(nb), dim3(1024), 0, st, V, nvox, (const TopkState*)state, (const u64*)cand, K,
+              out_score, out_idx);
+  return dlpd_check_launch();
+}
+
+// fold nb rotations' picks (rotation ids rot_ids, ascending) into the running global list
+int dlpd_topk_merge(const float* cand_score, const int* cand_idx, const int* rot_ids, int nb, int K, void* glist,
+                    void* stream) {
+  if (!cand_score || !cand_idx || !rot_ids || !glist || nb <= 0 || K <= 0) return DLPD_ERR_ARG;
+  if (K > TOPK_MAXK) return DLPD_ERR_UNSUPPORTED;
+  int KP = 1;
+  while (KP < K) KP <<= 1;
+  const size_t shmem = (size_t)4 * KP * sizeof(u64);
+  int rc = dlpd_set_max_dyn_shared((const void*)k_topk_merge, shmem);
+  if (rc) return rc;
+  DLPD_LAUNCH(k_topk_merge, dim3(1), dim3(1024), shmem, (hipStream_t)stream, cand_score, cand_idx, rot_ids, nb, K,
+              (u64*)glist);
+  return dlpd_check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,227 @@
+"""Host-side driver of the HIP pipeline: owns the device workspaces (as torch tensors) and
+enqueues the C-ABI calls of include/dlpd.h on torch's current stream.
+
+It mirrors the body of the reference's hot loop, src/Docker/Docker.py:211-236 (rotate ligand
+volumes, clash correlation + threshold, GlobalDockingModel.forward, mask multiply, update_top)
+for a single-resolution representation, without any host synchronisation inside the loop.
+torch is plumbing only (memory + streams); all arithmetic is in libdlpd.so.
+"""
+import numpy as np
+import torch
+
+from ._lib import get_lib
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream(device):
+    if device.type == "cuda":
+        return torch.cuda.current_stream(device).cuda_stream
+    return 0
+
+
+def key_to_float(key):
+    """Inverse of the order-preserving float key used in the device top-K list."""
+    key = np.asarray(key, dtype=np.uint32)
+    neg = (key & np.uint32(0x80000000)) == 0
+    bits = np.where(neg, ~key, key & np.uint32(0x7FFFFFFF)).astype(np.uint32)
+    return bits.view(np.float32)
+
+
+class DeviceTopList:
+    """Device-resident running top list: the state Docker.update_top keeps in ``self.top_list``
+    (Docker.py:100-105), plus the per-rotation pick buffers (Docker.py:89-98)."""
+
+    def __init__(self, K, batch, device, lib):
+        self.K, self.batch, self.device, self.lib = int(K), int(batch), torch.device(device), lib
+        dev = self.device
+        self.cand_score = torch.empty(batch, self.K, dtype=torch.float32, device=dev)
+        self.cand_idx = torch.empty(batch, self.K, dtype=torch.int32, device=dev)
+        self.ws = torch.empty(lib.call("dlpd_topk_workspace_bytes", batch, self.K), dtype=torch.uint8, device=dev)
+        self.glist = torch.zeros(lib.call("dlpd_topk_glist_bytes", self.K) // 8, dtype=torch.int64, device=dev)
+
+    def reset(self):
+        self.lib.call("dlpd_topk_glist_reset", _ptr(self.glist), self.K, _stream(self.device))
+
+    def select(self, V, nb):
+        """V (nb, nvox) contiguous -> (scores, flat indices) (nb, K) in the reference's pick order."""
+        nvox = V[0].numel()
+        self.lib.call("dlpd_topk_select", _ptr(V), nb, nvox, self.K, _ptr(self.cand_score), _ptr(self.cand_idx),
+                      _ptr(self.ws), _stream(self.device))
+        return self.cand_score[:nb], self.cand_idx[:nb]
+
+    def merge(self, rot_ids, nb):
+        """rot_ids int32 (nb,) on the device, ascending."""
+        self.lib.call("dlpd_topk_merge", _ptr(self.cand_score), _ptr(self.cand_idx), _ptr(rot_ids), nb, self.K,
+                      _ptr(self.glist), _stream(self.device))
+
+    def entries(self, glist=None):
+        """-> (rot, flat_idx, score, pick) numpy arrays sorted as the reference's top_list."""
+        g = (self.glist if glist is None else glist).cpu().numpy().view(np.uint64)
+        count = int(g[0])
+        hi = g[2:2 + count]
+        lo = g[2 + self.K:2 + self.K + count]
+        score = key_to_float((hi >> np.uint64(32)).astype(np.uint32)).copy()
+        negzero = ((lo >> np.uint64(31)) & np.uint64(1)).astype(bool)
+        score[negzero] = np.float32(-0.0)
+        rot = (hi & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        idx = (lo & np.uint64(0x7FFFFFFF)).astype(np.int64)
+        pick = (lo >> np.uint64(32)).astype(np.int64)
+        return rot, idx, score, pick
+
+    @staticmethod
+    def merge_entries(parts, K):
+        """Deterministic merge of several ranks' lists: sort by (score, rotation, pick), keep K.
+        Exact because the global top-K is a subset of the union of per-shard top-Ks and the key
+        reproduces the reference's stable insertion order."""
+        rot = np.concatenate([p[0] for p in parts])
+        idx = np.concatenate([p[1] for p in parts])
+        score = np.concatenate([p[2] for p in parts])
+        pick = np.concatenate([p[3] for p in parts])
+        order = np.lexsort((pick, rot, score + np.float32(0.0)))[:K]
+        return rot[order], idx[order], score[order], pick[order]
+
+    @staticmethod
+    def to_top_list(entries, N):
+        rot, idx, score, _ = entries
+        x, y, z = idx // (N * N), (idx // N) % N, idx % N
+        return [(int(rot[i]), int(x[i]), int(y[i]), int(z[i]), float(score[i])) for i in range(len(rot))]
+
+
+class DockingEngine:
+    """Exhaustive translation scoring for batches of rotations of ONE receptor/ligand pair.
+
+    Parameters follow the reference objects: ``W1,b1,W2,b2`` are SimpleFilter.fc[0]/fc[2]
+    (DockingModels.py:28-32), ``clip`` the VolumeConvolution(clip) of DockingModels.py:48,
+    ``threshold_clash`` Docker.py:226, ``max_conf`` Docker.py:26.
+    """
+
+    def __init__(self, L, C, W1, b1, W2, b2, clip=5.0, threshold_clash=300.0, has_clash=True,
+                 max_conf=1000, batch=8, device="cuda", lib=None, center=None):
+        self.device = torch.device(device)
+        if lib is None:
+            if self.device.type != "cuda":
+                raise RuntimeError("dlpd: the product path runs on an AMD GPU only "
+                                   "(no CPU fallback); got device %s" % self.device)
+            lib = get_lib()
+        self.lib = lib
+        if not lib.call("dlpd_grid_supported", int(L)):
+            raise RuntimeError("dlpd: box size L=%d has no compiled fused pipeline" % L)
+        self.L, self.N, self.C = int(L), 2 * int(L), int(C)
+        self.NZ = self.N // 2 + 1
+        self.has_clash = bool(has_clash)
+        self.CT = self.C + (1 if self.has_clash else 0)
+        self.center = float(L) / 2.0 if center is None else float(center)
+        self.clip = clip
+        self.threshold = float(threshold_clash)
+        self.K = int(max_conf)
+        self.batch = int(batch)
+        dev = self.device
+        f32 = torch.float32
+        W1 = torch.as_tensor(W1, dtype=f32).reshape(-1, self.C)
+        H = W1.shape[0]
+        HP = lib.call("dlpd_hidden_pad", int(H))
+        if HP < 0:
+            raise RuntimeError("dlpd: hidden width %d > 32 unsupported by the fused filter" % H)
+        self.H, self.HP = H, HP
+        W1t = torch.zeros(self.C, HP, dtype=f32)
+        W1t[:, :H] = W1.t()
+        b1p = torch.zeros(HP, dtype=f32)
+        b1p[:H] = torch.as_tensor(b1, dtype=f32).reshape(-1)
+        W2p = torch.zeros(HP, dtype=f32)
+        W2p[:H] = torch.as_tensor(W2, dtype=f32).reshape(-1)
+        self.W1t, self.b1, self.W2 = W1t.to(dev), b1p.to(dev), W2p.to(dev)
+        self.b2 = float(torch.as_tensor(b2).reshape(-1)[0])
+        nb, CT, NZ, N = self.batch, self.CT, self.NZ, self.N
+        self.lig = torch.zeros(CT, L, L, L, dtype=f32, device=dev)
+        self.recF = torch.zeros(CT, NZ, N, N, 2, dtype=f32, device=dev)
+        self.wsA = torch.empty(nb * CT * NZ * L * L * 2, dtype=f32, device=dev)
+        self.wsB = torch.empty(nb * CT * NZ * N * N * 2, dtype=f32, device=dev)
+        self.V = torch.empty(nb, N, N, N, dtype=f32, device=dev)
+        self.top = DeviceTopList(self.K, nb, dev, lib)
+
+    # ---- inputs ------------------------------------------------------------------------
+    def set_receptor(self, rec_volumes, rec_forbidden=None):
+        """rec_volumes (C,L,L,L); rec_forbidden (L,L,L).  Spectrum precomputed once per pair
+        (the reference recomputes it every batch inside VolumeConvolution, DockingModels.py:71)."""
+        L, N, CT = self.L, self.N, self.CT
+        rec = torch.zeros(CT, L, L, L, dtype=torch.float32, device=self.device)
+        rec[: self.C] = torch.as_tensor(rec_volumes, dtype=torch.float32).reshape(self.C, L, L, L).to(self.device)
+        if self.has_clash:
+            rec[self.C] = torch.as_tensor(rec_forbidden, dtype=torch.float32).reshape(L, L, L).to(self.device)
+        scale = 1.0 / float(N) ** 3
+        self.lib.call("dlpd_rfft3d_padded", _ptr(rec), _ptr(self.recF), _ptr(self.wsA), CT, L, scale,
+                      _stream(self.device))
+
+    def set_ligand(self, lig_volumes, lig_forbidden=None):
+        L = self.L
+        self.lig[: self.C] = torch.as_tensor(lig_volumes, dtype=torch.float32).reshape(self.C, L, L, L).to(self.device)
+        if self.has_clash:
+            self.lig[self.C] = torch.as_tensor(lig_forbidden, dtype=torch.float32).reshape(L, L, L).to(self.device)
+
+    # ---- hot loop ------------------------------------------------------------------------
+    def score_batch(self, R, mark=None):
+        """R (nb,3,3) float32 on the device, nb <= batch.  Returns V[:nb] (view of the engine's
+        buffer, overwritten by the next call): Docker.py:218-232."""
+        nb = R.shape[0]
+        assert nb <= self.batch and R.dtype == torch.float32 and R.is_contiguous()
+        has_clip = 0 if self.clip is None else 1
+        if mark is not None:
+            # same three stages as dlpd_score_rotations, with a timing mark after each
+            st = _stream(self.device)
+            mark("begin")
+            self.lib.call("dlpd_zfft", _ptr(self.lig), _ptr(R), _ptr(self.wsA), nb, self.CT, self.L, 0, 1,
+                          self.center, st)
+            mark("k1_rotate_zfft")
+            self.lib.call("dlpd_xy_correlate", _ptr(self.wsA), _ptr(self.recF), _ptr(self.wsB), nb, self.CT,
+                          self.L, 0, st)
+            mark("k2_xy_corr")
+            self.lib.call("dlpd_zifft_filter", _ptr(self.wsB), _ptr(self.V), nb, self.C, int(self.has_clash),
+                          self.L, _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2), self.b2, self.HP, has_clip,
+                          float(self.clip or 0.0), self.threshold, st)
+            mark("k3_zifft_filter")
+            return self.V[:nb]
+        self.lib.call("dlpd_score_rotations", _ptr(self.lig), _ptr(self.recF), _ptr(R), nb, self.C,
+                      int(self.has_clash), self.L, self.center, _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2),
+                      self.b2, self.HP, has_clip, float(self.clip or 0.0), self.threshold,
+                      _ptr(self.wsA), _ptr(self.wsB), _ptr(self.V), _stream(self.device))
+        return self.V[:nb]
+
+    def reset_top(self):
+        self.top.reset()
+
+    def select_batch(self, V, nb):
+        """Per-rotation picks of Docker.update_top (Docker.py:89-98) for V (nb, N^3)."""
+        return self.top.select(V.reshape(nb, -1), nb)
+
+    def merge_batch(self, rot_ids, nb):
+        """Docker.py:100-105 on the device-resident list.  rot_ids int32 (nb,) ascending."""
+        self.top.merge(rot_ids, nb)
+
+    def search(self, R_all, rot_ids=None, progress=None):
+        """Score every rotation in R_all (nrot,3,3) and fold it into the running top list.
+        rot_ids: global rotation indices (ascending) for this shard; default arange."""
+        dev = self.device
+        R_all = torch.as_tensor(R_all).to(device=dev, dtype=torch.float32).contiguous()
+        nrot = R_all.shape[0]
+        if rot_ids is None:
+            rot_ids = torch.arange(nrot, dtype=torch.int32)
+        rot_ids = torch.as_tensor(rot_ids).to(device=dev, dtype=torch.int32).contiguous()
+        for beg in range(0, nrot, self.batch):
+            end = min(beg + self.batch, nrot)
+            nb = end - beg
+            V = self.score_batch(R_all[beg:end])
+            self.select_batch(V, nb)
+            self.merge_batch(rot_ids[beg:end], nb)
+            if progress is not None:
+                progress(end)
+
+    # ---- results ------------------------------------------------------------------------
+    def top_entries(self):
+        return self.top.entries()
+
+    def top_list(self):
+        """[(rotation_index, x, y, z, score)] exactly as Docker.top_list (Docker.py:100-105)."""
+        return DeviceTopList.to_top_list(self.top.entries(), self.N)

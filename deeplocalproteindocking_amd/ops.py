@@ -1,0 +1,94 @@
+"""torch-facing operator objects with the call signatures the reference uses for
+TorchProteinLibrary's volume ops, backed by libdlpd.so.
+
+    VolumeRotation()(volume (B,C,L,L,L) f32 cuda, R (B,3,3) f32 cuda) -> (B,C,L,L,L)
+        reference call: src/Docker/Docker.py:40,218
+    VolumeConvolution(clip=None)(v1 (B,C,L,L,L), v2 same) -> (B,C,2L,2L,2L)
+        reference calls: src/Docker/Docker.py:32,225 ; src/Models/DockingModels.py:48,71
+
+Inference only (the docking search runs under torch.no_grad(), local_test.py:67).
+Build-defined conventions (TPL source absent, parity unpinned): rotation about index L/2 with
+trilinear interpolation and zeros outside; ``clip`` clamps the correlation OUTPUT to +-clip.
+"""
+import torch
+from torch import nn
+
+from ._lib import get_lib
+from .engine import _ptr, _stream
+
+
+def _check(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32):
+        raise RuntimeError("dlpd: %s must be a float32 CUDA (ROCm) tensor; there is no CPU path" % name)
+    return t.contiguous()
+
+
+class VolumeRotation(nn.Module):
+    def __init__(self, center=None):
+        super().__init__()
+        self.center = center
+
+    def forward(self, volume, R):
+        volume, R = _check(volume, "volume"), _check(R, "R")
+        B, C, L = volume.shape[0], volume.shape[1], volume.shape[2]
+        if R.shape[0] != B:
+            raise RuntimeError("dlpd: VolumeRotation batch mismatch: volume %d vs R %d" % (B, R.shape[0]))
+        out = torch.empty_like(volume)
+        c0 = float(L) / 2.0 if self.center is None else float(self.center)
+        get_lib().call("dlpd_rotate_trilinear", _ptr(volume), _ptr(R), _ptr(out), B, C, L, C * L ** 3, c0,
+                       _stream(volume.device))
+        return out
+
+
+class VolumeConvolution(nn.Module):
+    """Per-channel circular cross-correlation on the 2L zero-padded grid:
+    out[b,c,t mod 2L] = sum_r v1[b,c,r+t] * v2[b,c,r]  (semantics: MultiplyVolumes.py:13-47)."""
+
+    def __init__(self, clip=None):
+        super().__init__()
+        self.clip = clip
+
+    def forward(self, input_volume1, input_volume2):
+        v1, v2 = _check(input_volume1, "volume1"), _check(input_volume2, "volume2")
+        if v1.shape != v2.shape:
+            raise RuntimeError("dlpd: VolumeConvolution shape mismatch %s vs %s" % (tuple(v1.shape), tuple(v2.shape)))
+        B, C, L = v1.shape[0], v1.shape[1], v1.shape[2]
+        lib = get_lib()
+        if not lib.call("dlpd_grid_supported", L):
+            raise RuntimeError("dlpd: VolumeConvolution box size %d not compiled (supported: 32, 64)" % L)
+        N, NZ, nvol = 2 * L, L + 1, B * C
+        dev, st = v1.device, _stream(v1.device)
+        wsA = torch.empty(nvol * NZ * L * L * 2, dtype=torch.float32, device=dev)
+        spec = torch.empty(nvol * NZ * N * N * 2, dtype=torch.float32, device=dev)
+        lib.call("dlpd_rfft3d_padded", _ptr(v1), _ptr(spec), _ptr(wsA), nvol, L, 1.0 / float(N) ** 3, st)
+        lib.call("dlpd_zfft", _ptr(v2), 0, _ptr(wsA), 1, nvol, L, 0, 0, 0.0, st)
+        wsB = torch.empty(nvol * NZ * N * N * 2, dtype=torch.float32, device=dev)
+        lib.call("dlpd_xy_correlate", _ptr(wsA), _ptr(spec), _ptr(wsB), 1, nvol, L, 0, st)
+        out = torch.empty(B, C, N, N, N, dtype=torch.float32, device=dev)
+        lib.call("dlpd_zifft_real", _ptr(wsB), _ptr(out), 1, nvol, L, 0 if self.clip is None else 1,
+                 float(self.clip or 0.0), st)
+        return out
+
+
+def filter_volumes(conv_list, W1, b1, W2, b2, mask_norm=None, threshold=0.0):
+    """Nearest-upsample + concat + SimpleFilter MLP (+ optional clash mask) on materialised
+    correlation volumes -- DockingModels.py:74-83, Docker.py:226,232.  conv_list: one or two
+    tensors (B,C_i,N_i,N_i,N_i), N_0 the finest."""
+    c0 = _check(conv_list[0], "conv0")
+    B, C0, N0 = c0.shape[0], c0.shape[1], c0.shape[2]
+    if len(conv_list) > 2:
+        raise RuntimeError("dlpd: at most two resolutions are supported")
+    c1 = _check(conv_list[1], "conv1") if len(conv_list) == 2 else None
+    C1, N1 = (c1.shape[1], c1.shape[2]) if c1 is not None else (0, 0)
+    dev = c0.device
+    H = W1.shape[0]
+    W1t = W1.detach().to(dev, torch.float32).t().contiguous()       # (C, H)
+    b1 = b1.detach().to(dev, torch.float32).contiguous()
+    W2 = W2.detach().to(dev, torch.float32).reshape(-1).contiguous()
+    V = torch.empty(B, N0, N0, N0, dtype=torch.float32, device=dev)
+    has_clash = mask_norm is not None
+    if has_clash:
+        mask_norm = _check(mask_norm, "mask_norm")
+    get_lib().call("dlpd_filter_mask", _ptr(c0), C0, N0, _ptr(c1), C1, N1, _ptr(mask_norm), float(threshold),
+                   int(has_clash), _ptr(W1t), _ptr(b1), _ptr(W2), float(b2), H, _ptr(V), B, _stream(dev))
+    return V

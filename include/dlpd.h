@@ -1,0 +1,94 @@
+/* dlpd.h -- C ABI of libdlpd.so: MI355X (gfx950) kernels for the exhaustive rotation x translation
+ * correlation search of DeepLocalProteinDocking.
+ *
+ * The reference has no FFI; its boundary for this path is Python duck typing onto
+ * TorchProteinLibrary operator objects.  Each entry point below names the
+ * reference call site (file:line under /root/reference) whose arithmetic it replaces.  All
+ * functions: plain pointers and sizes, device pointers are borrowed for the duration of the call,
+ * work is enqueued on `stream` (a hipStream_t passed as void*), no allocation, no host
+ * synchronisation, return 0 on success (DLPD_ERR_* otherwise), never throw.
+ *
+ * Layouts: volumes are (.., L, L, L) float32, index [x][y][z], z contiguous.  N = 2L,
+ * NZ = N/2 + 1.  Spectra are (.., NZ, N, N) complex64 indexed [kz][kx][ky].
+ */
+#ifndef DLPD_H
+#define DLPD_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DLPD_OK 0
+#define DLPD_ERR_ARG 1
+#define DLPD_ERR_UNSUPPORTED 2
+#define DLPD_ERR_LAUNCH 3
+
+int dlpd_version(void);
+/* 1 if box size L has a compiled fused pipeline (N = 2L in {64, 128}) */
+int dlpd_grid_supported(int L);
+/* hidden width the filter kernel pads H to (2,4,8,16,24,32), -1 if H > 32 */
+int dlpd_hidden_pad(int H);
+
+/* TPL VolumeRotation call, src/Docker/Docker.py:218 (ctor :40; DockingModels.py:49).
+ * out[b,c](i) = trilinear vol[b,c]( center + R_b^T (i - center) ), zeros outside.
+ * vol (B,C,L^3) with batch stride vol_bstride floats (0: one volume set shared by all b). */
+int dlpd_rotate_trilinear(const float* vol, const float* R, float* out, int B, int C, int L,
+                          long long vol_bstride, float center, void* stream);
+
+/* Stage K1 of TPL VolumeConvolution (src/Models/DockingModels.py:71, src/Docker/Docker.py:225),
+ * optionally fused with the rotation of Docker.py:218: z-axis R2C of (rotated) volumes.
+ * wsA: nb*CT*NZ*L*L complex64. */
+int dlpd_zfft(const float* vol, const float* R, void* wsA, int nb, int CT, int L, long long vol_bstride,
+              int do_rotate, float center, void* stream);
+
+/* Zero-padded 3-D R2C spectrum (receptor side of VolumeConvolution, DockingModels.py:71):
+ * spec (nvol, NZ, N, N) = scale * rfftn(pad(vol)).  wsA: nvol*NZ*L*L complex64 scratch. */
+int dlpd_rfft3d_padded(const float* vol, void* spec, void* wsA, int nvol, int L, float scale, void* stream);
+
+/* Stage K2: per (b,c,kz) slab 2-D FFT, multiply rec * conj(lig), 2-D inverse.
+ * rec (CT spectra, or nb*CT with rec_bstride = CT*NZ*N*N); wsB: nb*CT*NZ*N*N complex64. */
+int dlpd_xy_correlate(const void* wsA, const void* rec, void* wsB, int nb, int CT, int L,
+                      long long rec_bstride, void* stream);
+
+/* Stage K3, plain: real correlation volumes out (nb, CT, N^3) [+ clamp to +-clip]
+ * (output of VolumeConvolution(clip), DockingModels.py:48,71). */
+int dlpd_zifft_real(const void* wsB, float* out, int nb, int CT, int L, int has_clip, float clip,
+                    void* stream);
+
+/* Stage K3, fused scoring: z C2R + clip + SimpleFilter MLP (DockingModels.py:28-32,79-83) +
+ * clash mask and multiply (Docker.py:226,232).  W1t (C,HP) transposed zero-padded first layer,
+ * b1 (HP), W2 (HP).  V (nb, N^3). */
+int dlpd_zifft_filter(const void* wsB, float* V, int nb, int C, int has_clash, int L, const float* W1t,
+                      const float* b1, const float* W2, float b2, int HP, int has_clip, float clip,
+                      float thr, void* stream);
+
+/* One batch of the hot loop, Docker.py:211-232 (single-resolution model): K1 + K2 + K3. */
+int dlpd_score_rotations(const float* lig, const void* recF, const float* R, int nb, int C, int has_clash,
+                         int L, float center, const float* W1t, const float* b1, const float* W2, float b2,
+                         int HP, int has_clip, float clip, float thr, void* wsA, void* wsB, float* V,
+                         void* stream);
+
+/* Per-voxel filter over materialised correlation volumes incl. nearest upsample of a second,
+ * coarser resolution (DockingModels.py:74-83) and mask multiply (Docker.py:232). */
+int dlpd_filter_mask(const float* conv0, int C0, int N0, const float* conv1, int C1, int N1,
+                     const float* mask_norm, float thr, int has_clash, const float* W1t, const float* b1,
+                     const float* W2, float b2, int H, float* V, int nb, void* stream);
+
+/* Docker.update_top pick loop, src/Docker/Docker.py:89-98: per rotation the K picks in pick order
+ * (incl. the zero-fill behaviour).  V (nb, nvox); out (nb, K). */
+size_t dlpd_topk_workspace_bytes(int nb, int K);
+int dlpd_topk_select(const float* V, int nb, long long nvox, int K, float* out_score, int* out_idx,
+                     void* ws, void* stream);
+
+/* Docker.update_top list maintenance, src/Docker/Docker.py:100-105: append, stable sort by score,
+ * truncate -- on a device-resident list.  glist: u64 count, u64 pad, u64 hi[K], u64 lo[K] with
+ * hi = score_key<<32 | rotation, lo = pick<<32 | negzero<<31 | flat_index. */
+size_t dlpd_topk_glist_bytes(int K);
+int dlpd_topk_glist_reset(void* glist, int K, void* stream);
+int dlpd_topk_merge(const float* cand_score, const int* cand_idx, const int* rot_ids, int nb, int K,
+                    void* glist, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

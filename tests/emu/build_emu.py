@@ -1,0 +1,28 @@
+"""Build the CPU-emulated kernel library (test harness): the unchanged csrc/*.hip sources compiled
+with g++ against tests/emu/dlpd_platform.h.  Output: tests/emu/libdlpd_emu.so"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.abspath(os.path.join(HERE, "..", "..", "deeplocalproteindocking_amd", "csrc"))
+OUT = os.path.join(HERE, "libdlpd_emu.so")
+SRCS = ["dlpd_corr.hip", "dlpd_topk.hip"]
+
+
+def build(force=False):
+    srcs = [os.path.join(CSRC, s) for s in SRCS]
+    deps = srcs + [os.path.join(CSRC, h) for h in ("dlpd_fft.h", "dlpd_internal.h")] + \
+        [os.path.join(HERE, "dlpd_platform.h")]
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) > os.path.getmtime(d) for d in deps):
+        return OUT
+    cmd = ["g++", "-O2", "-g", "-std=c++17", "-shared", "-fPIC", "-fpermissive", "-w",
+           "-I", HERE, "-I", CSRC, "-o", OUT]
+    for s in srcs:
+        cmd += ["-x", "c++", s]
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="-f" in sys.argv))

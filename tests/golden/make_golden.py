@@ -1,0 +1,201 @@
+"""Generate the golden fixtures in this directory by IMPORTING the reference's own code.
+
+Run in the authoring container only (needs /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference's hot-path arithmetic lives in TorchProteinLibrary / se3cnn, which are not
+installed, so those imports are replaced by MagicMock modules; every object whose OUTPUT is
+recorded below is the reference's real code:
+
+  G1  src/Models/MultiplyVolumes.py   MultiplyVolumes.forward     -> g1_multiply_volumes.npz
+  G2  src/Utils/Rotations.py          Rotations(20).R             -> g2_rotations.npz
+  G3  src/Docker/Docker.py            Docker.update_top           -> g3_update_top.npz
+  G4  src/Docker/Docker.py            Docker.write_conformations  -> g4_write_conformations.npz
+  G5  src/Models/DockingModels.py     GlobalDockingModel.forward, SimpleFilter
+                                      (with .convolve := oracle FFT correlation)
+                                                                  -> g5_global_forward.npz
+Only data (inputs + expected outputs) is written; no reference source is copied.
+"""
+import hashlib
+import io
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, "..", ".."))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+
+def install_stubs():
+    for name in ["TorchProteinLibrary", "TorchProteinLibrary.FullAtomModel",
+                 "TorchProteinLibrary.FullAtomModel.CoordsTransform",
+                 "TorchProteinLibrary.Volume", "_Volume", "se3cnn", "se3cnn.non_linearities",
+                 "se3cnn.blocks", "se3cnn.filter"]:
+        sys.modules[name] = MagicMock()
+    src = types.ModuleType("src")
+    src.__path__ = [os.path.join(REF, "src")]
+    src.REPOSITORY_DIR = REF
+    sys.modules["src"] = src
+
+
+def main():
+    install_stubs()
+    import importlib
+    from oracle import docking_oracle as orc
+
+    # ---------------- G1: MultiplyVolumes ----------------
+    MV = importlib.import_module("src.Models.MultiplyVolumes").MultiplyVolumes()
+    g = torch.Generator().manual_seed(101)
+    g1 = {}
+    for L in (4, 6):
+        C = 3
+        v1 = torch.randn(1, C, L, L, L, generator=g)
+        v2 = torch.randn(1, C, L, L, L, generator=g)
+        ts = [(dx, dy, dz) for dx in range(-(L - 1), L) for dy in range(-(L - 1), L)
+              for dz in range(-(L - 1), L)]
+        out = np.zeros((len(ts), C), dtype=np.float32)
+        for i, t in enumerate(ts):
+            T = torch.tensor([t], dtype=torch.float32)
+            out[i] = MV(v1, v2, T).numpy()[0]
+        g1["v1_L%d" % L] = v1.numpy(); g1["v2_L%d" % L] = v2.numpy()
+        g1["T_L%d" % L] = np.array(ts, dtype=np.int32); g1["out_L%d" % L] = out
+    # fractional translations: int() truncation toward zero (MultiplyVolumes.py:56-58)
+    L = 6
+    v1 = torch.from_numpy(g1["v1_L6"]).repeat(2, 1, 1, 1, 1)
+    v2 = torch.from_numpy(g1["v2_L6"]).repeat(2, 1, 1, 1, 1)
+    Tf = torch.tensor([[1.7, -2.2, 0.4], [-3.9, 2.2, 5.0]])
+    g1["Tfrac"] = Tf.numpy(); g1["out_frac"] = MV(v1, v2, Tf).numpy()
+    np.savez_compressed(os.path.join(HERE, "g1_multiply_volumes.npz"), **g1)
+
+    # ---------------- G2: Rotations ----------------
+    Rmod = importlib.import_module("src.Utils.Rotations")
+    g2 = {}
+    for inc in (20, 15, 12, 10):
+        R = Rmod.Rotations(inc).R.numpy()
+        g2["n_%d" % inc] = np.int64(R.shape[0])
+        g2["first8_%d" % inc] = R[:8].copy()
+        g2["last8_%d" % inc] = R[-8:].copy()
+        ang = np.loadtxt(os.path.join(REF, "data", "oim%02d.eul" % inc)).reshape(-1, 3)
+        g2["ang_first8_%d" % inc] = ang[:8].copy()      # 16 input rows so the Euler-convention
+        g2["ang_last8_%d" % inc] = ang[-8:].copy()      # check is self-contained
+        g2["sum_%d" % inc] = R.sum(axis=0)
+        g2["abs_sum_%d" % inc] = np.abs(R).sum(axis=0)
+        # order-sensitive checksum: sum_i (i+1) * R_i
+        w = np.arange(1, R.shape[0] + 1, dtype=np.float64)[:, None, None]
+        g2["wsum_%d" % inc] = (w * R).sum(axis=0)
+    np.savez_compressed(os.path.join(HERE, "g2_rotations.npz"), **g2)
+
+    # ---------------- G3 / G4: Docker.update_top, write_conformations ----------------
+    Dmod = importlib.import_module("src.Docker.Docker")
+    RefDocker = Dmod.Docker
+    dk = RefDocker(docking_model=None, angle_inc=20, box_size=4, resolution=1.25, max_conf=5,
+                   randomize_rot=False)
+    g3 = {}
+    cases = {}
+    g = torch.Generator().manual_seed(202)
+    cases["randn8_k5"] = (torch.randn(8, 8, 8, generator=g), 5)
+    cases["randn16_k40"] = (torch.randn(16, 16, 16, generator=g), 40)
+    z = torch.zeros(8, 8, 8); z[1, 2, 3] = -1.0
+    cases["onehot_k4"] = (z, 4)
+    pos = torch.rand(6, 6, 6, generator=g) + 0.5
+    cases["allpos_k4"] = (pos, 4)
+    ties = torch.randint(-3, 2, (8, 8, 8), generator=g).float()
+    cases["ties_k30"] = (ties, 30)
+    fewneg = torch.rand(8, 8, 8, generator=g) + 0.1
+    fewneg[7, 0, 1] = -2.0; fewneg[0, 5, 5] = -2.0; fewneg[3, 3, 3] = -0.5
+    cases["fewneg_k6"] = (fewneg, 6)
+    masked = torch.randn(8, 8, 8, generator=g) * (torch.rand(8, 8, 8, generator=g) < 0.02).float()
+    cases["masked_k12"] = (masked, 12)            # mostly +-0.0 entries, few negatives
+    for name, (V, K) in cases.items():
+        dk.max_conf = K
+        dk.top_list = []
+        Vin = V.clone()
+        dk.update_top(V, 7)
+        g3[name + "_V"] = Vin.numpy()
+        g3[name + "_K"] = np.int64(K)
+        g3[name + "_top"] = np.array(dk.top_list, dtype=np.float64)
+        g3[name + "_Vafter"] = V.numpy()
+    # multi-rotation accumulation (stable order across rotations)
+    dk.max_conf = 10
+    dk.top_list = []
+    seq = []
+    for r in range(4):
+        V = torch.randint(-4, 3, (6, 6, 6), generator=g).float()
+        seq.append(V.clone().numpy())
+        dk.update_top(V, r)
+    g3["seq_V"] = np.stack(seq); g3["seq_K"] = np.int64(10)
+    g3["seq_top"] = np.array(dk.top_list, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "g3_update_top.npz"), **g3)
+
+    # G4
+    dk.max_conf = 6
+    dk.box_size = 4
+    dk.top_list = [(0, 0, 0, 0, -3.5), (5, 7, 3, 4, -1.25), (1853, 3, 4, 7, -0.000001),
+                   (17, 1, 2, 5, 0.0), (100, 4, 4, 4, 2.5)]
+    buf = io.StringIO()
+    dk.log = buf
+    dk.write_conformations()
+    text = buf.getvalue()
+    dk.log = None
+    g4 = {"top_list": np.array(dk.top_list, dtype=np.float64), "box_size": np.int64(4),
+          "resolution": np.float64(1.25),
+          "R_used": dk.rot.R.numpy()[[0, 5, 1853, 17, 100]],
+          "rot_ids": np.array([0, 5, 1853, 17, 100]),
+          "text": np.frombuffer(text.encode(), dtype=np.uint8)}
+    # with randomize_rot
+    dk.randomize_rot = True
+    randR = orc.euler_to_matrix(0.3, 1.1, -2.0)
+    dk.randR = torch.from_numpy(randR).unsqueeze(0)
+    buf = io.StringIO(); dk.log = buf
+    dk.write_conformations()
+    g4["randR"] = randR
+    g4["text_rand"] = np.frombuffer(buf.getvalue().encode(), dtype=np.uint8)
+    dk.log = None
+    np.savez_compressed(os.path.join(HERE, "g4_write_conformations.npz"), **g4)
+
+    # ---------------- G5: GlobalDockingModel.forward ----------------
+    import warnings
+    warnings.filterwarnings("ignore")
+    DM = importlib.import_module("src.Models.DockingModels")
+    g5 = {}
+    for tag, sizes, L in (("multires", [16, 32], 8), ("single", [4], 6)):
+        torch.manual_seed(303)
+        filt = DM.SimpleFilter(sizes)
+        model = DM.GlobalDockingModel(representation=None, filter=filt, threshold_clash=300)
+        clip = 5.0
+        model.convolve = lambda a, b: orc.correlate_fft(a, b, clip=clip)
+        g = torch.Generator().manual_seed(304)
+        rec, lig = [], []
+        for i, c in enumerate(sizes):
+            Li = L // (2 ** i)
+            rec.append(torch.randn(2, c, Li, Li, Li, generator=g) * 0.3)
+            lig.append(torch.randn(2, c, Li, Li, Li, generator=g) * 0.3)
+        with torch.no_grad():
+            V = model(rec, lig)
+        for i in range(len(sizes)):
+            g5["%s_rec%d" % (tag, i)] = rec[i].numpy()
+            g5["%s_lig%d" % (tag, i)] = lig[i].numpy()
+        g5[tag + "_W1"] = filt.fc[0].weight.detach().numpy()
+        g5[tag + "_b1"] = filt.fc[0].bias.detach().numpy()
+        g5[tag + "_W2"] = filt.fc[2].weight.detach().numpy()
+        g5[tag + "_b2"] = filt.fc[2].bias.detach().numpy()
+        g5[tag + "_clip"] = np.float64(clip)
+        g5[tag + "_V"] = V.numpy()
+    np.savez_compressed(os.path.join(HERE, "g5_global_forward.npz"), **g5)
+
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            h = hashlib.sha256(open(os.path.join(HERE, f), "rb").read()).hexdigest()[:16]
+            print(f, os.path.getsize(os.path.join(HERE, f)), h)
+
+
+if __name__ == "__main__":
+    main()

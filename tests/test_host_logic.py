@@ -1,0 +1,172 @@
+"""CPU-side checks of the host mirror of the reference interface and of the C-ABI library."""
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import __graft_entry__ as entry
+from deeplocalproteindocking_amd.Utils.Rotations import Rotations, generate_angles, generated_set_size
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    entry.build()
+    from deeplocalproteindocking_amd._lib import DlpdLib
+    return DlpdLib(entry.LIB)
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    header = open(os.path.join(ROOT, "include", "dlpd.h")).read()
+    names = set(re.findall(r"\b(dlpd_[a-z0-9_]+)\s*\(", header))
+    assert len(names) >= 15
+    from deeplocalproteindocking_amd._lib import SIGNATURES
+    assert names == set(SIGNATURES), names ^ set(SIGNATURES)
+    import ctypes
+    dll = ctypes.CDLL(entry.LIB)
+    for n in names:
+        assert hasattr(dll, n), n
+    assert built_lib.call("dlpd_version") >= 100
+    assert built_lib.call("dlpd_grid_supported", 64) == 1 and built_lib.call("dlpd_grid_supported", 50) == 0
+    assert built_lib.call("dlpd_hidden_pad", 24) == 24 and built_lib.call("dlpd_hidden_pad", 3) == 4
+    assert built_lib.call("dlpd_topk_glist_bytes", 2000) == (2 + 4000) * 8
+
+
+def test_product_path_fails_loudly_without_gpu_or_library(tmp_path):
+    from deeplocalproteindocking_amd._lib import DlpdLib
+    from deeplocalproteindocking_amd.engine import DockingEngine
+    with pytest.raises(RuntimeError, match="not found"):
+        DlpdLib(str(tmp_path / "missing.so"))
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            DockingEngine(32, 4, torch.zeros(2, 4), torch.zeros(2), torch.zeros(1, 2), torch.zeros(1), device="cpu")
+        from deeplocalproteindocking_amd.ops import VolumeConvolution
+        with pytest.raises(RuntimeError, match="no CPU path"):
+            VolumeConvolution()(torch.zeros(1, 1, 32, 32, 32), torch.zeros(1, 1, 32, 32, 32))
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "deeplocalproteindocking_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(d, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), os.path.join(d, f)
+
+
+def test_rotations_generated_sets_match_soi_sizes():
+    sizes = {20: 1854, 15: 4392, 12: 8580, 10: 14868, 8: 29025, 6: 68760}
+    for inc, n in sizes.items():
+        ns, nphi = generated_set_size(inc)
+        assert ns * nphi == n
+    ang = generate_angles(20)
+    assert ang.shape == (1854, 3)
+    os.environ["DLPD_ROTATIONS_DIR"] = "/nonexistent-dir"
+    try:
+        r = Rotations(4, verbose=False)
+    finally:
+        del os.environ["DLPD_ROTATIONS_DIR"]
+    assert r.source == "generated" and r.R.shape == (232020, 3, 3) and r.R.dtype == torch.float64
+    RtR = torch.matmul(r.R[::997].transpose(1, 2), r.R[::997])
+    assert (RtR - torch.eye(3, dtype=torch.float64)).abs().max() < 1e-14
+    assert (torch.linalg.det(r.R[::997]) - 1).abs().max() < 1e-14
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/data/oim06.eul"), reason="reference data not present")
+def test_rotations_loader_reads_reference_files_incl_zero_padded_names(golden):
+    os.environ["DLPD_ROTATIONS_DIR"] = "/root/reference/data"
+    try:
+        g = golden("g2_rotations.npz")
+        for inc in (20, 15, 12, 10):
+            r = Rotations(inc, verbose=False)
+            R = r.R.numpy()
+            assert R.shape[0] == int(g["n_%d" % inc])
+            np.testing.assert_allclose(R[:8], g["first8_%d" % inc], atol=1e-15)
+            np.testing.assert_allclose(R[-8:], g["last8_%d" % inc], atol=1e-15)
+            np.testing.assert_allclose(R.sum(0), g["sum_%d" % inc], atol=1e-9)
+            w = np.arange(1, R.shape[0] + 1, dtype=np.float64)[:, None, None]
+            np.testing.assert_allclose((w * R).sum(0), g["wsum_%d" % inc], rtol=1e-12, atol=1e-6)
+        assert Rotations(6, verbose=False).R.shape[0] == 68760      # reference loader cannot open these
+        assert Rotations(8, verbose=False).R.shape[0] == 29025
+    finally:
+        del os.environ["DLPD_ROTATIONS_DIR"]
+
+
+def _docker(max_conf=6, box_size=4, rotations=None):
+    from deeplocalproteindocking_amd.Docker import Docker
+    if rotations is None:
+        rotations = np.tile(np.eye(3), (4, 1, 1))
+    return Docker(docking_model=None, angle_inc=20, box_size=box_size, resolution=1.25, max_conf=max_conf,
+                  rotations=rotations, device="cpu")
+
+
+def test_docker_write_conformations_matches_reference_text(golden):
+    g = golden("g4_write_conformations.npz")
+    nrot = int(g["rot_ids"].max()) + 1
+    R = np.zeros((nrot, 3, 3))
+    for k, i in enumerate(g["rot_ids"]):
+        R[int(i)] = g["R_used"][k]
+    dk = _docker(rotations=R)
+    dk.top_list = [(int(t[0]), int(t[1]), int(t[2]), int(t[3]), float(t[4])) for t in g["top_list"]]
+    dk.log = io.StringIO()
+    dk.write_conformations()
+    assert dk.log.getvalue() == bytes(g["text"]).decode()
+    dk.randomize_rot = True
+    dk.randR = torch.from_numpy(g["randR"]).unsqueeze(0)
+    dk.log = io.StringIO()
+    dk.write_conformations()
+    assert dk.log.getvalue() == bytes(g["text_rand"]).decode()
+    dk.log = None
+
+
+def test_docker_new_log_resume_rule(tmp_path):
+    dk = _docker()
+    f = str(tmp_path / "t.dat")
+    assert dk.new_log(f, rewrite=False) is True                 # new file
+    dk.log.write("1\n"); dk.cleanup()
+    assert dk.new_log(f, rewrite=False) is True                 # one line: not finished -> redo
+    dk.log.write("1\n\n2\n"); dk.cleanup()
+    assert dk.new_log(f, rewrite=False) is False                # >1 non-blank lines: skip (Docker.py:73-74)
+    assert dk.new_log(f, rewrite=True) is True
+    dk.cleanup()
+
+
+def test_docker_interface_surface():
+    import inspect
+    from deeplocalproteindocking_amd.Docker import Docker
+    sig = inspect.signature(Docker.__init__)
+    assert list(sig.parameters)[:7] == ["self", "docking_model", "angle_inc", "box_size", "resolution", "max_conf",
+                                        "randomize_rot"]
+    d = {k: v.default for k, v in sig.parameters.items()}
+    assert (d["angle_inc"], d["box_size"], d["resolution"], d["max_conf"], d["randomize_rot"]) == (15.0, 80, 1.25, 1000, False)
+    for m in ("load_batch", "new_log", "cleanup", "update_top", "write_conformations", "dockE3", "dockSE3",
+              "dock_volumes"):
+        assert callable(getattr(Docker, m))
+    assert list(inspect.signature(Docker.dockSE3).parameters) == ["self", "ureceptor", "uligand", "batch_size"]
+    dk = _docker()
+    with pytest.raises(Exception, match="coords_backend"):
+        dk.dockSE3("a.pdb", "b.pdb", batch_size=2)
+    assert dk.box_length == 5.0 and dk.shard(10).tolist() == list(range(10))
+    dk.rank, dk.world_size = 1, 4
+    assert dk.shard(10).tolist() == [1, 5, 9]
+
+
+def test_simple_filter_matches_reference_structure(golden):
+    from deeplocalproteindocking_amd.Models import SimpleFilter
+    torch.manual_seed(303)                      # same seed as the fixture generator
+    f = SimpleFilter([16, 32])
+    g = golden("g5_global_forward.npz")
+    np.testing.assert_array_equal(f.fc[0].weight.detach().numpy(), g["multires_W1"])   # same init stream
+    assert f.fc[0].weight.shape == (24, 48) and f.fc[2].weight.shape == (1, 24)
+
+
+def test_merge_entries_is_deterministic_and_stable():
+    from deeplocalproteindocking_amd.engine import DeviceTopList
+    a = (np.array([0, 2]), np.array([5, 6]), np.array([-3.0, -1.0], np.float32), np.array([0, 1]))
+    b = (np.array([1, 1, 3]), np.array([7, 8, 9]), np.array([-3.0, -1.0, -1.0], np.float32), np.array([0, 1, 0]))
+    rot, idx, score, pick = DeviceTopList.merge_entries([b, a], 4)
+    assert rot.tolist() == [0, 1, 1, 2] and idx.tolist() == [5, 7, 8, 6]

@@ -1,0 +1,171 @@
+"""The HIP kernel SOURCES executed on the CPU by the fiber emulator (tests/emu) and checked against
+the oracle and the golden fixtures.  This validates index logic / barrier structure without a GPU;
+the `-m gpu` tests repeat the checks on the real gfx950 build."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import docking_oracle as orc
+from deeplocalproteindocking_amd.engine import DeviceTopList, DockingEngine, _ptr
+
+
+def _pair(L, C, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    rec = torch.randn(C, L, L, L, generator=g) * 0.1
+    lig = torch.randn(C, L, L, L, generator=g) * 0.1
+    recf, ligf = torch.rand(L, L, L, generator=g), torch.rand(L, L, L, generator=g)
+    H = C // 2
+    W1, b1 = torch.randn(H, C, generator=g), torch.randn(H, generator=g)
+    W2, b2 = torch.randn(1, H, generator=g), torch.randn(1, generator=g)
+    return rec, lig, recf, ligf, W1, b1, W2, b2
+
+
+def test_fused_pipeline_matches_oracle(emu):
+    L, C = 32, 4
+    rec, lig, recf, ligf, W1, b1, W2, b2 = _pair(L, C)
+    thr = 4000.0
+    R = orc.euler_to_matrix([0.3, -1.0], [1.1, 0.4], [-2.0, 2.5])
+    eng = DockingEngine(L, C, W1, b1, W2, b2, clip=0.5, threshold_clash=thr, max_conf=16, batch=2, device="cpu", lib=emu)
+    eng.set_receptor(rec, recf)
+    eng.set_ligand(lig, ligf)
+    ref = torch.fft.rfftn(torch.cat([rec, recf[None]]), s=(2 * L,) * 3, dim=(1, 2, 3)) / (2 * L) ** 3
+    mine = torch.view_as_complex(eng.recF).permute(0, 2, 3, 1)
+    assert (mine - ref).abs().max() < 1e-6 * ref.abs().max() + 1e-8
+    V = eng.score_batch(torch.from_numpy(R).float().contiguous()).clone()
+    for i in range(2):
+        Rb = torch.from_numpy(R[i:i + 1]).float()
+        lr = orc.rotate_volume(lig[None], Rb)
+        lfr = orc.rotate_volume(ligf[None, None], Rb)
+        mask, norm = orc.clash_mask(recf[None, None], lfr, thr)
+        Vo = (mask * orc.score_volumes([rec[None]], [lr], W1, b1, W2, b2, clip=0.5))[0]
+        sure = (norm[0] - thr).abs() > 1e-3 * thr                       # away from the threshold
+        assert 0.5 < mask.mean() < 0.999                                 # the mask is exercised
+        assert ((V[i] - Vo).abs()[sure]).max() <= 1e-4 * Vo.abs().max()
+
+
+def test_search_with_odd_tail_matches_oracle_list(emu):
+    L, C, K = 32, 4, 40
+    rec, lig, recf, ligf, W1, b1, W2, b2 = _pair(L, C, seed=1)
+    R = orc.euler_to_matrix([0.3, -1.0, 2.0], [1.1, 0.4, 2.2], [-2.0, 2.5, 0.1])
+    eng = DockingEngine(L, C, W1, b1, W2, b2, clip=5.0, threshold_clash=4000.0, max_conf=K, batch=2, device="cpu", lib=emu)
+    eng.set_receptor(rec, recf)
+    eng.set_ligand(lig, ligf)
+    eng.reset_top()
+    eng.search(R)
+    got = eng.top_list()
+    want, Vs = orc.dock_volumes([rec[None]], [lig[None]], recf[None, None], ligf[None, None], R, W1, b1, W2, b2,
+                                4000.0, K, clip=5.0, faithful_topk=False, return_V=True)
+    scale = max(float(v.abs().max()) for v in Vs)
+    assert len(got) == K
+    assert max(abs(a[4] - b[4]) for a, b in zip(got, want)) <= 1e-4 * scale
+    assert sum(a[:4] == b[:4] for a, b in zip(got, want)) >= K - 4      # swaps only inside the error band
+
+
+@pytest.mark.parametrize("case", ["randn8_k5", "randn16_k40", "onehot_k4", "allpos_k4", "ties_k30", "fewneg_k6",
+                                  "masked_k12"])
+def test_topk_kernels_reproduce_reference_update_top(emu, golden, case):
+    g = golden("g3_update_top.npz")
+    V = torch.from_numpy(g[case + "_V"].copy())
+    K, N = int(g[case + "_K"]), V.shape[0]
+    top = DeviceTopList(K, 1, "cpu", emu)
+    top.reset()
+    top.select(V.reshape(1, -1), 1)
+    top.merge(torch.tensor([7], dtype=torch.int32), 1)
+    got = DeviceTopList.to_top_list(top.entries(), N)
+    ref = [(int(b[0]), int(b[1]), int(b[2]), int(b[3]), float(b[4])) for b in g[case + "_top"]]
+    assert got == ref
+    assert [np.signbit(a[4]) for a in got] == [np.signbit(b[4]) for b in ref]
+
+
+def test_topk_merge_sequence_reproduces_reference(emu, golden):
+    g = golden("g3_update_top.npz")
+    K = int(g["seq_K"])
+    for batch in (1, 3):
+        top = DeviceTopList(K, batch, "cpu", emu)
+        top.reset()
+        Vs = torch.from_numpy(g["seq_V"].copy())
+        for beg in range(0, Vs.shape[0], batch):
+            nb = min(batch, Vs.shape[0] - beg)
+            top.select(Vs[beg:beg + nb].reshape(nb, -1).contiguous(), nb)
+            top.merge(torch.arange(beg, beg + nb, dtype=torch.int32), nb)
+        got = DeviceTopList.to_top_list(top.entries(), Vs.shape[1])
+        assert got == [(int(b[0]), int(b[1]), int(b[2]), int(b[3]), float(b[4])) for b in g["seq_top"]]
+
+
+def test_topk_many_rotations_with_flushes(emu):
+    """More candidates than the merge kernel's staging capacity: forces mid-batch flushes."""
+    K, N, nrot = 100, 12, 7
+    g = torch.Generator().manual_seed(11)
+    Vs = torch.randn(nrot, N, N, N, generator=g)
+    Vs[3] = torch.randint(-2, 2, (N, N, N), generator=g).float()
+    top = DeviceTopList(K, nrot, "cpu", emu)
+    top.reset()
+    top.select(Vs.reshape(nrot, -1).contiguous(), nrot)
+    top.merge(torch.arange(nrot, dtype=torch.int32), nrot)
+    got = DeviceTopList.to_top_list(top.entries(), N)
+    want = []
+    for r in range(nrot):
+        want = orc.update_top(want, Vs[r].clone(), r, K)
+    assert got == [(r, x, y, z, float(np.float32(s))) for r, x, y, z, s in want]
+
+
+def test_rotate_kernel_matches_oracle(emu):
+    torch.manual_seed(2)
+    B, C, L = 2, 3, 10
+    vol = torch.randn(B, C, L, L, L)
+    R = torch.from_numpy(orc.euler_to_matrix([0.4, -1.3], [0.9, 2.0], [1.7, -0.2])).float().contiguous()
+    out = torch.empty_like(vol)
+    emu.call("dlpd_rotate_trilinear", _ptr(vol), _ptr(R), _ptr(out), B, C, L, C * L ** 3, L / 2.0, 0)
+    assert (out - orc.rotate_volume(vol, R)).abs().max() < 1e-5
+    ident = torch.eye(3).repeat(B, 1, 1).contiguous()
+    emu.call("dlpd_rotate_trilinear", _ptr(vol), _ptr(ident), _ptr(out), B, C, L, C * L ** 3, L / 2.0, 0)
+    assert torch.equal(out, vol)
+
+
+def test_volume_convolution_stages_match_oracle_and_definition(emu):
+    """rfft3d_padded + zfft + xy_correlate + zifft_real == VolumeConvolution; spot-checked against
+    the MultiplyVolumes definition (sum_r v1[r+t] v2[r])."""
+    torch.manual_seed(4)
+    L, nvol = 32, 2
+    N, NZ = 2 * L, L + 1
+    v1, v2 = torch.randn(nvol, L, L, L), torch.randn(nvol, L, L, L)
+    wsA = torch.empty(nvol * NZ * L * L * 2)
+    spec = torch.empty(nvol * NZ * N * N * 2)
+    wsB = torch.empty(nvol * NZ * N * N * 2)
+    out = torch.empty(nvol, N, N, N)
+    emu.call("dlpd_rfft3d_padded", _ptr(v1), _ptr(spec), _ptr(wsA), nvol, L, 1.0 / N ** 3, 0)
+    emu.call("dlpd_zfft", _ptr(v2), 0, _ptr(wsA), 1, nvol, L, 0, 0, 0.0, 0)
+    emu.call("dlpd_xy_correlate", _ptr(wsA), _ptr(spec), _ptr(wsB), 1, nvol, L, 0, 0)
+    emu.call("dlpd_zifft_real", _ptr(wsB), _ptr(out), 1, nvol, L, 0, 0.0, 0)
+    ref = orc.correlate_fft(v1[None], v2[None], dtype=torch.float64)[0]
+    assert (out.double() - ref).abs().max() < 1e-5 * ref.abs().max()
+    for t in [(0, 0, 0), (3, -2, 5), (-31, 31, 0), (7, 7, -7)]:
+        sl1 = tuple(slice(max(d, 0), L + min(d, 0)) for d in t)
+        sl2 = tuple(slice(max(-d, 0), L + min(-d, 0)) for d in t)
+        direct = (v1[(slice(None),) + sl1].double() * v2[(slice(None),) + sl2].double()).sum(dim=(1, 2, 3))
+        got = out[:, t[0] % N, t[1] % N, t[2] % N].double()
+        assert (got - direct).abs().max() < 1e-3
+    assert out[:, L, :, :].abs().max() < 1e-3          # |t| = L: no overlap
+    # clip variant
+    emu.call("dlpd_zifft_real", _ptr(wsB), _ptr(out), 1, nvol, L, 1, 2.0, 0)
+    assert (out.double() - ref.clamp(-2.0, 2.0)).abs().max() < 1e-4 and out.abs().max() <= 2.0
+
+
+@pytest.mark.parametrize("tag,nres", [("multires", 2), ("single", 1)])
+def test_generic_filter_kernel_reproduces_reference_forward(emu, golden, tag, nres):
+    """dlpd_filter_mask on oracle correlations == reference GlobalDockingModel.forward output (G5):
+    pins nearest-upsample index, channel concat order and the MLP."""
+    g = golden("g5_global_forward.npz")
+    rec = [torch.from_numpy(g["%s_rec%d" % (tag, i)]) for i in range(nres)]
+    lig = [torch.from_numpy(g["%s_lig%d" % (tag, i)]) for i in range(nres)]
+    conv = [orc.correlate_fft(r, l, clip=float(g[tag + "_clip"])).contiguous() for r, l in zip(rec, lig)]
+    W1 = torch.from_numpy(g[tag + "_W1"])
+    W1t = W1.t().contiguous()
+    b1, W2 = torch.from_numpy(g[tag + "_b1"]), torch.from_numpy(g[tag + "_W2"]).reshape(-1).contiguous()
+    B, N0 = conv[0].shape[0], conv[0].shape[2]
+    V = torch.empty(B, N0, N0, N0)
+    c1 = conv[1] if nres == 2 else None
+    emu.call("dlpd_filter_mask", _ptr(conv[0]), conv[0].shape[1], N0, _ptr(c1), c1.shape[1] if nres == 2 else 0,
+             c1.shape[2] if nres == 2 else 0, 0, 0.0, 0, _ptr(W1t), _ptr(b1), _ptr(W2), float(g[tag + "_b2"][0]),
+             W1.shape[0], _ptr(V), B, 0)
+    np.testing.assert_allclose(V.numpy(), g[tag + "_V"], rtol=1e-5, atol=1e-5)
