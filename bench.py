@@ -85,11 +85,24 @@ class StageTimer:
         return {k: tot[k] / cnt[k] for k in tot}
 
 
+def usable_cores():
+    """Host cores this process may really use: min(affinity, cgroup CPU quota).  (The GPU boxes show
+    256 logical CPUs behind a 16-core quota; oversubscribing it throttles torch ~30x.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(rec, lig, recf, ligf, W, R, thr, K, nrot_sample, V_gpu=None):
     """The oracle (restated reference path incl. the reference's update_top loop) on the host."""
     from oracle import docking_oracle as orc
     L = rec.shape[-1]
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(usable_cores())
     t0 = time.time()
     top, Vs = orc.dock_volumes([rec[None]], [lig[None]], recf[None, None], ligf[None, None], R[:nrot_sample],
                                *W, thr, K, clip=5.0, faithful_topk=True, return_V=True)

@@ -29,3 +29,21 @@ def emu():
     """CPU-emulated kernel library (tests/emu): same sources, same C ABI, host pointers."""
     from emu_lib import emu_lib
     return emu_lib()
+
+
+def _usable_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+try:  # the GPU boxes expose 256 logical CPUs behind a 16-core quota: do not oversubscribe the oracle
+    import torch
+    torch.set_num_threads(min(_usable_cores(), 16))
+except Exception:
+    pass

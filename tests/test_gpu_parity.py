@@ -173,8 +173,8 @@ def test_volume_ops_properties_at_full_size(dev):
     v1 = torch.randn(1, 2, L, L, L, generator=g)
     v2 = torch.zeros(1, 2, L, L, L)
     shift = (5, -7, 11)
-    src = v1[0, :, 10:40, 20:50, 5:35]
-    v2[0, :, 10 - shift[0]:40 - shift[0], 20 - shift[1]:50 - shift[1], 5 - shift[2]:35 - shift[2]] = src
+    src = v1[0, :, 10:40, 20:50, 15:45]
+    v2[0, :, 10 - shift[0]:40 - shift[0], 20 - shift[1]:50 - shift[1], 15 - shift[2]:45 - shift[2]] = src
     conv = VolumeConvolution()
     out = conv(v1.to(dev), v2.to(dev)).cpu()
     assert out.shape == (1, 2, N, N, N)
