@@ -42,7 +42,7 @@ ERRORS = {1: "DLPD_ERR_ARG (bad pointer/size)", 2: "DLPD_ERR_UNSUPPORTED (size n
 
 class DlpdLib:
     def __init__(self, path=None):
-        path = path or DEFAULT_PATH
+        path = path or os.environ.get("DLPD_LIB_PATH") or DEFAULT_PATH   # (override: A/B builds)
         if not os.path.exists(path):
             raise RuntimeError(
                 "dlpd: native library %s not found -- build it with "

@@ -31,26 +31,35 @@ template <int N> DLPD_D void init_twiddles(cplx* tw, int tid, int nthreads) {
 // trilinear sample of a (L,L,L) volume at position (px,py,pz), zeros outside
 // ------------------------------------------------------------------------------------------
 DLPD_D float trilinear_fetch(const float* __restrict__ v, int L, float px, float py, float pz) {
+  // branch-free: out-of-box corners get weight 0 and a clamped (valid) address, so the eight
+  // loads are unconditional and all in flight together
   const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
   const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
   const float ax = px - fx, ay = py - fy, az = pz - fz;
-  float acc = 0.f;
-#pragma unroll
-  for (int dx = 0; dx < 2; dx++) {
-    const int x = ix + dx;
-    const float wx = dx ? ax : 1.f - ax;
-    if (x < 0 || x >= L) continue;
-#pragma unroll
-    for (int dy = 0; dy < 2; dy++) {
-      const int y = iy + dy;
-      const float wy = dy ? ay : 1.f - ay;
-      if (y < 0 || y >= L) continue;
-      const float* row = v + ((size_t)x * L + y) * L;
-      const float wxy = wx * wy;
-      if (iz >= 0 && iz < L) acc += row[iz] * (wxy * (1.f - az));
-      if (iz + 1 >= 0 && iz + 1 < L) acc += row[iz + 1] * (wxy * az);
-    }
-  }
+  const int hi = L - 1;
+  const bool x0 = (ix >= 0) & (ix <= hi), x1 = (ix + 1 >= 0) & (ix + 1 <= hi);
+  const bool y0 = (iy >= 0) & (iy <= hi), y1 = (iy + 1 >= 0) & (iy + 1 <= hi);
+  const bool z0 = (iz >= 0) & (iz <= hi), z1 = (iz + 1 >= 0) & (iz + 1 <= hi);
+  const float wx0 = x0 ? 1.f - ax : 0.f, wx1 = x1 ? ax : 0.f;
+  const float wy0 = y0 ? 1.f - ay : 0.f, wy1 = y1 ? ay : 0.f;
+  const float wz0 = z0 ? 1.f - az : 0.f, wz1 = z1 ? az : 0.f;
+  const int cx0 = min(max(ix, 0), hi), cx1 = min(max(ix + 1, 0), hi);
+  const int cy0 = min(max(iy, 0), hi), cy1 = min(max(iy + 1, 0), hi);
+  const int cz0 = min(max(iz, 0), hi), cz1 = min(max(iz + 1, 0), hi);
+  const float* r00 = v + (cx0 * L + cy0) * L;
+  const float* r01 = v + (cx0 * L + cy1) * L;
+  const float* r10 = v + (cx1 * L + cy0) * L;
+  const float* r11 = v + (cx1 * L + cy1) * L;
+  const float v000 = r00[cz0], v001 = r00[cz1], v010 = r01[cz0], v011 = r01[cz1];
+  const float v100 = r10[cz0], v101 = r10[cz1], v110 = r11[cz0], v111 = r11[cz1];
+  float acc = v000 * (wx0 * wy0 * wz0);
+  acc += v001 * (wx0 * wy0 * wz1);
+  acc += v010 * (wx0 * wy1 * wz0);
+  acc += v011 * (wx0 * wy1 * wz1);
+  acc += v100 * (wx1 * wy0 * wz0);
+  acc += v101 * (wx1 * wy0 * wz1);
+  acc += v110 * (wx1 * wy1 * wz0);
+  acc += v111 * (wx1 * wy1 * wz1);
   return acc;
 }
 
@@ -75,21 +84,28 @@ __global__ void __launch_bounds__(256) k_rotate(const float* __restrict__ vol, c
 }
 
 // ------------------------------------------------------------------------------------------
-// K1: (optional) rotation + z-axis R2C.  grid (L [x], CT, nb), block (L/2)*T threads.
+// K1: (optional) rotation + z-axis R2C.  1-D grid of nb*CT*L blocks (XCD-aware decode), block (L/2)*T threads.
 //   vol   (.., CT, L,L,L), batch stride vol_bstride (0: one ligand shared by every rotation)
 //   R     (nb, 9) row-major rotation matrices (ignored when do_rotate == 0)
 //   A     (nb, CT, NZ, L, L) complex, [kz][x][y]
 // ------------------------------------------------------------------------------------------
 template <int N> __global__ void __launch_bounds__((N / 4) * FftPlan<N>::T)
 k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* __restrict__ A,
-              int CT, long long vol_bstride, int do_rotate, float c0) {
+              int CT, int nb, long long vol_bstride, int do_rotate, float c0) {
   constexpr int L = N / 2, NZ = N / 2 + 1, RS = N + 1, NP = L / 2;
   constexpr int T = FftPlan<N>::T, R1 = FftPlan<N>::R1, R2 = FftPlan<N>::R2;
   constexpr int NT = NP * T;
   __shared__ cplx S[NP * RS + N];
   cplx* tw = S + NP * RS;
   const int tid = threadIdx.x;
-  const int x = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
+  // XCD-aware decode: consecutive block ids are dealt round-robin over the 8 XCDs, so the L
+  // x-planes of one (b,c) volume are given ids of equal (id % 8): they run on one XCD and the
+  // 1 MiB source volume is fetched into ONE L2 instead of eight.  Speed only, never correctness.
+  const int bid = blockIdx.x, jj = bid >> 3;
+  const int grp = (bid & 7) + 8 * (jj / L);
+  const int x = jj % L;
+  if (grp >= CT * nb) return;
+  const int c = grp % CT, b = grp / CT;
   init_twiddles<N>(tw, tid, NT);
   const float* v = vol + (size_t)b * vol_bstride + (size_t)c * L * L * L;
   float* Sf = reinterpret_cast<float*>(S);
@@ -145,128 +161,186 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
 }
 
 // ------------------------------------------------------------------------------------------
-// K2: per (b, c, kz) slab.  grid (nb, NZ, CT), block N*T threads, dynamic LDS (N*RS+N)*8 B.
+// K2: one block per (c, kz), looping over the nb rotations of the batch (persistent over b).
+//   grid (NZ, CT), block N*T/2 threads (two pencils per thread), dynamic LDS (N*RS+N)*8 B (one N x N slab).
 //   MODE 0: forward only -> out[(b*CT+c)][kz][kx][ky] = scale * FFT2(pad(A))     (receptor prep)
 //   MODE 1: correlate    -> out = IFFT2( rec * conj(FFT2(pad(A))) )  (unnormalised inverse;
 //                           the 1/N^3 lives in rec)
 //   rec_bstride: element stride between batch entries of rec (0: shared receptor)
+// Per slab: y-forward on the L non-zero rows, x-forward on all columns (pruned first passes), the
+// receptor multiply in registers, and -- because the Stockham output of the last forward x pass
+// leaves thread t with exactly the elements {t + 8m} that the first inverse x pass needs -- the
+// inverse x transform starts from those registers without a trip through LDS.  The next
+// rotation's A slab and this slab's receptor values are prefetched into registers while the
+// current passes run (plain global loads stay in flight across barriers).
 // ------------------------------------------------------------------------------------------
-template <int N, int MODE> __global__ void __launch_bounds__(N * FftPlan<N>::T)
+#define DLPD_K2_PPT 2     // pencils per thread: N*T/2 threads per block leave 256 VGPRs per thread
+template <int N, int MODE> __global__ void __launch_bounds__(N * FftPlan<N>::T / DLPD_K2_PPT)
 k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __restrict__ out,
-          int CT, long long rec_bstride, float scale) {
+          int CT, int nb, long long rec_bstride, float scale) {
   constexpr int L = N / 2, NZ = N / 2 + 1, RS = N + 1;
   constexpr int T = FftPlan<N>::T, R1 = FftPlan<N>::R1, R2 = FftPlan<N>::R2;
-  constexpr int NT = N * T;
+  constexpr int PPT = DLPD_K2_PPT, NPB = N / PPT;  // thread (p,t) owns pencils p, p+NPB, ...
+  constexpr int NT = NPB * T;
+  constexpr int NLOAD = (L * L / 2) / NT;          // float4 (2 complex) per thread of an A slab
+  static_assert((L * L / 2) % NT == 0 && NLOAD >= 1, "A slab must split evenly over the block");
+  typedef FftPass<N, R2, R1, -1, T> FwdP2;
+  typedef FftPass<N, R1, 1, +1, T> InvP1;
+  static_assert(InvP1::PER == 1 && InvP1::NBF == T, "register hand-over needs one radix-R1 butterfly per thread");
   DLPD_DYN_SHARED(cplx, S);
   cplx* tw = S + N * RS;
   const int tid = threadIdx.x;
-  const int b = blockIdx.x, kz = blockIdx.y, c = blockIdx.z;
+  const int kz = blockIdx.x, c = blockIdx.y;
   init_twiddles<N>(tw, tid, NT);
+  const int p = tid % NPB, t = tid / NPB;
+
+  float4 apref[NLOAD];
   {
-    const float4* a = reinterpret_cast<const float4*>(A + (((size_t)b * CT + c) * NZ + kz) * L * L);
-    for (int i = tid; i < L * L / 2; i += NT) {
-      const float4 q = a[i];
-      const int e = 2 * i, x = e / L, y = e % L;
-      S[x * RS + y] = c_make(q.x, q.y);
-      S[x * RS + y + 1] = c_make(q.z, q.w);
+    const float4* a = reinterpret_cast<const float4*>(A + (((size_t)0 * CT + c) * NZ + kz) * L * L);
+#pragma unroll
+    for (int i = 0; i < NLOAD; i++) apref[i] = a[tid + i * NT];
+  }
+  for (int b = 0; b < nb; b++) {
+#pragma unroll
+    for (int i = 0; i < NLOAD; i++) {
+      const int e = 2 * (tid + i * NT), x = e / L, y = e % L;
+      S[x * RS + y] = c_make(apref[i].x, apref[i].y);
+      S[x * RS + y + 1] = c_make(apref[i].z, apref[i].w);
     }
-  }
-  __syncthreads();
-  const int p = tid % N, t = tid / N;
-  // forward along y on the L non-zero rows
-  {
-    FftPass<N, R1, 1, -1, T, L> ps;
-    if (p < L) ps.load(S + p * RS, 1, t, tw);
     __syncthreads();
-    if (p < L) ps.store(S + p * RS, 1, t);
-    __syncthreads();
-  }
-  {
-    FftPass<N, R2, R1, -1, T> ps;
-    if (p < L) ps.load(S + p * RS, 1, t, tw);
-    __syncthreads();
-    if (p < L) ps.store(S + p * RS, 1, t);
-    __syncthreads();
-  }
-  // forward along x on all N columns (rows >= L are implicit zeros)
-  {
-    FftPass<N, R1, 1, -1, T, L> ps;
-    ps.load(S + p, RS, t, tw);
-    __syncthreads();
-    ps.store(S + p, RS, t);
-    __syncthreads();
-  }
-  {
-    FftPass<N, R2, R1, -1, T> ps;
-    ps.load(S + p, RS, t, tw);
-    __syncthreads();
-    if (MODE == 1) {
-      const cplx* r = rec + (size_t)b * rec_bstride + ((size_t)c * NZ + kz) * N * N + p;
+    // forward along y on the L non-zero rows
+    {
+      FftPass<N, R1, 1, -1, T, L> ps[PPT];
 #pragma unroll
-      for (int i = 0; i < ps.PER; i++) {
+      for (int u = 0; u < PPT; u++) if (p + u * NPB < L) ps[u].load(S + (p + u * NPB) * RS, 1, t, tw);
+      __syncthreads();
 #pragma unroll
-        for (int q = 0; q < R2; q++) {
-          const int kx = ps.out_index(i, q, t);
-          ps.v[i][q] = c_mulc(r[(size_t)kx * N], ps.v[i][q]);
-        }
+      for (int u = 0; u < PPT; u++) if (p + u * NPB < L) ps[u].store(S + (p + u * NPB) * RS, 1, t);
+      __syncthreads();
+    }
+    {
+      FftPass<N, R2, R1, -1, T> ps[PPT];
+#pragma unroll
+      for (int u = 0; u < PPT; u++) if (p + u * NPB < L) ps[u].load(S + (p + u * NPB) * RS, 1, t, tw);
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < PPT; u++) if (p + u * NPB < L) ps[u].store(S + (p + u * NPB) * RS, 1, t);
+      __syncthreads();
+    }
+    // forward along x on all N columns (rows >= L are implicit zeros)
+    {
+      FftPass<N, R1, 1, -1, T, L> ps[PPT];
+#pragma unroll
+      for (int u = 0; u < PPT; u++) ps[u].load(S + p + u * NPB, RS, t, tw);
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < PPT; u++) ps[u].store(S + p + u * NPB, RS, t);
+    }
+    // receptor values: pencil u's 16 loads are issued one step ahead of their use (pencil 0 before
+    // the barrier, pencil u+1 before pencil u's butterflies), 32-bit offsets from a uniform base
+    cplx rv[2][FwdP2::PER][R2];
+    const cplx* rbase = rec + (size_t)b * rec_bstride + ((size_t)c * NZ + kz) * N * N;
+    const unsigned roff = (unsigned)t * N + p;
+    auto load_rec = [&](int u, cplx (&dst)[FwdP2::PER][R2]) {
+#pragma unroll
+      for (int i = 0; i < FwdP2::PER; i++)
+#pragma unroll
+        for (int q = 0; q < R2; q++) dst[i][q] = rbase[roff + (unsigned)(u * NPB + (i * T + q * R1) * N)];
+    };
+    if (MODE == 1) load_rec(0, rv[0]);
+    __syncthreads();
+    if (MODE == 0) {
+      FwdP2 ps[PPT];
+#pragma unroll
+      for (int u = 0; u < PPT; u++) ps[u].load(S + p + u * NPB, RS, t, tw);
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < PPT; u++) ps[u].store(S + p + u * NPB, RS, t);
+      __syncthreads();
+    } else {
+      InvP1 qs[PPT];
+#pragma unroll
+      for (int u = 0; u < PPT; u++) {
+        if (u + 1 < PPT) load_rec(u + 1, rv[(u + 1) & 1]);
+        FwdP2 ps;
+        ps.load(S + p + u * NPB, RS, t, tw);
+        // thread t now owns kx = t + i*T + q*R1; the inverse radix-R1 butterfly j = t wants
+        // input r1 at kx = t + r1*T  ->  r1 = (i*T + q*R1) / T
+#pragma unroll
+        for (int i = 0; i < FwdP2::PER; i++)
+#pragma unroll
+          for (int q = 0; q < R2; q++) qs[u].v[0][(i * T + q * R1) / T] = c_mulc(rv[u & 1][i][q], ps.v[i][q]);
+        SmallDft<R1, +1>::run(qs[u].v[0]);
+      }
+      __syncthreads();                                   // every forward-pass read is done
+#pragma unroll
+      for (int u = 0; u < PPT; u++) qs[u].store(S + p + u * NPB, RS, t);
+      __syncthreads();
+      {
+        FftPass<N, R2, R1, +1, T> ps[PPT];
+#pragma unroll
+        for (int u = 0; u < PPT; u++) ps[u].load(S + p + u * NPB, RS, t, tw);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PPT; u++) ps[u].store(S + p + u * NPB, RS, t);
+        __syncthreads();
+      }
+      // next rotation's A slab: issued now, consumed at the top of the next iteration
+      if (b + 1 < nb) {
+        const float4* a = reinterpret_cast<const float4*>(A + (((size_t)(b + 1) * CT + c) * NZ + kz) * L * L);
+#pragma unroll
+        for (int i = 0; i < NLOAD; i++) apref[i] = a[tid + i * NT];
+      }
+      {
+        FftPass<N, R1, 1, +1, T> ps[PPT];
+#pragma unroll
+        for (int u = 0; u < PPT; u++) ps[u].load(S + (p + u * NPB) * RS, 1, t, tw);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PPT; u++) ps[u].store(S + (p + u * NPB) * RS, 1, t);
+        __syncthreads();
+      }
+      {
+        FftPass<N, R2, R1, +1, T> ps[PPT];
+#pragma unroll
+        for (int u = 0; u < PPT; u++) ps[u].load(S + (p + u * NPB) * RS, 1, t, tw);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PPT; u++) ps[u].store(S + (p + u * NPB) * RS, 1, t);
+        __syncthreads();
       }
     }
-    ps.store(S + p, RS, t);
-    __syncthreads();
-  }
-  if (MODE == 1) {
-    // inverse along x (columns), then along y (rows)
     {
-      FftPass<N, R1, 1, +1, T> ps;
-      ps.load(S + p, RS, t, tw);
-      __syncthreads();
-      ps.store(S + p, RS, t);
-      __syncthreads();
+      float4* o = reinterpret_cast<float4*>(out + (((size_t)b * CT + c) * NZ + kz) * N * N);
+      const float sc = (MODE == 0) ? scale : 1.0f;
+      for (int i = tid; i < N * N / 2; i += NT) {
+        const int e = 2 * i, x = e / N, y = e % N;
+        const cplx u = S[x * RS + y], w = S[x * RS + y + 1];
+        o[i] = make_float4(u.x * sc, u.y * sc, w.x * sc, w.y * sc);
+      }
     }
-    {
-      FftPass<N, R2, R1, +1, T> ps;
-      ps.load(S + p, RS, t, tw);
-      __syncthreads();
-      ps.store(S + p, RS, t);
-      __syncthreads();
+    if (MODE == 0 && b + 1 < nb) {
+      const float4* a = reinterpret_cast<const float4*>(A + (((size_t)(b + 1) * CT + c) * NZ + kz) * L * L);
+#pragma unroll
+      for (int i = 0; i < NLOAD; i++) apref[i] = a[tid + i * NT];
     }
-    {
-      FftPass<N, R1, 1, +1, T> ps;
-      ps.load(S + p * RS, 1, t, tw);
-      __syncthreads();
-      ps.store(S + p * RS, 1, t);
-      __syncthreads();
-    }
-    {
-      FftPass<N, R2, R1, +1, T> ps;
-      ps.load(S + p * RS, 1, t, tw);
-      __syncthreads();
-      ps.store(S + p * RS, 1, t);
-      __syncthreads();
-    }
-  }
-  {
-    float4* o = reinterpret_cast<float4*>(out + (((size_t)b * CT + c) * NZ + kz) * N * N);
-    const float sc = (MODE == 0) ? scale : 1.0f;
-    for (int i = tid; i < N * N / 2; i += NT) {
-      const int e = 2 * i, x = e / N, y = e % N;
-      const cplx u = S[x * RS + y], w = S[x * RS + y + 1];
-      o[i] = make_float4(u.x * sc, u.y * sc, w.x * sc, w.y * sc);
-    }
+    __syncthreads();                                     // slab fully read before it is refilled
   }
 }
 
 // ------------------------------------------------------------------------------------------
 // K3: z-axis C2R + (MODE 1) filter MLP + clash mask, or (MODE 0) plain real output.
-//   grid (N/TY, N [x'], nb), block 512 threads, dynamic LDS (64*RS + N)*8 B.
+//   grid (N/TY, N [x'], nb), block DLPD_K3_THREADS, dynamic LDS ((NT/T)*RS + N)*8 B.
 //   Bw   (nb, CT, NZ, N, N) complex [kz][x'][y']
 //   MODE 0: out (nb, CT, N,N,N) real, optionally clamped to +-clip
 //   MODE 1: V   (nb, N,N,N) = mask * (W2 . relu(W1 . clamp(corr) + b1) + b2)
 //           score channels [0,C), clash channel C if has_clash (mask = corr_C < thr)
 //   W1t  (C, HP) transposed + zero padded, b1 (HP), W2 (HP)
 // ------------------------------------------------------------------------------------------
+#ifndef DLPD_K3_THREADS
 #define DLPD_K3_THREADS 512
 #define DLPD_K3_TY 16
+#endif
 template <int N, int HP, int MODE> __global__ void __launch_bounds__(DLPD_K3_THREADS)
 k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int C, int has_clash, int G,
                const float* __restrict__ W1t, const float* __restrict__ b1, const float* __restrict__ W2,
@@ -280,6 +354,7 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
   static_assert((NPAIR * N) % NT == 0 || NPAIR * N < NT, "tile/thread mismatch");
   DLPD_DYN_SHARED(cplx, S);
   cplx* tw = S + MAXP * RS;
+  float4* raw = reinterpret_cast<float4*>(tw + N);   // staging of the next group's raw spectra
   const int tid = threadIdx.x;
   const int y0 = blockIdx.x * TY, xo = blockIdx.y, b = blockIdx.z;
   init_twiddles<N>(tw, tid, NT);
@@ -298,14 +373,29 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
   const bool owner = (NPAIR * N >= NT) || (m0 < NPAIR);
   const int p = tid % MAXP, t = tid / MAXP;    // FFT pencil ownership
 
+  // Software pipeline: the raw spectra of channel group i+1 stream HBM -> LDS by LDS-DMA
+  // (global_load_lds, no VGPRs) while group i is transformed and folded into the MLP.  Inside
+  // the loop only LDS-scope barriers are used: a __syncthreads() would drain vmcnt and stall on
+  // the DMA in flight.
+  auto issue_group = [&](int cb) {
+    const int cnt = ((CT - cb) < G ? (CT - cb) : G) * NZ * NPAIR;
+    for (int s0 = (tid & ~63); s0 < cnt; s0 += NT) {
+      int sidx = s0 + (tid & 63);
+      sidx = sidx < cnt ? sidx : cnt - 1;      // tail lanes re-read the last element (in bounds)
+      const int m = sidx % NPAIR, k = (sidx / NPAIR) % NZ, g = sidx / (NPAIR * NZ);
+      DLPD_GLDS16(Bw + ((((size_t)b * CT + cb + g) * NZ + k) * N + xo) * N + y0 + 2 * m, raw + s0);
+    }
+  };
+  issue_group(0);
+  DLPD_WAIT_VMEM();
+  DLPD_LDS_BARRIER();                          // twiddles + first raw group visible
+
   for (int cbase = 0; cbase < CT; cbase += G) {
     const int gn = (CT - cbase) < G ? (CT - cbase) : G;
-    __syncthreads();                           // previous group's reads done
-    // load: thread <-> (g, k, m): two complex (rows 2m, 2m+1) at frequency k
+    // build the packed pencils: thread <-> (g, k, m): two complex (rows 2m, 2m+1) at frequency k
     for (int s = tid; s < gn * NZ * NPAIR; s += NT) {
       const int m = s % NPAIR, k = (s / NPAIR) % NZ, g = s / (NPAIR * NZ);
-      const float4 q = *reinterpret_cast<const float4*>(
-          Bw + ((((size_t)b * CT + cbase + g) * NZ + k) * N + xo) * N + y0 + 2 * m);
+      const float4 q = raw[s];
       cplx* P = S + (g * NPAIR + m) * RS;
       if (k == 0 || k == N / 2) {
         P[k] = c_make(q.x, q.z);               // purely real bins of both rows
@@ -314,21 +404,22 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
         P[N - k] = c_make(q.x + q.w, q.z - q.y);   // conj(A) + i conj(B)
       }
     }
-    __syncthreads();
+    DLPD_LDS_BARRIER();                        // raw consumed, pencils complete
+    if (cbase + G < CT) issue_group(cbase + G);
     const bool act = p < gn * NPAIR;
     {
       FftPass<N, R1, 1, +1, T> ps;
       if (act) ps.load(S + p * RS, 1, t, tw);
-      __syncthreads();
+      DLPD_LDS_BARRIER();
       if (act) ps.store(S + p * RS, 1, t);
-      __syncthreads();
+      DLPD_LDS_BARRIER();
     }
     {
       FftPass<N, R2, R1, +1, T> ps;
       if (act) ps.load(S + p * RS, 1, t, tw);
-      __syncthreads();
+      DLPD_LDS_BARRIER();
       if (act) ps.store(S + p * RS, 1, t);
-      __syncthreads();
+      DLPD_LDS_BARRIER();
     }
     if (owner) {
       for (int g = 0; g < gn; g++) {
@@ -360,6 +451,8 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
         }
       }
     }
+    DLPD_WAIT_VMEM();                          // next group landed in raw
+    DLPD_LDS_BARRIER();                        // ... and everybody is done with the pencils
   }
   if (MODE == 1 && owner) {
 #pragma unroll
@@ -421,8 +514,9 @@ k_filter_generic(const float* __restrict__ conv0, int C0, int N0, const float* _
 template <int N> static int launch_k1(const float* vol, const float* R, cplx* A, int CT, int nb, long long vbs,
                                       int do_rotate, float c0, hipStream_t st) {
   constexpr int L = N / 2;
-  dim3 grid(L, CT, nb), block((N / 4) * FftPlan<N>::T);
-  DLPD_LAUNCH((k_rotate_zfft<N>), grid, block, 0, st, vol, R, A, CT, vbs, do_rotate, c0);
+  const int groups = ((CT * nb + 7) / 8) * 8;
+  dim3 grid(groups * L), block((N / 4) * FftPlan<N>::T);
+  DLPD_LAUNCH((k_rotate_zfft<N>), grid, block, 0, st, vol, R, A, CT, nb, vbs, do_rotate, c0);
   return dlpd_check_launch();
 }
 
@@ -432,8 +526,8 @@ template <int N, int MODE> static int launch_k2(const cplx* A, const cplx* rec, 
   const size_t shmem = (size_t)(N * RS + N) * sizeof(cplx);
   int rc = dlpd_set_max_dyn_shared((const void*)k_xy_corr<N, MODE>, shmem);
   if (rc) return rc;
-  dim3 grid(nb, NZ, CT), block(N * FftPlan<N>::T);
-  DLPD_LAUNCH((k_xy_corr<N, MODE>), grid, block, shmem, st, A, rec, out, CT, rbs, scale);
+  dim3 grid(NZ, CT), block(N * FftPlan<N>::T / DLPD_K2_PPT);
+  DLPD_LAUNCH((k_xy_corr<N, MODE>), grid, block, shmem, st, A, rec, out, CT, nb, rbs, scale);
   return dlpd_check_launch();
 }
 
@@ -446,8 +540,10 @@ template <int N, int HP, int MODE> static int launch_k3(const cplx* Bw, float* o
                                                         int nb, const float* W1t, const float* b1, const float* W2,
                                                         float b2, int has_clip, float clip, float thr,
                                                         hipStream_t st) {
-  constexpr int RS = N + 1, MAXP = DLPD_K3_THREADS / FftPlan<N>::T;
-  const size_t shmem = (size_t)(MAXP * RS + N) * sizeof(cplx);
+  constexpr int RS = N + 1, MAXP = DLPD_K3_THREADS / FftPlan<N>::T, NZ = N / 2 + 1;
+  constexpr int GMAX = MAXP / (DLPD_K3_TY / 2);
+  constexpr int RAW = ((GMAX * NZ * (DLPD_K3_TY / 2) + 63) / 64) * 64;      // float4 slots, whole waves
+  const size_t shmem = (size_t)(MAXP * RS + N) * sizeof(cplx) + (size_t)RAW * 16;
   int rc = dlpd_set_max_dyn_shared((const void*)k_zifft_filter<N, HP, MODE>, shmem);
   if (rc) return rc;
   const int G = k3_group(CT, MAXP / (DLPD_K3_TY / 2));

@@ -13,3 +13,17 @@
 // dynamic LDS, 16-byte aligned base (guide G17)
 #define DLPD_DYN_SHARED(type, name) extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw_[]; \
   type* name = reinterpret_cast<type*>(name##_raw_)
+
+// LDS-DMA: each lane's 16 B at global address g go straight to LDS at (wave-uniform) l + lane*16
+// Written as inline asm on purpose: hipcc tracks the builtin form as an LDS store of unknown
+// extent and puts `s_waitcnt vmcnt(0)` in front of every later ds_read, which serialises the
+// prefetch it is meant to overlap.  The issuer counts it by hand (DLPD_WAIT_VMEM).
+__device__ __forceinline__ void dlpd_glds16(const void* g, void* l) {
+  const unsigned la =
+      __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)l);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(g) : "memory", "m0");
+}
+#define DLPD_GLDS16(g, l) dlpd_glds16((const void*)(g), (void*)(l))
+// barrier that orders LDS traffic only (leaves global loads / LDS-DMA in flight)
+#define DLPD_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define DLPD_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")

@@ -1,0 +1,10 @@
+#!/bin/bash
+# quick A/B: default lib vs variant libs given as args (paths), same process settings
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+cd $ROOT
+run() { timeout 200 python bench.py --steps 40 --warmup 5 --cpu_rotations 0 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('%-28s poses/s %.4g rot/s %.1f | '%(sys.argv[1], d['value'], d['rot_per_s']) + ' '.join('%s=%.3f'%(k.split('_')[0],v['ms_per_launch']) for k,v in d['stages'].items()))" "$1"; }
+run default
+for lib in "$@"; do DLPD_LIB_PATH=$ROOT/$lib run $lib; done

@@ -213,3 +213,8 @@ static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c);
 static inline void sincospi(double x, double* s, double* c) { *s = sin(M_PI * x); *c = cos(M_PI * x); }
 #define hipFuncAttributeMaxDynamicSharedMemorySize 0
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return 0; }
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }
+#define DLPD_GLDS16(g, l) memcpy(reinterpret_cast<char*>(l) + 16 * (emu::S().cur % 64), (const void*)(g), 16)
+#define DLPD_LDS_BARRIER() emu::barrier()
+#define DLPD_WAIT_VMEM() ((void)0)
