@@ -31,8 +31,9 @@ template <int N> DLPD_D void init_twiddles(cplx* tw, int tid, int nthreads) {
 // trilinear sample of a (L,L,L) volume at position (px,py,pz), zeros outside
 // ------------------------------------------------------------------------------------------
 DLPD_D float trilinear_fetch(const float* __restrict__ v, int L, float px, float py, float pz) {
-  // branch-free: out-of-box corners get weight 0 and a clamped (valid) address, so the eight
-  // loads are unconditional and all in flight together
+  // branch-free: out-of-box corners get weight 0 and a clamped (valid) address, so all loads are
+  // unconditional and in flight together; the two z-neighbours come from ONE 8-byte load
+  // (half the address-unit work of eight scalar gathers)
   const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
   const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
   const float ax = px - fx, ay = py - fy, az = pz - fz;
@@ -45,13 +46,17 @@ DLPD_D float trilinear_fetch(const float* __restrict__ v, int L, float px, float
   const float wz0 = z0 ? 1.f - az : 0.f, wz1 = z1 ? az : 0.f;
   const int cx0 = min(max(ix, 0), hi), cx1 = min(max(ix + 1, 0), hi);
   const int cy0 = min(max(iy, 0), hi), cy1 = min(max(iy + 1, 0), hi);
-  const int cz0 = min(max(iz, 0), hi), cz1 = min(max(iz + 1, 0), hi);
-  const float* r00 = v + (cx0 * L + cy0) * L;
-  const float* r01 = v + (cx0 * L + cy1) * L;
-  const float* r10 = v + (cx1 * L + cy0) * L;
-  const float* r11 = v + (cx1 * L + cy1) * L;
-  const float v000 = r00[cz0], v001 = r00[cz1], v010 = r01[cz0], v011 = r01[cz1];
-  const float v100 = r10[cz0], v101 = r10[cz1], v110 = r11[cz0], v111 = r11[cz1];
+  const int zb = min(max(iz, 0), hi - 1);          // pair (zb, zb+1) always inside the row
+  const int d = iz - zb;                           // 0 inside; -1 / +1 at the two faces
+  DLPD_PAIR p00 = dlpd_load_pair(v + (cx0 * L + cy0) * L + zb);
+  DLPD_PAIR p01 = dlpd_load_pair(v + (cx0 * L + cy1) * L + zb);
+  DLPD_PAIR p10 = dlpd_load_pair(v + (cx1 * L + cy0) * L + zb);
+  DLPD_PAIR p11 = dlpd_load_pair(v + (cx1 * L + cy1) * L + zb);
+  // value at z0 = iz is .x unless iz = zb+1 ; value at z1 = iz+1 is .y unless iz+1 = zb
+  const float v000 = d > 0 ? p00.y : p00.x, v001 = d < 0 ? p00.x : p00.y;
+  const float v010 = d > 0 ? p01.y : p01.x, v011 = d < 0 ? p01.x : p01.y;
+  const float v100 = d > 0 ? p10.y : p10.x, v101 = d < 0 ? p10.x : p10.y;
+  const float v110 = d > 0 ? p11.y : p11.x, v111 = d < 0 ? p11.x : p11.y;
   float acc = v000 * (wx0 * wy0 * wz0);
   acc += v001 * (wx0 * wy0 * wz1);
   acc += v010 * (wx0 * wy1 * wz0);
@@ -162,7 +167,7 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
 
 // ------------------------------------------------------------------------------------------
 // K2: one block per (c, kz), looping over the nb rotations of the batch (persistent over b).
-//   grid (NZ, CT), block N*T/2 threads (two pencils per thread), dynamic LDS (N*RS+N)*8 B (one N x N slab).
+//   grid (NZ, CT), block 4N threads (N/16 waves), dynamic LDS N*(N+8)*8 B (one swizzled N x N slab).
 //   MODE 0: forward only -> out[(b*CT+c)][kz][kx][ky] = scale * FFT2(pad(A))     (receptor prep)
 //   MODE 1: correlate    -> out = IFFT2( rec * conj(FFT2(pad(A))) )  (unnormalised inverse;
 //                           the 1/N^3 lives in rec)
@@ -172,27 +177,33 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
 // leaves thread t with exactly the elements {t + 8m} that the first inverse x pass needs -- the
 // inverse x transform starts from those registers without a trip through LDS.  The next
 // rotation's A slab and this slab's receptor values are prefetched into registers while the
-// current passes run (plain global loads stay in flight across barriers).
+// current passes run (plain global loads stay in flight across barriers).  The FFT passes are
+// wave-local (dlpd_fft.h): 5 block barriers per slab, waves drift apart between them.
 // ------------------------------------------------------------------------------------------
-#define DLPD_K2_PPT 2     // pencils per thread: N*T/2 threads per block leave 256 VGPRs per thread
-template <int N, int MODE> __global__ void __launch_bounds__(N * FftPlan<N>::T / DLPD_K2_PPT)
+#define DLPD_K2_THREADS(N) ((N) * 4)   // N/16 waves; each owns 8 pencils per step (wave-local FFT passes)
+template <int N, int MODE> __global__ void __launch_bounds__(DLPD_K2_THREADS(N))
 k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __restrict__ out,
           int CT, int nb, long long rec_bstride, float scale) {
-  constexpr int L = N / 2, NZ = N / 2 + 1, RS = N + 1;
+  constexpr int L = N / 2, NZ = N / 2 + 1, RS = N + 8;
   constexpr int T = FftPlan<N>::T, R1 = FftPlan<N>::R1, R2 = FftPlan<N>::R2;
-  constexpr int PPT = DLPD_K2_PPT, NPB = N / PPT;  // thread (p,t) owns pencils p, p+NPB, ...
-  constexpr int NT = NPB * T;
+  static_assert(T == 8 && RS % 32 == 8, "wave-local layout assumes 8 threads per pencil");
+  constexpr int NT = DLPD_K2_THREADS(N), W = NT / 64;
+  constexpr int NSET = N / 8;                      // pencil sets (8 pencils) per direction
   constexpr int NLOAD = (L * L / 2) / NT;          // float4 (2 complex) per thread of an A slab
-  static_assert((L * L / 2) % NT == 0 && NLOAD >= 1, "A slab must split evenly over the block");
-  typedef FftPass<N, R2, R1, -1, T> FwdP2;
-  typedef FftPass<N, R1, 1, +1, T> InvP1;
+  static_assert((L * L / 2) % NT == 0 && NLOAD >= 1 && NSET % W == 0 && (L / 8) % W == 0, "shape");
+  typedef FftPassW<N, R1, 1, -1, T, L> FwdP1;      // pruned: only the first L inputs are non-zero
+  typedef FftPassW<N, R2, R1, -1, T> FwdP2;
+  typedef FftPassW<N, R1, 1, +1, T> InvP1;
+  typedef FftPassW<N, R2, R1, +1, T> InvP2;
   static_assert(InvP1::PER == 1 && InvP1::NBF == T, "register hand-over needs one radix-R1 butterfly per thread");
   DLPD_DYN_SHARED(cplx, S);
-  cplx* tw = S + N * RS;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kz = blockIdx.x, c = blockIdx.y;
+  // row phase: lane = 8*q + t  (pencil q of the set, thread t); column phase: lane = 8*t + c8
+  const int tr = lane & 7, qr = lane >> 3;
+  const int tc = lane >> 3, c8 = lane & 7;
+  cplx* tw = S + N * RS;
   init_twiddles<N>(tw, tid, NT);
-  const int p = tid % NPB, t = tid / NPB;
 
   float4 apref[NLOAD];
   {
@@ -204,125 +215,113 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
 #pragma unroll
     for (int i = 0; i < NLOAD; i++) {
       const int e = 2 * (tid + i * NT), x = e / L, y = e % L;
-      S[x * RS + y] = c_make(apref[i].x, apref[i].y);
-      S[x * RS + y + 1] = c_make(apref[i].z, apref[i].w);
+      S[x * RS + slab_swz(y)] = c_make(apref[i].x, apref[i].y);
+      S[x * RS + slab_swz(y + 1)] = c_make(apref[i].z, apref[i].w);
     }
     __syncthreads();
-    // forward along y on the L non-zero rows
-    {
-      FftPass<N, R1, 1, -1, T, L> ps[PPT];
-#pragma unroll
-      for (int u = 0; u < PPT; u++) if (p + u * NPB < L) ps[u].load(S + (p + u * NPB) * RS, 1, t, tw);
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < PPT; u++) if (p + u * NPB < L) ps[u].store(S + (p + u * NPB) * RS, 1, t);
-      __syncthreads();
-    }
-    {
-      FftPass<N, R2, R1, -1, T> ps[PPT];
-#pragma unroll
-      for (int u = 0; u < PPT; u++) if (p + u * NPB < L) ps[u].load(S + (p + u * NPB) * RS, 1, t, tw);
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < PPT; u++) if (p + u * NPB < L) ps[u].store(S + (p + u * NPB) * RS, 1, t);
-      __syncthreads();
-    }
-    // forward along x on all N columns (rows >= L are implicit zeros)
-    {
-      FftPass<N, R1, 1, -1, T, L> ps[PPT];
-#pragma unroll
-      for (int u = 0; u < PPT; u++) ps[u].load(S + p + u * NPB, RS, t, tw);
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < PPT; u++) ps[u].store(S + p + u * NPB, RS, t);
-    }
-    // receptor values: pencil u's 16 loads are issued one step ahead of their use (pencil 0 before
-    // the barrier, pencil u+1 before pencil u's butterflies), 32-bit offsets from a uniform base
-    cplx rv[2][FwdP2::PER][R2];
-    const cplx* rbase = rec + (size_t)b * rec_bstride + ((size_t)c * NZ + kz) * N * N;
-    const unsigned roff = (unsigned)t * N + p;
-    auto load_rec = [&](int u, cplx (&dst)[FwdP2::PER][R2]) {
-#pragma unroll
-      for (int i = 0; i < FwdP2::PER; i++)
-#pragma unroll
-        for (int q = 0; q < R2; q++) dst[i][q] = rbase[roff + (unsigned)(u * NPB + (i * T + q * R1) * N)];
-    };
-    if (MODE == 1) load_rec(0, rv[0]);
-    __syncthreads();
-    if (MODE == 0) {
-      FwdP2 ps[PPT];
-#pragma unroll
-      for (int u = 0; u < PPT; u++) ps[u].load(S + p + u * NPB, RS, t, tw);
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < PPT; u++) ps[u].store(S + p + u * NPB, RS, t);
-      __syncthreads();
-    } else {
-      InvP1 qs[PPT];
-#pragma unroll
-      for (int u = 0; u < PPT; u++) {
-        if (u + 1 < PPT) load_rec(u + 1, rv[(u + 1) & 1]);
+    // ---- forward along y on the L non-zero rows: L/8 pencil sets over W waves
+#pragma unroll 1
+    for (int set = wave; set < L / 8; set += W) {
+      const RowAddr<RS> ad = {(set * 8 + qr) * RS};
+      {
+        FwdP1 ps;
+        ps.load(S, ad, tr, nullptr);
+        DLPD_WAVE_SYNC();
+        ps.store(S, ad, tr);
+        DLPD_WAVE_SYNC();
+      }
+      {
         FwdP2 ps;
-        ps.load(S + p + u * NPB, RS, t, tw);
-        // thread t now owns kx = t + i*T + q*R1; the inverse radix-R1 butterfly j = t wants
-        // input r1 at kx = t + r1*T  ->  r1 = (i*T + q*R1) / T
+        ps.load(S, ad, tr, tw);
+        DLPD_WAVE_SYNC();
+        ps.store(S, ad, tr);
+      }
+    }
+    __syncthreads();
+    // ---- columns: forward x, receptor multiply, inverse x -- all inside one wave per set
+#pragma unroll 1
+    for (int set = wave; set < NSET; set += W) {
+      const int col = set * 8 + c8;
+      const ColAddr<RS> ad = {slab_swz(col)};
+      cplx rv[FwdP2::PER][R2];
+      if (MODE == 1) {                                   // receptor values: in flight during pass 1
+        const cplx* rbase = rec + (size_t)b * rec_bstride + ((size_t)c * NZ + kz) * N * N;
+        const unsigned roff = (unsigned)tc * N + col;
 #pragma unroll
         for (int i = 0; i < FwdP2::PER; i++)
 #pragma unroll
-          for (int q = 0; q < R2; q++) qs[u].v[0][(i * T + q * R1) / T] = c_mulc(rv[u & 1][i][q], ps.v[i][q]);
-        SmallDft<R1, +1>::run(qs[u].v[0]);
+          for (int q = 0; q < R2; q++) rv[i][q] = rbase[roff + (unsigned)((i * T + q * R1) * N)];
       }
-      __syncthreads();                                   // every forward-pass read is done
+      {
+        FwdP1 ps;
+        ps.load(S, ad, tc, nullptr);
+        DLPD_WAVE_SYNC();
+        ps.store(S, ad, tc);
+        DLPD_WAVE_SYNC();
+      }
+      if (MODE == 0) {
+        FwdP2 ps;
+        ps.load(S, ad, tc, tw);
+        DLPD_WAVE_SYNC();
+        ps.store(S, ad, tc);
+      } else {
+        InvP1 qs;
+        {
+          FwdP2 ps;
+          ps.load(S, ad, tc, tw);
+          // thread t owns kx = t + i*T + q*R1; the inverse radix-R1 butterfly j = t wants input r1
+          // at kx = t + r1*T  ->  r1 = (i*T + q*R1) / T : a pure register renaming
 #pragma unroll
-      for (int u = 0; u < PPT; u++) qs[u].store(S + p + u * NPB, RS, t);
+          for (int i = 0; i < FwdP2::PER; i++)
+#pragma unroll
+            for (int q = 0; q < R2; q++) qs.v[0][(i * T + q * R1) / T] = c_mulc(rv[i][q], ps.v[i][q]);
+        }
+        SmallDft<R1, +1>::run(qs.v[0]);
+        DLPD_WAVE_SYNC();
+        qs.store(S, ad, tc);
+        DLPD_WAVE_SYNC();
+        InvP2 ps;
+        ps.load(S, ad, tc, tw);
+        DLPD_WAVE_SYNC();
+        ps.store(S, ad, tc);
+      }
+    }
+    __syncthreads();
+    // next rotation's A slab: issued now, consumed at the top of the next iteration
+    if (b + 1 < nb) {
+      const float4* a = reinterpret_cast<const float4*>(A + (((size_t)(b + 1) * CT + c) * NZ + kz) * L * L);
+#pragma unroll
+      for (int i = 0; i < NLOAD; i++) apref[i] = a[tid + i * NT];
+    }
+    if (MODE == 1) {
+      // ---- inverse along y on all N rows
+  #pragma unroll 1
+    for (int set = wave; set < NSET; set += W) {
+        const RowAddr<RS> ad = {(set * 8 + qr) * RS};
+        {
+          InvP1 ps;
+          ps.load(S, ad, tr, nullptr);
+          DLPD_WAVE_SYNC();
+          ps.store(S, ad, tr);
+          DLPD_WAVE_SYNC();
+        }
+        {
+          InvP2 ps;
+          ps.load(S, ad, tr, tw);
+          DLPD_WAVE_SYNC();
+          ps.store(S, ad, tr);
+        }
+      }
       __syncthreads();
-      {
-        FftPass<N, R2, R1, +1, T> ps[PPT];
-#pragma unroll
-        for (int u = 0; u < PPT; u++) ps[u].load(S + p + u * NPB, RS, t, tw);
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < PPT; u++) ps[u].store(S + p + u * NPB, RS, t);
-        __syncthreads();
-      }
-      // next rotation's A slab: issued now, consumed at the top of the next iteration
-      if (b + 1 < nb) {
-        const float4* a = reinterpret_cast<const float4*>(A + (((size_t)(b + 1) * CT + c) * NZ + kz) * L * L);
-#pragma unroll
-        for (int i = 0; i < NLOAD; i++) apref[i] = a[tid + i * NT];
-      }
-      {
-        FftPass<N, R1, 1, +1, T> ps[PPT];
-#pragma unroll
-        for (int u = 0; u < PPT; u++) ps[u].load(S + (p + u * NPB) * RS, 1, t, tw);
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < PPT; u++) ps[u].store(S + (p + u * NPB) * RS, 1, t);
-        __syncthreads();
-      }
-      {
-        FftPass<N, R2, R1, +1, T> ps[PPT];
-#pragma unroll
-        for (int u = 0; u < PPT; u++) ps[u].load(S + (p + u * NPB) * RS, 1, t, tw);
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < PPT; u++) ps[u].store(S + (p + u * NPB) * RS, 1, t);
-        __syncthreads();
-      }
     }
     {
       float4* o = reinterpret_cast<float4*>(out + (((size_t)b * CT + c) * NZ + kz) * N * N);
       const float sc = (MODE == 0) ? scale : 1.0f;
       for (int i = tid; i < N * N / 2; i += NT) {
         const int e = 2 * i, x = e / N, y = e % N;
-        const cplx u = S[x * RS + y], w = S[x * RS + y + 1];
+        const cplx u = S[x * RS + slab_swz(y)], w = S[x * RS + slab_swz(y + 1)];
         o[i] = make_float4(u.x * sc, u.y * sc, w.x * sc, w.y * sc);
       }
-    }
-    if (MODE == 0 && b + 1 < nb) {
-      const float4* a = reinterpret_cast<const float4*>(A + (((size_t)(b + 1) * CT + c) * NZ + kz) * L * L);
-#pragma unroll
-      for (int i = 0; i < NLOAD; i++) apref[i] = a[tid + i * NT];
     }
     __syncthreads();                                     // slab fully read before it is refilled
   }
@@ -330,32 +329,36 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
 
 // ------------------------------------------------------------------------------------------
 // K3: z-axis C2R + (MODE 1) filter MLP + clash mask, or (MODE 0) plain real output.
-//   grid (N/TY, N [x'], nb), block DLPD_K3_THREADS, dynamic LDS ((NT/T)*RS + N)*8 B.
+//   grid (N/16, N [x'], nb), block 512 threads (8 waves), dynamic LDS: 64 pencils + twiddles + raw staging.
 //   Bw   (nb, CT, NZ, N, N) complex [kz][x'][y']
 //   MODE 0: out (nb, CT, N,N,N) real, optionally clamped to +-clip
 //   MODE 1: V   (nb, N,N,N) = mask * (W2 . relu(W1 . clamp(corr) + b1) + b2)
 //           score channels [0,C), clash channel C if has_clash (mask = corr_C < thr)
 //   W1t  (C, HP) transposed + zero padded, b1 (HP), W2 (HP)
 // ------------------------------------------------------------------------------------------
-#ifndef DLPD_K3_THREADS
+// One wave owns one channel of the current group: it streams that channel's raw spectra
+// HBM -> LDS with LDS-DMA (for the NEXT group, overlapped with everything else), packs them into
+// 8 two-row pencils, and runs the two wave-local FFT passes -- no block barrier involved.  Two
+// block barriers per group separate "all pencils transformed" from the accumulation phase, in
+// which every thread folds all channels of the group into the hidden units of its 4 voxels.
 #define DLPD_K3_THREADS 512
 #define DLPD_K3_TY 16
-#endif
 template <int N, int HP, int MODE> __global__ void __launch_bounds__(DLPD_K3_THREADS)
 k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int C, int has_clash, int G,
                const float* __restrict__ W1t, const float* __restrict__ b1, const float* __restrict__ W2,
                float b2, int has_clip, float clip, float thr) {
-  constexpr int NZ = N / 2 + 1, RS = N + 1, TY = DLPD_K3_TY, NPAIR = TY / 2;
+  constexpr int NZ = N / 2 + 1, RS = N + 8, TY = DLPD_K3_TY, NPAIR = TY / 2;
   constexpr int T = FftPlan<N>::T, R1 = FftPlan<N>::R1, R2 = FftPlan<N>::R2;
-  constexpr int NT = DLPD_K3_THREADS;
-  constexpr int MAXP = NT / T;                 // pencils per group (G * NPAIR <= MAXP)
+  constexpr int NT = DLPD_K3_THREADS, W = NT / 64;
+  static_assert(T == 8 && NPAIR == 8, "one wave = 8 pencils x 8 threads = one channel of the tile");
   constexpr int EPT = (NPAIR * N) / NT > 0 ? (NPAIR * N) / NT : 1;   // complex outputs per thread per channel
   constexpr int MSTEP = NT / N;                // pair stride between a thread's outputs
   static_assert((NPAIR * N) % NT == 0 || NPAIR * N < NT, "tile/thread mismatch");
+  constexpr int RAWC = ((NZ * NPAIR + 63) / 64) * 64;    // float4 slots per channel (whole waves)
   DLPD_DYN_SHARED(cplx, S);
-  cplx* tw = S + MAXP * RS;
-  float4* raw = reinterpret_cast<float4*>(tw + N);   // staging of the next group's raw spectra
-  const int tid = threadIdx.x;
+  cplx* tw = S + W * NPAIR * RS;
+  float4* raw = reinterpret_cast<float4*>(tw + N);        // [W][RAWC] staging of raw spectra
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int y0 = blockIdx.x * TY, xo = blockIdx.y, b = blockIdx.z;
   init_twiddles<N>(tw, tid, NT);
 
@@ -371,63 +374,73 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
   }
   const int zz = tid % N, m0 = tid / N;        // output ownership
   const bool owner = (NPAIR * N >= NT) || (m0 < NPAIR);
-  const int p = tid % MAXP, t = tid / MAXP;    // FFT pencil ownership
+  const int tr = lane & 7, qr = lane >> 3;     // FFT: lane = 8*pencil + thread
+  const RowAddr<RS> ad = {(wave * NPAIR + qr) * RS};
+  float4* rawg = raw + wave * RAWC;
 
-  // Software pipeline: the raw spectra of channel group i+1 stream HBM -> LDS by LDS-DMA
-  // (global_load_lds, no VGPRs) while group i is transformed and folded into the MLP.  Inside
-  // the loop only LDS-scope barriers are used: a __syncthreads() would drain vmcnt and stall on
-  // the DMA in flight.
-  auto issue_group = [&](int cb) {
-    const int cnt = ((CT - cb) < G ? (CT - cb) : G) * NZ * NPAIR;
-    for (int s0 = (tid & ~63); s0 < cnt; s0 += NT) {
-      int sidx = s0 + (tid & 63);
-      sidx = sidx < cnt ? sidx : cnt - 1;      // tail lanes re-read the last element (in bounds)
-      const int m = sidx % NPAIR, k = (sidx / NPAIR) % NZ, g = sidx / (NPAIR * NZ);
-      DLPD_GLDS16(Bw + ((((size_t)b * CT + cb + g) * NZ + k) * N + xo) * N + y0 + 2 * m, raw + s0);
+  // this wave's channel of group `cb`: raw[k][m] <- Bw[b][cb+wave][k][xo][y0+2m .. +1]
+  auto issue_channel = [&](int cb) {
+    if (wave < G && cb + wave < CT) {
+      const cplx* src = Bw + (((size_t)b * CT + cb + wave) * NZ * N + xo) * N + y0;
+#pragma unroll 1
+      for (int s0 = 0; s0 < NZ * NPAIR; s0 += 64) {
+        int sidx = s0 + lane;
+        sidx = sidx < NZ * NPAIR ? sidx : NZ * NPAIR - 1;   // tail lanes re-read the last element
+        DLPD_GLDS16(src + (size_t)(sidx >> 3) * N * N + 2 * (sidx & 7), rawg + s0);
+      }
     }
   };
-  issue_group(0);
-  DLPD_WAIT_VMEM();
-  DLPD_LDS_BARRIER();                          // twiddles + first raw group visible
+  issue_channel(0);
+  __syncthreads();                             // twiddle table visible
 
   for (int cbase = 0; cbase < CT; cbase += G) {
     const int gn = (CT - cbase) < G ? (CT - cbase) : G;
-    // build the packed pencils: thread <-> (g, k, m): two complex (rows 2m, 2m+1) at frequency k
-    for (int s = tid; s < gn * NZ * NPAIR; s += NT) {
-      const int m = s % NPAIR, k = (s / NPAIR) % NZ, g = s / (NPAIR * NZ);
-      const float4 q = raw[s];
-      cplx* P = S + (g * NPAIR + m) * RS;
-      if (k == 0 || k == N / 2) {
-        P[k] = c_make(q.x, q.z);               // purely real bins of both rows
-      } else {
-        P[k] = c_make(q.x - q.w, q.y + q.z);   // A + i B
-        P[N - k] = c_make(q.x + q.w, q.z - q.y);   // conj(A) + i conj(B)
+    if (wave < gn) {
+      DLPD_WAIT_VMEM();                        // this wave's own DMA has landed
+      DLPD_WAVE_SYNC();
+      // pack two rows per complex pencil: Z[k] = A[k] + i B[k], Z[N-k] = conj(A[k]) + i conj(B[k])
+#pragma unroll 1
+      for (int s0 = 0; s0 < NZ * NPAIR; s0 += 64) {
+        const int sidx = s0 + lane;
+        if (sidx < NZ * NPAIR) {
+          const int m = sidx & 7, k = sidx >> 3;
+          const float4 q = rawg[sidx];
+          cplx* P = S + (wave * NPAIR + m) * RS;
+          if (k == 0 || k == N / 2) {
+            P[slab_swz(k)] = c_make(q.x, q.z);             // purely real bins of both rows
+          } else {
+            P[slab_swz(k)] = c_make(q.x - q.w, q.y + q.z);
+            P[slab_swz(N - k)] = c_make(q.x + q.w, q.z - q.y);
+          }
+        }
+      }
+      DLPD_WAIT_LDS();                         // raw fully read before it is refilled
+      DLPD_WAVE_SYNC();
+    }
+    issue_channel(cbase + G);                  // next group's channel streams in behind the math
+    if (wave < gn) {
+      {
+        FftPassW<N, R1, 1, +1, T> ps;
+        ps.load(S, ad, tr, nullptr);
+        DLPD_WAVE_SYNC();
+        ps.store(S, ad, tr);
+        DLPD_WAVE_SYNC();
+      }
+      {
+        FftPassW<N, R2, R1, +1, T> ps;
+        ps.load(S, ad, tr, tw);
+        DLPD_WAVE_SYNC();
+        ps.store(S, ad, tr);
       }
     }
-    DLPD_LDS_BARRIER();                        // raw consumed, pencils complete
-    if (cbase + G < CT) issue_group(cbase + G);
-    const bool act = p < gn * NPAIR;
-    {
-      FftPass<N, R1, 1, +1, T> ps;
-      if (act) ps.load(S + p * RS, 1, t, tw);
-      DLPD_LDS_BARRIER();
-      if (act) ps.store(S + p * RS, 1, t);
-      DLPD_LDS_BARRIER();
-    }
-    {
-      FftPass<N, R2, R1, +1, T> ps;
-      if (act) ps.load(S + p * RS, 1, t, tw);
-      DLPD_LDS_BARRIER();
-      if (act) ps.store(S + p * RS, 1, t);
-      DLPD_LDS_BARRIER();
-    }
+    DLPD_LDS_BARRIER();                        // all channels of the group transformed
     if (owner) {
       for (int g = 0; g < gn; g++) {
         const int c = cbase + g;
 #pragma unroll
         for (int e = 0; e < EPT; e++) {
           const int m = m0 + e * MSTEP;
-          const cplx val = S[(g * NPAIR + m) * RS + zz];
+          const cplx val = S[(g * NPAIR + m) * RS + slab_swz(zz)];
           float v0 = val.x, v1 = val.y;
           if (MODE == 0) {
             if (has_clip) { v0 = fminf(fmaxf(v0, -clip), clip); v1 = fminf(fmaxf(v1, -clip), clip); }
@@ -451,8 +464,7 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
         }
       }
     }
-    DLPD_WAIT_VMEM();                          // next group landed in raw
-    DLPD_LDS_BARRIER();                        // ... and everybody is done with the pencils
+    DLPD_LDS_BARRIER();                        // pencils free for the next group
   }
   if (MODE == 1 && owner) {
 #pragma unroll
@@ -522,11 +534,11 @@ template <int N> static int launch_k1(const float* vol, const float* R, cplx* A,
 
 template <int N, int MODE> static int launch_k2(const cplx* A, const cplx* rec, cplx* out, int CT, int nb,
                                                 long long rbs, float scale, hipStream_t st) {
-  constexpr int NZ = N / 2 + 1, RS = N + 1;
+  constexpr int NZ = N / 2 + 1, RS = N + 8;
   const size_t shmem = (size_t)(N * RS + N) * sizeof(cplx);
   int rc = dlpd_set_max_dyn_shared((const void*)k_xy_corr<N, MODE>, shmem);
   if (rc) return rc;
-  dim3 grid(NZ, CT), block(N * FftPlan<N>::T / DLPD_K2_PPT);
+  dim3 grid(NZ, CT), block(DLPD_K2_THREADS(N));
   DLPD_LAUNCH((k_xy_corr<N, MODE>), grid, block, shmem, st, A, rec, out, CT, nb, rbs, scale);
   return dlpd_check_launch();
 }
@@ -540,13 +552,12 @@ template <int N, int HP, int MODE> static int launch_k3(const cplx* Bw, float* o
                                                         int nb, const float* W1t, const float* b1, const float* W2,
                                                         float b2, int has_clip, float clip, float thr,
                                                         hipStream_t st) {
-  constexpr int RS = N + 1, MAXP = DLPD_K3_THREADS / FftPlan<N>::T, NZ = N / 2 + 1;
-  constexpr int GMAX = MAXP / (DLPD_K3_TY / 2);
-  constexpr int RAW = ((GMAX * NZ * (DLPD_K3_TY / 2) + 63) / 64) * 64;      // float4 slots, whole waves
-  const size_t shmem = (size_t)(MAXP * RS + N) * sizeof(cplx) + (size_t)RAW * 16;
+  constexpr int RS = N + 8, NZ = N / 2 + 1, W = DLPD_K3_THREADS / 64, NPAIR = DLPD_K3_TY / 2;
+  constexpr int RAWC = ((NZ * NPAIR + 63) / 64) * 64;
+  const size_t shmem = (size_t)(W * NPAIR * RS + N) * sizeof(cplx) + (size_t)W * RAWC * 16;
   int rc = dlpd_set_max_dyn_shared((const void*)k_zifft_filter<N, HP, MODE>, shmem);
   if (rc) return rc;
-  const int G = k3_group(CT, MAXP / (DLPD_K3_TY / 2));
+  const int G = k3_group(CT, W);               // channels per group (one wave each), <= W
   dim3 grid(N / DLPD_K3_TY, N, nb), block(DLPD_K3_THREADS);
   DLPD_LAUNCH((k_zifft_filter<N, HP, MODE>), grid, block, shmem, st, Bw, out, CT, C, has_clash, G, W1t, b1, W2, b2,
               has_clip, clip, thr);

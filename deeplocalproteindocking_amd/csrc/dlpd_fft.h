@@ -210,3 +210,61 @@ template <> struct FftPlan<64> { static constexpr int R1 = 8, R2 = 8, T = 8; };
 template <> struct FftPlan<128> { static constexpr int R1 = 16, R2 = 8, T = 8; };
 template <> struct FftPlan<80> { static constexpr int R1 = 8, R2 = 10, T = 10; };
 template <> struct FftPlan<160> { static constexpr int R1 = 16, R2 = 10, T = 10; };
+
+// ------------------------------------------------------------------------------------------
+// Wave-local variant: the T (= 8) threads of a pencil are lanes of ONE wave and a wave owns 8
+// pencils, so the load -> store hand-over of a pass needs only wave-level ordering
+// (DLPD_WAVE_SYNC: LDS instructions of a wave execute in issue order) and the waves of a block
+// drift apart, overlapping one wave's LDS traffic with another's butterflies.  Addressing goes
+// through a functor (swizzled slabs).
+// ------------------------------------------------------------------------------------------
+template <int N, int R, int NS, int DIR, int T, int NNZ = N> struct FftPassW {
+  static constexpr int NBF = N / R;
+  static constexpr int PER = (NBF + T - 1) / T;
+  static constexpr int RNZ = NNZ / NBF;
+  static_assert(N % R == 0 && NNZ % NBF == 0 && NBF % T == 0, "unsupported wave-local pass shape");
+  cplx v[PER][R];
+
+  // tw: LDS table of exp(-2 pi i k / N)
+  template <class Addr> DLPD_D void load(const cplx* S, const Addr& ad, int t, const cplx* tw) {
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+      const int j = t + i * T;
+#pragma unroll
+      for (int r = 0; r < R; r++) v[i][r] = (r < RNZ) ? S[ad(j + r * NBF)] : c_make(0.f, 0.f);
+      if (NS > 1) {
+        const int k = (j % NS) * (N / (NS * R));
+#pragma unroll
+        for (int r = 1; r < R; r++)
+          if (r < RNZ) {
+            const cplx w = tw[k * r];
+            v[i][r] = DIR < 0 ? c_mul(v[i][r], w) : c_mulc(v[i][r], w);
+          }
+      }
+      SmallDft<R, DIR>::run(v[i]);
+    }
+  }
+  DLPD_HD int out_index(int i, int r, int t) const {
+    const int j = t + i * T;
+    return (j / NS) * NS * R + (j % NS) + r * NS;
+  }
+  template <class Addr> DLPD_D void store(cplx* S, const Addr& ad, int t) const {
+#pragma unroll
+    for (int i = 0; i < PER; i++)
+#pragma unroll
+      for (int r = 0; r < R; r++) S[ad(out_index(i, r, t))] = v[i][r];
+  }
+};
+
+// slab addressing: element (row, col) of an N x N complex slab with row stride RS (RS % 32 == 8)
+// lives at row*RS + swz(col), swz(c) = c ^ ((c >> 4) & 15): both the contiguous (row pencil) and
+// the strided (column pencil) Stockham accesses of 8 pencils x 8 threads are LDS-bank-conflict free.
+DLPD_HD int slab_swz(int c) { return c ^ ((c >> 4) & 15); }
+template <int RS> struct RowAddr {
+  int base;   // row * RS
+  DLPD_HD int operator()(int e) const { return base + slab_swz(e); }
+};
+template <int RS> struct ColAddr {
+  int base;   // swz(col)
+  DLPD_HD int operator()(int e) const { return e * RS + base; }
+};

@@ -27,3 +27,11 @@ __device__ __forceinline__ void dlpd_glds16(const void* g, void* l) {
 // barrier that orders LDS traffic only (leaves global loads / LDS-DMA in flight)
 #define DLPD_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define DLPD_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// ordering point between lanes of ONE wave that exchange data through LDS: the hardware runs a
+// wave's LDS instructions in order, so only the compiler must be kept from reordering them
+#define DLPD_WAVE_SYNC() asm volatile("" ::: "memory")
+#define DLPD_WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// two consecutive floats from a 4-byte-aligned address with one global_load_dwordx2
+struct __attribute__((packed, aligned(4))) dlpd_pair_t { float x, y; };
+#define DLPD_PAIR dlpd_pair_t
+__device__ __forceinline__ dlpd_pair_t dlpd_load_pair(const float* p) { return *reinterpret_cast<const dlpd_pair_t*>(p); }

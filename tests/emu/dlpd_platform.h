@@ -218,3 +218,8 @@ static inline int max(int a, int b) { return a > b ? a : b; }
 #define DLPD_GLDS16(g, l) memcpy(reinterpret_cast<char*>(l) + 16 * (emu::S().cur % 64), (const void*)(g), 16)
 #define DLPD_LDS_BARRIER() emu::barrier()
 #define DLPD_WAIT_VMEM() ((void)0)
+#define DLPD_WAVE_SYNC() emu::wave_sync()
+#define DLPD_WAIT_LDS() ((void)0)
+struct dlpd_pair_t { float x, y; };
+#define DLPD_PAIR dlpd_pair_t
+static inline dlpd_pair_t dlpd_load_pair(const float* p) { dlpd_pair_t r; r.x = p[0]; r.y = p[1]; return r; }
