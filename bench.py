@@ -226,6 +226,14 @@ def main():
         }
         dom = max((k for k in stages if k in alg), key=lambda k: stages[k])
         ach = alg[dom] / (stages[dom] * 1e-3) / 1e9
+        traffic = None           # PMC-measured bytes per launch of the same command (profiles/)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if pmc["config"] == {"channels": C, "box": L, "batch": nb} and dom in pmc["bytes_per_launch"]:
+                t = pmc["bytes_per_launch"][dom]
+                traffic = (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0
+        except Exception:
+            traffic = None
         out = {
             "metric": "pose correlations/sec (48ch x 64^3 pair, oim06.eul)" if (C, L) == (48, 64)
                       else "pose correlations/sec (%dch x %d^3 pair)" % (C, L),
@@ -242,7 +250,8 @@ def main():
                        "masked_fraction": None if V_first is None else float((V_first == 0).float().mean())},
             "rot_per_s": args.steps * nb * world / elapsed,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": None if traffic is None else "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per gfx950 note)",
                          "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": stages[dom]},
             "stages": {k: {"ms_per_launch": v, "alg_GBps": alg[k] / (v * 1e-3) / 1e9} for k, v in stages.items()},
         }
