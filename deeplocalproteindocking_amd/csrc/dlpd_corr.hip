@@ -161,169 +161,7 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
     o.y = 0.5f * (zk.y - zn.y);
     o.z = 0.5f * (zk.y + zn.y);
     o.w = 0.5f * (zn.x - zk.x);
-    *reinterpret_cast<float4*>(a + (size_t)k * L * L + 2 * m) = o;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// K2: one block per (c, kz), looping over the nb rotations of the batch (persistent over b).
-//   grid (NZ, CT), block 4N threads (N/16 waves), dynamic LDS N*(N+8)*8 B (one swizzled N x N slab).
-//   MODE 0: forward only -> out[(b*CT+c)][kz][kx][ky] = scale * FFT2(pad(A))     (receptor prep)
-//   MODE 1: correlate    -> out = IFFT2( rec * conj(FFT2(pad(A))) )  (unnormalised inverse;
-//                           the 1/N^3 lives in rec)
-//   rec_bstride: element stride between batch entries of rec (0: shared receptor)
-// Per slab: y-forward on the L non-zero rows, x-forward on all columns (pruned first passes), the
-// receptor multiply in registers, and -- because the Stockham output of the last forward x pass
-// leaves thread t with exactly the elements {t + 8m} that the first inverse x pass needs -- the
-// inverse x transform starts from those registers without a trip through LDS.  The next
-// rotation's A slab and this slab's receptor values are prefetched into registers while the
-// current passes run (plain global loads stay in flight across barriers).  The FFT passes are
-// wave-local (dlpd_fft.h): 5 block barriers per slab, waves drift apart between them.
-// ------------------------------------------------------------------------------------------
-#define DLPD_K2_THREADS(N) ((N) * 4)   // N/16 waves; each owns 8 pencils per step (wave-local FFT passes)
-template <int N, int MODE> __global__ void __launch_bounds__(DLPD_K2_THREADS(N))
-k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __restrict__ out,
-          int CT, int nb, long long rec_bstride, float scale) {
-  constexpr int L = N / 2, NZ = N / 2 + 1, RS = N + 8;
-  constexpr int T = FftPlan<N>::T, R1 = FftPlan<N>::R1, R2 = FftPlan<N>::R2;
-  static_assert(T == 8 && RS % 32 == 8, "wave-local layout assumes 8 threads per pencil");
-  constexpr int NT = DLPD_K2_THREADS(N), W = NT / 64;
-  constexpr int NSET = N / 8;                      // pencil sets (8 pencils) per direction
-  constexpr int NLOAD = (L * L / 2) / NT;          // float4 (2 complex) per thread of an A slab
-  static_assert((L * L / 2) % NT == 0 && NLOAD >= 1 && NSET % W == 0 && (L / 8) % W == 0, "shape");
-  typedef FftPassW<N, R1, 1, -1, T, L> FwdP1;      // pruned: only the first L inputs are non-zero
-  typedef FftPassW<N, R2, R1, -1, T> FwdP2;
-  typedef FftPassW<N, R1, 1, +1, T> InvP1;
-  typedef FftPassW<N, R2, R1, +1, T> InvP2;
-  static_assert(InvP1::PER == 1 && InvP1::NBF == T, "register hand-over needs one radix-R1 butterfly per thread");
-  DLPD_DYN_SHARED(cplx, S);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kz = blockIdx.x, c = blockIdx.y;
-  // row phase: lane = 8*q + t  (pencil q of the set, thread t); column phase: lane = 8*t + c8
-  const int tr = lane & 7, qr = lane >> 3;
-  const int tc = lane >> 3, c8 = lane & 7;
-  cplx* tw = S + N * RS;
-  init_twiddles<N>(tw, tid, NT);
-
-  float4 apref[NLOAD];
-  {
-    const float4* a = reinterpret_cast<const float4*>(A + (((size_t)0 * CT + c) * NZ + kz) * L * L);
-#pragma unroll
-    for (int i = 0; i < NLOAD; i++) apref[i] = a[tid + i * NT];
-  }
-  for (int b = 0; b < nb; b++) {
-#pragma unroll
-    for (int i = 0; i < NLOAD; i++) {
-      const int e = 2 * (tid + i * NT), x = e / L, y = e % L;
-      S[x * RS + slab_swz(y)] = c_make(apref[i].x, apref[i].y);
-      S[x * RS + slab_swz(y + 1)] = c_make(apref[i].z, apref[i].w);
-    }
-    __syncthreads();
-    // ---- forward along y on the L non-zero rows: L/8 pencil sets over W waves
-#pragma unroll 1
-    for (int set = wave; set < L / 8; set += W) {
-      const RowAddr<RS> ad = {(set * 8 + qr) * RS};
-      {
-        FwdP1 ps;
-        ps.load(S, ad, tr, nullptr);
-        DLPD_WAVE_SYNC();
-        ps.store(S, ad, tr);
-        DLPD_WAVE_SYNC();
-      }
-      {
-        FwdP2 ps;
-        ps.load(S, ad, tr, tw);
-        DLPD_WAVE_SYNC();
-        ps.store(S, ad, tr);
-      }
-    }
-    __syncthreads();
-    // ---- columns: forward x, receptor multiply, inverse x -- all inside one wave per set
-#pragma unroll 1
-    for (int set = wave; set < NSET; set += W) {
-      const int col = set * 8 + c8;
-      const ColAddr<RS> ad = {slab_swz(col)};
-      cplx rv[FwdP2::PER][R2];
-      if (MODE == 1) {                                   // receptor values: in flight during pass 1
-        const cplx* rbase = rec + (size_t)b * rec_bstride + ((size_t)c * NZ + kz) * N * N;
-        const unsigned roff = (unsigned)tc * N + col;
-#pragma unroll
-        for (int i = 0; i < FwdP2::PER; i++)
-#pragma unroll
-          for (int q = 0; q < R2; q++) rv[i][q] = rbase[roff + (unsigned)((i * T + q * R1) * N)];
-      }
-      {
-        FwdP1 ps;
-        ps.load(S, ad, tc, nullptr);
-        DLPD_WAVE_SYNC();
-        ps.store(S, ad, tc);
-        DLPD_WAVE_SYNC();
-      }
-      if (MODE == 0) {
-        FwdP2 ps;
-        ps.load(S, ad, tc, tw);
-        DLPD_WAVE_SYNC();
-        ps.store(S, ad, tc);
-      } else {
-        InvP1 qs;
-        {
-          FwdP2 ps;
-          ps.load(S, ad, tc, tw);
-          // thread t owns kx = t + i*T + q*R1; the inverse radix-R1 butterfly j = t wants input r1
-          // at kx = t + r1*T  ->  r1 = (i*T + q*R1) / T : a pure register renaming
-#pragma unroll
-          for (int i = 0; i < FwdP2::PER; i++)
-#pragma unroll
-            for (int q = 0; q < R2; q++) qs.v[0][(i * T + q * R1) / T] = c_mulc(rv[i][q], ps.v[i][q]);
-        }
-        SmallDft<R1, +1>::run(qs.v[0]);
-        DLPD_WAVE_SYNC();
-        qs.store(S, ad, tc);
-        DLPD_WAVE_SYNC();
-        InvP2 ps;
-        ps.load(S, ad, tc, tw);
-        DLPD_WAVE_SYNC();
-        ps.store(S, ad, tc);
-      }
-    }
-    __syncthreads();
-    // next rotation's A slab: issued now, consumed at the top of the next iteration
-    if (b + 1 < nb) {
-      const float4* a = reinterpret_cast<const float4*>(A + (((size_t)(b + 1) * CT + c) * NZ + kz) * L * L);
-#pragma unroll
-      for (int i = 0; i < NLOAD; i++) apref[i] = a[tid + i * NT];
-    }
-    if (MODE == 1) {
-      // ---- inverse along y on all N rows
-  #pragma unroll 1
-    for (int set = wave; set < NSET; set += W) {
-        const RowAddr<RS> ad = {(set * 8 + qr) * RS};
-        {
-          InvP1 ps;
-          ps.load(S, ad, tr, nullptr);
-          DLPD_WAVE_SYNC();
-          ps.store(S, ad, tr);
-          DLPD_WAVE_SYNC();
-        }
-        {
-          InvP2 ps;
-          ps.load(S, ad, tr, tw);
-          DLPD_WAVE_SYNC();
-          ps.store(S, ad, tr);
-        }
-      }
-      __syncthreads();
-    }
-    {
-      float4* o = reinterpret_cast<float4*>(out + (((size_t)b * CT + c) * NZ + kz) * N * N);
-      const float sc = (MODE == 0) ? scale : 1.0f;
-      for (int i = tid; i < N * N / 2; i += NT) {
-        const int e = 2 * i, x = e / N, y = e % N;
-        const cplx u = S[x * RS + slab_swz(y)], w = S[x * RS + slab_swz(y + 1)];
-        o[i] = make_float4(u.x * sc, u.y * sc, w.x * sc, w.y * sc);
-      }
-    }
-    __syncthreads();                                     // slab fully read before it is refilled
+    DLPD_STORE_STREAM(reinterpret_cast<float4*>(a + (size_t)k * L * L + 2 * m), o);
   }
 }
 
@@ -343,6 +181,19 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
 // which every thread folds all channels of the group into the hidden units of its 4 voxels.
 #define DLPD_K3_THREADS 512
 #define DLPD_K3_TY 16
+#ifdef DLPD_STAMPS   // diagnostic build only (scripts/stamps_k3.py): where a K3 wave spends its cycles
+__device__ unsigned long long dlpd_stamps[16];
+#define DLPD_STAMP_DECL unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last; \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory")
+#define DLPD_STAMP(slot) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+  st_sum[slot] += t_ - st_last; st_last = t_; } while (0)
+#define DLPD_STAMP_FLUSH(w) do { if (lane == 0 && wave == (w)) { for (int i_ = 0; i_ < 8; i_++) atomicAdd(&dlpd_stamps[i_], st_sum[i_]); \
+  atomicAdd(&dlpd_stamps[15], 1ull); } } while (0)
+#else
+#define DLPD_STAMP_DECL
+#define DLPD_STAMP(slot)
+#define DLPD_STAMP_FLUSH(w)
+#endif
 template <int N, int HP, int MODE> __global__ void __launch_bounds__(DLPD_K3_THREADS)
 k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int C, int has_clash, int G,
                const float* __restrict__ W1t, const float* __restrict__ b1, const float* __restrict__ W2,
@@ -362,6 +213,8 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
   const int y0 = blockIdx.x * TY, xo = blockIdx.y, b = blockIdx.z;
   init_twiddles<N>(tw, tid, NT);
 
+  // hidden pre-activations of the thread's 2*EPT voxels (the SLP vectoriser pairs adjacent
+  // hidden units into v_pk_fma_f32 with the weight pair in SGPRs and the voxel value broadcast)
   float h[EPT * 2][HP > 0 ? HP : 1];
   float nrm[EPT * 2];
   if (MODE == 1) {
@@ -379,45 +232,55 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
   float4* rawg = raw + wave * RAWC;
 
   // this wave's channel of group `cb`: raw[k][m] <- Bw[b][cb+wave][k][xo][y0+2m .. +1]
+  // (lane = 8*(k&7) + m: eight 128-byte runs per DMA instruction; k = N/2 is the ninth, short one)
+  constexpr int NFULL = N / 16;                // full 64-lane DMA instructions per channel (bins 0..N/2-1)
+  static_assert(NZ * NPAIR == NFULL * 64 + NPAIR, "raw channel = NFULL full DMA instructions + one of 8 lanes");
   auto issue_channel = [&](int cb) {
     if (wave < G && cb + wave < CT) {
       const cplx* src = Bw + (((size_t)b * CT + cb + wave) * NZ * N + xo) * N + y0;
-#pragma unroll 1
-      for (int s0 = 0; s0 < NZ * NPAIR; s0 += 64) {
-        int sidx = s0 + lane;
-        sidx = sidx < NZ * NPAIR ? sidx : NZ * NPAIR - 1;   // tail lanes re-read the last element
-        DLPD_GLDS16(src + (size_t)(sidx >> 3) * N * N + 2 * (sidx & 7), rawg + s0);
-      }
+      const cplx* lane_src = src + (size_t)(lane >> 3) * N * N + 2 * (lane & 7);
+#pragma unroll
+      for (int it = 0; it < NFULL; it++) DLPD_GLDS16(lane_src + (size_t)it * 8 * N * N, rawg + it * 64);
+      const int mt = (lane & 7);                            // tail lanes re-read valid elements
+      DLPD_GLDS16(src + (size_t)(N / 2) * N * N + 2 * mt, rawg + NFULL * 64);
     }
   };
   issue_channel(0);
   __syncthreads();                             // twiddle table visible
+  DLPD_STAMP_DECL;
 
   for (int cbase = 0; cbase < CT; cbase += G) {
     const int gn = (CT - cbase) < G ? (CT - cbase) : G;
     if (wave < gn) {
       DLPD_WAIT_VMEM();                        // this wave's own DMA has landed
       DLPD_WAVE_SYNC();
+      DLPD_STAMP(0);
       // pack two rows per complex pencil: Z[k] = A[k] + i B[k], Z[N-k] = conj(A[k]) + i conj(B[k])
-#pragma unroll 1
-      for (int s0 = 0; s0 < NZ * NPAIR; s0 += 64) {
-        const int sidx = s0 + lane;
-        if (sidx < NZ * NPAIR) {
-          const int m = sidx & 7, k = sidx >> 3;
-          const float4 q = rawg[sidx];
-          cplx* P = S + (wave * NPAIR + m) * RS;
-          if (k == 0 || k == N / 2) {
-            P[slab_swz(k)] = c_make(q.x, q.z);             // purely real bins of both rows
+      {
+        const int m = lane & 7, kq = lane >> 3;
+        cplx* P = S + (wave * NPAIR + m) * RS;
+        float4 q[NFULL];
+#pragma unroll
+        for (int it = 0; it < NFULL; it++) q[it] = rawg[it * 64 + lane];
+        const float4 qh = rawg[NFULL * 64 + m];             // k = N/2
+#pragma unroll
+        for (int it = 0; it < NFULL; it++) {
+          const int k = it * 8 + kq;
+          if (it == 0 && kq == 0) {
+            P[slab_swz(0)] = c_make(q[0].x, q[0].z);        // purely real bin of both rows
           } else {
-            P[slab_swz(k)] = c_make(q.x - q.w, q.y + q.z);
-            P[slab_swz(N - k)] = c_make(q.x + q.w, q.z - q.y);
+            P[slab_swz(k)] = c_make(q[it].x - q[it].w, q[it].y + q[it].z);
+            P[slab_swz(N - k)] = c_make(q[it].x + q[it].w, q[it].z - q[it].y);
           }
         }
+        if (kq == 0) P[slab_swz(N / 2)] = c_make(qh.x, qh.z);
       }
       DLPD_WAIT_LDS();                         // raw fully read before it is refilled
       DLPD_WAVE_SYNC();
     }
+    DLPD_STAMP(1);
     issue_channel(cbase + G);                  // next group's channel streams in behind the math
+    DLPD_STAMP(2);
     if (wave < gn) {
       {
         FftPassW<N, R1, 1, +1, T> ps;
@@ -433,39 +296,79 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
         ps.store(S, ad, tr);
       }
     }
+    DLPD_STAMP(3);
     DLPD_LDS_BARRIER();                        // all channels of the group transformed
+    DLPD_STAMP(4);
     if (owner) {
-      for (int g = 0; g < gn; g++) {
-        const int c = cbase + g;
+      if (MODE == 0) {
+        for (int g = 0; g < gn; g++) {
+          const int c = cbase + g;
 #pragma unroll
-        for (int e = 0; e < EPT; e++) {
-          const int m = m0 + e * MSTEP;
-          const cplx val = S[(g * NPAIR + m) * RS + slab_swz(zz)];
-          float v0 = val.x, v1 = val.y;
-          if (MODE == 0) {
-            if (has_clip) { v0 = fminf(fmaxf(v0, -clip), clip); v1 = fminf(fmaxf(v1, -clip), clip); }
+          for (int e = 0; e < EPT; e++) {
+            const int m = m0 + e * MSTEP;
+            const cplx val = S[(g * NPAIR + m) * RS + slab_swz(zz)];
+            float v0 = val.x, v1 = val.y;
+            if (has_clip) { v0 = DLPD_CLAMP(v0, clip); v1 = DLPD_CLAMP(v1, clip); }
             float* o = out + ((((size_t)b * CT + c) * N + xo) * N + y0 + 2 * m) * N + zz;
             o[0] = v0;
             o[N] = v1;
-          } else {
-            if (has_clash && c == C) {
-              nrm[2 * e] = v0; nrm[2 * e + 1] = v1;
-            } else {
-              if (has_clip) { v0 = fminf(fmaxf(v0, -clip), clip); v1 = fminf(fmaxf(v1, -clip), clip); }
-              const float* w = W1t + (size_t)c * HP;
+          }
+        }
+      } else {
+        // score channels of this group; the clash channel (index C, always last) is peeled off
+        const int gs = (cbase + gn <= C) ? gn : (C - cbase > 0 ? C - cbase : 0);
+        // first-layer weights are wave-uniform (scalar loads): channel g+1's row is requested
+        // before channel g's FMAs so the scalar-load latency hides behind them
+        float wcur[HP > 0 ? HP : 1], wnxt[HP > 0 ? HP : 1];
+        cplx vcur[EPT], vnxt[EPT];
+        if (gs > 0) {
 #pragma unroll
-              for (int j = 0; j < HP; j++) {
-                const float wj = w[j];
-                h[2 * e][j] = fmaf(wj, v0, h[2 * e][j]);
-                h[2 * e + 1][j] = fmaf(wj, v1, h[2 * e + 1][j]);
-              }
+          for (int j = 0; j < HP; j++) wcur[j] = W1t[(size_t)cbase * HP + j];
+#pragma unroll
+          for (int e = 0; e < EPT; e++) vcur[e] = S[(m0 + e * MSTEP) * RS + slab_swz(zz)];
+        }
+        for (int g = 0; g < gs; g++) {
+          // channel g+1's weights (scalar loads) and values (LDS) are requested here, one
+          // iteration ahead: both share lgkmcnt, so the only wait sits at the top of the next
+          // iteration, behind this channel's 96 FMAs
+          const int gn1 = (g + 1 < gs ? g + 1 : g);
+#pragma unroll
+          for (int j = 0; j < HP; j++) wnxt[j] = W1t[(size_t)(cbase + gn1) * HP + j];
+#pragma unroll
+          for (int e = 0; e < EPT; e++) vnxt[e] = S[(gn1 * NPAIR + m0 + e * MSTEP) * RS + slab_swz(zz)];
+          DLPD_SCHED_FENCE();
+#pragma unroll
+          for (int e = 0; e < EPT; e++) {
+            float v0 = vcur[e].x, v1 = vcur[e].y;
+            if (has_clip) { v0 = DLPD_CLAMP(v0, clip); v1 = DLPD_CLAMP(v1, clip); }
+#pragma unroll
+            for (int j = 0; j < HP; j++) {
+              h[2 * e][j] = fmaf(wcur[j], v0, h[2 * e][j]);
+              h[2 * e + 1][j] = fmaf(wcur[j], v1, h[2 * e + 1][j]);
             }
+          }
+          DLPD_SCHED_FENCE();
+#pragma unroll
+          for (int j = 0; j < HP; j++) wcur[j] = wnxt[j];
+#pragma unroll
+          for (int e = 0; e < EPT; e++) vcur[e] = vnxt[e];
+        }
+        if (has_clash && cbase + gn > C) {
+          const int g = C - cbase;
+#pragma unroll
+          for (int e = 0; e < EPT; e++) {
+            const cplx v = S[(g * NPAIR + m0 + e * MSTEP) * RS + slab_swz(zz)];
+            nrm[2 * e] = v.x;
+            nrm[2 * e + 1] = v.y;
           }
         }
       }
     }
+    DLPD_STAMP(5);
     DLPD_LDS_BARRIER();                        // pencils free for the next group
+    DLPD_STAMP(6);
   }
+  DLPD_STAMP_FLUSH(DLPD_STAMPS);
   if (MODE == 1 && owner) {
 #pragma unroll
     for (int e = 0; e < EPT; e++) {
@@ -532,16 +435,9 @@ template <int N> static int launch_k1(const float* vol, const float* R, cplx* A,
   return dlpd_check_launch();
 }
 
-template <int N, int MODE> static int launch_k2(const cplx* A, const cplx* rec, cplx* out, int CT, int nb,
-                                                long long rbs, float scale, hipStream_t st) {
-  constexpr int NZ = N / 2 + 1, RS = N + 8;
-  const size_t shmem = (size_t)(N * RS + N) * sizeof(cplx);
-  int rc = dlpd_set_max_dyn_shared((const void*)k_xy_corr<N, MODE>, shmem);
-  if (rc) return rc;
-  dim3 grid(NZ, CT), block(DLPD_K2_THREADS(N));
-  DLPD_LAUNCH((k_xy_corr<N, MODE>), grid, block, shmem, st, A, rec, out, CT, nb, rbs, scale);
-  return dlpd_check_launch();
-}
+// K2 lives in dlpd_k2.hip (its own translation unit: it is built with -fno-slp-vectorize)
+int dlpd_k2_forward(const cplx* A, cplx* out, int CT, int nb, int L, float scale, hipStream_t st);
+int dlpd_k2_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, int L, long long rbs, hipStream_t st);
 
 static int k3_group(int CT, int maxg) {
   int ng = (CT + maxg - 1) / maxg;
@@ -579,6 +475,14 @@ template <int N> static int k3_filter_dispatch(int HP, const cplx* Bw, float* V,
 }
 
 extern "C" {
+
+#ifdef DLPD_STAMPS
+int dlpd_debug_read_stamps(unsigned long long* host16) {
+  if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(dlpd_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  unsigned long long z[16] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(dlpd_stamps), z, sizeof(z)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 int dlpd_version(void) { return 100; }
 
@@ -621,11 +525,7 @@ int dlpd_rfft3d_padded(const float* vol, void* spec, void* wsA, int nvol, int L,
   hipStream_t st = (hipStream_t)stream;
   int rc = dlpd_zfft(vol, nullptr, wsA, 1, nvol, L, 0, 0, 0.f, stream);
   if (rc) return rc;
-  switch (L) {
-    case 32: return launch_k2<64, 0>((const cplx*)wsA, nullptr, (cplx*)spec, nvol, 1, 0, scale, st);
-    case 64: return launch_k2<128, 0>((const cplx*)wsA, nullptr, (cplx*)spec, nvol, 1, 0, scale, st);
-    default: return DLPD_ERR_UNSUPPORTED;
-  }
+  return dlpd_k2_forward((const cplx*)wsA, (cplx*)spec, nvol, 1, L, scale, st);
 }
 
 // wsA (nb, CT, NZ, L, L) x rec (CT or nb*CT spectra) -> wsB (nb, CT, NZ, N, N)
@@ -633,11 +533,7 @@ int dlpd_xy_correlate(const void* wsA, const void* rec, void* wsB, int nb, int C
                       void* stream) {
   if (!wsA || !rec || !wsB || nb <= 0 || CT <= 0) return DLPD_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  switch (L) {
-    case 32: return launch_k2<64, 1>((const cplx*)wsA, (const cplx*)rec, (cplx*)wsB, CT, nb, rec_bstride, 1.f, st);
-    case 64: return launch_k2<128, 1>((const cplx*)wsA, (const cplx*)rec, (cplx*)wsB, CT, nb, rec_bstride, 1.f, st);
-    default: return DLPD_ERR_UNSUPPORTED;
-  }
+  return dlpd_k2_correlate((const cplx*)wsA, (const cplx*)rec, (cplx*)wsB, CT, nb, L, rec_bstride, st);
 }
 
 // wsB -> real correlation volumes out (nb, CT, N^3), optional clamp

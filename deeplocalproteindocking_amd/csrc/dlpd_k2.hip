@@ -1,0 +1,218 @@
+// K2 of the correlation pipeline (see dlpd_corr.hip for the overview): the per-slab 2-D FFT /
+// receptor multiply / 2-D inverse.  Separate translation unit because this kernel runs ~13 %
+// faster built with -fno-slp-vectorize (at 248 VGPRs the SLP vectoriser's register pairing costs
+// more moves than its packed adds save), while K3's MLP wants the vectoriser's v_pk_fma_f32.
+#include <dlpd_platform.h>
+#include "dlpd_fft.h"
+#include "dlpd_internal.h"
+
+template <int N> DLPD_D void init_twiddles(cplx* tw, int tid, int nthreads) {
+  for (int k = tid; k < N; k += nthreads) {
+    double s, c;
+    sincospi(-2.0 * (double)k / (double)N, &s, &c);
+    tw[k] = c_make((float)c, (float)s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: one block per (c, kz), looping over the nb rotations of the batch (persistent over b).
+//   1-D grid NZ*CT*nsplit, block 4N threads (N/16 waves), dynamic LDS N*(N+8)*8 B (one swizzled N x N slab).
+//   MODE 0: forward only -> out[(b*CT+c)][kz][kx][ky] = scale * FFT2(pad(A))     (receptor prep)
+//   MODE 1: correlate    -> out = IFFT2( rec * conj(FFT2(pad(A))) )  (unnormalised inverse;
+//                           the 1/N^3 lives in rec)
+//   rec_bstride: element stride between batch entries of rec (0: shared receptor)
+// Per slab: y-forward on the L non-zero rows, x-forward on all columns (pruned first passes), the
+// receptor multiply in registers, and -- because the Stockham output of the last forward x pass
+// leaves thread t with exactly the elements {t + 8m} that the first inverse x pass needs -- the
+// inverse x transform starts from those registers without a trip through LDS.  The next
+// rotation's A slab and this slab's receptor values are prefetched into registers while the
+// current passes run (plain global loads stay in flight across barriers).  The FFT passes are
+// wave-local (dlpd_fft.h): 5 block barriers per slab, waves drift apart between them.
+// ------------------------------------------------------------------------------------------
+#define DLPD_K2_THREADS(N) ((N) * 4)   // N/16 waves; each owns 8 pencils per step (wave-local FFT passes)
+template <int N, int MODE> __global__ void __launch_bounds__(DLPD_K2_THREADS(N))
+k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __restrict__ out,
+          int CT, int nb, int nsplit, long long rec_bstride, float scale) {
+  constexpr int L = N / 2, NZ = N / 2 + 1, RS = N + 8;
+  constexpr int T = FftPlan<N>::T, R1 = FftPlan<N>::R1, R2 = FftPlan<N>::R2;
+  static_assert(T == 8 && RS % 32 == 8, "wave-local layout assumes 8 threads per pencil");
+  constexpr int NT = DLPD_K2_THREADS(N), W = NT / 64;
+  constexpr int NSET = N / 8;                      // pencil sets (8 pencils) per direction
+  constexpr int NLOAD = (L * L / 2) / NT;          // float4 (2 complex) per thread of an A slab
+  static_assert((L * L / 2) % NT == 0 && NLOAD >= 1 && NSET % W == 0 && (L / 8) % W == 0, "shape");
+  typedef FftPassW<N, R1, 1, -1, T, L> FwdP1;      // pruned: only the first L inputs are non-zero
+  typedef FftPassW<N, R2, R1, -1, T> FwdP2;
+  typedef FftPassW<N, R1, 1, +1, T> InvP1;
+  typedef FftPassW<N, R2, R1, +1, T> InvP2;
+  static_assert(InvP1::PER == 1 && InvP1::NBF == T, "register hand-over needs one radix-R1 butterfly per thread");
+  DLPD_DYN_SHARED(cplx, S);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // 1-D grid of NZ*CT*nsplit blocks.  The batch is cut into nsplit parts handled by blocks whose
+  // ids differ by 8 (same XCD under round-robin dispatch, close in time), so the receptor slab
+  // they share is served by that XCD's L2 instead of crossing the fabric once per rotation.
+  // Speed only: any placement gives the same result.
+  const int bid = blockIdx.x;
+  const int part = (bid >> 3) % nsplit;
+  const int slab = (bid / (8 * nsplit)) * 8 + (bid & 7);
+  if (slab >= NZ * CT) return;
+  const int kz = slab % NZ, c = slab / NZ;
+  const int b_beg = (int)(((long long)nb * part) / nsplit), b_end = (int)(((long long)nb * (part + 1)) / nsplit);
+  if (b_beg >= b_end) return;
+  // row phase: lane = 8*q + t  (pencil q of the set, thread t); column phase: lane = 8*t + c8
+  const int tr = lane & 7, qr = lane >> 3;
+  const int tc = lane >> 3, c8 = lane & 7;
+  cplx* tw = S + N * RS;
+  init_twiddles<N>(tw, tid, NT);
+
+  float4 apref[NLOAD];
+  {
+    const float4* a = reinterpret_cast<const float4*>(A + (((size_t)b_beg * CT + c) * NZ + kz) * L * L);
+#pragma unroll
+    for (int i = 0; i < NLOAD; i++) apref[i] = DLPD_LOAD_STREAM(a + tid + i * NT);
+  }
+  for (int b = b_beg; b < b_end; b++) {
+#pragma unroll
+    for (int i = 0; i < NLOAD; i++) {
+      const int e = 2 * (tid + i * NT), x = e / L, y = e % L;
+      S[x * RS + slab_swz(y)] = c_make(apref[i].x, apref[i].y);
+      S[x * RS + slab_swz(y + 1)] = c_make(apref[i].z, apref[i].w);
+    }
+    __syncthreads();
+    // ---- forward along y on the L non-zero rows: L/8 pencil sets over W waves
+#pragma unroll 1
+    for (int set = wave; set < L / 8; set += W) {
+      const RowAddr<RS> ad = {(set * 8 + qr) * RS};
+      {
+        FwdP1 ps;
+        ps.load(S, ad, tr, nullptr);
+        DLPD_WAVE_SYNC();
+        ps.store(S, ad, tr);
+        DLPD_WAVE_SYNC();
+      }
+      {
+        FwdP2 ps;
+        ps.load(S, ad, tr, tw);
+        DLPD_WAVE_SYNC();
+        ps.store(S, ad, tr);
+      }
+    }
+    __syncthreads();
+    // ---- columns: forward x, receptor multiply, inverse x -- all inside one wave per set
+#pragma unroll 1
+    for (int set = wave; set < NSET; set += W) {
+      const int col = set * 8 + c8;
+      const ColAddr<RS> ad = {slab_swz(col)};
+      cplx rv[FwdP2::PER][R2];
+      if (MODE == 1) {                                   // receptor values: in flight during pass 1
+        const cplx* rbase = rec + (size_t)b * rec_bstride + ((size_t)c * NZ + kz) * N * N;
+        const unsigned roff = (unsigned)tc * N + col;
+#pragma unroll
+        for (int i = 0; i < FwdP2::PER; i++)
+#pragma unroll
+          for (int q = 0; q < R2; q++) rv[i][q] = rbase[roff + (unsigned)((i * T + q * R1) * N)];
+      }
+      {
+        FwdP1 ps;
+        ps.load(S, ad, tc, nullptr);
+        DLPD_WAVE_SYNC();
+        ps.store(S, ad, tc);
+        DLPD_WAVE_SYNC();
+      }
+      if (MODE == 0) {
+        FwdP2 ps;
+        ps.load(S, ad, tc, tw);
+        DLPD_WAVE_SYNC();
+        ps.store(S, ad, tc);
+      } else {
+        InvP1 qs;
+        {
+          FwdP2 ps;
+          ps.load(S, ad, tc, tw);
+          // thread t owns kx = t + i*T + q*R1; the inverse radix-R1 butterfly j = t wants input r1
+          // at kx = t + r1*T  ->  r1 = (i*T + q*R1) / T : a pure register renaming
+#pragma unroll
+          for (int i = 0; i < FwdP2::PER; i++)
+#pragma unroll
+            for (int q = 0; q < R2; q++) qs.v[0][(i * T + q * R1) / T] = c_mulc(rv[i][q], ps.v[i][q]);
+        }
+        SmallDft<R1, +1>::run(qs.v[0]);
+        DLPD_WAVE_SYNC();
+        qs.store(S, ad, tc);
+        DLPD_WAVE_SYNC();
+        InvP2 ps;
+        ps.load(S, ad, tc, tw);
+        DLPD_WAVE_SYNC();
+        ps.store(S, ad, tc);
+      }
+    }
+    __syncthreads();
+    // next rotation's A slab: issued now, consumed at the top of the next iteration
+    if (b + 1 < b_end) {
+      const float4* a = reinterpret_cast<const float4*>(A + (((size_t)(b + 1) * CT + c) * NZ + kz) * L * L);
+#pragma unroll
+      for (int i = 0; i < NLOAD; i++) apref[i] = DLPD_LOAD_STREAM(a + tid + i * NT);
+    }
+    if (MODE == 1) {
+      // ---- inverse along y on all N rows
+  #pragma unroll 1
+    for (int set = wave; set < NSET; set += W) {
+        const RowAddr<RS> ad = {(set * 8 + qr) * RS};
+        {
+          InvP1 ps;
+          ps.load(S, ad, tr, nullptr);
+          DLPD_WAVE_SYNC();
+          ps.store(S, ad, tr);
+          DLPD_WAVE_SYNC();
+        }
+        {
+          InvP2 ps;
+          ps.load(S, ad, tr, tw);
+          DLPD_WAVE_SYNC();
+          ps.store(S, ad, tr);
+        }
+      }
+      __syncthreads();
+    }
+    {
+      float4* o = reinterpret_cast<float4*>(out + (((size_t)b * CT + c) * NZ + kz) * N * N);
+      const float sc = (MODE == 0) ? scale : 1.0f;
+      for (int i = tid; i < N * N / 2; i += NT) {
+        const int e = 2 * i, x = e / N, y = e % N;
+        const cplx u = S[x * RS + slab_swz(y)], w = S[x * RS + slab_swz(y + 1)];
+        DLPD_STORE_STREAM(o + i, make_float4(u.x * sc, u.y * sc, w.x * sc, w.y * sc));
+      }
+    }
+    __syncthreads();                                     // slab fully read before it is refilled
+  }
+}
+
+template <int N, int MODE> static int launch_k2(const cplx* A, const cplx* rec, cplx* out, int CT, int nb,
+                                                long long rbs, float scale, hipStream_t st) {
+  constexpr int NZ = N / 2 + 1, RS = N + 8;
+  const size_t shmem = (size_t)(N * RS + N) * sizeof(cplx);
+  int rc = dlpd_set_max_dyn_shared((const void*)k_xy_corr<N, MODE>, shmem);
+  if (rc) return rc;
+  int nsplit = (MODE == 1 && nb >= 8) ? 2 : 1;
+  if (const char* e = getenv("DLPD_K2_NSPLIT")) nsplit = atoi(e) > 0 ? atoi(e) : nsplit;
+  const int slabs8 = ((NZ * CT + 7) / 8) * 8;
+  dim3 grid(slabs8 * nsplit), block(DLPD_K2_THREADS(N));
+  DLPD_LAUNCH((k_xy_corr<N, MODE>), grid, block, shmem, st, A, rec, out, CT, nb, nsplit, rbs, scale);
+  return dlpd_check_launch();
+}
+
+
+int dlpd_k2_forward(const cplx* A, cplx* out, int CT, int nb, int L, float scale, hipStream_t st) {
+  switch (L) {
+    case 32: return launch_k2<64, 0>(A, nullptr, out, CT, nb, 0, scale, st);
+    case 64: return launch_k2<128, 0>(A, nullptr, out, CT, nb, 0, scale, st);
+    default: return DLPD_ERR_UNSUPPORTED;
+  }
+}
+
+int dlpd_k2_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, int L, long long rbs, hipStream_t st) {
+  switch (L) {
+    case 32: return launch_k2<64, 1>(A, rec, out, CT, nb, rbs, 1.f, st);
+    case 64: return launch_k2<128, 1>(A, rec, out, CT, nb, rbs, 1.f, st);
+    default: return DLPD_ERR_UNSUPPORTED;
+  }
+}

@@ -21,7 +21,7 @@
 __device__ __forceinline__ void dlpd_glds16(const void* g, void* l) {
   const unsigned la =
       __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)l);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(g) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(la), "v"(g) : "memory", "m0");
 }
 #define DLPD_GLDS16(g, l) dlpd_glds16((const void*)(g), (void*)(l))
 // barrier that orders LDS traffic only (leaves global loads / LDS-DMA in flight)
@@ -35,3 +35,26 @@ __device__ __forceinline__ void dlpd_glds16(const void* g, void* l) {
 struct __attribute__((packed, aligned(4))) dlpd_pair_t { float x, y; };
 #define DLPD_PAIR dlpd_pair_t
 __device__ __forceinline__ dlpd_pair_t dlpd_load_pair(const float* p) { return *reinterpret_cast<const dlpd_pair_t*>(p); }
+// streaming (touch-once) global accesses: non-temporal, so they do not evict the reused lines
+typedef float dlpd_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 dlpd_load_stream(const float4* p) {
+  const dlpd_f4v v = __builtin_nontemporal_load(reinterpret_cast<const dlpd_f4v*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void dlpd_store_stream(float4* p, float4 v) {
+  const dlpd_f4v q = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(q, reinterpret_cast<dlpd_f4v*>(p));
+}
+#define DLPD_LOAD_STREAM(p) dlpd_load_stream(p)
+#define DLPD_STORE_STREAM(p, v) dlpd_store_stream((p), (v))
+#include <stdlib.h>
+// clamp to [-c, c] in one v_med3_f32
+#define DLPD_CLAMP(v, c) __builtin_amdgcn_fmed3f((v), -(c), (c))
+// keeps the compiler from moving instructions across this point (software-pipelined loops)
+#define DLPD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// explicit 2 x f32 packed math (v_pk_fma_f32), independent of the SLP vectoriser
+typedef float dlpd_f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ dlpd_f2v dlpd_f2_make(float a, float b) { dlpd_f2v r = {a, b}; return r; }
+__device__ __forceinline__ dlpd_f2v dlpd_f2_splat(float a) { dlpd_f2v r = {a, a}; return r; }
+__device__ __forceinline__ float dlpd_f2_get(dlpd_f2v v, int i) { return i ? v.y : v.x; }
+__device__ __forceinline__ dlpd_f2v dlpd_pk_fma(dlpd_f2v a, dlpd_f2v b, dlpd_f2v c) { return __builtin_elementwise_fma(a, b, c); }

@@ -223,3 +223,12 @@ static inline int max(int a, int b) { return a > b ? a : b; }
 struct dlpd_pair_t { float x, y; };
 #define DLPD_PAIR dlpd_pair_t
 static inline dlpd_pair_t dlpd_load_pair(const float* p) { dlpd_pair_t r; r.x = p[0]; r.y = p[1]; return r; }
+#define DLPD_LOAD_STREAM(p) (*(p))
+#define DLPD_STORE_STREAM(p, v) (*(p) = (v))
+#define DLPD_CLAMP(v, c) fminf(fmaxf((v), -(c)), (c))
+#define DLPD_SCHED_FENCE() ((void)0)
+struct dlpd_f2v { float x, y; };
+static inline dlpd_f2v dlpd_f2_make(float a, float b) { dlpd_f2v r = {a, b}; return r; }
+static inline dlpd_f2v dlpd_f2_splat(float a) { dlpd_f2v r = {a, a}; return r; }
+static inline float dlpd_f2_get(dlpd_f2v v, int i) { return i ? v.y : v.x; }
+static inline dlpd_f2v dlpd_pk_fma(dlpd_f2v a, dlpd_f2v b, dlpd_f2v c) { dlpd_f2v r = {fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; return r; }
