@@ -181,18 +181,8 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
 // which every thread folds all channels of the group into the hidden units of its 4 voxels.
 #define DLPD_K3_THREADS 512
 #define DLPD_K3_TY 16
-#ifdef DLPD_STAMPS   // diagnostic build only (scripts/stamps_k3.py): where a K3 wave spends its cycles
+#ifdef DLPD_STAMPS   // diagnostic build only (scripts/stamps.py): where a K3 wave spends its cycles
 __device__ unsigned long long dlpd_stamps[16];
-#define DLPD_STAMP_DECL unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last; \
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory")
-#define DLPD_STAMP(slot) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
-  st_sum[slot] += t_ - st_last; st_last = t_; } while (0)
-#define DLPD_STAMP_FLUSH(w) do { if (lane == 0 && wave == (w)) { for (int i_ = 0; i_ < 8; i_++) atomicAdd(&dlpd_stamps[i_], st_sum[i_]); \
-  atomicAdd(&dlpd_stamps[15], 1ull); } } while (0)
-#else
-#define DLPD_STAMP_DECL
-#define DLPD_STAMP(slot)
-#define DLPD_STAMP_FLUSH(w)
 #endif
 template <int N, int HP, int MODE> __global__ void __launch_bounds__(DLPD_K3_THREADS)
 k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int C, int has_clash, int G,
@@ -368,7 +358,7 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
     DLPD_LDS_BARRIER();                        // pencils free for the next group
     DLPD_STAMP(6);
   }
-  DLPD_STAMP_FLUSH(DLPD_STAMPS);
+  DLPD_STAMP_FLUSH(dlpd_stamps, DLPD_STAMPS);
   if (MODE == 1 && owner) {
 #pragma unroll
     for (int e = 0; e < EPT; e++) {

@@ -31,3 +31,19 @@ static inline int dlpd_set_max_dyn_shared(const void* fn, size_t bytes) {
   }
   return DLPD_OK;
 }
+
+// In-kernel cycle stamps for DIAGNOSTIC builds (-DDLPD_STAMPS=<wave>): per-phase s_memtime deltas of
+// one wave per block, summed into a __device__ array named `dlpd_stamps`.  Compiles to nothing in
+// the product build; a stamped build is never timed (MI355X guide, "In-kernel stamps").
+#ifdef DLPD_STAMPS
+#define DLPD_STAMP_DECL unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last; \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory")
+#define DLPD_STAMP(slot) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+  st_sum[slot] += t_ - st_last; st_last = t_; } while (0)
+#define DLPD_STAMP_FLUSH(arr, w) do { if (lane == 0 && wave == (w)) { for (int i_ = 0; i_ < 8; i_++) atomicAdd(&arr[i_], st_sum[i_]); \
+  atomicAdd(&arr[15], 1ull); } } while (0)
+#else
+#define DLPD_STAMP_DECL
+#define DLPD_STAMP(slot)
+#define DLPD_STAMP_FLUSH(arr, w)
+#endif

@@ -29,7 +29,18 @@ template <int N> DLPD_D void init_twiddles(cplx* tw, int tid, int nthreads) {
 // current passes run (plain global loads stay in flight across barriers).  The FFT passes are
 // wave-local (dlpd_fft.h): 5 block barriers per slab, waves drift apart between them.
 // ------------------------------------------------------------------------------------------
-#define DLPD_K2_THREADS(N) ((N) * 4)   // N/16 waves; each owns 8 pencils per step (wave-local FFT passes)
+#ifdef DLPD_STAMPS
+__device__ unsigned long long dlpd_stamps_k2[16];
+extern "C" int dlpd_debug_read_stamps_k2(unsigned long long* host16) {
+  if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(dlpd_stamps_k2), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  unsigned long long z[16] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(dlpd_stamps_k2), z, sizeof(z)) == hipSuccess ? 0 : 1;
+}
+#endif
+#ifndef DLPD_K2_WPS
+#define DLPD_K2_WPS 4                    // threads per block = N * DLPD_K2_WPS
+#endif
+#define DLPD_K2_THREADS(N) ((N) * DLPD_K2_WPS)   // N*WPS/64 waves; each owns 8 pencils per step (wave-local FFT passes)
 template <int N, int MODE> __global__ void __launch_bounds__(DLPD_K2_THREADS(N))
 k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __restrict__ out,
           int CT, int nb, int nsplit, long long rec_bstride, float scale) {
@@ -39,7 +50,7 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
   constexpr int NT = DLPD_K2_THREADS(N), W = NT / 64;
   constexpr int NSET = N / 8;                      // pencil sets (8 pencils) per direction
   constexpr int NLOAD = (L * L / 2) / NT;          // float4 (2 complex) per thread of an A slab
-  static_assert((L * L / 2) % NT == 0 && NLOAD >= 1 && NSET % W == 0 && (L / 8) % W == 0, "shape");
+  static_assert((L * L / 2) % NT == 0 && NLOAD >= 1 && NSET % W == 0, "shape");
   typedef FftPassW<N, R1, 1, -1, T, L> FwdP1;      // pruned: only the first L inputs are non-zero
   typedef FftPassW<N, R2, R1, -1, T> FwdP2;
   typedef FftPassW<N, R1, 1, +1, T> InvP1;
@@ -70,14 +81,18 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
 #pragma unroll
     for (int i = 0; i < NLOAD; i++) apref[i] = DLPD_LOAD_STREAM(a + tid + i * NT);
   }
+  DLPD_STAMP_DECL;
   for (int b = b_beg; b < b_end; b++) {
+    DLPD_STAMP(7);
 #pragma unroll
     for (int i = 0; i < NLOAD; i++) {
       const int e = 2 * (tid + i * NT), x = e / L, y = e % L;
       S[x * RS + slab_swz(y)] = c_make(apref[i].x, apref[i].y);
       S[x * RS + slab_swz(y + 1)] = c_make(apref[i].z, apref[i].w);
     }
+    DLPD_STAMP(0);
     __syncthreads();
+    DLPD_STAMP(1);
     // ---- forward along y on the L non-zero rows: L/8 pencil sets over W waves
 #pragma unroll 1
     for (int set = wave; set < L / 8; set += W) {
@@ -96,7 +111,9 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
         ps.store(S, ad, tr);
       }
     }
+    DLPD_STAMP(2);
     __syncthreads();
+    DLPD_STAMP(1);
     // ---- columns: forward x, receptor multiply, inverse x -- all inside one wave per set
 #pragma unroll 1
     for (int set = wave; set < NSET; set += W) {
@@ -145,7 +162,9 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
         ps.store(S, ad, tc);
       }
     }
+    DLPD_STAMP(3);
     __syncthreads();
+    DLPD_STAMP(1);
     // next rotation's A slab: issued now, consumed at the top of the next iteration
     if (b + 1 < b_end) {
       const float4* a = reinterpret_cast<const float4*>(A + (((size_t)(b + 1) * CT + c) * NZ + kz) * L * L);
@@ -171,7 +190,9 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
           ps.store(S, ad, tr);
         }
       }
+      DLPD_STAMP(4);
       __syncthreads();
+      DLPD_STAMP(1);
     }
     {
       float4* o = reinterpret_cast<float4*>(out + (((size_t)b * CT + c) * NZ + kz) * N * N);
@@ -182,8 +203,11 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
         DLPD_STORE_STREAM(o + i, make_float4(u.x * sc, u.y * sc, w.x * sc, w.y * sc));
       }
     }
+    DLPD_STAMP(5);
     __syncthreads();                                     // slab fully read before it is refilled
+    DLPD_STAMP(1);
   }
+  DLPD_STAMP_FLUSH(dlpd_stamps_k2, DLPD_STAMPS);
 }
 
 template <int N, int MODE> static int launch_k2(const cplx* A, const cplx* rec, cplx* out, int CT, int nb,
