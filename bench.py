@@ -174,22 +174,31 @@ def main():
     eng.reset_top()
 
     def step(i, mark=None):
+        # K1,K2,K3 on the main stream; select+merge of the same batch on the engine's side stream
+        # (overlapping the next batch), see DockingEngine.step
+        sl = slice(i * nb, (i + 1) * nb)
+        eng.step(Rd[sl], idd[sl], mark=mark)
+
+    def step_serial(i, mark):
         sl = slice(i * nb, (i + 1) * nb)
         V = eng.score_batch(Rd[sl], mark=mark)
         eng.select_batch(V, nb)
-        if mark:
-            mark("topk_select")
+        mark("topk_select")
         eng.merge_batch(idd[sl], nb)
-        if mark:
-            mark("topk_merge")
+        mark("topk_merge")
 
     for i in range(args.warmup):
         step(i)
     V_first = None
+    eng.finish()
     if rank == 0 and world == 1 and args.cpu_rotations > 0:
         V_first = eng.score_batch(Rd[:nb]).cpu()[:args.cpu_rotations].clone()
-    eng.reset_top()
     timer = StageTimer()
+    for i in range(min(args.warmup, 3)):                   # untimed: per-stage launch durations
+        step_serial(i, timer.mark)
+    torch.cuda.synchronize()
+    stages = timer.summary()
+    eng.reset_top()
 
     def barrier():
         if world > 1:
@@ -198,9 +207,10 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
+    timer = StageTimer()
     for i in range(args.warmup, args.warmup + args.steps):
         step(i, mark=timer.mark)
-    entries = eng.top.entries()                              # D2H of this rank's list
+    entries = eng.top_entries()                              # waits for the side stream; D2H of this rank's list
     if world > 1:                                            # single all-gather + deterministic merge
         from deeplocalproteindocking_amd.Docker import Docker
         dk = Docker.__new__(Docker)
@@ -215,7 +225,7 @@ def main():
 
     if rank == 0:
         poses = float(args.steps) * nb * N ** 3 * world
-        stages = timer.summary()
+        stages.update(timer.summary())                      # K1/K2/K3 as measured inside the timed region
         CT, NZ = C + 1, L + 1
         alg = {   # algorithmic bytes per launch (each kernel's compulsory input + output, fp32)
             "k1_rotate_zfft": CT * L ** 3 * 4 + nb * CT * NZ * L * L * 8,

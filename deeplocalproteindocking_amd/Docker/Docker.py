@@ -187,7 +187,7 @@ class Docker:
             eng.reset_top()
             eng.search(R_all[ids], rot_ids=ids)
             self.engine = eng
-            entries = eng.top.entries()
+            entries = eng.top_entries()
         else:
             entries = self._dock_volumes_multires(rec, lig, receptor_forbidden, ligand_forbidden, batch_size, ids)
         entries = self._gather(entries)

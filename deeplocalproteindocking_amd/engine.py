@@ -162,12 +162,13 @@ class DockingEngine:
             self.lig[self.C] = torch.as_tensor(lig_forbidden, dtype=torch.float32).reshape(L, L, L).to(self.device)
 
     # ---- hot loop ------------------------------------------------------------------------
-    def score_batch(self, R, mark=None):
+    def score_batch(self, R, mark=None, out=None):
         """R (nb,3,3) float32 on the device, nb <= batch.  Returns V[:nb] (view of the engine's
         buffer, overwritten by the next call): Docker.py:218-232."""
         nb = R.shape[0]
         assert nb <= self.batch and R.dtype == torch.float32 and R.is_contiguous()
         has_clip = 0 if self.clip is None else 1
+        V = self.V if out is None else out
         if mark is not None:
             # same three stages as dlpd_score_rotations, with a timing mark after each
             st = _stream(self.device)
@@ -178,18 +179,19 @@ class DockingEngine:
             self.lib.call("dlpd_xy_correlate", _ptr(self.wsA), _ptr(self.recF), _ptr(self.wsB), nb, self.CT,
                           self.L, 0, st)
             mark("k2_xy_corr")
-            self.lib.call("dlpd_zifft_filter", _ptr(self.wsB), _ptr(self.V), nb, self.C, int(self.has_clash),
+            self.lib.call("dlpd_zifft_filter", _ptr(self.wsB), _ptr(V), nb, self.C, int(self.has_clash),
                           self.L, _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2), self.b2, self.HP, has_clip,
                           float(self.clip or 0.0), self.threshold, st)
             mark("k3_zifft_filter")
-            return self.V[:nb]
+            return V[:nb]
         self.lib.call("dlpd_score_rotations", _ptr(self.lig), _ptr(self.recF), _ptr(R), nb, self.C,
                       int(self.has_clash), self.L, self.center, _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2),
                       self.b2, self.HP, has_clip, float(self.clip or 0.0), self.threshold,
-                      _ptr(self.wsA), _ptr(self.wsB), _ptr(self.V), _stream(self.device))
-        return self.V[:nb]
+                      _ptr(self.wsA), _ptr(self.wsB), _ptr(V), _stream(self.device))
+        return V[:nb]
 
     def reset_top(self):
+        self.finish()                                   # nothing of the previous pair still in flight
         self.top.reset()
 
     def select_batch(self, V, nb):
@@ -199,6 +201,42 @@ class DockingEngine:
     def merge_batch(self, rot_ids, nb):
         """Docker.py:100-105 on the device-resident list.  rot_ids int32 (nb,) ascending."""
         self.top.merge(rot_ids, nb)
+
+    # ---- two-stream pipeline: top-K of batch i overlaps K1/K2 of batch i+1 -----------------
+    def step(self, R, rot_ids, mark=None):
+        """One batch: score on the current stream; select + merge on a side stream (they are
+        latency-bound one-block kernels that fit beside the FFT blocks).  V is double-buffered;
+        call finish() before reading the list."""
+        nb = R.shape[0]
+        if self.device.type != "cuda":
+            V = self.score_batch(R, mark=mark)
+            self.select_batch(V, nb)
+            self.merge_batch(rot_ids, nb)
+            return
+        if not hasattr(self, "_side"):
+            self._side = torch.cuda.Stream(device=self.device)
+            self._Vbuf = [self.V, torch.empty_like(self.V)]
+            self._consumed = [None, None]
+            self._k = 0
+        k = self._k
+        self._k ^= 1
+        main = torch.cuda.current_stream(self.device)
+        if self._consumed[k] is not None:
+            main.wait_event(self._consumed[k])          # V[k] free again
+        V = self.score_batch(R, mark=mark, out=self._Vbuf[k])
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ready)
+            self.select_batch(V, nb)
+            self.merge_batch(rot_ids, nb)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        self._consumed[k] = done
+
+    def finish(self):
+        if hasattr(self, "_side"):
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
 
     def search(self, R_all, rot_ids=None, progress=None):
         """Score every rotation in R_all (nrot,3,3) and fold it into the running top list.
@@ -212,14 +250,14 @@ class DockingEngine:
         for beg in range(0, nrot, self.batch):
             end = min(beg + self.batch, nrot)
             nb = end - beg
-            V = self.score_batch(R_all[beg:end])
-            self.select_batch(V, nb)
-            self.merge_batch(rot_ids[beg:end], nb)
+            self.step(R_all[beg:end], rot_ids[beg:end])
             if progress is not None:
                 progress(end)
+        self.finish()
 
     # ---- results ------------------------------------------------------------------------
     def top_entries(self):
+        self.finish()
         return self.top.entries()
 
     def top_list(self):
