@@ -179,26 +179,31 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
 // 8 two-row pencils, and runs the two wave-local FFT passes -- no block barrier involved.  Two
 // block barriers per group separate "all pencils transformed" from the accumulation phase, in
 // which every thread folds all channels of the group into the hidden units of its 4 voxels.
-#define DLPD_K3_THREADS 512
 #define DLPD_K3_TY 16
+// threads per block and number of channel-owning waves (LDS: WC * (8 pencils + raw staging))
+template <int N> struct K3Cfg;
+template <> struct K3Cfg<64> { static constexpr int NT = 512, WC = 8; };
+template <> struct K3Cfg<128> { static constexpr int NT = 512, WC = 8; };
+template <> struct K3Cfg<80> { static constexpr int NT = 320, WC = 5; };
+template <> struct K3Cfg<160> { static constexpr int NT = 640, WC = 5; };
 #ifdef DLPD_STAMPS   // diagnostic build only (scripts/stamps.py): where a K3 wave spends its cycles
 __device__ unsigned long long dlpd_stamps[16];
 #endif
-template <int N, int HP, int MODE> __global__ void __launch_bounds__(DLPD_K3_THREADS)
+template <int N, int HP, int MODE> __global__ void __launch_bounds__(K3Cfg<N>::NT)
 k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int C, int has_clash, int G,
                const float* __restrict__ W1t, const float* __restrict__ b1, const float* __restrict__ W2,
                float b2, int has_clip, float clip, float thr) {
   constexpr int NZ = N / 2 + 1, RS = N + 8, TY = DLPD_K3_TY, NPAIR = TY / 2;
-  constexpr int T = FftPlan<N>::T, R1 = FftPlan<N>::R1, R2 = FftPlan<N>::R2;
-  constexpr int NT = DLPD_K3_THREADS, W = NT / 64;
-  static_assert(T == 8 && NPAIR == 8, "one wave = 8 pencils x 8 threads = one channel of the tile");
+  constexpr int T = 8, R1 = FftPlanW<N>::R1, R2 = FftPlanW<N>::R2;
+  constexpr int NT = K3Cfg<N>::NT, WC = K3Cfg<N>::WC;
+  static_assert(NPAIR == 8 && WC * 64 <= NT, "one wave = 8 pencils x 8 threads = one channel of the tile");
   constexpr int EPT = (NPAIR * N) / NT > 0 ? (NPAIR * N) / NT : 1;   // complex outputs per thread per channel
   constexpr int MSTEP = NT / N;                // pair stride between a thread's outputs
   static_assert((NPAIR * N) % NT == 0 || NPAIR * N < NT, "tile/thread mismatch");
   constexpr int RAWC = ((NZ * NPAIR + 63) / 64) * 64;    // float4 slots per channel (whole waves)
   DLPD_DYN_SHARED(cplx, S);
-  cplx* tw = S + W * NPAIR * RS;
-  float4* raw = reinterpret_cast<float4*>(tw + N);        // [W][RAWC] staging of raw spectra
+  cplx* tw = S + WC * NPAIR * RS;
+  float4* raw = reinterpret_cast<float4*>(tw + N);        // [WC][RAWC] staging of raw spectra
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int y0 = blockIdx.x * TY, xo = blockIdx.y, b = blockIdx.z;
   init_twiddles<N>(tw, tid, NT);
@@ -438,13 +443,13 @@ template <int N, int HP, int MODE> static int launch_k3(const cplx* Bw, float* o
                                                         int nb, const float* W1t, const float* b1, const float* W2,
                                                         float b2, int has_clip, float clip, float thr,
                                                         hipStream_t st) {
-  constexpr int RS = N + 8, NZ = N / 2 + 1, W = DLPD_K3_THREADS / 64, NPAIR = DLPD_K3_TY / 2;
+  constexpr int RS = N + 8, NZ = N / 2 + 1, W = K3Cfg<N>::WC, NPAIR = DLPD_K3_TY / 2;
   constexpr int RAWC = ((NZ * NPAIR + 63) / 64) * 64;
   const size_t shmem = (size_t)(W * NPAIR * RS + N) * sizeof(cplx) + (size_t)W * RAWC * 16;
   int rc = dlpd_set_max_dyn_shared((const void*)k_zifft_filter<N, HP, MODE>, shmem);
   if (rc) return rc;
   const int G = k3_group(CT, W);               // channels per group (one wave each), <= W
-  dim3 grid(N / DLPD_K3_TY, N, nb), block(DLPD_K3_THREADS);
+  dim3 grid(N / DLPD_K3_TY, N, nb), block(K3Cfg<N>::NT);
   DLPD_LAUNCH((k_zifft_filter<N, HP, MODE>), grid, block, shmem, st, Bw, out, CT, C, has_clash, G, W1t, b1, W2, b2,
               has_clip, clip, thr);
   return dlpd_check_launch();
@@ -483,7 +488,7 @@ int dlpd_hidden_pad(int H) {
   return -1;
 }
 
-int dlpd_grid_supported(int L) { return (L == 32 || L == 64) ? 1 : 0; }
+int dlpd_grid_supported(int L) { return (L == 32 || L == 40 || L == 64 || L == 80) ? 1 : 0; }
 
 int dlpd_rotate_trilinear(const float* vol, const float* R, float* out, int B, int C, int L, long long vol_bstride,
                           float center, void* stream) {
@@ -504,7 +509,9 @@ int dlpd_zfft(const float* vol, const float* R, void* wsA, int nb, int CT, int L
   hipStream_t st = (hipStream_t)stream;
   switch (L) {
     case 32: return launch_k1<64>(vol, R, (cplx*)wsA, CT, nb, vol_bstride, do_rotate, center, st);
+    case 40: return launch_k1<80>(vol, R, (cplx*)wsA, CT, nb, vol_bstride, do_rotate, center, st);
     case 64: return launch_k1<128>(vol, R, (cplx*)wsA, CT, nb, vol_bstride, do_rotate, center, st);
+    case 80: return launch_k1<160>(vol, R, (cplx*)wsA, CT, nb, vol_bstride, do_rotate, center, st);
     default: return DLPD_ERR_UNSUPPORTED;
   }
 }
@@ -532,7 +539,9 @@ int dlpd_zifft_real(const void* wsB, float* out, int nb, int CT, int L, int has_
   hipStream_t st = (hipStream_t)stream;
   switch (L) {
     case 32: return launch_k3<64, 0, 0>((const cplx*)wsB, out, CT, CT, 0, nb, nullptr, nullptr, nullptr, 0.f, has_clip, clip, 0.f, st);
+    case 40: return launch_k3<80, 0, 0>((const cplx*)wsB, out, CT, CT, 0, nb, nullptr, nullptr, nullptr, 0.f, has_clip, clip, 0.f, st);
     case 64: return launch_k3<128, 0, 0>((const cplx*)wsB, out, CT, CT, 0, nb, nullptr, nullptr, nullptr, 0.f, has_clip, clip, 0.f, st);
+    case 80: return launch_k3<160, 0, 0>((const cplx*)wsB, out, CT, CT, 0, nb, nullptr, nullptr, nullptr, 0.f, has_clip, clip, 0.f, st);
     default: return DLPD_ERR_UNSUPPORTED;
   }
 }
@@ -546,7 +555,9 @@ int dlpd_zifft_filter(const void* wsB, float* V, int nb, int C, int has_clash, i
   const int CT = C + (has_clash ? 1 : 0);
   switch (L) {
     case 32: return k3_filter_dispatch<64>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st);
+    case 40: return k3_filter_dispatch<80>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st);
     case 64: return k3_filter_dispatch<128>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st);
+    case 80: return k3_filter_dispatch<160>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st);
     default: return DLPD_ERR_UNSUPPORTED;
   }
 }

@@ -222,26 +222,30 @@ template <int N, int R, int NS, int DIR, int T, int NNZ = N> struct FftPassW {
   static constexpr int NBF = N / R;
   static constexpr int PER = (NBF + T - 1) / T;
   static constexpr int RNZ = NNZ / NBF;
-  static_assert(N % R == 0 && NNZ % NBF == 0 && NBF % T == 0, "unsupported wave-local pass shape");
+  static_assert(N % R == 0 && NNZ % NBF == 0, "unsupported wave-local pass shape");
+  static constexpr bool FULL = (NBF % T == 0);     // otherwise the last round is partly idle
   cplx v[PER][R];
 
+  DLPD_HD bool active(int i, int t) const { return FULL || (t + i * T) < NBF; }
   // tw: LDS table of exp(-2 pi i k / N)
   template <class Addr> DLPD_D void load(const cplx* S, const Addr& ad, int t, const cplx* tw) {
 #pragma unroll
     for (int i = 0; i < PER; i++) {
       const int j = t + i * T;
+      if (active(i, t)) {
 #pragma unroll
-      for (int r = 0; r < R; r++) v[i][r] = (r < RNZ) ? S[ad(j + r * NBF)] : c_make(0.f, 0.f);
-      if (NS > 1) {
-        const int k = (j % NS) * (N / (NS * R));
+        for (int r = 0; r < R; r++) v[i][r] = (r < RNZ) ? S[ad(j + r * NBF)] : c_make(0.f, 0.f);
+        if (NS > 1) {
+          const int k = (j % NS) * (N / (NS * R));
 #pragma unroll
-        for (int r = 1; r < R; r++)
-          if (r < RNZ) {
-            const cplx w = tw[k * r];
-            v[i][r] = DIR < 0 ? c_mul(v[i][r], w) : c_mulc(v[i][r], w);
-          }
+          for (int r = 1; r < R; r++)
+            if (r < RNZ) {
+              const cplx w = tw[k * r];
+              v[i][r] = DIR < 0 ? c_mul(v[i][r], w) : c_mulc(v[i][r], w);
+            }
+        }
+        SmallDft<R, DIR>::run(v[i]);
       }
-      SmallDft<R, DIR>::run(v[i]);
     }
   }
   DLPD_HD int out_index(int i, int r, int t) const {
@@ -251,10 +255,19 @@ template <int N, int R, int NS, int DIR, int T, int NNZ = N> struct FftPassW {
   template <class Addr> DLPD_D void store(cplx* S, const Addr& ad, int t) const {
 #pragma unroll
     for (int i = 0; i < PER; i++)
+      if (active(i, t)) {
 #pragma unroll
-      for (int r = 0; r < R; r++) S[ad(out_index(i, r, t))] = v[i][r];
+        for (int r = 0; r < R; r++) S[ad(out_index(i, r, t))] = v[i][r];
+      }
   }
 };
+
+// wave-local plans: 8 threads per pencil, first pass radix R1 (pruned), second radix R2
+template <int N> struct FftPlanW;
+template <> struct FftPlanW<64> { static constexpr int R1 = 8, R2 = 8; };
+template <> struct FftPlanW<128> { static constexpr int R1 = 16, R2 = 8; };
+template <> struct FftPlanW<80> { static constexpr int R1 = 10, R2 = 8; };
+template <> struct FftPlanW<160> { static constexpr int R1 = 10, R2 = 16; };
 
 // slab addressing: element (row, col) of an N x N complex slab with row stride RS (RS % 32 == 8)
 // lives at row*RS + swz(col), swz(c) = c ^ ((c >> 4) & 15): both the contiguous (row pencil) and

@@ -45,17 +45,18 @@ template <int N, int MODE> __global__ void __launch_bounds__(DLPD_K2_THREADS(N))
 k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __restrict__ out,
           int CT, int nb, int nsplit, long long rec_bstride, float scale) {
   constexpr int L = N / 2, NZ = N / 2 + 1, RS = N + 8;
-  constexpr int T = FftPlan<N>::T, R1 = FftPlan<N>::R1, R2 = FftPlan<N>::R2;
-  static_assert(T == 8 && RS % 32 == 8, "wave-local layout assumes 8 threads per pencil");
+  constexpr int T = 8, R1 = FftPlanW<N>::R1, R2 = FftPlanW<N>::R2;
+  static_assert(RS % 16 == 8, "row stride must be an odd multiple of 8 elements (bank spreading)");
   constexpr int NT = DLPD_K2_THREADS(N), W = NT / 64;
   constexpr int NSET = N / 8;                      // pencil sets (8 pencils) per direction
-  constexpr int NLOAD = (L * L / 2) / NT;          // float4 (2 complex) per thread of an A slab
-  static_assert((L * L / 2) % NT == 0 && NLOAD >= 1 && NSET % W == 0, "shape");
+  constexpr int NLOAD = (L * L / 2 + NT - 1) / NT; // float4 (2 complex) per thread of an A slab
+  static_assert(NSET % W == 0, "shape");
   typedef FftPassW<N, R1, 1, -1, T, L> FwdP1;      // pruned: only the first L inputs are non-zero
   typedef FftPassW<N, R2, R1, -1, T> FwdP2;
   typedef FftPassW<N, R1, 1, +1, T> InvP1;
   typedef FftPassW<N, R2, R1, +1, T> InvP2;
-  static_assert(InvP1::PER == 1 && InvP1::NBF == T, "register hand-over needs one radix-R1 butterfly per thread");
+  // register hand-over forward-x pass 2 -> inverse-x pass 1 (power-of-two plans only)
+  constexpr bool HANDOVER = InvP1::PER == 1 && InvP1::NBF == T && (R1 % T == 0) && FwdP2::NBF <= R1;
   DLPD_DYN_SHARED(cplx, S);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // 1-D grid of NZ*CT*nsplit blocks.  The batch is cut into nsplit parts handled by blocks whose
@@ -79,7 +80,8 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
   {
     const float4* a = reinterpret_cast<const float4*>(A + (((size_t)b_beg * CT + c) * NZ + kz) * L * L);
 #pragma unroll
-    for (int i = 0; i < NLOAD; i++) apref[i] = DLPD_LOAD_STREAM(a + tid + i * NT);
+    for (int i = 0; i < NLOAD; i++)
+      if (tid + i * NT < L * L / 2) apref[i] = DLPD_LOAD_STREAM(a + tid + i * NT);
   }
   DLPD_STAMP_DECL;
   for (int b = b_beg; b < b_end; b++) {
@@ -87,8 +89,10 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
 #pragma unroll
     for (int i = 0; i < NLOAD; i++) {
       const int e = 2 * (tid + i * NT), x = e / L, y = e % L;
-      S[x * RS + slab_swz(y)] = c_make(apref[i].x, apref[i].y);
-      S[x * RS + slab_swz(y + 1)] = c_make(apref[i].z, apref[i].w);
+      if (e < L * L) {
+        S[x * RS + slab_swz(y)] = c_make(apref[i].x, apref[i].y);
+        S[x * RS + slab_swz(y + 1)] = c_make(apref[i].z, apref[i].w);
+      }
     }
     DLPD_STAMP(0);
     __syncthreads();
@@ -122,11 +126,13 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
       cplx rv[FwdP2::PER][R2];
       if (MODE == 1) {                                   // receptor values: in flight during pass 1
         const cplx* rbase = rec + (size_t)b * rec_bstride + ((size_t)c * NZ + kz) * N * N;
-        const unsigned roff = (unsigned)tc * N + col;
+        FwdP2 idx;
 #pragma unroll
         for (int i = 0; i < FwdP2::PER; i++)
+          if (idx.active(i, tc)) {
 #pragma unroll
-          for (int q = 0; q < R2; q++) rv[i][q] = rbase[roff + (unsigned)((i * T + q * R1) * N)];
+            for (int q = 0; q < R2; q++) rv[i][q] = rbase[(unsigned)(idx.out_index(i, q, tc) * N) + (unsigned)col];
+          }
       }
       {
         FwdP1 ps;
@@ -137,6 +143,29 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
       }
       if (MODE == 0) {
         FwdP2 ps;
+        ps.load(S, ad, tc, tw);
+        DLPD_WAVE_SYNC();
+        ps.store(S, ad, tc);
+      } else if (!HANDOVER) {
+        {
+          FwdP2 ps;
+          ps.load(S, ad, tc, tw);
+#pragma unroll
+          for (int i = 0; i < FwdP2::PER; i++)
+#pragma unroll
+            for (int q = 0; q < R2; q++) ps.v[i][q] = c_mulc(rv[i][q], ps.v[i][q]);
+          DLPD_WAVE_SYNC();
+          ps.store(S, ad, tc);
+          DLPD_WAVE_SYNC();
+        }
+        {
+          InvP1 ps;
+          ps.load(S, ad, tc, nullptr);
+          DLPD_WAVE_SYNC();
+          ps.store(S, ad, tc);
+          DLPD_WAVE_SYNC();
+        }
+        InvP2 ps;
         ps.load(S, ad, tc, tw);
         DLPD_WAVE_SYNC();
         ps.store(S, ad, tc);
@@ -169,7 +198,8 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
     if (b + 1 < b_end) {
       const float4* a = reinterpret_cast<const float4*>(A + (((size_t)(b + 1) * CT + c) * NZ + kz) * L * L);
 #pragma unroll
-      for (int i = 0; i < NLOAD; i++) apref[i] = DLPD_LOAD_STREAM(a + tid + i * NT);
+      for (int i = 0; i < NLOAD; i++)
+        if (tid + i * NT < L * L / 2) apref[i] = DLPD_LOAD_STREAM(a + tid + i * NT);
     }
     if (MODE == 1) {
       // ---- inverse along y on all N rows
@@ -225,10 +255,154 @@ template <int N, int MODE> static int launch_k2(const cplx* A, const cplx* rec, 
 }
 
 
+// ------------------------------------------------------------------------------------------
+// Split path for grids whose N x N complex slab does not fit the 160 KB LDS (N = 160, the
+// reference's box_size 80): the same per-slab transform as k_xy_corr in three tile kernels that
+// work IN PLACE on the output slab (rows 0..L-1 hold the y-forward result in between), so no
+// extra workspace is needed.  Plain barrier-separated passes (FftPass); correctness path for the
+// reference's real model shapes, not tuned.
+// ------------------------------------------------------------------------------------------
+template <int N, int RT> __global__ void __launch_bounds__(RT * FftPlan<N>::T)
+k2s_fwd_y(const cplx* __restrict__ A, cplx* __restrict__ B) {
+  constexpr int L = N / 2, RS = N + 1;
+  constexpr int T = FftPlan<N>::T, R1 = FftPlan<N>::R1, R2 = FftPlan<N>::R2, NT = RT * T;
+  __shared__ cplx S[RT * RS + N];
+  cplx* tw = S + RT * RS;
+  const int tid = threadIdx.x, r0 = blockIdx.y * RT;
+  const size_t slab = blockIdx.x;
+  init_twiddles<N>(tw, tid, NT);
+  const cplx* a = A + slab * L * L + (size_t)r0 * L;
+  for (int i = tid; i < RT * L; i += NT) S[(i / L) * RS + (i % L)] = a[i];
+  __syncthreads();
+  const int p = tid % RT, t = tid / RT;
+  {
+    FftPass<N, R1, 1, -1, T, L> ps;
+    ps.load(S + p * RS, 1, t, tw);
+    __syncthreads();
+    ps.store(S + p * RS, 1, t);
+    __syncthreads();
+  }
+  {
+    FftPass<N, R2, R1, -1, T> ps;
+    ps.load(S + p * RS, 1, t, tw);
+    __syncthreads();
+    ps.store(S + p * RS, 1, t);
+    __syncthreads();
+  }
+  cplx* o = B + slab * N * N + (size_t)r0 * N;
+  for (int i = tid; i < RT * N; i += NT) o[i] = S[(i / N) * RS + (i % N)];
+}
+
+template <int N, int MODE, int CW> __global__ void __launch_bounds__(CW * FftPlan<N>::T)
+k2s_cols(cplx* __restrict__ B, const cplx* __restrict__ rec, int CT, long long rec_bstride, float scale) {
+  constexpr int L = N / 2, NZ = N / 2 + 1, RSC = CW + 1;
+  constexpr int T = FftPlan<N>::T, R1 = FftPlan<N>::R1, R2 = FftPlan<N>::R2, NT = CW * T;
+  DLPD_DYN_SHARED(cplx, S);
+  cplx* tw = S + N * RSC;
+  const int tid = threadIdx.x, c0 = blockIdx.y * CW;
+  const size_t slab = blockIdx.x;
+  const int kz = (int)(slab % NZ), c = (int)((slab / NZ) % CT), b = (int)(slab / ((size_t)NZ * CT));
+  init_twiddles<N>(tw, tid, NT);
+  cplx* bs = B + slab * N * N + c0;
+  for (int i = tid; i < L * CW; i += NT) S[(i / CW) * RSC + (i % CW)] = bs[(size_t)(i / CW) * N + (i % CW)];
+  __syncthreads();
+  const int p = tid % CW, t = tid / CW;
+  {
+    FftPass<N, R1, 1, -1, T, L> ps;
+    ps.load(S + p, RSC, t, tw);
+    __syncthreads();
+    ps.store(S + p, RSC, t);
+    __syncthreads();
+  }
+  {
+    FftPass<N, R2, R1, -1, T> ps;
+    ps.load(S + p, RSC, t, tw);
+    __syncthreads();
+    if (MODE == 1) {
+      const cplx* r = rec + (size_t)b * rec_bstride + ((size_t)c * NZ + kz) * N * N + c0 + p;
+#pragma unroll
+      for (int i = 0; i < ps.PER; i++)
+        if (ps.active(i, t)) {
+#pragma unroll
+          for (int q = 0; q < R2; q++) ps.v[i][q] = c_mulc(r[(size_t)ps.out_index(i, q, t) * N], ps.v[i][q]);
+        }
+    }
+    ps.store(S + p, RSC, t);
+    __syncthreads();
+  }
+  if (MODE == 1) {
+    {
+      FftPass<N, R1, 1, +1, T> ps;
+      ps.load(S + p, RSC, t, tw);
+      __syncthreads();
+      ps.store(S + p, RSC, t);
+      __syncthreads();
+    }
+    {
+      FftPass<N, R2, R1, +1, T> ps;
+      ps.load(S + p, RSC, t, tw);
+      __syncthreads();
+      ps.store(S + p, RSC, t);
+      __syncthreads();
+    }
+  }
+  const float sc = (MODE == 0) ? scale : 1.0f;
+  for (int i = tid; i < N * CW; i += NT) {
+    const cplx u = S[(i / CW) * RSC + (i % CW)];
+    bs[(size_t)(i / CW) * N + (i % CW)] = c_make(u.x * sc, u.y * sc);
+  }
+}
+
+template <int N, int RT> __global__ void __launch_bounds__(RT * FftPlan<N>::T)
+k2s_inv_y(cplx* __restrict__ B) {
+  constexpr int RS = N + 1;
+  constexpr int T = FftPlan<N>::T, R1 = FftPlan<N>::R1, R2 = FftPlan<N>::R2, NT = RT * T;
+  __shared__ cplx S[RT * RS + N];
+  cplx* tw = S + RT * RS;
+  const int tid = threadIdx.x, r0 = blockIdx.y * RT;
+  const size_t slab = blockIdx.x;
+  init_twiddles<N>(tw, tid, NT);
+  cplx* o = B + slab * N * N + (size_t)r0 * N;
+  for (int i = tid; i < RT * N; i += NT) S[(i / N) * RS + (i % N)] = o[i];
+  __syncthreads();
+  const int p = tid % RT, t = tid / RT;
+  {
+    FftPass<N, R1, 1, +1, T> ps;
+    ps.load(S + p * RS, 1, t, tw);
+    __syncthreads();
+    ps.store(S + p * RS, 1, t);
+    __syncthreads();
+  }
+  {
+    FftPass<N, R2, R1, +1, T> ps;
+    ps.load(S + p * RS, 1, t, tw);
+    __syncthreads();
+    ps.store(S + p * RS, 1, t);
+    __syncthreads();
+  }
+  for (int i = tid; i < RT * N; i += NT) o[i] = S[(i / N) * RS + (i % N)];
+}
+
+template <int N, int MODE> static int launch_k2_split(const cplx* A, const cplx* rec, cplx* out, int CT, int nb,
+                                                      long long rbs, float scale, hipStream_t st) {
+  constexpr int L = N / 2, NZ = N / 2 + 1, RT = 16, CW = 32, T = FftPlan<N>::T;
+  static_assert(L % RT == 0 && N % RT == 0 && N % CW == 0, "tile sizes must divide the grid");
+  const unsigned nslab = (unsigned)nb * CT * NZ;
+  DLPD_LAUNCH((k2s_fwd_y<N, RT>), dim3(nslab, L / RT), dim3(RT * T), 0, st, A, out);
+  const size_t shmem = (size_t)(N * (CW + 1) + N) * sizeof(cplx);
+  int rc = dlpd_set_max_dyn_shared((const void*)k2s_cols<N, MODE, CW>, shmem);
+  if (rc) return rc;
+  DLPD_LAUNCH((k2s_cols<N, MODE, CW>), dim3(nslab, N / CW), dim3(CW * T), shmem, st, out, rec, CT, rbs, scale);
+  if (MODE == 1) DLPD_LAUNCH((k2s_inv_y<N, RT>), dim3(nslab, N / RT), dim3(RT * T), 0, st, out);
+  return dlpd_check_launch();
+}
+
 int dlpd_k2_forward(const cplx* A, cplx* out, int CT, int nb, int L, float scale, hipStream_t st) {
   switch (L) {
     case 32: return launch_k2<64, 0>(A, nullptr, out, CT, nb, 0, scale, st);
+    case 40: return launch_k2<80, 0>(A, nullptr, out, CT, nb, 0, scale, st);
     case 64: return launch_k2<128, 0>(A, nullptr, out, CT, nb, 0, scale, st);
+    case 80: return launch_k2_split<160, 0>(A, nullptr, out, CT, nb, 0, scale, st);
     default: return DLPD_ERR_UNSUPPORTED;
   }
 }
@@ -236,7 +410,9 @@ int dlpd_k2_forward(const cplx* A, cplx* out, int CT, int nb, int L, float scale
 int dlpd_k2_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, int L, long long rbs, hipStream_t st) {
   switch (L) {
     case 32: return launch_k2<64, 1>(A, rec, out, CT, nb, rbs, 1.f, st);
+    case 40: return launch_k2<80, 1>(A, rec, out, CT, nb, rbs, 1.f, st);
     case 64: return launch_k2<128, 1>(A, rec, out, CT, nb, rbs, 1.f, st);
+    case 80: return launch_k2_split<160, 1>(A, rec, out, CT, nb, rbs, 1.f, st);
     default: return DLPD_ERR_UNSUPPORTED;
   }
 }

@@ -55,7 +55,7 @@ class VolumeConvolution(nn.Module):
         B, C, L = v1.shape[0], v1.shape[1], v1.shape[2]
         lib = get_lib()
         if not lib.call("dlpd_grid_supported", L):
-            raise RuntimeError("dlpd: VolumeConvolution box size %d not compiled (supported: 32, 64)" % L)
+            raise RuntimeError("dlpd: VolumeConvolution box size %d not compiled (supported: 32, 40, 64, 80)" % L)
         N, NZ, nvol = 2 * L, L + 1, B * C
         dev, st = v1.device, _stream(v1.device)
         wsA = torch.empty(nvol * NZ * L * L * 2, dtype=torch.float32, device=dev)

@@ -49,7 +49,7 @@ def _oracle_V(rec, lig, recf, ligf, W, R1, thr, clip):
 
 
 @pytest.mark.parametrize("L,C,nrot,clip", [(32, 4, 5, 5.0), (32, 4, 3, 0.3), (32, 48, 2, 5.0), (64, 48, 2, 5.0),
-                                           (64, 6, 3, None)])
+                                           (64, 6, 3, None), (40, 32, 2, 5.0), (80, 16, 2, 5.0)])
 def test_scores_match_oracle(dev, L, C, nrot, clip):
     from deeplocalproteindocking_amd.engine import DockingEngine
     rec, lig, recf, ligf, W1, b1, W2, b2 = _pair(L, C, seed=L + C, amp=0.05)
@@ -207,6 +207,36 @@ def test_volume_ops_properties_at_full_size(dev):
     Rr = torch.from_numpy(_rots(2, seed=8)).float()
     got = rot(vol, Rr.to(dev)).cpu()
     assert (got - orc.rotate_volume(volc, Rr)).abs().max() < 1e-4
+
+
+def test_reference_model_shapes_multires(dev):
+    """The reference's real layout [16 @ 80^3, 32 @ 40^3] -> 160^3 (local_train.py:23,30;
+    ProteinRepresentationModels.py:35-36): GlobalDockingModel.forward on the stand-alone ops and
+    Docker.dock_volumes (multi-resolution path) against the oracle."""
+    from deeplocalproteindocking_amd.Docker import Docker
+    from deeplocalproteindocking_amd.Models import GlobalDockingModel, SimpleFilter, SyntheticRepr
+    L, K = 80, 50
+    torch.manual_seed(31)
+    repr_ = SyntheticRepr(num_outputs=(16, 32), seed=5, amplitude=0.12)
+    filt = SimpleFilter(repr_.get_num_outputs())
+    model = GlobalDockingModel(repr_, filt, threshold_clash=0.02 * L ** 3).to(dev)
+    rec, lig = repr_.make(L, "rec"), repr_.make(L, "lig")
+    assert [tuple(v.shape) for v in rec] == [(1, 16, 80, 80, 80), (1, 32, 40, 40, 40)]
+    W = [w.cpu() for w in filt.parameters_tuple()]
+    V = model([v.to(dev) for v in rec], [v.to(dev) for v in lig]).cpu()
+    Vo = orc.score_volumes(rec, lig, *W, clip=5.0)
+    assert V.shape == (1, 160, 160, 160)
+    assert (V - Vo).abs().max() <= TOL * Vo.abs().max()
+    R = _rots(3, seed=15)
+    g = torch.Generator().manual_seed(32)
+    recf, ligf = torch.rand(L, L, L, generator=g), torch.rand(L, L, L, generator=g)
+    dk = Docker(model, box_size=L, max_conf=K, rotations=R, device=dev)
+    got = dk.dock_volumes(rec, lig, recf, ligf, batch_size=2, write=False)
+    want = orc.dock_volumes(rec, lig, recf[None, None], ligf[None, None], R, *W, 0.02 * L ** 3, K, clip=5.0,
+                            faithful_topk=False)
+    scale = float(Vo.abs().max())
+    assert max(abs(a[4] - b[4]) for a, b in zip(got, want)) <= TOL * scale
+    assert sum(a[:4] == b[:4] for a, b in zip(got, want)) >= K - 3
 
 
 def test_global_docking_model_forward_and_docker_dock_volumes(dev):

@@ -43,6 +43,24 @@ def test_fused_pipeline_matches_oracle(emu):
         assert ((V[i] - Vo).abs()[sure]).max() <= 1e-4 * Vo.abs().max()
 
 
+def test_fused_pipeline_radix5_grid(emu):
+    """L = 40 (N = 80 = 10 x 8): radix-5/10 butterflies, partly idle passes, no register hand-over."""
+    L, C = 40, 3
+    rec, lig, recf, ligf, W1, b1, W2, b2 = _pair(L, 4, seed=7)
+    rec, lig, W1 = rec[:C], lig[:C], W1[:, :C]
+    thr = 0.125 * L ** 3
+    R = orc.euler_to_matrix([0.9], [0.7], [-1.4])
+    eng = DockingEngine(L, C, W1, b1, W2, b2, clip=5.0, threshold_clash=thr, max_conf=16, batch=1, device="cpu", lib=emu)
+    eng.set_receptor(rec, recf)
+    eng.set_ligand(lig, ligf)
+    V = eng.score_batch(torch.from_numpy(R).float().contiguous()).clone()
+    Rb = torch.from_numpy(R).float()
+    mask, norm = orc.clash_mask(recf[None, None], orc.rotate_volume(ligf[None, None], Rb), thr)
+    Vo = (mask * orc.score_volumes([rec[None]], [orc.rotate_volume(lig[None], Rb)], W1, b1, W2, b2, clip=5.0))[0]
+    sure = (norm[0] - thr).abs() > 1e-3 * thr
+    assert ((V[0] - Vo).abs()[sure]).max() <= 1e-4 * Vo.abs().max()
+
+
 def test_search_with_odd_tail_matches_oracle_list(emu):
     L, C, K = 32, 4, 40
     rec, lig, recf, ligf, W1, b1, W2, b2 = _pair(L, C, seed=1)
