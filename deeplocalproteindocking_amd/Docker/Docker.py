@@ -156,7 +156,7 @@ class Docker:
         return np.arange(self.rank, nrot, self.world_size, dtype=np.int64)
 
     def dock_volumes(self, receptor_volumes, ligand_volumes, receptor_forbidden=None, ligand_forbidden=None,
-                     batch_size=8, rot_indices=None, write=True):
+                     batch_size=8, rot_indices=None, write=True, clash_provider=None):
         """Search all rotations for one pair given its representation volumes.
 
         receptor_volumes / ligand_volumes: lists of (1,C_i,L_i,L_i,L_i) (or (C_i,L_i,..)) tensors
@@ -183,20 +183,22 @@ class Docker:
                                 has_clash=has_clash, max_conf=self.max_conf, batch=batch_size, device=self.device,
                                 lib=self._lib)
             eng.set_receptor(rec[0], receptor_forbidden)
-            eng.set_ligand(lig[0], ligand_forbidden)
+            eng.set_ligand(lig[0], ligand_forbidden if ligand_forbidden is not None else torch.zeros(L, L, L))
+            eng.clash_provider = clash_provider
             eng.reset_top()
             eng.search(R_all[ids], rot_ids=ids)
             self.engine = eng
             entries = eng.top_entries()
         else:
-            entries = self._dock_volumes_multires(rec, lig, receptor_forbidden, ligand_forbidden, batch_size, ids)
+            entries = self._dock_volumes_multires(rec, lig, receptor_forbidden, ligand_forbidden, batch_size, ids,
+                                                  clash_provider)
         entries = self._gather(entries)
         self.top_list = DeviceTopList.to_top_list(entries, 2 * L)
         if write:
             self.write_conformations()
         return self.top_list
 
-    def _dock_volumes_multires(self, rec, lig, rec_forb, lig_forb, batch_size, ids):
+    def _dock_volumes_multires(self, rec, lig, rec_forb, lig_forb, batch_size, ids, clash_provider=None):
         """Reference-shaped loop on the stand-alone ops (any number of resolutions): rotate,
         clash correlation, model forward, mask multiply, device top-K."""
         from deeplocalproteindocking_amd.ops import VolumeConvolution, VolumeRotation, filter_volumes
@@ -211,7 +213,8 @@ class Docker:
         has_clash = rec_forb is not None
         if has_clash:
             rf = torch.as_tensor(rec_forb, dtype=torch.float32).reshape(1, 1, L, L, L).to(dev)
-            lf = torch.as_tensor(lig_forb, dtype=torch.float32).reshape(1, 1, L, L, L).to(dev)
+            if clash_provider is None:
+                lf = torch.as_tensor(lig_forb, dtype=torch.float32).reshape(1, 1, L, L, L).to(dev)
         R_all = self.rot.R
         W1, b1, W2, b2 = model.filter.parameters_tuple()
         for beg in range(0, len(ids), batch_size):
@@ -223,8 +226,9 @@ class Docker:
             convolved = [model.convolve(r, l) for r, l in zip(rec_b, lig_rot)]
             norm = None
             if has_clash:
-                norm = conv_noclip(rf.expand(nb, -1, -1, -1, -1).contiguous(),
-                                   rotate(lf.expand(nb, -1, -1, -1, -1).contiguous(), Rb)).squeeze(1).contiguous()
+                lfr = (clash_provider(Rb).reshape(nb, 1, L, L, L).contiguous() if clash_provider is not None
+                       else rotate(lf.expand(nb, -1, -1, -1, -1).contiguous(), Rb))
+                norm = conv_noclip(rf.expand(nb, -1, -1, -1, -1).contiguous(), lfr).squeeze(1).contiguous()
             V = filter_volumes(convolved, W1, b1, W2, float(b2.reshape(-1)[0]), mask_norm=norm,
                                threshold=model.threshold_clash)
             top.select(V.reshape(nb, -1), nb)
@@ -270,6 +274,7 @@ class Docker:
         be = self._need_backend()
         coords, chains, resnames, resnums, atomnames, num_atoms = be.pdb2coords(filenames)
         coords, num_atoms_of_type, offsets = be.assign_types(coords, resnames, atomnames, num_atoms)
+        num_atoms = getattr(be, "last_num_typed", num_atoms)        # untyped atoms (hydrogens) were dropped
         a, b = be.get_bbox(coords, num_atoms)
         if bbox_center:
             translation = -(a + b) * 0.5 + self.box_length / 2.0
@@ -279,7 +284,9 @@ class Docker:
         return coords, num_atoms_of_type, offsets, translation, num_atoms
 
     def dockSE3(self, ureceptor, uligand, batch_size):
-        """Docker.py:184-238: representations computed once, ligand volumes rotated on the GPU."""
+        """Docker.py:184-238: representations computed once, ligand volumes rotated on the GPU, and
+        the ligand forbidden volume re-projected from the rotated ATOMS every batch (Docker.py:221-224)
+        -- by one kernel that rotates on the fly, without the reference's per-batch host round trip."""
         be = self._need_backend()
         self.top_list = []
         self.docking_model.eval()
@@ -289,15 +296,20 @@ class Docker:
             rcoords = be.rotate(rcoords, self.randR, rnatoms)
         rcoords = be.translate(rcoords, self.box_center, rnatoms)
         lcoords_trans = be.translate(lcoords, self.box_center, lnatoms)
+        L, res, dev = self.box_size, self.resolution, self.device
         with torch.no_grad():
-            receptor = be.project(rcoords, rnat, roff, self.box_size, self.resolution, self.device)
+            receptor = be.project(rcoords, rnat, roff, L, res, dev)
             receptor_volumes = self.docking_model.representation(receptor)
             receptor_forbidden = receptor.sum(dim=1)[0]
-            ligand = be.project(lcoords_trans, lnat, loff, self.box_size, self.resolution, self.device)
+            ligand = be.project(lcoords_trans, lnat, loff, L, res, dev)
             ligand_volumes = self.docking_model.representation(ligand)
-            ligand_forbidden = ligand.sum(dim=1)[0]
-            self.dock_volumes(receptor_volumes, ligand_volumes, receptor_forbidden, ligand_forbidden,
-                              batch_size=batch_size)
+            lc, ln, lo = be.to_device(lcoords, lnat, loff, dev)          # origin-centred ligand atoms
+
+            def provider(Rb):   # rotate about the origin, translate to the box centre, project, sum types
+                return be.project(lc, ln, lo, L, res, dev, R=Rb, shift=self.box_center, sum_types=True)
+
+            self.dock_volumes(receptor_volumes, ligand_volumes, receptor_forbidden, None, batch_size=batch_size,
+                              clash_provider=provider)
 
     def dockE3(self, ureceptor, uligand, batch_size):
         """Docker.py:135-182: the ligand is rotated in coordinate space and re-projected and
@@ -322,13 +334,13 @@ class Docker:
             receptor = be.project(rcoords, rnat, roff, self.box_size, self.resolution, dev)
             receptor_volumes = model.representation(receptor)
             receptor_forbidden = receptor.sum(dim=1).unsqueeze(dim=1).contiguous()
+            lc, ln, lo = be.to_device(lcoords, lnat, loff, dev)
             for beg in range(0, len(ids), batch_size):
                 bid = ids[beg:beg + batch_size]
                 nb = len(bid)
-                r_batch = self.rot.R[bid]
-                lrot = be.rotate(lcoords.expand(nb, -1), r_batch, lnatoms.expand(nb))
-                lrot = be.translate(lrot, self.box_center.expand(nb, -1), lnatoms.expand(nb))
-                ligand = be.project(lrot, lnat.expand(nb, -1), loff.expand(nb, -1), self.box_size, self.resolution, dev)
+                Rb = self.rot.R[bid].to(device=dev, dtype=torch.float32).contiguous()
+                # rotate + translate + project in one kernel (Docker.py:163-165)
+                ligand = be.project(lc, ln, lo, self.box_size, self.resolution, dev, R=Rb, shift=self.box_center)
                 ligand_volumes = model.representation(ligand)
                 ligand_forbidden = ligand.sum(dim=1).unsqueeze(dim=1).contiguous()
                 norm = conv_noclip(receptor_forbidden.expand(nb, -1, -1, -1, -1).contiguous(), ligand_forbidden)

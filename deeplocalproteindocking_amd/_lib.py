@@ -22,6 +22,8 @@ SIGNATURES = {
     "dlpd_hidden_pad": (_i, [_i]),
     "dlpd_rotate_trilinear": (_i, [_p, _p, _p, _i, _i, _i, _ll, _f, _p]),
     "dlpd_zfft": (_i, [_p, _p, _p, _i, _i, _i, _ll, _i, _f, _p]),
+    "dlpd_zfft_into": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _ll, _i, _f, _p]),
+    "dlpd_project_atoms": (_i, [_p, _p, _p, _p, _f, _f, _f, _p, _i, _i, _i, _i, _f, _i, _p]),
     "dlpd_rfft3d_padded": (_i, [_p, _p, _p, _i, _i, _f, _p]),
     "dlpd_xy_correlate": (_i, [_p, _p, _p, _i, _i, _i, _ll, _p]),
     "dlpd_zifft_real": (_i, [_p, _p, _i, _i, _i, _i, _f, _p]),
@@ -49,6 +51,10 @@ class DlpdLib:
                 "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
                 "There is no CPU fallback." % path)
         self.path = path
+        # torch must be imported BEFORE the library is loaded: it brings its own libamdhip64, and
+        # libdlpd.so's DT_NEEDED entry then binds to that already-loaded runtime.  Loaded the other
+        # way round the process holds two HIP runtimes and ours sees "no ROCm-capable device".
+        import torch  # noqa: F401
         self._dll = ctypes.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(self._dll, name)          # AttributeError if a symbol is missing

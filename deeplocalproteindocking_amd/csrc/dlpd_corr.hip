@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(256) k_rotate(const float* __restrict__ vol, c
 // ------------------------------------------------------------------------------------------
 template <int N> __global__ void __launch_bounds__((N / 4) * FftPlan<N>::T)
 k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* __restrict__ A,
-              int CT, int nb, long long vol_bstride, int do_rotate, float c0) {
+              int CT, int nb, long long vol_bstride, int do_rotate, float c0, int CT_out, int c_base) {
   constexpr int L = N / 2, NZ = N / 2 + 1, RS = N + 1, NP = L / 2;
   constexpr int T = FftPlan<N>::T, R1 = FftPlan<N>::R1, R2 = FftPlan<N>::R2;
   constexpr int NT = NP * T;
@@ -150,7 +150,7 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
     __syncthreads();
   }
   // untangle the two real rows packed in each complex pencil; write [kz][x][y]
-  cplx* a = A + ((size_t)b * CT + c) * NZ * L * L + (size_t)x * L;
+  cplx* a = A + ((size_t)b * CT_out + c_base + c) * NZ * L * L + (size_t)x * L;
   for (int s = tid; s < NP * NZ; s += NT) {
     const int m = s % NP, k = s / NP;
     const cplx zk = S[m * RS + k];
@@ -422,11 +422,12 @@ k_filter_generic(const float* __restrict__ conv0, int C0, int N0, const float* _
 // host-side launchers
 // ------------------------------------------------------------------------------------------
 template <int N> static int launch_k1(const float* vol, const float* R, cplx* A, int CT, int nb, long long vbs,
-                                      int do_rotate, float c0, hipStream_t st) {
+                                      int do_rotate, float c0, hipStream_t st, int CT_out = 0, int c_base = 0) {
   constexpr int L = N / 2;
   const int groups = ((CT * nb + 7) / 8) * 8;
   dim3 grid(groups * L), block((N / 4) * FftPlan<N>::T);
-  DLPD_LAUNCH((k_rotate_zfft<N>), grid, block, 0, st, vol, R, A, CT, nb, vbs, do_rotate, c0);
+  DLPD_LAUNCH((k_rotate_zfft<N>), grid, block, 0, st, vol, R, A, CT, nb, vbs, do_rotate, c0,
+              CT_out > 0 ? CT_out : CT, c_base);
   return dlpd_check_launch();
 }
 
@@ -501,19 +502,25 @@ int dlpd_rotate_trilinear(const float* vol, const float* R, float* out, int B, i
   return dlpd_check_launch();
 }
 
-// vol (nb*CT volumes as (nb, CT, L^3), or one (CT, L^3) set with vol_bstride = 0) -> wsA
-int dlpd_zfft(const float* vol, const float* R, void* wsA, int nb, int CT, int L, long long vol_bstride,
-              int do_rotate, float center, void* stream) {
-  if (!vol || !wsA || nb <= 0 || CT <= 0) return DLPD_ERR_ARG;
+// vol (nb*CT volumes as (nb, CT, L^3), or one (CT, L^3) set with vol_bstride = 0) -> channels
+// [c_base, c_base + CT) of wsA (nb, CT_out, NZ, L, L)
+int dlpd_zfft_into(const float* vol, const float* R, void* wsA, int nb, int CT, int CT_out, int c_base, int L,
+                   long long vol_bstride, int do_rotate, float center, void* stream) {
+  if (!vol || !wsA || nb <= 0 || CT <= 0 || c_base < 0 || c_base + CT > CT_out) return DLPD_ERR_ARG;
   if (do_rotate && !R) return DLPD_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   switch (L) {
-    case 32: return launch_k1<64>(vol, R, (cplx*)wsA, CT, nb, vol_bstride, do_rotate, center, st);
-    case 40: return launch_k1<80>(vol, R, (cplx*)wsA, CT, nb, vol_bstride, do_rotate, center, st);
-    case 64: return launch_k1<128>(vol, R, (cplx*)wsA, CT, nb, vol_bstride, do_rotate, center, st);
-    case 80: return launch_k1<160>(vol, R, (cplx*)wsA, CT, nb, vol_bstride, do_rotate, center, st);
+    case 32: return launch_k1<64>(vol, R, (cplx*)wsA, CT, nb, vol_bstride, do_rotate, center, st, CT_out, c_base);
+    case 40: return launch_k1<80>(vol, R, (cplx*)wsA, CT, nb, vol_bstride, do_rotate, center, st, CT_out, c_base);
+    case 64: return launch_k1<128>(vol, R, (cplx*)wsA, CT, nb, vol_bstride, do_rotate, center, st, CT_out, c_base);
+    case 80: return launch_k1<160>(vol, R, (cplx*)wsA, CT, nb, vol_bstride, do_rotate, center, st, CT_out, c_base);
     default: return DLPD_ERR_UNSUPPORTED;
   }
+}
+
+int dlpd_zfft(const float* vol, const float* R, void* wsA, int nb, int CT, int L, long long vol_bstride,
+              int do_rotate, float center, void* stream) {
+  return dlpd_zfft_into(vol, R, wsA, nb, CT, CT, 0, L, vol_bstride, do_rotate, center, stream);
 }
 
 // Padded 3-D R2C spectrum of nvol real (L^3) volumes: spec (nvol, NZ, N, N) [kz][kx][ky], times scale.

@@ -1,6 +1,7 @@
 // Internal helpers shared by the dlpd kernel translation units.
 #pragma once
 #include <dlpd_platform.h>
+#include <stdio.h>
 
 #define DLPD_OK 0
 #define DLPD_ERR_ARG 1          // null pointer / non-positive size
@@ -16,7 +17,11 @@ static inline int& dlpd_launch_failed() { static thread_local int f = 0; return 
   do {                                                                  \
     (void)hipGetLastError();                                            \
     DLPD_LAUNCH_RAW(kern, grid, block, shmem, stream, __VA_ARGS__);     \
-    if (hipGetLastError() != hipSuccess) dlpd_launch_failed() = 1;      \
+    const hipError_t e_ = hipGetLastError();                            \
+    if (e_ != hipSuccess) {                                             \
+      dlpd_launch_failed() = 1;                                         \
+      fprintf(stderr, "dlpd: launch of %s failed: %s\n", #kern, hipGetErrorString(e_)); \
+    }                                                                   \
   } while (0)
 static inline int dlpd_check_launch() {
   const int f = dlpd_launch_failed();

@@ -141,6 +141,9 @@ class DockingEngine:
         self.wsB = torch.empty(nb * CT * NZ * N * N * 2, dtype=f32, device=dev)
         self.V = torch.empty(nb, N, N, N, dtype=f32, device=dev)
         self.top = DeviceTopList(self.K, nb, dev, lib)
+        # optional: callable(R (nb,3,3) f32 device) -> (nb,L,L,L) f32 device ligand forbidden volumes
+        # re-projected from rotated ATOMS (Docker.py:221-224) instead of the rotated volume
+        self.clash_provider = None
 
     # ---- inputs ------------------------------------------------------------------------
     def set_receptor(self, rec_volumes, rec_forbidden=None):
@@ -169,6 +172,19 @@ class DockingEngine:
         assert nb <= self.batch and R.dtype == torch.float32 and R.is_contiguous()
         has_clip = 0 if self.clip is None else 1
         V = self.V if out is None else out
+        if self.clash_provider is not None and self.has_clash:
+            st = _stream(self.device)
+            forb = self.clash_provider(R).reshape(nb, self.L, self.L, self.L).contiguous()
+            self.lib.call("dlpd_zfft_into", _ptr(self.lig), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0,
+                          self.L, 0, 1, self.center, st)
+            self.lib.call("dlpd_zfft_into", _ptr(forb), 0, _ptr(self.wsA), nb, 1, self.CT, self.C, self.L,
+                          self.L ** 3, 0, 0.0, st)
+            self.lib.call("dlpd_xy_correlate", _ptr(self.wsA), _ptr(self.recF), _ptr(self.wsB), nb, self.CT,
+                          self.L, 0, st)
+            self.lib.call("dlpd_zifft_filter", _ptr(self.wsB), _ptr(V), nb, self.C, 1, self.L, _ptr(self.W1t),
+                          _ptr(self.b1), _ptr(self.W2), self.b2, self.HP, has_clip, float(self.clip or 0.0),
+                          self.threshold, st)
+            return V[:nb]
         if mark is not None:
             # same three stages as dlpd_score_rotations, with a timing mark after each
             st = _stream(self.device)

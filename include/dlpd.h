@@ -41,6 +41,20 @@ int dlpd_rotate_trilinear(const float* vol, const float* R, float* out, int B, i
 int dlpd_zfft(const float* vol, const float* R, void* wsA, int nb, int CT, int L, long long vol_bstride,
               int do_rotate, float center, void* stream);
 
+/* Same, writing channels [c_base, c_base+CT) of a (nb, CT_out, NZ, L, L) workspace: lets the clash
+ * channel come from per-rotation re-projected atoms (Docker.py:221-224) while the score channels are
+ * rotated volumes (Docker.py:218). */
+int dlpd_zfft_into(const float* vol, const float* R, void* wsA, int nb, int CT, int CT_out, int c_base, int L,
+                   long long vol_bstride, int do_rotate, float center, void* stream);
+
+/* CoordsRotate + CoordsTranslate + TypedCoords2Volume (+ channel sum) of src/Docker/Docker.py:204,
+ * 208,221-224 in one kernel: p' = R_b p + shift, density exp(-|r - p'|^2 / 2) on the 5^3 voxels
+ * around each atom (build-defined shape).  coords (B, 3*stride_atoms) ordered by type,
+ * num_atoms_of_type / offsets (B, ntypes) int32.  out (B, ntypes, L^3) or (B, 1, L^3) if sum_types. */
+int dlpd_project_atoms(const float* coords, const int* num_atoms_of_type, const int* offsets, const float* R,
+                       float shift_x, float shift_y, float shift_z, float* out, int B, int stride_atoms,
+                       int ntypes, int L, float resolution, int sum_types, void* stream);
+
 /* Zero-padded 3-D R2C spectrum (receptor side of VolumeConvolution, DockingModels.py:71):
  * spec (nvol, NZ, N, N) = scale * rfftn(pad(vol)).  wsA: nvol*NZ*L*L complex64 scratch. */
 int dlpd_rfft3d_padded(const float* vol, void* spec, void* wsA, int nvol, int L, float scale, void* stream);

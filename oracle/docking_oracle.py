@@ -295,6 +295,31 @@ def format_conformations(top_list, R_all, box_size, resolution, randR=None):
 
 
 # --------------------------------------------------------------------------------------
+# Atom projection (TPL TypedCoords2Volume at Docker.py:204,208,223) -- build-defined shape
+# --------------------------------------------------------------------------------------
+
+def project_atoms(coords, num_atoms_of_type, offsets, L, resolution, R=None, shift=None, sum_types=False):
+    """coords (3*Nmax,) ordered by type; every atom adds exp(-|r - p'|^2 / 2) to the 5^3 voxels
+    around p' = R p + shift (voxel (i,j,k) at (i,j,k)*resolution).  float64.  -> (T or 1, L,L,L)."""
+    T = len(num_atoms_of_type)
+    out = np.zeros((1 if sum_types else T, L, L, L), dtype=np.float64)
+    xyz = np.asarray(coords, dtype=np.float64).reshape(-1, 3)
+    R = np.eye(3) if R is None else np.asarray(R, dtype=np.float64)
+    shift = np.zeros(3) if shift is None else np.asarray(shift, dtype=np.float64).reshape(3)
+    for t in range(T):
+        for a in range(int(offsets[t]), int(offsets[t]) + int(num_atoms_of_type[t])):
+            p = R @ xyz[a] + shift
+            c = np.floor(p / resolution).astype(int)
+            for i in range(c[0] - 2, c[0] + 3):
+                for j in range(c[1] - 2, c[1] + 3):
+                    for k in range(c[2] - 2, c[2] + 3):
+                        if 0 <= i < L and 0 <= j < L and 0 <= k < L:
+                            d = p - np.array([i, j, k]) * resolution
+                            out[0 if sum_types else t, i, j, k] += np.exp(-0.5 * d @ d)
+    return out
+
+
+# --------------------------------------------------------------------------------------
 # Whole search (Docker.dockSE3 loop, Docker.py:211-238) on volumes
 # --------------------------------------------------------------------------------------
 

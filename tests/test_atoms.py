@@ -1,0 +1,241 @@
+"""Atom-level front end (SURVEY.md 8(f) rows 1,3): PDB reader, 11-type typing, projection kernel and
+Docker.dockSE3 / dockE3 end to end.  CPU tests run the kernel sources under the emulator."""
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import docking_oracle as orc
+from deeplocalproteindocking_amd.Utils.FullAtom import CoordsBackend, NUM_ATOM_TYPES, atom_type, read_pdb_atoms
+
+RES = {"GLY": ["N", "CA", "C", "O"], "ALA": ["N", "CA", "C", "O", "CB"],
+       "SER": ["N", "CA", "C", "O", "CB", "OG"], "CYS": ["N", "CA", "C", "O", "CB", "SG"],
+       "LYS": ["N", "CA", "C", "O", "CB", "CG", "CD", "CE", "NZ"],
+       "ASP": ["N", "CA", "C", "O", "CB", "CG", "OD1", "OD2"],
+       "ARG": ["N", "CA", "C", "O", "CB", "CG", "CD", "NE", "CZ", "NH1", "NH2"],
+       "PHE": ["N", "CA", "C", "O", "CB", "CG", "CD1", "CD2", "CE1", "CE2", "CZ"],
+       "HIS": ["N", "CA", "C", "O", "CB", "CG", "ND1", "CD2", "CE1", "NE2"],
+       "ASN": ["N", "CA", "C", "O", "CB", "CG", "OD1", "ND2"]}
+
+
+def write_fake_pdb(path, nres, seed, radius=10.0):
+    """A random-coil 'protein': residues of mixed types scattered in a ball (geometry is irrelevant
+    to the code under test), plus a hydrogen and a HETATM line that must be ignored."""
+    rng = np.random.RandomState(seed)
+    names = list(RES)
+    lines, serial = [], 1
+    for r in range(nres):
+        rn = names[rng.randint(len(names))]
+        centre = rng.normal(size=3) * radius / 2.0
+        for an in RES[rn]:
+            x, y, z = centre + rng.normal(size=3) * 1.5
+            lines.append("ATOM  %5d %-4s %3s A%4d    %8.3f%8.3f%8.3f  1.00  0.00" % (
+                serial, (" " + an) if len(an) < 4 else an, rn, r + 1, x, y, z))
+            serial += 1
+    lines.insert(3, "ATOM  %5d  H   GLY A   1    %8.3f%8.3f%8.3f  1.00  0.00" % (9999, 0.0, 0.0, 0.0))
+    lines.append("HETATM%5d  O   HOH A 999    %8.3f%8.3f%8.3f  1.00  0.00" % (serial, 1.0, 1.0, 1.0))
+    lines.append("END")
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    return serial - 1
+
+
+def test_atom_typing_table():
+    assert atom_type("CYS", "SG") == 0 and atom_type("MET", "SD") == 0
+    assert atom_type("ALA", "N") == 1 and atom_type("ASN", "ND2") == 1
+    assert atom_type("HIS", "NE2") == 2 and atom_type("TRP", "NE1") == 2
+    assert atom_type("ARG", "NH1") == 3 and atom_type("LYS", "NZ") == 4
+    assert atom_type("GLY", "O") == 5 and atom_type("GLN", "OE1") == 5
+    assert atom_type("SER", "OG") == 6 and atom_type("TYR", "OH") == 6
+    assert atom_type("ASP", "OD2") == 7 and atom_type("GLU", "OE1") == 7 and atom_type("LEU", "OXT") == 7
+    assert atom_type("ALA", "C") == 8 and atom_type("ARG", "CZ") == 8
+    assert atom_type("PHE", "CZ") == 9 and atom_type("TRP", "CH2") == 9
+    assert atom_type("ALA", "CA") == 10 and atom_type("LEU", "CD1") == 10
+    assert atom_type("GLY", "H") == -1 and atom_type("ALA", "1HB") == -1
+
+
+def test_backend_parsing_typing_and_transforms(tmp_path):
+    f = str(tmp_path / "a.pdb")
+    nheavy = write_fake_pdb(f, 12, seed=1)
+    xyz, chains, resn, resi, atn = read_pdb_atoms(f)
+    assert len(xyz) == nheavy + 1                                  # the H is read, HETATM is not
+    be = CoordsBackend()
+    coords, ch, rn, ri, an, nat = be.pdb2coords([f, f])
+    typed, counts, offs = be.assign_types(coords, rn, an, nat)
+    assert counts.shape == (2, NUM_ATOM_TYPES) and int(counts[0].sum()) == nheavy
+    assert be.last_num_typed.tolist() == [nheavy, nheavy]
+    assert offs[0].tolist() == (np.cumsum(counts[0].numpy()) - counts[0].numpy()).tolist()
+    # atoms of type t sit in slots [offs[t], offs[t]+counts[t]) and keep file order
+    ty = np.array([atom_type(rn[0][i], an[0][i]) for i in range(len(an[0]))])
+    for t in range(NUM_ATOM_TYPES):
+        want = xyz[ty == t]
+        got = typed[0, 3 * int(offs[0, t]):3 * int(offs[0, t] + counts[0, t])].reshape(-1, 3).numpy()
+        np.testing.assert_allclose(got, want)
+    a, b = be.get_bbox(typed, be.last_num_typed)
+    np.testing.assert_allclose(a[0].numpy(), xyz[ty >= 0].min(0))
+    T = -(a + b) * 0.5
+    centred = be.translate(typed, T, be.last_num_typed)
+    a2, b2 = be.get_bbox(centred, be.last_num_typed)
+    assert (a2 + b2).abs().max() < 1e-9
+    R = torch.from_numpy(orc.euler_to_matrix([0.4], [1.0], [-0.7]))
+    rot = be.rotate(centred, R, be.last_num_typed)
+    n = nheavy
+    np.testing.assert_allclose(rot[0, :3 * n].reshape(n, 3).numpy(),
+                               centred[0, :3 * n].reshape(n, 3).numpy() @ R[0].numpy().T, atol=1e-12)
+    assert rot[0, 3 * n:].abs().max() == 0 if rot.shape[1] > 3 * n else True
+
+
+def _typed(tmp_path, nres, seed):
+    f = str(tmp_path / ("p%d.pdb" % seed))
+    write_fake_pdb(f, nres, seed)
+    be = CoordsBackend()
+    coords, ch, rn, ri, an, nat = be.pdb2coords([f])
+    typed, counts, offs = be.assign_types(coords, rn, an, nat)
+    a, b = be.get_bbox(typed, be.last_num_typed)
+    return f, be.translate(typed, -(a + b) * 0.5, be.last_num_typed), counts, offs
+
+
+def test_projection_kernel_matches_oracle(emu, tmp_path):
+    L, res = 24, 1.25
+    _, coords, counts, offs = _typed(tmp_path, 10, seed=3)
+    be = CoordsBackend(lib=emu)
+    centre = torch.full((1, 3), L * res / 2.0, dtype=torch.double)
+    R = torch.from_numpy(orc.euler_to_matrix([0.4, -2.0], [1.0, 0.3], [-0.7, 1.9])).float()
+    vol = be.project(coords, counts, offs, L, res, "cpu", R=R, shift=centre)
+    assert vol.shape == (2, NUM_ATOM_TYPES, L, L, L)
+    for b in range(2):
+        want = orc.project_atoms(coords[0].numpy(), counts[0].numpy(), offs[0].numpy(), L, res,
+                                 R=R[b].double().numpy(), shift=centre[0].numpy())
+        assert np.abs(vol[b].numpy() - want).max() < 1e-4
+        assert want.sum() > 10
+    s = be.project(coords, counts, offs, L, res, "cpu", R=R, shift=centre, sum_types=True)
+    assert (s[:, 0] - vol.sum(dim=1)).abs().max() < 1e-4
+    plain = be.project(be.translate(coords, centre, torch.tensor([int(counts.sum())])), counts, offs, L, res, "cpu")
+    want = orc.project_atoms(coords[0].numpy(), counts[0].numpy(), offs[0].numpy(), L, res, shift=centre[0].numpy())
+    assert np.abs(plain[0].numpy() - want).max() < 1e-4
+
+
+class _TinyRepr(torch.nn.Module):
+    """single-resolution stand-in for a representation plugin: fixed random 11 -> C 3x3x3 conv"""
+
+    def __init__(self, C=4):
+        super().__init__()
+        torch.manual_seed(77)
+        self.conv = torch.nn.Conv3d(NUM_ATOM_TYPES, C, 3, padding=1, bias=False)
+        self.C = C
+
+    def get_num_outputs(self):
+        return [self.C]
+
+    def forward(self, volume):
+        return [self.conv(volume) * 0.05]
+
+
+class _Model(torch.nn.Module):
+    def __init__(self, repr_, filt, thr):
+        super().__init__()
+        self.representation, self.filter, self.threshold_clash, self.clip = repr_, filt, thr, 5.0
+
+
+def _dock_reference_shape(be, model, frec, flig, R, L, res, K):
+    """The reference loop of Docker.dockSE3 restated with the oracle pieces."""
+    centre = torch.full((1, 3), L * res / 2.0, dtype=torch.double)
+
+    def load(f):
+        c, ch, rn, ri, an, nat = be.pdb2coords([f])
+        t, cnt, off = be.assign_types(c, rn, an, nat)
+        a, b = be.get_bbox(t, be.last_num_typed)
+        return be.translate(t, -(a + b) * 0.5, be.last_num_typed), cnt, off
+    rc, rn_, ro = load(frec)
+    lc, ln_, lo = load(flig)
+    rec = torch.from_numpy(orc.project_atoms(rc[0].numpy(), rn_[0].numpy(), ro[0].numpy(), L, res,
+                                             shift=centre[0].numpy())).float()[None]
+    lig = torch.from_numpy(orc.project_atoms(lc[0].numpy(), ln_[0].numpy(), lo[0].numpy(), L, res,
+                                             shift=centre[0].numpy())).float()[None]
+    with torch.no_grad():
+        rv, lv = model.representation(rec), model.representation(lig)
+    W = [w.cpu() for w in model.filter.parameters_tuple()]
+    top, scale = [], 0.0
+    for ri in range(R.shape[0]):
+        Rb = torch.from_numpy(R[ri:ri + 1]).float()
+        lrot = [orc.rotate_volume(v, Rb) for v in lv]
+        lforb = torch.from_numpy(orc.project_atoms(lc[0].numpy(), ln_[0].numpy(), lo[0].numpy(), L, res, R=R[ri],
+                                                   shift=centre[0].numpy(), sum_types=True)).float()[None]
+        mask, _ = orc.clash_mask(rec.sum(dim=1, keepdim=True), lforb, model.threshold_clash)
+        V = (mask * orc.score_volumes(rv, lrot, *W, clip=5.0))[0].contiguous()
+        scale = max(scale, float(V.abs().max()))
+        idx, sc = orc.rotation_picks_fast(V.numpy(), K)
+        x, y, z = orc.flat_to_xyz(idx, 2 * L)
+        top += [(ri, int(x[i]), int(y[i]), int(z[i]), float(sc[i])) for i in range(K)]
+        top.sort(key=lambda t: t[4])
+        top = top[:K]
+    return top, scale
+
+
+def test_dockSE3_end_to_end_emulated(emu, tmp_path):
+    """PDB files -> Docker.dockSE3 -> .dat, all kernels emulated, vs the oracle restatement."""
+    from deeplocalproteindocking_amd.Docker import Docker
+    from deeplocalproteindocking_amd.Models import SimpleFilter
+    L, res, K = 32, 1.25, 20
+    frec, _, _, _ = _typed(tmp_path, 14, seed=5)
+    flig, _, _, _ = _typed(tmp_path, 9, seed=6)
+    torch.manual_seed(78)
+    model = _Model(_TinyRepr(4), SimpleFilter([4]), thr=3.0)
+    R = orc.euler_to_matrix([0.3, -1.0, 2.0], [1.1, 0.4, 2.2], [-2.0, 2.5, 0.1])
+    be = CoordsBackend(lib=emu)
+    dk = Docker(model, box_size=L, resolution=res, max_conf=K, rotations=R, device="cpu", coords_backend=be, lib=emu)
+    log = str(tmp_path / "out.dat")
+    assert dk.new_log(log)
+    with torch.no_grad():
+        dk.dockSE3(frec, flig, batch_size=2)
+    dk.cleanup()
+    want, scale = _dock_reference_shape(be, model, frec, flig, R, L, res, K)
+    assert len(dk.top_list) == K
+    assert max(abs(a[4] - b[4]) for a, b in zip(dk.top_list, want)) <= 1e-4 * scale
+    assert sum(a[:4] == b[:4] for a, b in zip(dk.top_list, want)) >= K - 2
+    lines = open(log).read().strip().split("\n")
+    assert len(lines) == K and all(len(l.split("\t")) == 13 for l in lines)
+    assert dk.new_log(log, rewrite=False) is False              # finished target is skipped on resume
+
+
+@pytest.mark.gpu
+def test_dockSE3_and_dockE3_on_gpu(tmp_path):
+    """Same on the real device, plus dockE3 (re-projection + representation per batch) with the
+    reference-shaped two-resolution CNN plugin; both entry points must agree on a single-resolution
+    model up to the trilinear-vs-reprojection difference being absent (E3 == SE3 only for R = I)."""
+    import __graft_entry__ as entry
+    entry.build()
+    from deeplocalproteindocking_amd.Docker import Docker
+    from deeplocalproteindocking_amd.Models import E3MultiResRepr4x4, GlobalDockingModel, SimpleFilter
+    dev = torch.device("cuda:0")
+    L, res, K = 32, 1.25, 30
+    frec, _, _, _ = _typed(tmp_path, 14, seed=5)
+    flig, _, _, _ = _typed(tmp_path, 9, seed=6)
+    torch.manual_seed(78)
+    model = _Model(_TinyRepr(4), SimpleFilter([4]), thr=3.0).to(dev)
+    R = orc.euler_to_matrix([0.3, -1.0, 2.0], [1.1, 0.4, 2.2], [-2.0, 2.5, 0.1])
+    be = CoordsBackend()
+    dk = Docker(model, box_size=L, resolution=res, max_conf=K, rotations=R, device=dev, coords_backend=be)
+    with torch.no_grad():
+        dk.dockSE3(frec, flig, batch_size=2)
+    cpu_model = _Model(_TinyRepr(4), model.filter.cpu(), thr=3.0)
+    want, scale = _dock_reference_shape(be, cpu_model, frec, flig, R, L, res, K)
+    assert max(abs(a[4] - b[4]) for a, b in zip(dk.top_list, want)) <= 1e-4 * scale
+    assert sum(a[:4] == b[:4] for a, b in zip(dk.top_list, want)) >= K - 2
+    # two-resolution reference-shaped plugin through dockE3 and dockSE3 with the identity rotation:
+    # both must give the same list (no rotation -> re-projection == the unrotated volumes)
+    torch.manual_seed(79)
+    repr2 = E3MultiResRepr4x4(multiplier=2)
+    gm = GlobalDockingModel(repr2, SimpleFilter(repr2.get_num_outputs()), threshold_clash=3.0).to(dev)
+    I = np.eye(3)[None]
+    L2 = 64                                                   # second resolution 32^3 (16^3 is not compiled)
+    d1 = Docker(gm, box_size=L2, resolution=res, max_conf=K, rotations=I, device=dev, coords_backend=be)
+    d2 = Docker(gm, box_size=L2, resolution=res, max_conf=K, rotations=I, device=dev, coords_backend=be)
+    with torch.no_grad():
+        d1.dockSE3(frec, flig, batch_size=1)
+        d2.dockE3(frec, flig, batch_size=1)
+    s = max(abs(t[4]) for t in d1.top_list) + 1e-6
+    assert max(abs(a[4] - b[4]) for a, b in zip(d1.top_list, d2.top_list)) <= 1e-4 * s
+    assert sum(a[:4] == b[:4] for a, b in zip(d1.top_list, d2.top_list)) >= K - 2
