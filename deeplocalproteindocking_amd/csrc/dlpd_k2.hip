@@ -37,6 +37,9 @@ extern "C" int dlpd_debug_read_stamps_k2(unsigned long long* host16) {
   return hipMemcpyToSymbol(HIP_SYMBOL(dlpd_stamps_k2), z, sizeof(z)) == hipSuccess ? 0 : 1;
 }
 #endif
+#ifndef DLPD_K2_LATE_REC
+#define DLPD_K2_LATE_REC 0
+#endif
 #ifndef DLPD_K2_WPS
 #define DLPD_K2_WPS 4                    // threads per block = N * DLPD_K2_WPS
 #endif
@@ -124,7 +127,7 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
       const int col = set * 8 + c8;
       const ColAddr<RS> ad = {slab_swz(col)};
       cplx rv[FwdP2::PER][R2];
-      if (MODE == 1) {                                   // receptor values: in flight during pass 1
+      auto load_rec = [&]() {
         const cplx* rbase = rec + (size_t)b * rec_bstride + ((size_t)c * NZ + kz) * N * N;
         FwdP2 idx;
 #pragma unroll
@@ -133,7 +136,10 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
 #pragma unroll
             for (int q = 0; q < R2; q++) rv[i][q] = rbase[(unsigned)(idx.out_index(i, q, tc) * N) + (unsigned)col];
           }
-      }
+      };
+      // receptor values: requested before the first x pass (in flight during it) when registers
+      // allow (2 waves/SIMD build), else right before their use
+      if (MODE == 1 && !DLPD_K2_LATE_REC) load_rec();
       {
         FwdP1 ps;
         ps.load(S, ad, tc, nullptr);
@@ -141,6 +147,7 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
         ps.store(S, ad, tc);
         DLPD_WAVE_SYNC();
       }
+      if (MODE == 1 && DLPD_K2_LATE_REC) load_rec();
       if (MODE == 0) {
         FwdP2 ps;
         ps.load(S, ad, tc, tw);
