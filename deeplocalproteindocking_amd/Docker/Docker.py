@@ -176,14 +176,16 @@ class Docker:
         has_clash = receptor_forbidden is not None
         R_all = self.rot.R
         ids = self.shard(R_all.shape[0]) if rot_indices is None else np.asarray(rot_indices, dtype=np.int64)
-        if len(rec) == 1:
+        two_res = len(rec) == 2 and rec[1].shape[-1] * 2 == L and self._library().call("dlpd_grid_supported", L // 2)
+        if len(rec) == 1 or two_res:
             W1, b1, W2, b2 = model.filter.parameters_tuple()
             eng = DockingEngine(L, rec[0].shape[0], W1.cpu(), b1.cpu(), W2.cpu(), b2.cpu(),
                                 clip=getattr(model, "clip", 5.0), threshold_clash=model.threshold_clash,
                                 has_clash=has_clash, max_conf=self.max_conf, batch=batch_size, device=self.device,
-                                lib=self._lib)
-            eng.set_receptor(rec[0], receptor_forbidden)
-            eng.set_ligand(lig[0], ligand_forbidden if ligand_forbidden is not None else torch.zeros(L, L, L))
+                                lib=self._lib, coarse_channels=rec[1].shape[0] if two_res else 0)
+            eng.set_receptor(rec[0], receptor_forbidden, rec[1] if two_res else None)
+            eng.set_ligand(lig[0], ligand_forbidden if ligand_forbidden is not None else torch.zeros(L, L, L),
+                           lig[1] if two_res else None)
             eng.clash_provider = clash_provider
             eng.reset_top()
             eng.search(R_all[ids], rot_ids=ids)

@@ -186,13 +186,19 @@ template <> struct K3Cfg<64> { static constexpr int NT = 512, WC = 8; };
 template <> struct K3Cfg<128> { static constexpr int NT = 512, WC = 8; };
 template <> struct K3Cfg<80> { static constexpr int NT = 320, WC = 5; };
 template <> struct K3Cfg<160> { static constexpr int NT = 640, WC = 5; };
+// Extra first-layer inputs that are already real volumes: the clipped correlations of a coarser
+// resolution (N/2 grid), nearest-upsampled by index (DockingModels.py:74-76), W1t rows C..C+Caux-1
+struct K3Aux {
+  const float* p;   // (nb, Caux, Naux^3), Naux = N/2
+  int C, N;
+};
 #ifdef DLPD_STAMPS   // diagnostic build only (scripts/stamps.py): where a K3 wave spends its cycles
 __device__ unsigned long long dlpd_stamps[16];
 #endif
 template <int N, int HP, int MODE> __global__ void __launch_bounds__(K3Cfg<N>::NT)
 k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int C, int has_clash, int G,
                const float* __restrict__ W1t, const float* __restrict__ b1, const float* __restrict__ W2,
-               float b2, int has_clip, float clip, float thr) {
+               float b2, int has_clip, float clip, float thr, K3Aux aux) {
   constexpr int NZ = N / 2 + 1, RS = N + 8, TY = DLPD_K3_TY, NPAIR = TY / 2;
   constexpr int T = 8, R1 = FftPlanW<N>::R1, R2 = FftPlanW<N>::R2;
   constexpr int NT = K3Cfg<N>::NT, WC = K3Cfg<N>::WC;
@@ -364,6 +370,23 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
     DLPD_STAMP(6);
   }
   DLPD_STAMP_FLUSH(dlpd_stamps, DLPD_STAMPS);
+  if (MODE == 1 && owner && aux.C > 0) {
+    // coarse-resolution channels: rows 2m and 2m+1 and columns z, z^1 share one coarse voxel
+    const int Na = aux.N;
+    const float* ab = aux.p + (size_t)b * aux.C * Na * Na * Na + ((size_t)(xo >> 1) * Na + (y0 >> 1)) * Na + (zz >> 1);
+    for (int ca = 0; ca < aux.C; ca++) {
+      const float* w = W1t + (size_t)(C + ca) * HP;
+#pragma unroll
+      for (int e = 0; e < EPT; e++) {
+        const float v = ab[(size_t)ca * Na * Na * Na + (size_t)(m0 + e * MSTEP) * Na];
+#pragma unroll
+        for (int j = 0; j < HP; j++) {
+          h[2 * e][j] = fmaf(w[j], v, h[2 * e][j]);
+          h[2 * e + 1][j] = fmaf(w[j], v, h[2 * e + 1][j]);
+        }
+      }
+    }
+  }
   if (MODE == 1 && owner) {
 #pragma unroll
     for (int e = 0; e < EPT; e++) {
@@ -443,7 +466,7 @@ static int k3_group(int CT, int maxg) {
 template <int N, int HP, int MODE> static int launch_k3(const cplx* Bw, float* out, int CT, int C, int has_clash,
                                                         int nb, const float* W1t, const float* b1, const float* W2,
                                                         float b2, int has_clip, float clip, float thr,
-                                                        hipStream_t st) {
+                                                        hipStream_t st, K3Aux aux = K3Aux{nullptr, 0, 0}) {
   constexpr int RS = N + 8, NZ = N / 2 + 1, W = K3Cfg<N>::WC, NPAIR = DLPD_K3_TY / 2;
   constexpr int RAWC = ((NZ * NPAIR + 63) / 64) * 64;
   const size_t shmem = (size_t)(W * NPAIR * RS + N) * sizeof(cplx) + (size_t)W * RAWC * 16;
@@ -452,20 +475,21 @@ template <int N, int HP, int MODE> static int launch_k3(const cplx* Bw, float* o
   const int G = k3_group(CT, W);               // channels per group (one wave each), <= W
   dim3 grid(N / DLPD_K3_TY, N, nb), block(K3Cfg<N>::NT);
   DLPD_LAUNCH((k_zifft_filter<N, HP, MODE>), grid, block, shmem, st, Bw, out, CT, C, has_clash, G, W1t, b1, W2, b2,
-              has_clip, clip, thr);
+              has_clip, clip, thr, aux);
   return dlpd_check_launch();
 }
 
 template <int N> static int k3_filter_dispatch(int HP, const cplx* Bw, float* V, int CT, int C, int has_clash, int nb,
                                                const float* W1t, const float* b1, const float* W2, float b2,
-                                               int has_clip, float clip, float thr, hipStream_t st) {
+                                               int has_clip, float clip, float thr, hipStream_t st,
+                                               K3Aux aux = K3Aux{nullptr, 0, 0}) {
   switch (HP) {
-    case 2: return launch_k3<N, 2, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st);
-    case 4: return launch_k3<N, 4, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st);
-    case 8: return launch_k3<N, 8, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st);
-    case 16: return launch_k3<N, 16, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st);
-    case 24: return launch_k3<N, 24, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st);
-    case 32: return launch_k3<N, 32, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st);
+    case 2: return launch_k3<N, 2, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux);
+    case 4: return launch_k3<N, 4, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux);
+    case 8: return launch_k3<N, 8, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux);
+    case 16: return launch_k3<N, 16, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux);
+    case 24: return launch_k3<N, 24, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux);
+    case 32: return launch_k3<N, 32, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux);
     default: return DLPD_ERR_UNSUPPORTED;
   }
 }
@@ -554,19 +578,28 @@ int dlpd_zifft_real(const void* wsB, float* out, int nb, int CT, int L, int has_
 }
 
 // wsB -> V (nb, N^3): z C2R + clip + MLP + clash mask
+// aux (nb, Caux, (N/2)^3): already-real first-layer inputs of a coarser resolution (may be null)
+int dlpd_zifft_filter_aux(const void* wsB, float* V, int nb, int C, int has_clash, int L, const float* W1t,
+                          const float* b1, const float* W2, float b2, int HP, int has_clip, float clip, float thr,
+                          const float* aux, int Caux, void* stream) {
+  if (!wsB || !V || !W1t || !b1 || !W2 || nb <= 0 || C <= 0 || Caux < 0 || (Caux > 0 && !aux)) return DLPD_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int CT = C + (has_clash ? 1 : 0);
+  const K3Aux ax = {aux, Caux, L};              // coarse grid N/2 = L
+  switch (L) {
+    case 32: return k3_filter_dispatch<64>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, ax);
+    case 40: return k3_filter_dispatch<80>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, ax);
+    case 64: return k3_filter_dispatch<128>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, ax);
+    case 80: return k3_filter_dispatch<160>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, ax);
+    default: return DLPD_ERR_UNSUPPORTED;
+  }
+}
+
 int dlpd_zifft_filter(const void* wsB, float* V, int nb, int C, int has_clash, int L, const float* W1t,
                       const float* b1, const float* W2, float b2, int HP, int has_clip, float clip, float thr,
                       void* stream) {
-  if (!wsB || !V || !W1t || !b1 || !W2 || nb <= 0 || C <= 0) return DLPD_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  const int CT = C + (has_clash ? 1 : 0);
-  switch (L) {
-    case 32: return k3_filter_dispatch<64>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st);
-    case 40: return k3_filter_dispatch<80>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st);
-    case 64: return k3_filter_dispatch<128>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st);
-    case 80: return k3_filter_dispatch<160>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st);
-    default: return DLPD_ERR_UNSUPPORTED;
-  }
+  return dlpd_zifft_filter_aux(wsB, V, nb, C, has_clash, L, W1t, b1, W2, b2, HP, has_clip, clip, thr, nullptr, 0,
+                               stream);
 }
 
 // Fused driver for one batch of rotations (single-resolution model):

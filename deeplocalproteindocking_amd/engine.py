@@ -99,7 +99,9 @@ class DockingEngine:
     """
 
     def __init__(self, L, C, W1, b1, W2, b2, clip=5.0, threshold_clash=300.0, has_clash=True,
-                 max_conf=1000, batch=8, device="cuda", lib=None, center=None):
+                 max_conf=1000, batch=8, device="cuda", lib=None, center=None, coarse_channels=0):
+        """coarse_channels > 0: the reference's two-resolution layout -- C channels at L^3 plus
+        ``coarse_channels`` at (L/2)^3 (ProteinRepresentationModels.py:72-76); W1 is (H, C+coarse)."""
         self.device = torch.device(device)
         if lib is None:
             if self.device.type != "cuda":
@@ -120,13 +122,14 @@ class DockingEngine:
         self.batch = int(batch)
         dev = self.device
         f32 = torch.float32
-        W1 = torch.as_tensor(W1, dtype=f32).reshape(-1, self.C)
+        self.C1 = int(coarse_channels)
+        W1 = torch.as_tensor(W1, dtype=f32).reshape(-1, self.C + self.C1)
         H = W1.shape[0]
         HP = lib.call("dlpd_hidden_pad", int(H))
         if HP < 0:
             raise RuntimeError("dlpd: hidden width %d > 32 unsupported by the fused filter" % H)
         self.H, self.HP = H, HP
-        W1t = torch.zeros(self.C, HP, dtype=f32)
+        W1t = torch.zeros(self.C + self.C1, HP, dtype=f32)
         W1t[:, :H] = W1.t()
         b1p = torch.zeros(HP, dtype=f32)
         b1p[:H] = torch.as_tensor(b1, dtype=f32).reshape(-1)
@@ -140,16 +143,33 @@ class DockingEngine:
         self.wsA = torch.empty(nb * CT * NZ * L * L * 2, dtype=f32, device=dev)
         self.wsB = torch.empty(nb * CT * NZ * N * N * 2, dtype=f32, device=dev)
         self.V = torch.empty(nb, N, N, N, dtype=f32, device=dev)
+        if self.C1:
+            L1 = self.L // 2
+            if self.L % 2 or not lib.call("dlpd_grid_supported", L1):
+                raise RuntimeError("dlpd: coarse box size %d has no compiled pipeline" % L1)
+            N1, NZ1, C1 = 2 * L1, L1 + 1, self.C1
+            self.L1 = L1
+            self.lig1 = torch.zeros(C1, L1, L1, L1, dtype=f32, device=dev)
+            self.recF1 = torch.zeros(C1, NZ1, N1, N1, 2, dtype=f32, device=dev)
+            self.wsA1 = torch.empty(nb * C1 * NZ1 * L1 * L1 * 2, dtype=f32, device=dev)
+            self.wsB1 = torch.empty(nb * C1 * NZ1 * N1 * N1 * 2, dtype=f32, device=dev)
+            self.aux = torch.empty(nb, C1, N1, N1, N1, dtype=f32, device=dev)      # clipped coarse correlations
         self.top = DeviceTopList(self.K, nb, dev, lib)
         # optional: callable(R (nb,3,3) f32 device) -> (nb,L,L,L) f32 device ligand forbidden volumes
         # re-projected from rotated ATOMS (Docker.py:221-224) instead of the rotated volume
         self.clash_provider = None
 
     # ---- inputs ------------------------------------------------------------------------
-    def set_receptor(self, rec_volumes, rec_forbidden=None):
-        """rec_volumes (C,L,L,L); rec_forbidden (L,L,L).  Spectrum precomputed once per pair
-        (the reference recomputes it every batch inside VolumeConvolution, DockingModels.py:71)."""
+    def set_receptor(self, rec_volumes, rec_forbidden=None, rec_coarse=None):
+        """rec_volumes (C,L,L,L); rec_forbidden (L,L,L); rec_coarse (C1,L/2,..).  Spectra precomputed
+        once per pair (the reference recomputes them every batch inside VolumeConvolution,
+        DockingModels.py:71)."""
         L, N, CT = self.L, self.N, self.CT
+        if self.C1:
+            L1 = self.L1
+            r1 = torch.as_tensor(rec_coarse, dtype=torch.float32).reshape(self.C1, L1, L1, L1).to(self.device).contiguous()
+            self.lib.call("dlpd_rfft3d_padded", _ptr(r1), _ptr(self.recF1), _ptr(self.wsA1), self.C1, L1,
+                          1.0 / float(2 * L1) ** 3, _stream(self.device))
         rec = torch.zeros(CT, L, L, L, dtype=torch.float32, device=self.device)
         rec[: self.C] = torch.as_tensor(rec_volumes, dtype=torch.float32).reshape(self.C, L, L, L).to(self.device)
         if self.has_clash:
@@ -158,8 +178,10 @@ class DockingEngine:
         self.lib.call("dlpd_rfft3d_padded", _ptr(rec), _ptr(self.recF), _ptr(self.wsA), CT, L, scale,
                       _stream(self.device))
 
-    def set_ligand(self, lig_volumes, lig_forbidden=None):
+    def set_ligand(self, lig_volumes, lig_forbidden=None, lig_coarse=None):
         L = self.L
+        if self.C1:
+            self.lig1.copy_(torch.as_tensor(lig_coarse, dtype=torch.float32).reshape(self.lig1.shape))
         self.lig[: self.C] = torch.as_tensor(lig_volumes, dtype=torch.float32).reshape(self.C, L, L, L).to(self.device)
         if self.has_clash:
             self.lig[self.C] = torch.as_tensor(lig_forbidden, dtype=torch.float32).reshape(L, L, L).to(self.device)
@@ -172,6 +194,30 @@ class DockingEngine:
         assert nb <= self.batch and R.dtype == torch.float32 and R.is_contiguous()
         has_clip = 0 if self.clip is None else 1
         V = self.V if out is None else out
+        if self.C1:
+            # coarse resolution first: rotate + correlate + clip -> real volumes the fine K3 reads
+            st, L1 = _stream(self.device), self.L1
+            self.lib.call("dlpd_zfft", _ptr(self.lig1), _ptr(R), _ptr(self.wsA1), nb, self.C1, L1, 0, 1,
+                          float(L1) / 2.0, st)
+            self.lib.call("dlpd_xy_correlate", _ptr(self.wsA1), _ptr(self.recF1), _ptr(self.wsB1), nb, self.C1,
+                          L1, 0, st)
+            self.lib.call("dlpd_zifft_real", _ptr(self.wsB1), _ptr(self.aux), nb, self.C1, L1, has_clip,
+                          float(self.clip or 0.0), st)
+            if self.clash_provider is not None and self.has_clash:
+                forb = self.clash_provider(R).reshape(nb, self.L, self.L, self.L).contiguous()
+                self.lib.call("dlpd_zfft_into", _ptr(self.lig), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0,
+                              self.L, 0, 1, self.center, st)
+                self.lib.call("dlpd_zfft_into", _ptr(forb), 0, _ptr(self.wsA), nb, 1, self.CT, self.C, self.L,
+                              self.L ** 3, 0, 0.0, st)
+            else:
+                self.lib.call("dlpd_zfft", _ptr(self.lig), _ptr(R), _ptr(self.wsA), nb, self.CT, self.L, 0, 1,
+                              self.center, st)
+            self.lib.call("dlpd_xy_correlate", _ptr(self.wsA), _ptr(self.recF), _ptr(self.wsB), nb, self.CT,
+                          self.L, 0, st)
+            self.lib.call("dlpd_zifft_filter_aux", _ptr(self.wsB), _ptr(V), nb, self.C, int(self.has_clash),
+                          self.L, _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2), self.b2, self.HP, has_clip,
+                          float(self.clip or 0.0), self.threshold, _ptr(self.aux), self.C1, st)
+            return V[:nb]
         if self.clash_provider is not None and self.has_clash:
             st = _stream(self.device)
             forb = self.clash_provider(R).reshape(nb, self.L, self.L, self.L).contiguous()

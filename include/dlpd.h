@@ -76,6 +76,13 @@ int dlpd_zifft_filter(const void* wsB, float* V, int nb, int C, int has_clash, i
                       const float* b1, const float* W2, float b2, int HP, int has_clip, float clip,
                       float thr, void* stream);
 
+/* Same for the reference's two-resolution layout (ProteinRepresentationModels.py:72-76): the Caux
+ * channels of the coarser resolution arrive as clipped real correlation volumes aux (nb, Caux, L^3)
+ * (grid N/2 = L) and are nearest-upsampled by index (DockingModels.py:74-76); W1t has C + Caux rows. */
+int dlpd_zifft_filter_aux(const void* wsB, float* V, int nb, int C, int has_clash, int L, const float* W1t,
+                          const float* b1, const float* W2, float b2, int HP, int has_clip, float clip,
+                          float thr, const float* aux, int Caux, void* stream);
+
 /* One batch of the hot loop, Docker.py:211-232 (single-resolution model): K1 + K2 + K3. */
 int dlpd_score_rotations(const float* lig, const void* recF, const float* R, int nb, int C, int has_clash,
                          int L, float center, const float* W1t, const float* b1, const float* W2, float b2,

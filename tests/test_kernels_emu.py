@@ -187,3 +187,31 @@ def test_generic_filter_kernel_reproduces_reference_forward(emu, golden, tag, nr
              c1.shape[2] if nres == 2 else 0, 0, 0.0, 0, _ptr(W1t), _ptr(b1), _ptr(W2), float(g[tag + "_b2"][0]),
              W1.shape[0], _ptr(V), B, 0)
     np.testing.assert_allclose(V.numpy(), g[tag + "_V"], rtol=1e-5, atol=1e-5)
+
+
+def test_fused_two_resolution_pipeline(emu):
+    """[C0 @ 64^3, C1 @ 32^3] -> 128^3 through the fused engine (coarse correlations enter K3 as
+    auxiliary real channels, nearest-upsampled by index) against the oracle's GlobalDockingModel.forward."""
+    L, C0, C1 = 64, 2, 3
+    g = torch.Generator().manual_seed(41)
+    rec0, lig0 = torch.randn(C0, L, L, L, generator=g) * 0.05, torch.randn(C0, L, L, L, generator=g) * 0.05
+    rec1 = torch.randn(C1, L // 2, L // 2, L // 2, generator=g) * 0.1
+    lig1 = torch.randn(C1, L // 2, L // 2, L // 2, generator=g) * 0.1
+    recf, ligf = torch.rand(L, L, L, generator=g), torch.rand(L, L, L, generator=g)
+    H = 2
+    W1, b1 = torch.randn(H, C0 + C1, generator=g), torch.randn(H, generator=g)
+    W2, b2 = torch.randn(1, H, generator=g), torch.randn(1, generator=g)
+    thr = 0.125 * L ** 3
+    R = orc.euler_to_matrix([0.9], [0.7], [-1.4])
+    eng = DockingEngine(L, C0, W1, b1, W2, b2, clip=0.8, threshold_clash=thr, max_conf=16, batch=1, device="cpu",
+                        lib=emu, coarse_channels=C1)
+    eng.set_receptor(rec0, recf, rec1)
+    eng.set_ligand(lig0, ligf, lig1)
+    V = eng.score_batch(torch.from_numpy(R).float().contiguous()).clone()
+    Rb = torch.from_numpy(R).float()
+    mask, norm = orc.clash_mask(recf[None, None], orc.rotate_volume(ligf[None, None], Rb), thr)
+    Vo = (mask * orc.score_volumes([rec0[None], rec1[None]],
+                                   [orc.rotate_volume(lig0[None], Rb), orc.rotate_volume(lig1[None], Rb)],
+                                   W1, b1, W2, b2, clip=0.8))[0]
+    sure = (norm[0] - thr).abs() > 1e-3 * thr
+    assert ((V[0] - Vo).abs()[sure]).max() <= 1e-4 * Vo.abs().max()
