@@ -182,10 +182,12 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
 #define DLPD_K3_TY 16
 // threads per block and number of channel-owning waves (LDS: WC * (8 pencils + raw staging))
 template <int N> struct K3Cfg;
-template <> struct K3Cfg<64> { static constexpr int NT = 512, WC = 8; };
-template <> struct K3Cfg<128> { static constexpr int NT = 512, WC = 8; };
-template <> struct K3Cfg<80> { static constexpr int NT = 320, WC = 5; };
-template <> struct K3Cfg<160> { static constexpr int NT = 640, WC = 5; };
+// HS: the hidden units are processed in HS slices (the transforms are repeated per slice): N = 160
+// needs 10 waves per block, i.e. 3 on one SIMD and a 168-VGPR cap, which 96 accumulators overflow
+template <> struct K3Cfg<64> { static constexpr int NT = 512, WC = 8, HS = 1; };
+template <> struct K3Cfg<128> { static constexpr int NT = 512, WC = 8, HS = 1; };
+template <> struct K3Cfg<80> { static constexpr int NT = 320, WC = 5, HS = 1; };
+template <> struct K3Cfg<160> { static constexpr int NT = 320, WC = 5, HS = 2; };
 // Extra first-layer inputs that are already real volumes: the clipped correlations of a coarser
 // resolution (N/2 grid), nearest-upsampled by index (DockingModels.py:74-76), W1t rows C..C+Caux-1
 struct K3Aux {
@@ -200,7 +202,6 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
                const float* __restrict__ W1t, const float* __restrict__ b1, const float* __restrict__ W2,
                float b2, int has_clip, float clip, float thr, K3Aux aux) {
   constexpr int NZ = N / 2 + 1, RS = N + 8, TY = DLPD_K3_TY, NPAIR = TY / 2;
-  constexpr int T = 8, R1 = FftPlanW<N>::R1, R2 = FftPlanW<N>::R2;
   constexpr int NT = K3Cfg<N>::NT, WC = K3Cfg<N>::WC;
   static_assert(NPAIR == 8 && WC * 64 <= NT, "one wave = 8 pencils x 8 threads = one channel of the tile");
   constexpr int EPT = (NPAIR * N) / NT > 0 ? (NPAIR * N) / NT : 1;   // complex outputs per thread per channel
@@ -216,16 +217,12 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
 
   // hidden pre-activations of the thread's 2*EPT voxels (the SLP vectoriser pairs adjacent
   // hidden units into v_pk_fma_f32 with the weight pair in SGPRs and the voxel value broadcast)
-  float h[EPT * 2][HP > 0 ? HP : 1];
+  constexpr int HS = (MODE == 1 && HP % K3Cfg<N>::HS == 0) ? K3Cfg<N>::HS : 1;
+  constexpr int HPH = HP / HS;                 // hidden units per slice
   float nrm[EPT * 2];
-  if (MODE == 1) {
+  float total[EPT * 2];
 #pragma unroll
-    for (int e = 0; e < EPT * 2; e++) {
-      nrm[e] = 0.f;
-#pragma unroll
-      for (int j = 0; j < HP; j++) h[e][j] = b1[j];
-    }
-  }
+  for (int e = 0; e < EPT * 2; e++) { nrm[e] = 0.f; total[e] = b2; }
   const int zz = tid % N, m0 = tid / N;        // output ownership
   const bool owner = (NPAIR * N >= NT) || (m0 < NPAIR);
   const int tr = lane & 7, qr = lane >> 3;     // FFT: lane = 8*pencil + thread
@@ -246,9 +243,19 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
       DLPD_GLDS16(src + (size_t)(N / 2) * N * N + 2 * mt, rawg + NFULL * 64);
     }
   };
-  issue_channel(0);
-  __syncthreads();                             // twiddle table visible
   DLPD_STAMP_DECL;
+#pragma unroll 1
+  for (int hs = 0; hs < HS; hs++) {
+  const int j0 = hs * HPH;
+  float h[EPT * 2][HPH > 0 ? HPH : 1];
+  if (MODE == 1) {
+#pragma unroll
+    for (int e = 0; e < EPT * 2; e++)
+#pragma unroll
+      for (int j = 0; j < HPH; j++) h[e][j] = b1[j0 + j];
+  }
+  issue_channel(0);
+  __syncthreads();                             // twiddle table visible; previous slice fully consumed
 
   for (int cbase = 0; cbase < CT; cbase += G) {
     const int gn = (CT - cbase) < G ? (CT - cbase) : G;
@@ -260,18 +267,22 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
       {
         const int m = lane & 7, kq = lane >> 3;
         cplx* P = S + (wave * NPAIR + m) * RS;
-        float4 q[NFULL];
-#pragma unroll
-        for (int it = 0; it < NFULL; it++) q[it] = rawg[it * 64 + lane];
+        constexpr int PCH = NFULL > 8 ? NFULL / 2 : NFULL;   // raw elements in flight per lane
         const float4 qh = rawg[NFULL * 64 + m];             // k = N/2
 #pragma unroll
-        for (int it = 0; it < NFULL; it++) {
-          const int k = it * 8 + kq;
-          if (it == 0 && kq == 0) {
-            P[slab_swz(0)] = c_make(q[0].x, q[0].z);        // purely real bin of both rows
-          } else {
-            P[slab_swz(k)] = c_make(q[it].x - q[it].w, q[it].y + q[it].z);
-            P[slab_swz(N - k)] = c_make(q[it].x + q[it].w, q[it].z - q[it].y);
+        for (int it0 = 0; it0 < NFULL; it0 += PCH) {
+          float4 q[PCH];
+#pragma unroll
+          for (int u = 0; u < PCH; u++) q[u] = rawg[(it0 + u) * 64 + lane];
+#pragma unroll
+          for (int u = 0; u < PCH; u++) {
+            const int it = it0 + u, k = it * 8 + kq;
+            if (it == 0 && kq == 0) {
+              P[slab_swz(0)] = c_make(q[u].x, q[u].z);      // purely real bin of both rows
+            } else {
+              P[slab_swz(k)] = c_make(q[u].x - q[u].w, q[u].y + q[u].z);
+              P[slab_swz(N - k)] = c_make(q[u].x + q[u].w, q[u].z - q[u].y);
+            }
           }
         }
         if (kq == 0) P[slab_swz(N / 2)] = c_make(qh.x, qh.z);
@@ -282,21 +293,7 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
     DLPD_STAMP(1);
     issue_channel(cbase + G);                  // next group's channel streams in behind the math
     DLPD_STAMP(2);
-    if (wave < gn) {
-      {
-        FftPassW<N, R1, 1, +1, T> ps;
-        ps.load(S, ad, tr, nullptr);
-        DLPD_WAVE_SYNC();
-        ps.store(S, ad, tr);
-        DLPD_WAVE_SYNC();
-      }
-      {
-        FftPassW<N, R2, R1, +1, T> ps;
-        ps.load(S, ad, tr, tw);
-        DLPD_WAVE_SYNC();
-        ps.store(S, ad, tr);
-      }
-    }
+    if (wave < gn) fft_wave<N, +1, N>(S, ad, tr, tw);
     DLPD_STAMP(3);
     DLPD_LDS_BARRIER();                        // all channels of the group transformed
     DLPD_STAMP(4);
@@ -309,7 +306,7 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
             const int m = m0 + e * MSTEP;
             const cplx val = S[(g * NPAIR + m) * RS + slab_swz(zz)];
             float v0 = val.x, v1 = val.y;
-            if (has_clip) { v0 = DLPD_CLAMP(v0, clip); v1 = DLPD_CLAMP(v1, clip); }
+            if (has_clip && c < C) { v0 = DLPD_CLAMP(v0, clip); v1 = DLPD_CLAMP(v1, clip); }
             float* o = out + ((((size_t)b * CT + c) * N + xo) * N + y0 + 2 * m) * N + zz;
             o[0] = v0;
             o[N] = v1;
@@ -320,11 +317,11 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
         const int gs = (cbase + gn <= C) ? gn : (C - cbase > 0 ? C - cbase : 0);
         // first-layer weights are wave-uniform (scalar loads): channel g+1's row is requested
         // before channel g's FMAs so the scalar-load latency hides behind them
-        float wcur[HP > 0 ? HP : 1], wnxt[HP > 0 ? HP : 1];
+        float wcur[HPH > 0 ? HPH : 1], wnxt[HPH > 0 ? HPH : 1];
         cplx vcur[EPT], vnxt[EPT];
         if (gs > 0) {
 #pragma unroll
-          for (int j = 0; j < HP; j++) wcur[j] = W1t[(size_t)cbase * HP + j];
+          for (int j = 0; j < HPH; j++) wcur[j] = W1t[(size_t)cbase * HP + j0 + j];
 #pragma unroll
           for (int e = 0; e < EPT; e++) vcur[e] = S[(m0 + e * MSTEP) * RS + slab_swz(zz)];
         }
@@ -334,7 +331,7 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
           // iteration, behind this channel's 96 FMAs
           const int gn1 = (g + 1 < gs ? g + 1 : g);
 #pragma unroll
-          for (int j = 0; j < HP; j++) wnxt[j] = W1t[(size_t)(cbase + gn1) * HP + j];
+          for (int j = 0; j < HPH; j++) wnxt[j] = W1t[(size_t)(cbase + gn1) * HP + j0 + j];
 #pragma unroll
           for (int e = 0; e < EPT; e++) vnxt[e] = S[(gn1 * NPAIR + m0 + e * MSTEP) * RS + slab_swz(zz)];
           DLPD_SCHED_FENCE();
@@ -343,14 +340,14 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
             float v0 = vcur[e].x, v1 = vcur[e].y;
             if (has_clip) { v0 = DLPD_CLAMP(v0, clip); v1 = DLPD_CLAMP(v1, clip); }
 #pragma unroll
-            for (int j = 0; j < HP; j++) {
+            for (int j = 0; j < HPH; j++) {
               h[2 * e][j] = fmaf(wcur[j], v0, h[2 * e][j]);
               h[2 * e + 1][j] = fmaf(wcur[j], v1, h[2 * e + 1][j]);
             }
           }
           DLPD_SCHED_FENCE();
 #pragma unroll
-          for (int j = 0; j < HP; j++) wcur[j] = wnxt[j];
+          for (int j = 0; j < HPH; j++) wcur[j] = wnxt[j];
 #pragma unroll
           for (int e = 0; e < EPT; e++) vcur[e] = vnxt[e];
         }
@@ -374,28 +371,46 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
     // coarse-resolution channels: rows 2m and 2m+1 and columns z, z^1 share one coarse voxel
     const int Na = aux.N;
     const float* ab = aux.p + (size_t)b * aux.C * Na * Na * Na + ((size_t)(xo >> 1) * Na + (y0 >> 1)) * Na + (zz >> 1);
-    for (int ca = 0; ca < aux.C; ca++) {
-      const float* w = W1t + (size_t)(C + ca) * HP;
+    constexpr int CH = EPT > 2 ? 4 : 8;       // channels per chunk: EPT*CH loads in flight per thread
+    const size_t cstride = (size_t)Na * Na * Na;
+    for (int cb = 0; cb < aux.C; cb += CH) {
+      float av[CH][EPT];
 #pragma unroll
-      for (int e = 0; e < EPT; e++) {
-        const float v = ab[(size_t)ca * Na * Na * Na + (size_t)(m0 + e * MSTEP) * Na];
+      for (int k = 0; k < CH; k++)
 #pragma unroll
-        for (int j = 0; j < HP; j++) {
-          h[2 * e][j] = fmaf(w[j], v, h[2 * e][j]);
-          h[2 * e + 1][j] = fmaf(w[j], v, h[2 * e + 1][j]);
+        for (int e = 0; e < EPT; e++)
+          av[k][e] = (cb + k < aux.C) ? ab[(size_t)(cb + k) * cstride + (size_t)(m0 + e * MSTEP) * Na] : 0.f;
+#pragma unroll
+      for (int k = 0; k < CH; k++) {
+        if (cb + k < aux.C) {
+          const float* w = W1t + (size_t)(C + cb + k) * HP + j0;
+#pragma unroll
+          for (int e = 0; e < EPT; e++) {
+            const float v = av[k][e];
+#pragma unroll
+            for (int j = 0; j < HPH; j++) {
+              h[2 * e][j] = fmaf(w[j], v, h[2 * e][j]);
+              h[2 * e + 1][j] = fmaf(w[j], v, h[2 * e + 1][j]);
+            }
+          }
         }
       }
     }
   }
   if (MODE == 1 && owner) {
 #pragma unroll
+    for (int e = 0; e < EPT * 2; e++)
+#pragma unroll
+      for (int j = 0; j < HPH; j++) total[e] = fmaf(W2[j0 + j], fmaxf(h[e][j], 0.f), total[e]);
+  }
+  }   // hidden slices
+  if (MODE == 1 && owner) {
+#pragma unroll
     for (int e = 0; e < EPT; e++) {
       const int m = m0 + e * MSTEP;
 #pragma unroll
       for (int u = 0; u < 2; u++) {
-        float acc = b2;
-#pragma unroll
-        for (int j = 0; j < HP; j++) acc = fmaf(W2[j], fmaxf(h[2 * e + u][j], 0.f), acc);
+        float acc = total[2 * e + u];
         if (has_clash) acc = acc * ((nrm[2 * e + u] < thr) ? 1.0f : 0.0f);
         out[(((size_t)b * N + xo) * N + y0 + 2 * m + u) * N + zz] = acc;
       }
@@ -439,6 +454,101 @@ k_filter_generic(const float* __restrict__ conv0, int C0, int N0, const float* _
     if (has_clash) acc = acc * ((mask_norm[i] < thr) ? 1.0f : 0.0f);
     V[i] = acc;
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Vectorised per-voxel filter over real correlation volumes: 4 z-consecutive voxels per thread
+// (float4 loads, 4 x HP accumulators in registers, first-layer weights by scalar loads).  Used
+// where the MLP is not fused into the inverse FFT (N = 160, and GlobalDockingModel.forward).
+//   conv0 (nb, *, N^3) with batch stride c0_bstride, first C0 channels used
+//   conv1 (nb, C1, N1^3), N1 = N or N/2 (nearest upsample by index, DockingModels.py:74-76)
+//   mask  clash correlation (batch stride mask_bstride), V = (mask < thr) * mlp
+// ------------------------------------------------------------------------------------------
+template <int HP> __global__ void __launch_bounds__(256)
+k_filter_vec(const float* __restrict__ conv0, int C0, long long c0_bstride, int N, const float* __restrict__ conv1,
+             int C1, int N1, const float* __restrict__ mask, long long mask_bstride, float thr, int has_clash,
+             const float* __restrict__ W1t, const float* __restrict__ b1, const float* __restrict__ W2, float b2,
+             float* __restrict__ V, int nb) {
+  const size_t N3 = (size_t)N * N * N, q3 = N3 / 4;
+  const size_t total = (size_t)nb * q3;
+  const size_t N13 = (size_t)N1 * N1 * N1;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(g / q3);
+    const size_t r = (g % q3) * 4;
+    float h[4][HP];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int j = 0; j < HP; j++) h[k][j] = b1[j];
+    const float* c0 = conv0 + (size_t)b * c0_bstride + r;
+    for (int c = 0; c < C0; c++) {
+      const float4 v = *reinterpret_cast<const float4*>(c0 + (size_t)c * N3);
+      const float* w = W1t + (size_t)c * HP;
+#pragma unroll
+      for (int j = 0; j < HP; j++) {
+        const float wj = w[j];
+        h[0][j] = fmaf(wj, v.x, h[0][j]);
+        h[1][j] = fmaf(wj, v.y, h[1][j]);
+        h[2][j] = fmaf(wj, v.z, h[2][j]);
+        h[3][j] = fmaf(wj, v.w, h[3][j]);
+      }
+    }
+    if (C1 > 0) {
+      const int z = (int)(r % N), y = (int)((r / N) % N), x = (int)(r / ((size_t)N * N));
+      const int s = N / N1;
+      const float* c1 = conv1 + (size_t)b * C1 * N13 + ((size_t)(x / s) * N1 + (y / s)) * N1;
+      for (int c = 0; c < C1; c++) {
+        float v0, v1, v2, v3;
+        const float* p = c1 + (size_t)c * N13;
+        if (s == 2) {
+          const float2 u = *reinterpret_cast<const float2*>(p + (z >> 1));
+          v0 = v1 = u.x; v2 = v3 = u.y;
+        } else if (s == 1) {
+          const float4 u = *reinterpret_cast<const float4*>(p + z);
+          v0 = u.x; v1 = u.y; v2 = u.z; v3 = u.w;
+        } else {
+          v0 = p[z / s]; v1 = p[(z + 1) / s]; v2 = p[(z + 2) / s]; v3 = p[(z + 3) / s];
+        }
+        const float* w = W1t + (size_t)(C0 + c) * HP;
+#pragma unroll
+        for (int j = 0; j < HP; j++) {
+          const float wj = w[j];
+          h[0][j] = fmaf(wj, v0, h[0][j]);
+          h[1][j] = fmaf(wj, v1, h[1][j]);
+          h[2][j] = fmaf(wj, v2, h[2][j]);
+          h[3][j] = fmaf(wj, v3, h[3][j]);
+        }
+      }
+    }
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      float acc = b2;
+#pragma unroll
+      for (int j = 0; j < HP; j++) acc = fmaf(W2[j], fmaxf(h[k][j], 0.f), acc);
+      o[k] = acc;
+    }
+    if (has_clash) {
+      const float4 nm = *reinterpret_cast<const float4*>(mask + (size_t)b * mask_bstride + r);
+      o[0] *= (nm.x < thr) ? 1.0f : 0.0f;
+      o[1] *= (nm.y < thr) ? 1.0f : 0.0f;
+      o[2] *= (nm.z < thr) ? 1.0f : 0.0f;
+      o[3] *= (nm.w < thr) ? 1.0f : 0.0f;
+    }
+    *reinterpret_cast<float4*>(V + (size_t)b * N3 + r) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+template <int HP> static int launch_filter_vec(const float* conv0, int C0, long long c0bs, int N, const float* conv1,
+                                               int C1, int N1, const float* mask, long long mbs, float thr,
+                                               int has_clash, const float* W1t, const float* b1, const float* W2,
+                                               float b2, float* V, int nb, hipStream_t st) {
+  const size_t total = (size_t)nb * N * N * N / 4;
+  size_t nblk = (total + 255) / 256;
+  if (nblk > 65536) nblk = 65536;
+  DLPD_LAUNCH((k_filter_vec<HP>), dim3((unsigned)nblk), dim3(256), 0, st, conv0, C0, c0bs, N, conv1, C1, N1, mask, mbs,
+              thr, has_clash, W1t, b1, W2, b2, V, nb);
+  return dlpd_check_launch();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -565,16 +675,22 @@ int dlpd_xy_correlate(const void* wsA, const void* rec, void* wsB, int nb, int C
 }
 
 // wsB -> real correlation volumes out (nb, CT, N^3), optional clamp
-int dlpd_zifft_real(const void* wsB, float* out, int nb, int CT, int L, int has_clip, float clip, void* stream) {
+// channels [0, nclip) are clamped to +-clip, the rest (e.g. the clash correlation) are left alone
+int dlpd_zifft_real_part(const void* wsB, float* out, int nb, int CT, int nclip, int L, int has_clip, float clip,
+                         void* stream) {
   if (!wsB || !out || nb <= 0 || CT <= 0) return DLPD_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   switch (L) {
-    case 32: return launch_k3<64, 0, 0>((const cplx*)wsB, out, CT, CT, 0, nb, nullptr, nullptr, nullptr, 0.f, has_clip, clip, 0.f, st);
-    case 40: return launch_k3<80, 0, 0>((const cplx*)wsB, out, CT, CT, 0, nb, nullptr, nullptr, nullptr, 0.f, has_clip, clip, 0.f, st);
-    case 64: return launch_k3<128, 0, 0>((const cplx*)wsB, out, CT, CT, 0, nb, nullptr, nullptr, nullptr, 0.f, has_clip, clip, 0.f, st);
-    case 80: return launch_k3<160, 0, 0>((const cplx*)wsB, out, CT, CT, 0, nb, nullptr, nullptr, nullptr, 0.f, has_clip, clip, 0.f, st);
+    case 32: return launch_k3<64, 0, 0>((const cplx*)wsB, out, CT, nclip, 0, nb, nullptr, nullptr, nullptr, 0.f, has_clip, clip, 0.f, st);
+    case 40: return launch_k3<80, 0, 0>((const cplx*)wsB, out, CT, nclip, 0, nb, nullptr, nullptr, nullptr, 0.f, has_clip, clip, 0.f, st);
+    case 64: return launch_k3<128, 0, 0>((const cplx*)wsB, out, CT, nclip, 0, nb, nullptr, nullptr, nullptr, 0.f, has_clip, clip, 0.f, st);
+    case 80: return launch_k3<160, 0, 0>((const cplx*)wsB, out, CT, nclip, 0, nb, nullptr, nullptr, nullptr, 0.f, has_clip, clip, 0.f, st);
     default: return DLPD_ERR_UNSUPPORTED;
   }
+}
+
+int dlpd_zifft_real(const void* wsB, float* out, int nb, int CT, int L, int has_clip, float clip, void* stream) {
+  return dlpd_zifft_real_part(wsB, out, nb, CT, CT, L, has_clip, clip, stream);
 }
 
 // wsB -> V (nb, N^3): z C2R + clip + MLP + clash mask
@@ -617,6 +733,24 @@ int dlpd_score_rotations(const float* lig, const void* recF, const float* R, int
   return dlpd_zifft_filter(wsB, V, nb, C, has_clash, L, W1t, b1, W2, b2, HP, has_clip, clip, thr, stream);
 }
 
+// Vectorised filter: weights padded to HP (dlpd_hidden_pad), strided channel/batch layouts.
+int dlpd_filter_volumes(const float* conv0, int C0, long long conv0_bstride, int N0, const float* conv1, int C1,
+                        int N1, const float* mask_norm, long long mask_bstride, float thr, int has_clash,
+                        const float* W1t, const float* b1, const float* W2, float b2, int HP, float* V, int nb,
+                        void* stream) {
+  if (!conv0 || !V || !W1t || !b1 || !W2 || nb <= 0 || C0 <= 0 || N0 <= 0 || N0 % 4) return DLPD_ERR_ARG;
+  if (C1 > 0 && (!conv1 || N1 <= 0 || N0 % N1 != 0 || (N0 / N1 == 2 && N1 % 2))) return DLPD_ERR_ARG;
+  if (has_clash && !mask_norm) return DLPD_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+#define DLPD_FV(H) case H: return launch_filter_vec<H>(conv0, C0, conv0_bstride, N0, conv1, C1, N1, mask_norm, \
+                                                      mask_bstride, thr, has_clash, W1t, b1, W2, b2, V, nb, st)
+  switch (HP) {
+    DLPD_FV(2); DLPD_FV(4); DLPD_FV(8); DLPD_FV(16); DLPD_FV(24); DLPD_FV(32);
+    default: return DLPD_ERR_UNSUPPORTED;
+  }
+#undef DLPD_FV
+}
+
 // Generic per-voxel filter over real correlation volumes (multi-resolution model).
 int dlpd_filter_mask(const float* conv0, int C0, int N0, const float* conv1, int C1, int N1, const float* mask_norm,
                      float thr, int has_clash, const float* W1t, const float* b1, const float* W2, float b2, int H,
@@ -624,6 +758,9 @@ int dlpd_filter_mask(const float* conv0, int C0, int N0, const float* conv1, int
   if (!conv0 || !V || !W1t || !b1 || !W2 || nb <= 0 || H <= 0 || H > DLPD_MAX_HIDDEN) return DLPD_ERR_ARG;
   if (C1 > 0 && (!conv1 || N1 <= 0 || N0 % N1 != 0)) return DLPD_ERR_ARG;
   if (has_clash && !mask_norm) return DLPD_ERR_ARG;
+  if (dlpd_hidden_pad(H) == H && N0 % 4 == 0 && (C1 == 0 || N0 / N1 != 2 || N1 % 2 == 0))   // no padding needed
+    return dlpd_filter_volumes(conv0, C0, (long long)C0 * N0 * N0 * N0, N0, conv1, C1, N1, mask_norm,
+                               (long long)N0 * N0 * N0, thr, has_clash, W1t, b1, W2, b2, H, V, nb, stream);
   const size_t total = (size_t)nb * N0 * N0 * N0;
   size_t nblk = (total + 255) / 256;
   if (nblk > 16384) nblk = 16384;

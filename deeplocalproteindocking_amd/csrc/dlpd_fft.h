@@ -262,12 +262,14 @@ template <int N, int R, int NS, int DIR, int T, int NNZ = N> struct FftPassW {
   }
 };
 
-// wave-local plans: 8 threads per pencil, first pass radix R1 (pruned), second radix R2
+// wave-local plans: 8 threads per pencil; passes of radix R1 (pruned), R2 and optionally R3.
+// N = 160 takes three small-radix passes: with two (10 x 16) one pass needs 2 radix-16 butterflies
+// per thread = 64 data registers + temporaries, which does not fit beside the MLP accumulators.
 template <int N> struct FftPlanW;
-template <> struct FftPlanW<64> { static constexpr int R1 = 8, R2 = 8; };
-template <> struct FftPlanW<128> { static constexpr int R1 = 16, R2 = 8; };
-template <> struct FftPlanW<80> { static constexpr int R1 = 10, R2 = 8; };
-template <> struct FftPlanW<160> { static constexpr int R1 = 10, R2 = 16; };
+template <> struct FftPlanW<64> { static constexpr int R1 = 8, R2 = 8, R3 = 1; };
+template <> struct FftPlanW<128> { static constexpr int R1 = 16, R2 = 8, R3 = 1; };
+template <> struct FftPlanW<80> { static constexpr int R1 = 10, R2 = 8, R3 = 1; };
+template <> struct FftPlanW<160> { static constexpr int R1 = 8, R2 = 4, R3 = 5; };
 
 // slab addressing: element (row, col) of an N x N complex slab with row stride RS (RS % 32 == 8)
 // lives at row*RS + swz(col), swz(c) = c ^ ((c >> 4) & 15): both the contiguous (row pencil) and
@@ -281,3 +283,28 @@ template <int RS> struct ColAddr {
   int base;   // swz(col)
   DLPD_HD int operator()(int e) const { return e * RS + base; }
 };
+
+// all passes of a wave-local transform of one pencil set, in place (ends without a trailing sync)
+template <int N, int DIR, int NNZ, class Addr> DLPD_D void fft_wave(cplx* S, const Addr& ad, int t, const cplx* tw) {
+  typedef FftPlanW<N> P;
+  {
+    FftPassW<N, P::R1, 1, DIR, 8, NNZ> ps;
+    ps.load(S, ad, t, tw);
+    DLPD_WAVE_SYNC();
+    ps.store(S, ad, t);
+    DLPD_WAVE_SYNC();
+  }
+  {
+    FftPassW<N, P::R2, P::R1, DIR, 8> ps;
+    ps.load(S, ad, t, tw);
+    DLPD_WAVE_SYNC();
+    ps.store(S, ad, t);
+  }
+  if (P::R3 > 1) {
+    DLPD_WAVE_SYNC();
+    FftPassW<N, (P::R3 > 1 ? P::R3 : 2), P::R1 * P::R2, DIR, 8> ps;
+    ps.load(S, ad, t, tw);
+    DLPD_WAVE_SYNC();
+    ps.store(S, ad, t);
+  }
+}

@@ -99,7 +99,8 @@ class DockingEngine:
     """
 
     def __init__(self, L, C, W1, b1, W2, b2, clip=5.0, threshold_clash=300.0, has_clash=True,
-                 max_conf=1000, batch=8, device="cuda", lib=None, center=None, coarse_channels=0):
+                 max_conf=1000, batch=8, device="cuda", lib=None, center=None, coarse_channels=0,
+                 fine_unfused=None):
         """coarse_channels > 0: the reference's two-resolution layout -- C channels at L^3 plus
         ``coarse_channels`` at (L/2)^3 (ProteinRepresentationModels.py:72-76); W1 is (H, C+coarse)."""
         self.device = torch.device(device)
@@ -154,6 +155,11 @@ class DockingEngine:
             self.wsA1 = torch.empty(nb * C1 * NZ1 * L1 * L1 * 2, dtype=f32, device=dev)
             self.wsB1 = torch.empty(nb * C1 * NZ1 * N1 * N1 * 2, dtype=f32, device=dev)
             self.aux = torch.empty(nb, C1, N1, N1, N1, dtype=f32, device=dev)      # clipped coarse correlations
+            # N = 160: the fused z-inverse + MLP kernel does not fit the register file,
+            # so the fine grid materialises its real correlations and a vectorised filter follows
+            self.fine_unfused = (N == 160) if fine_unfused is None else bool(fine_unfused)
+            if self.fine_unfused:
+                self.conv = torch.empty(nb, CT, N, N, N, dtype=f32, device=dev)
         self.top = DeviceTopList(self.K, nb, dev, lib)
         # optional: callable(R (nb,3,3) f32 device) -> (nb,L,L,L) f32 device ligand forbidden volumes
         # re-projected from rotated ATOMS (Docker.py:221-224) instead of the rotated volume
@@ -214,6 +220,16 @@ class DockingEngine:
                               self.center, st)
             self.lib.call("dlpd_xy_correlate", _ptr(self.wsA), _ptr(self.recF), _ptr(self.wsB), nb, self.CT,
                           self.L, 0, st)
+            if self.fine_unfused:
+                N3 = self.N ** 3
+                self.lib.call("dlpd_zifft_real_part", _ptr(self.wsB), _ptr(self.conv), nb, self.CT, self.C,
+                              self.L, has_clip, float(self.clip or 0.0), st)
+                mask = self.conv.data_ptr() + self.C * N3 * 4 if self.has_clash else 0
+                self.lib.call("dlpd_filter_volumes", _ptr(self.conv), self.C, self.CT * N3, self.N,
+                              _ptr(self.aux), self.C1, 2 * L1, mask, self.CT * N3, self.threshold,
+                              int(self.has_clash), _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2), self.b2,
+                              self.HP, _ptr(V), nb, st)
+                return V[:nb]
             self.lib.call("dlpd_zifft_filter_aux", _ptr(self.wsB), _ptr(V), nb, self.C, int(self.has_clash),
                           self.L, _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2), self.b2, self.HP, has_clip,
                           float(self.clip or 0.0), self.threshold, _ptr(self.aux), self.C1, st)

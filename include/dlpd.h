@@ -95,6 +95,18 @@ int dlpd_filter_mask(const float* conv0, int C0, int N0, const float* conv1, int
                      const float* mask_norm, float thr, int has_clash, const float* W1t, const float* b1,
                      const float* W2, float b2, int H, float* V, int nb, void* stream);
 
+/* Same with strided layouts and weights padded to HP = dlpd_hidden_pad(H): 4 voxels per thread,
+ * float4 traffic.  conv0 (nb, *, N0^3) uses its first C0 channels (batch stride conv0_bstride);
+ * mask_norm has batch stride mask_bstride (so it may be a channel of conv0). */
+int dlpd_filter_volumes(const float* conv0, int C0, long long conv0_bstride, int N0, const float* conv1, int C1,
+                        int N1, const float* mask_norm, long long mask_bstride, float thr, int has_clash,
+                        const float* W1t, const float* b1, const float* W2, float b2, int HP, float* V, int nb,
+                        void* stream);
+
+/* dlpd_zifft_real with the clamp restricted to channels [0, nclip). */
+int dlpd_zifft_real_part(const void* wsB, float* out, int nb, int CT, int nclip, int L, int has_clip, float clip,
+                         void* stream);
+
 /* Docker.update_top pick loop, src/Docker/Docker.py:89-98: per rotation the K picks in pick order
  * (incl. the zero-fill behaviour).  V (nb, nvox); out (nb, K). */
 size_t dlpd_topk_workspace_bytes(int nb, int K);

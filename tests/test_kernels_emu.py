@@ -189,9 +189,11 @@ def test_generic_filter_kernel_reproduces_reference_forward(emu, golden, tag, nr
     np.testing.assert_allclose(V.numpy(), g[tag + "_V"], rtol=1e-5, atol=1e-5)
 
 
-def test_fused_two_resolution_pipeline(emu):
+@pytest.mark.parametrize("unfused", [False, True])
+def test_fused_two_resolution_pipeline(emu, unfused):
     """[C0 @ 64^3, C1 @ 32^3] -> 128^3 through the fused engine (coarse correlations enter K3 as
-    auxiliary real channels, nearest-upsampled by index) against the oracle's GlobalDockingModel.forward."""
+    auxiliary real channels, nearest-upsampled by index) against the oracle's GlobalDockingModel.forward.
+    unfused: the N = 160 route (real volumes + dlpd_filter_volumes), forced here at N = 128."""
     L, C0, C1 = 64, 2, 3
     g = torch.Generator().manual_seed(41)
     rec0, lig0 = torch.randn(C0, L, L, L, generator=g) * 0.05, torch.randn(C0, L, L, L, generator=g) * 0.05
@@ -204,7 +206,7 @@ def test_fused_two_resolution_pipeline(emu):
     thr = 0.125 * L ** 3
     R = orc.euler_to_matrix([0.9], [0.7], [-1.4])
     eng = DockingEngine(L, C0, W1, b1, W2, b2, clip=0.8, threshold_clash=thr, max_conf=16, batch=1, device="cpu",
-                        lib=emu, coarse_channels=C1)
+                        lib=emu, coarse_channels=C1, fine_unfused=unfused)
     eng.set_receptor(rec0, recf, rec1)
     eng.set_ligand(lig0, ligf, lig1)
     V = eng.score_batch(torch.from_numpy(R).float().contiguous()).clone()
