@@ -1,12 +1,6 @@
-"""Benchmark table loaders are outside the accelerated path.
-The names the reference's drivers import exist so that ``local_test.py`` imports; calling them
-explains what is missing."""
-
-
-def get_benchmark_stream(*args, **kwargs):
-    raise Exception("Dataset.get_benchmark_stream: DockingBenchmark table parsing "
-                    "(reference src/Dataset/SplitComplexBenchmark.py:20-46,114-117) is not part of this build; "
-                    "feed Docker.dock_volumes()/dockSE3() directly")
+"""``from Dataset import get_benchmark_stream`` as the reference's local_test.py:8 does.  The
+training stream (SplitComplexDataset) is outside the docking path (out of scope)."""
+from .SplitComplexBenchmark import get_benchmark_stream, read_pdb_list, read_dataset_list, SplitComplexBenchmark
 
 
 def get_dataset_stream(*args, **kwargs):

@@ -15,6 +15,9 @@ recorded below is the reference's real code:
   G5  src/Models/DockingModels.py     GlobalDockingModel.forward, SimpleFilter
                                       (with .convolve := oracle FFT correlation)
                                                                   -> g5_global_forward.npz
+  G6  scripts/Results/Benchmark/DockerParser.py   DockerParser.parse_output (on G4's text)
+      src/Dataset/SplitComplexBenchmark.py        read_pdb_list, read_dataset_list (synthetic tables)
+                                                                  -> g6_consumers.npz
 Only data (inputs + expected outputs) is written; no reference source is copied.
 """
 import hashlib
@@ -190,6 +193,47 @@ def main():
         g5[tag + "_clip"] = np.float64(clip)
         g5[tag + "_V"] = V.numpy()
     np.savez_compressed(os.path.join(HERE, "g5_global_forward.npz"), **g5)
+
+    # ---------------- G6: .dat consumer + benchmark table loader ----------------
+    import tempfile, json
+    import importlib.util
+    for name in ["TorchProteinLibrary.RMSD", "Dataset", "Dataset.processing_utils", "DockingBenchmark",
+                 "VisualizeBenchmark", "matplotlib", "matplotlib.pylab"]:
+        sys.modules[name] = MagicMock()
+    sys.modules["src"].LOG_DIR = sys.modules["src"].DATA_DIR = "/nonexistent"
+    bdir = os.path.join(REF, "scripts", "Results", "Benchmark")
+    sys.path.insert(0, bdir)
+    spec = importlib.util.spec_from_file_location("ref_DockerParser", os.path.join(bdir, "DockerParser.py"))
+    DP = importlib.util.module_from_spec(spec); spec.loader.exec_module(DP)
+    g6 = {}
+    with tempfile.TemporaryDirectory() as td:
+        dat = bytes(g4["text"]).decode() + "0.5 0 0 0 0.5 0 0 0 1\t-3.75\t2.5\t-0.99\t-1.5e-3\n"
+        open(os.path.join(td, "T1.dat"), "w").write(dat)
+        res = DP.DockerParser(td).parse_output("T1", header_only=False)
+        g6["dat_text"] = np.frombuffer(dat.encode(), dtype=np.uint8)
+        g6["parsed_R"] = np.stack([c[0].numpy()[0] for c in res["conformations"]])
+        g6["parsed_t"] = np.stack([c[1].numpy()[0] for c in res["conformations"]])
+        g6["parsed_score"] = np.array([c[2] for c in res["conformations"]])
+        assert DP.DockerParser(td).parse_output("missing") is None
+        # benchmark tables
+        del sys.modules["Dataset"], sys.modules["Dataset.processing_utils"]
+        SB = importlib.import_module("src.Dataset.SplitComplexBenchmark")
+        table = ("Complex\tCat.\tPDB ID 1\n1ABC_A:B\tE\tx\n"          # before any section: ignored
+                 "Rigid-body (151)\t\t\n1AHW_AB:C\tA\t1FGN_LH\n1BVK_DE:F\tA\t1BVL_BA\n"
+                 "Medium Difficulty (45)\t\t\n1BGX_HL:T\tA\t1AY1_HL\n"
+                 "Difficult (34)\t\t\n1E4K_AB:C\tO\t2DTQ_AB\n2HMI_AB:CD\tO\t1S6P_AB\n")
+        open(os.path.join(td, "Table.csv"), "w").write(table)
+        t1 = SB.read_pdb_list(td, os.path.join(td, "Table.csv"), struct_folder="structs")
+        os.mkdir(os.path.join(td, "Description"))
+        open(os.path.join(td, "Description", "set.dat"), "w").write("1AAA extra\n2BBB\n")
+        open(os.path.join(td, "Description", "1AAA.dat"), "w").write("Receptor Ligand\n/p/r1.pdb /p/l1.pdb 3\n")
+        open(os.path.join(td, "Description", "2BBB.dat"), "w").write("hdr\nr2.pdb l2.pdb\nmore\n")
+        t2 = SB.read_dataset_list(td, os.path.join(td, "Description", "set.dat"))
+        rel = lambda rows: [[(v.replace(td, "<D>") if isinstance(v, str) else v) for v in r] for r in rows]
+        g6["table_text"] = np.frombuffer(table.encode(), dtype=np.uint8)
+        g6["pdb_list_json"] = np.frombuffer(json.dumps(rel(t1)).encode(), dtype=np.uint8)
+        g6["dataset_list_json"] = np.frombuffer(json.dumps(rel(t2)).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "g6_consumers.npz"), **g6)
 
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
