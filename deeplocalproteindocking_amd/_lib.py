@@ -32,7 +32,8 @@ SIGNATURES = {
     "dlpd_score_rotations": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _f, _i, _i, _f, _f,
                                   _p, _p, _p, _p]),
     "dlpd_filter_mask": (_i, [_p, _i, _i, _p, _i, _i, _p, _f, _i, _p, _p, _p, _f, _i, _p, _i, _p]),
-    "dlpd_filter_volumes": (_i, [_p, _i, _ll, _i, _p, _i, _i, _p, _ll, _f, _i, _p, _p, _p, _f, _i, _p, _i, _p]),
+    "dlpd_filter_preact": (_i, [_p, _i, _i, _p, _p, _i, _p, _i, _p]),
+    "dlpd_filter_volumes": (_i, [_p, _i, _ll, _i, _p, _i, _i, _i, _p, _ll, _f, _i, _p, _p, _p, _f, _i, _p, _i, _p]),
     "dlpd_zifft_real_part": (_i, [_p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "dlpd_topk_workspace_bytes": (_sz, [_i, _i]),
     "dlpd_topk_select": (_i, [_p, _i, _ll, _i, _p, _p, _p, _p]),

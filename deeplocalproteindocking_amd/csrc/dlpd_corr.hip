@@ -466,7 +466,7 @@ k_filter_generic(const float* __restrict__ conv0, int C0, int N0, const float* _
 // ------------------------------------------------------------------------------------------
 template <int HP> __global__ void __launch_bounds__(256)
 k_filter_vec(const float* __restrict__ conv0, int C0, long long c0_bstride, int N, const float* __restrict__ conv1,
-             int C1, int N1, const float* __restrict__ mask, long long mask_bstride, float thr, int has_clash,
+             int C1, int N1, int pre1, const float* __restrict__ mask, long long mask_bstride, float thr, int has_clash,
              const float* __restrict__ W1t, const float* __restrict__ b1, const float* __restrict__ W2, float b2,
              float* __restrict__ V, int nb) {
   const size_t N3 = (size_t)N * N * N, q3 = N3 / 4;
@@ -476,24 +476,52 @@ k_filter_vec(const float* __restrict__ conv0, int C0, long long c0_bstride, int 
     const int b = (int)(g / q3);
     const size_t r = (g % q3) * 4;
     float h[4][HP];
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-#pragma unroll
-      for (int j = 0; j < HP; j++) h[k][j] = b1[j];
-    const float* c0 = conv0 + (size_t)b * c0_bstride + r;
-    for (int c = 0; c < C0; c++) {
-      const float4 v = *reinterpret_cast<const float4*>(c0 + (size_t)c * N3);
-      const float* w = W1t + (size_t)c * HP;
+    if (pre1) {
+      // conv1 holds the HP first-layer pre-activations of the coarse channels (bias included),
+      // computed once per coarse voxel by k_filter_preact: 8x fewer FMAs than per fine voxel
+      const int z = (int)(r % N), y = (int)((r / N) % N), x = (int)(r / ((size_t)N * N));
+      const int s = N / N1;
+      const float* p = conv1 + (size_t)b * HP * N13 + ((size_t)(x / s) * N1 + (y / s)) * N1;
 #pragma unroll
       for (int j = 0; j < HP; j++) {
-        const float wj = w[j];
-        h[0][j] = fmaf(wj, v.x, h[0][j]);
-        h[1][j] = fmaf(wj, v.y, h[1][j]);
-        h[2][j] = fmaf(wj, v.z, h[2][j]);
-        h[3][j] = fmaf(wj, v.w, h[3][j]);
+        if (s == 2) {
+          const float2 u = *reinterpret_cast<const float2*>(p + (size_t)j * N13 + (z >> 1));
+          h[0][j] = h[1][j] = u.x; h[2][j] = h[3][j] = u.y;
+        } else {
+          const float4 u = *reinterpret_cast<const float4*>(p + (size_t)j * N13 + z);
+          h[0][j] = u.x; h[1][j] = u.y; h[2][j] = u.z; h[3][j] = u.w;
+        }
       }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int j = 0; j < HP; j++) h[k][j] = b1[j];
     }
-    if (C1 > 0) {
+    const float* c0 = conv0 + (size_t)b * c0_bstride + r;
+    // channels in groups of CH: all loads of a group are issued before its multiply-adds (the
+    // kernel is latency-bound otherwise: one 16-byte load in flight per thread)
+    constexpr int CH = 8;
+    for (int cb = 0; cb < C0; cb += CH) {
+      float4 v[CH];
+#pragma unroll
+      for (int u = 0; u < CH; u++)
+        if (cb + u < C0) v[u] = DLPD_LOAD_STREAM(reinterpret_cast<const float4*>(c0 + (size_t)(cb + u) * N3));
+#pragma unroll
+      for (int u = 0; u < CH; u++)
+        if (cb + u < C0) {
+          const float* w = W1t + (size_t)(cb + u) * HP;
+#pragma unroll
+          for (int j = 0; j < HP; j++) {
+            const float wj = w[j];
+            h[0][j] = fmaf(wj, v[u].x, h[0][j]);
+            h[1][j] = fmaf(wj, v[u].y, h[1][j]);
+            h[2][j] = fmaf(wj, v[u].z, h[2][j]);
+            h[3][j] = fmaf(wj, v[u].w, h[3][j]);
+          }
+        }
+    }
+    if (C1 > 0 && !pre1) {
       const int z = (int)(r % N), y = (int)((r / N) % N), x = (int)(r / ((size_t)N * N));
       const int s = N / N1;
       const float* c1 = conv1 + (size_t)b * C1 * N13 + ((size_t)(x / s) * N1 + (y / s)) * N1;
@@ -539,14 +567,46 @@ k_filter_vec(const float* __restrict__ conv0, int C0, long long c0_bstride, int 
   }
 }
 
+// pre (nb, HP, n) = b1 + W1rows^T conv1 (nb, C1, n): the coarse half of the first layer on the coarse grid
+template <int HP> __global__ void __launch_bounds__(256)
+k_filter_preact(const float* __restrict__ conv1, int C1, size_t n, const float* __restrict__ W1rows,
+                const float* __restrict__ b1, float* __restrict__ pre, int nb) {
+  const size_t q = n / 4, total = (size_t)nb * q;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(g / q);
+    const size_t r = (g % q) * 4;
+    float h[4][HP];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int j = 0; j < HP; j++) h[k][j] = b1[j];
+    const float* c1 = conv1 + (size_t)b * C1 * n + r;
+    for (int c = 0; c < C1; c++) {
+      const float4 v = *reinterpret_cast<const float4*>(c1 + (size_t)c * n);
+      const float* w = W1rows + (size_t)c * HP;
+#pragma unroll
+      for (int j = 0; j < HP; j++) {
+        const float wj = w[j];
+        h[0][j] = fmaf(wj, v.x, h[0][j]);
+        h[1][j] = fmaf(wj, v.y, h[1][j]);
+        h[2][j] = fmaf(wj, v.z, h[2][j]);
+        h[3][j] = fmaf(wj, v.w, h[3][j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < HP; j++)
+      *reinterpret_cast<float4*>(pre + ((size_t)b * HP + j) * n + r) = make_float4(h[0][j], h[1][j], h[2][j], h[3][j]);
+  }
+}
+
 template <int HP> static int launch_filter_vec(const float* conv0, int C0, long long c0bs, int N, const float* conv1,
-                                               int C1, int N1, const float* mask, long long mbs, float thr,
+                                               int C1, int N1, int pre1, const float* mask, long long mbs, float thr,
                                                int has_clash, const float* W1t, const float* b1, const float* W2,
                                                float b2, float* V, int nb, hipStream_t st) {
   const size_t total = (size_t)nb * N * N * N / 4;
   size_t nblk = (total + 255) / 256;
   if (nblk > 65536) nblk = 65536;
-  DLPD_LAUNCH((k_filter_vec<HP>), dim3((unsigned)nblk), dim3(256), 0, st, conv0, C0, c0bs, N, conv1, C1, N1, mask, mbs,
+  DLPD_LAUNCH((k_filter_vec<HP>), dim3((unsigned)nblk), dim3(256), 0, st, conv0, C0, c0bs, N, conv1, C1, N1, pre1, mask, mbs,
               thr, has_clash, W1t, b1, W2, b2, V, nb);
   return dlpd_check_launch();
 }
@@ -734,15 +794,32 @@ int dlpd_score_rotations(const float* lig, const void* recF, const float* R, int
 }
 
 // Vectorised filter: weights padded to HP (dlpd_hidden_pad), strided channel/batch layouts.
+int dlpd_filter_preact(const float* conv1, int C1, int N1, const float* W1rows, const float* b1, int HP,
+                       float* pre, int nb, void* stream) {
+  if (!conv1 || !W1rows || !b1 || !pre || nb <= 0 || C1 <= 0 || N1 <= 0 || N1 % 4) return DLPD_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n = (size_t)N1 * N1 * N1;
+  size_t nblk = ((size_t)nb * n / 4 + 255) / 256;
+  if (nblk > 65536) nblk = 65536;
+#define DLPD_FP(H) case H: DLPD_LAUNCH((k_filter_preact<H>), dim3((unsigned)nblk), dim3(256), 0, st, conv1, C1, n, \
+                                       W1rows, b1, pre, nb); return dlpd_check_launch()
+  switch (HP) {
+    DLPD_FP(2); DLPD_FP(4); DLPD_FP(8); DLPD_FP(16); DLPD_FP(24); DLPD_FP(32);
+    default: return DLPD_ERR_UNSUPPORTED;
+  }
+#undef DLPD_FP
+}
+
 int dlpd_filter_volumes(const float* conv0, int C0, long long conv0_bstride, int N0, const float* conv1, int C1,
-                        int N1, const float* mask_norm, long long mask_bstride, float thr, int has_clash,
+                        int N1, int conv1_is_preact, const float* mask_norm, long long mask_bstride, float thr, int has_clash,
                         const float* W1t, const float* b1, const float* W2, float b2, int HP, float* V, int nb,
                         void* stream) {
   if (!conv0 || !V || !W1t || !b1 || !W2 || nb <= 0 || C0 <= 0 || N0 <= 0 || N0 % 4) return DLPD_ERR_ARG;
   if (C1 > 0 && (!conv1 || N1 <= 0 || N0 % N1 != 0 || (N0 / N1 == 2 && N1 % 2))) return DLPD_ERR_ARG;
+  if (conv1_is_preact && (C1 <= 0 || N0 / N1 > 2)) return DLPD_ERR_ARG;
   if (has_clash && !mask_norm) return DLPD_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-#define DLPD_FV(H) case H: return launch_filter_vec<H>(conv0, C0, conv0_bstride, N0, conv1, C1, N1, mask_norm, \
+#define DLPD_FV(H) case H: return launch_filter_vec<H>(conv0, C0, conv0_bstride, N0, conv1, C1, N1, conv1_is_preact, mask_norm, \
                                                       mask_bstride, thr, has_clash, W1t, b1, W2, b2, V, nb, st)
   switch (HP) {
     DLPD_FV(2); DLPD_FV(4); DLPD_FV(8); DLPD_FV(16); DLPD_FV(24); DLPD_FV(32);
@@ -759,7 +836,7 @@ int dlpd_filter_mask(const float* conv0, int C0, int N0, const float* conv1, int
   if (C1 > 0 && (!conv1 || N1 <= 0 || N0 % N1 != 0)) return DLPD_ERR_ARG;
   if (has_clash && !mask_norm) return DLPD_ERR_ARG;
   if (dlpd_hidden_pad(H) == H && N0 % 4 == 0 && (C1 == 0 || N0 / N1 != 2 || N1 % 2 == 0))   // no padding needed
-    return dlpd_filter_volumes(conv0, C0, (long long)C0 * N0 * N0 * N0, N0, conv1, C1, N1, mask_norm,
+    return dlpd_filter_volumes(conv0, C0, (long long)C0 * N0 * N0 * N0, N0, conv1, C1, N1, 0, mask_norm,
                                (long long)N0 * N0 * N0, thr, has_clash, W1t, b1, W2, b2, H, V, nb, stream);
   const size_t total = (size_t)nb * N0 * N0 * N0;
   size_t nblk = (total + 255) / 256;

@@ -404,6 +404,213 @@ template <int N, int MODE> static int launch_k2_split(const cplx* A, const cplx*
   return dlpd_check_launch();
 }
 
+// ------------------------------------------------------------------------------------------
+// K2 for grids whose N x N slab does not fit LDS (N = 160): decimation in frequency along y.
+// With only the first N/2 inputs of a y row non-zero, its even outputs are the N/2-point FFT of the
+// row and its odd outputs the N/2-point FFT of the row times w_N^y; likewise the inverse along y is
+//     out[n'] = G0[n'] + conj(w_N^n') G1[n'],  out[n' + N/2] = G0[n'] - conj(w_N^n') G1[n'],
+// G_p = N/2-point inverse over the parity-p columns.  So one block runs the whole slab as two
+// half-width passes over an N x (N/2) LDS slab (110 KB at N = 160): G0 waits in registers
+// (N*N/4/NT complex per thread) while parity 1 runs, the A slab stays in registers for both
+// parities, and the output is written once, fully coalesced.  Same in/out layout as k_xy_corr.
+//   grid NZ*CT*nsplit (XCD-aware decode as above), block 4N = 640 threads (10 waves: one column
+//   pencil set each), persistent over the rotations of its part of the batch.
+// ------------------------------------------------------------------------------------------
+#ifndef DLPD_K2D_WAVES
+#define DLPD_K2D_WAVES 8                 // waves per block (256-VGPR budget; 10 would match the 10 column sets but spills)
+#endif
+#ifndef DLPD_K2D_G0REG
+#define DLPD_K2D_G0REG 0                 // 1: G0 waits in registers (spills at 8 waves); 0: in the output slab, re-read from L2
+#endif
+template <int N> __global__ void __launch_bounds__(64 * DLPD_K2D_WAVES)
+k_xy_corr_dif(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __restrict__ out,
+              int CT, int nb, int nsplit, long long rec_bstride) {
+  constexpr int L = N / 2, H = N / 2, NZ = N / 2 + 1, RS = H + 8;
+  static_assert(RS % 16 == 8, "row stride must be an odd multiple of 8 elements (bank spreading)");
+  constexpr int NT = 64 * DLPD_K2D_WAVES, W = NT / 64;
+  constexpr int NLOAD = (L * L / 2 + NT - 1) / NT;     // float4 (2 complex) per thread of an A slab
+  constexpr int NG = (N * H / 2 + NT - 1) / NT;        // float4 per thread of a G slab
+  typedef FftPlanW<N> P;
+  static_assert(P::R3 > 1, "three-pass plan expected");
+  typedef FftPassW<N, P::R1, 1, -1, 8, L> FwdP1;
+  typedef FftPassW<N, P::R2, P::R1, -1, 8> FwdP2;
+  typedef FftPassW<N, P::R3, P::R1 * P::R2, -1, 8> FwdP3;
+  DLPD_DYN_SHARED(cplx, S);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bid = blockIdx.x;
+  const int part = (bid >> 3) % nsplit;
+  const int slab = (bid / (8 * nsplit)) * 8 + (bid & 7);
+  if (slab >= NZ * CT) return;
+  const int kz = slab % NZ, c = slab / NZ;
+  const int b_beg = (int)(((long long)nb * part) / nsplit), b_end = (int)(((long long)nb * (part + 1)) / nsplit);
+  if (b_beg >= b_end) return;
+  const int tr = lane & 7, qr = lane >> 3;             // row phase: lane = 8*pencil + thread
+  const int c8 = lane & 7;                             // column phase: lane = 8*thread + column
+  cplx* tw = S + N * RS;                               // exp(-2 pi i k / N)
+  cplx* twh = tw + N;                                  // exp(-2 pi i k / H)
+  init_twiddles<N>(tw, tid, NT);
+  init_twiddles<H>(twh, tid, NT);
+
+  float4 apref[NLOAD];
+  auto fetch_A = [&](int b) {
+    const float4* a = reinterpret_cast<const float4*>(A + (((size_t)b * CT + c) * NZ + kz) * L * L);
+#pragma unroll
+    for (int i = 0; i < NLOAD; i++)
+      if (tid + i * NT < L * L / 2) apref[i] = DLPD_LOAD_STREAM(a + tid + i * NT);
+  };
+  fetch_A(b_beg);
+  __syncthreads();                                     // twiddle tables visible
+  DLPD_STAMP_DECL;
+  for (int b = b_beg; b < b_end; b++) {
+#if DLPD_K2D_G0REG
+    float4 g0[NG];
+#endif
+    float4* o = reinterpret_cast<float4*>(out + (((size_t)b * CT + c) * NZ + kz) * N * N);
+#pragma unroll 1
+    for (int par = 0; par < 2; par++) {
+      // ---- A slab (registers) -> rows 0..L-1, times w_N^y for the odd outputs
+      DLPD_STAMP(7);
+      int tq = tid;
+      DLPD_OPAQUE(tq);               // keeps the ~60 slab offsets below from being hoisted out of the loops and spilled
+#pragma unroll
+      for (int i = 0; i < NLOAD; i++) {
+        const int e = 2 * (tq + i * NT), x = e / L, y = e % L;
+        if (e < L * L) {
+          cplx u = c_make(apref[i].x, apref[i].y), v = c_make(apref[i].z, apref[i].w);
+          if (par) { u = c_mul(u, tw[y]); v = c_mul(v, tw[y + 1]); }
+          S[x * RS + slab_swz(y)] = u;
+          S[x * RS + slab_swz(y + 1)] = v;
+        }
+      }
+      if (par == 1 && b + 1 < b_end) fetch_A(b + 1);   // next rotation's slab, in flight over this parity
+      DLPD_STAMP(0);
+      __syncthreads();
+      DLPD_STAMP(1);
+      // ---- forward along y: H-point transforms of the L non-zero rows
+#pragma unroll 1
+      for (int set = wave; set < L / 8; set += W) {
+        const RowAddr<RS> ad = {(set * 8 + qr) * RS};
+        int t = tr;
+        DLPD_OPAQUE(t);
+        fft_wave<H, -1, H>(S, ad, t, twh);
+      }
+      DLPD_STAMP(2);
+      __syncthreads();
+      DLPD_STAMP(1);
+      // ---- columns ky = 2m + par: forward x (pruned), receptor multiply, inverse x
+#pragma unroll 1
+      for (int set = wave; set < H / 8; set += W) {
+        const int col = set * 8 + c8;
+        const ColAddr<RS> ad = {slab_swz(col)};
+        int tc = lane >> 3;
+        DLPD_OPAQUE(tc);
+        // receptor values of this pencil set: requested first, in flight during the forward passes
+        cplx rv[FwdP3::PER][P::R3];
+        {
+          const cplx* rbase = rec + (size_t)b * rec_bstride + ((size_t)c * NZ + kz) * N * N + (2 * col + par);
+          FwdP3 idx;
+#pragma unroll
+          for (int i = 0; i < FwdP3::PER; i++)
+            if (idx.active(i, tc)) {
+#pragma unroll
+              for (int q = 0; q < P::R3; q++) rv[i][q] = rbase[(unsigned)(idx.out_index(i, q, tc) * N)];
+            }
+        }
+        {
+          FwdP1 ps;
+          ps.load(S, ad, tc, tw);
+          DLPD_WAVE_SYNC();
+          ps.store(S, ad, tc);
+          DLPD_WAVE_SYNC();
+        }
+        {
+          FwdP2 ps;
+          ps.load(S, ad, tc, tw);
+          DLPD_WAVE_SYNC();
+          ps.store(S, ad, tc);
+          DLPD_WAVE_SYNC();
+        }
+        {
+          FwdP3 ps;
+          ps.load(S, ad, tc, tw);
+#pragma unroll
+          for (int i = 0; i < FwdP3::PER; i++)
+            if (ps.active(i, tc)) {
+#pragma unroll
+              for (int q = 0; q < P::R3; q++) ps.v[i][q] = c_mulc(rv[i][q], ps.v[i][q]);
+            }
+          DLPD_WAVE_SYNC();
+          ps.store(S, ad, tc);
+          DLPD_WAVE_SYNC();
+        }
+        fft_wave<N, +1, N>(S, ad, tc, tw);
+      }
+      DLPD_STAMP(3);
+      __syncthreads();
+      DLPD_STAMP(1);
+      // ---- inverse along y: H-point transforms of all N rows -> G_par
+#pragma unroll 1
+      for (int set = wave; set < N / 8; set += W) {
+        const RowAddr<RS> ad = {(set * 8 + qr) * RS};
+        int t = tr;
+        DLPD_OPAQUE(t);
+        fft_wave<H, +1, H>(S, ad, t, twh);
+      }
+      DLPD_STAMP(4);
+      __syncthreads();
+      DLPD_STAMP(1);
+      DLPD_OPAQUE(tq);
+      if (par == 0) {
+#pragma unroll
+        for (int i = 0; i < NG; i++) {
+          const int e = 2 * (tq + i * NT), x = e / H, y = e % H;
+          if (e < N * H) {
+            const cplx u = S[x * RS + slab_swz(y)], v = S[x * RS + slab_swz(y + 1)];
+#if DLPD_K2D_G0REG
+            g0[i] = make_float4(u.x, u.y, v.x, v.y);
+#else
+            o[(x * N + y) / 2] = make_float4(u.x, u.y, v.x, v.y);
+#endif
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NG; i++) {
+          const int e = 2 * (tq + i * NT), x = e / H, y = e % H;
+          if (e < N * H) {
+            const cplx u = c_mulc(S[x * RS + slab_swz(y)], tw[y]);          // conj(w^y) * G1
+            const cplx v = c_mulc(S[x * RS + slab_swz(y + 1)], tw[y + 1]);
+#if DLPD_K2D_G0REG
+            const float4 g = g0[i];
+#else
+            const float4 g = o[(x * N + y) / 2];
+#endif
+            DLPD_STORE_STREAM(o + (x * N + y) / 2, make_float4(g.x + u.x, g.y + u.y, g.z + v.x, g.w + v.y));
+            DLPD_STORE_STREAM(o + (x * N + y + H) / 2, make_float4(g.x - u.x, g.y - u.y, g.z - v.x, g.w - v.y));
+          }
+        }
+      }
+      DLPD_STAMP(5);
+      __syncthreads();                                 // slab fully read before it is refilled
+      DLPD_STAMP(1);
+    }
+  }
+  DLPD_STAMP_FLUSH(dlpd_stamps_k2, DLPD_STAMPS);
+}
+
+template <int N> static int launch_k2_dif(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, long long rbs,
+                                          hipStream_t st) {
+  constexpr int NZ = N / 2 + 1, H = N / 2, RS = H + 8;
+  const size_t shmem = (size_t)(N * RS + N + H) * sizeof(cplx);
+  int rc = dlpd_set_max_dyn_shared((const void*)k_xy_corr_dif<N>, shmem);
+  if (rc) return rc;
+  int nsplit = nb >= 8 ? 2 : 1;
+  if (const char* e = getenv("DLPD_K2_NSPLIT")) nsplit = atoi(e) > 0 ? atoi(e) : nsplit;
+  const int slabs8 = ((NZ * CT + 7) / 8) * 8;
+  DLPD_LAUNCH((k_xy_corr_dif<N>), dim3(slabs8 * nsplit), dim3(64 * DLPD_K2D_WAVES), shmem, st, A, rec, out, CT, nb, nsplit, rbs);
+  return dlpd_check_launch();
+}
+
 int dlpd_k2_forward(const cplx* A, cplx* out, int CT, int nb, int L, float scale, hipStream_t st) {
   switch (L) {
     case 32: return launch_k2<64, 0>(A, nullptr, out, CT, nb, 0, scale, st);
@@ -419,7 +626,8 @@ int dlpd_k2_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb,
     case 32: return launch_k2<64, 1>(A, rec, out, CT, nb, rbs, 1.f, st);
     case 40: return launch_k2<80, 1>(A, rec, out, CT, nb, rbs, 1.f, st);
     case 64: return launch_k2<128, 1>(A, rec, out, CT, nb, rbs, 1.f, st);
-    case 80: return launch_k2_split<160, 1>(A, rec, out, CT, nb, rbs, 1.f, st);
+    case 80: return getenv("DLPD_K2_SPLIT") ? launch_k2_split<160, 1>(A, rec, out, CT, nb, rbs, 1.f, st)
+                                          : launch_k2_dif<160>(A, rec, out, CT, nb, rbs, st);
     default: return DLPD_ERR_UNSUPPORTED;
   }
 }

@@ -52,6 +52,10 @@ __device__ __forceinline__ void dlpd_store_stream(float4* p, float4 v) {
 #define DLPD_CLAMP(v, c) __builtin_amdgcn_fmed3f((v), -(c), (c))
 // keeps the compiler from moving instructions across this point (software-pipelined loops)
 #define DLPD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// make a lane-dependent int opaque to the optimiser at this point: stops loop-invariant code motion
+// from hoisting dozens of swizzled LDS offsets out of the pencil-set loops (they are cheap to
+// recompute and expensive to keep in VGPRs)
+#define DLPD_OPAQUE(x) asm volatile("" : "+v"(x))
 // explicit 2 x f32 packed math (v_pk_fma_f32), independent of the SLP vectoriser
 typedef float dlpd_f2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ dlpd_f2v dlpd_f2_make(float a, float b) { dlpd_f2v r = {a, b}; return r; }

@@ -155,11 +155,13 @@ class DockingEngine:
             self.wsA1 = torch.empty(nb * C1 * NZ1 * L1 * L1 * 2, dtype=f32, device=dev)
             self.wsB1 = torch.empty(nb * C1 * NZ1 * N1 * N1 * 2, dtype=f32, device=dev)
             self.aux = torch.empty(nb, C1, N1, N1, N1, dtype=f32, device=dev)      # clipped coarse correlations
-            # N = 160: the fused z-inverse + MLP kernel does not fit the register file,
-            # so the fine grid materialises its real correlations and a vectorised filter follows
-            self.fine_unfused = (N == 160) if fine_unfused is None else bool(fine_unfused)
-            if self.fine_unfused:
-                self.conv = torch.empty(nb, CT, N, N, N, dtype=f32, device=dev)
+        # N = 160: the fused z-inverse + MLP kernel does not fit the register file,
+        # so that grid materialises its real correlations and a vectorised filter follows
+        self.fine_unfused = (N == 160) if fine_unfused is None else bool(fine_unfused)
+        if self.fine_unfused:
+            self.conv = torch.empty(nb, CT, N, N, N, dtype=f32, device=dev)
+            if self.C1:
+                self.pre = torch.empty(nb, HP, 2 * self.L1, 2 * self.L1, 2 * self.L1, dtype=f32, device=dev)
         self.top = DeviceTopList(self.K, nb, dev, lib)
         # optional: callable(R (nb,3,3) f32 device) -> (nb,L,L,L) f32 device ligand forbidden volumes
         # re-projected from rotated ATOMS (Docker.py:221-224) instead of the rotated volume
@@ -195,77 +197,63 @@ class DockingEngine:
     # ---- hot loop ------------------------------------------------------------------------
     def score_batch(self, R, mark=None, out=None):
         """R (nb,3,3) float32 on the device, nb <= batch.  Returns V[:nb] (view of the engine's
-        buffer, overwritten by the next call): Docker.py:218-232."""
+        buffer, overwritten by the next call): Docker.py:218-232.  mark(name): optional callback
+        after each stage (timing)."""
         nb = R.shape[0]
         assert nb <= self.batch and R.dtype == torch.float32 and R.is_contiguous()
-        has_clip = 0 if self.clip is None else 1
+        has_clip, clip = (0 if self.clip is None else 1), float(self.clip or 0.0)
         V = self.V if out is None else out
+        call, st, L = self.lib.call, _stream(self.device), self.L
+        provider = self.clash_provider if self.has_clash else None
+        if not (self.C1 or provider or self.fine_unfused or mark):
+            call("dlpd_score_rotations", _ptr(self.lig), _ptr(self.recF), _ptr(R), nb, self.C,
+                 int(self.has_clash), L, self.center, _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2), self.b2,
+                 self.HP, has_clip, clip, self.threshold, _ptr(self.wsA), _ptr(self.wsB), _ptr(V), st)
+            return V[:nb]
+        mark = mark or (lambda name: None)
+        mark("begin")
         if self.C1:
-            # coarse resolution first: rotate + correlate + clip -> real volumes the fine K3 reads
-            st, L1 = _stream(self.device), self.L1
-            self.lib.call("dlpd_zfft", _ptr(self.lig1), _ptr(R), _ptr(self.wsA1), nb, self.C1, L1, 0, 1,
-                          float(L1) / 2.0, st)
-            self.lib.call("dlpd_xy_correlate", _ptr(self.wsA1), _ptr(self.recF1), _ptr(self.wsB1), nb, self.C1,
-                          L1, 0, st)
-            self.lib.call("dlpd_zifft_real", _ptr(self.wsB1), _ptr(self.aux), nb, self.C1, L1, has_clip,
-                          float(self.clip or 0.0), st)
-            if self.clash_provider is not None and self.has_clash:
-                forb = self.clash_provider(R).reshape(nb, self.L, self.L, self.L).contiguous()
-                self.lib.call("dlpd_zfft_into", _ptr(self.lig), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0,
-                              self.L, 0, 1, self.center, st)
-                self.lib.call("dlpd_zfft_into", _ptr(forb), 0, _ptr(self.wsA), nb, 1, self.CT, self.C, self.L,
-                              self.L ** 3, 0, 0.0, st)
-            else:
-                self.lib.call("dlpd_zfft", _ptr(self.lig), _ptr(R), _ptr(self.wsA), nb, self.CT, self.L, 0, 1,
-                              self.center, st)
-            self.lib.call("dlpd_xy_correlate", _ptr(self.wsA), _ptr(self.recF), _ptr(self.wsB), nb, self.CT,
-                          self.L, 0, st)
-            if self.fine_unfused:
-                N3 = self.N ** 3
-                self.lib.call("dlpd_zifft_real_part", _ptr(self.wsB), _ptr(self.conv), nb, self.CT, self.C,
-                              self.L, has_clip, float(self.clip or 0.0), st)
-                mask = self.conv.data_ptr() + self.C * N3 * 4 if self.has_clash else 0
-                self.lib.call("dlpd_filter_volumes", _ptr(self.conv), self.C, self.CT * N3, self.N,
-                              _ptr(self.aux), self.C1, 2 * L1, mask, self.CT * N3, self.threshold,
-                              int(self.has_clash), _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2), self.b2,
-                              self.HP, _ptr(V), nb, st)
-                return V[:nb]
-            self.lib.call("dlpd_zifft_filter_aux", _ptr(self.wsB), _ptr(V), nb, self.C, int(self.has_clash),
-                          self.L, _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2), self.b2, self.HP, has_clip,
-                          float(self.clip or 0.0), self.threshold, _ptr(self.aux), self.C1, st)
-            return V[:nb]
-        if self.clash_provider is not None and self.has_clash:
-            st = _stream(self.device)
-            forb = self.clash_provider(R).reshape(nb, self.L, self.L, self.L).contiguous()
-            self.lib.call("dlpd_zfft_into", _ptr(self.lig), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0,
-                          self.L, 0, 1, self.center, st)
-            self.lib.call("dlpd_zfft_into", _ptr(forb), 0, _ptr(self.wsA), nb, 1, self.CT, self.C, self.L,
-                          self.L ** 3, 0, 0.0, st)
-            self.lib.call("dlpd_xy_correlate", _ptr(self.wsA), _ptr(self.recF), _ptr(self.wsB), nb, self.CT,
-                          self.L, 0, st)
-            self.lib.call("dlpd_zifft_filter", _ptr(self.wsB), _ptr(V), nb, self.C, 1, self.L, _ptr(self.W1t),
-                          _ptr(self.b1), _ptr(self.W2), self.b2, self.HP, has_clip, float(self.clip or 0.0),
-                          self.threshold, st)
-            return V[:nb]
-        if mark is not None:
-            # same three stages as dlpd_score_rotations, with a timing mark after each
-            st = _stream(self.device)
-            mark("begin")
-            self.lib.call("dlpd_zfft", _ptr(self.lig), _ptr(R), _ptr(self.wsA), nb, self.CT, self.L, 0, 1,
-                          self.center, st)
-            mark("k1_rotate_zfft")
-            self.lib.call("dlpd_xy_correlate", _ptr(self.wsA), _ptr(self.recF), _ptr(self.wsB), nb, self.CT,
-                          self.L, 0, st)
-            mark("k2_xy_corr")
-            self.lib.call("dlpd_zifft_filter", _ptr(self.wsB), _ptr(V), nb, self.C, int(self.has_clash),
-                          self.L, _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2), self.b2, self.HP, has_clip,
-                          float(self.clip or 0.0), self.threshold, st)
+            # coarse resolution first: rotate + correlate + clip -> real volumes the fine filter reads
+            L1 = self.L1
+            call("dlpd_zfft", _ptr(self.lig1), _ptr(R), _ptr(self.wsA1), nb, self.C1, L1, 0, 1, float(L1) / 2.0, st)
+            call("dlpd_xy_correlate", _ptr(self.wsA1), _ptr(self.recF1), _ptr(self.wsB1), nb, self.C1, L1, 0, st)
+            call("dlpd_zifft_real", _ptr(self.wsB1), _ptr(self.aux), nb, self.C1, L1, has_clip, clip, st)
+            mark("coarse")
+        if provider is not None:
+            # clash channel from re-projected rotated ATOMS (Docker.py:221-224), scores from rotated volumes
+            forb = provider(R).reshape(nb, L, L, L).contiguous()
+            call("dlpd_zfft_into", _ptr(self.lig), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0, L, 0, 1,
+                 self.center, st)
+            call("dlpd_zfft_into", _ptr(forb), 0, _ptr(self.wsA), nb, 1, self.CT, self.C, L, L ** 3, 0, 0.0, st)
+        else:
+            call("dlpd_zfft", _ptr(self.lig), _ptr(R), _ptr(self.wsA), nb, self.CT, L, 0, 1, self.center, st)
+        mark("k1_rotate_zfft")
+        call("dlpd_xy_correlate", _ptr(self.wsA), _ptr(self.recF), _ptr(self.wsB), nb, self.CT, L, 0, st)
+        mark("k2_xy_corr")
+        aux, C1, N1 = (_ptr(self.aux), self.C1, 2 * self.L1) if self.C1 else (0, 0, 0)
+        if self.fine_unfused:
+            N3 = self.N ** 3
+            call("dlpd_zifft_real_part", _ptr(self.wsB), _ptr(self.conv), nb, self.CT, self.C, L, has_clip, clip, st)
+            mark("k3_zifft")
+            mask = self.conv.data_ptr() + self.C * N3 * 4 if self.has_clash else 0
+            if C1:
+                # first layer is linear: its coarse half runs once per COARSE voxel (DockingModels.py:74-83)
+                call("dlpd_filter_preact", aux, C1, N1, self.W1t.data_ptr() + self.C * self.HP * 4, _ptr(self.b1),
+                     self.HP, _ptr(self.pre), nb, st)
+                aux = _ptr(self.pre)
+            call("dlpd_filter_volumes", _ptr(self.conv), self.C, self.CT * N3, self.N, aux, C1, N1, int(C1 > 0), mask,
+                 self.CT * N3, self.threshold, int(self.has_clash), _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2),
+                 self.b2, self.HP, _ptr(V), nb, st)
+            mark("filter")
+        elif self.C1:
+            call("dlpd_zifft_filter_aux", _ptr(self.wsB), _ptr(V), nb, self.C, int(self.has_clash), L,
+                 _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2), self.b2, self.HP, has_clip, clip, self.threshold,
+                 aux, C1, st)
             mark("k3_zifft_filter")
-            return V[:nb]
-        self.lib.call("dlpd_score_rotations", _ptr(self.lig), _ptr(self.recF), _ptr(R), nb, self.C,
-                      int(self.has_clash), self.L, self.center, _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2),
-                      self.b2, self.HP, has_clip, float(self.clip or 0.0), self.threshold,
-                      _ptr(self.wsA), _ptr(self.wsB), _ptr(V), _stream(self.device))
+        else:
+            call("dlpd_zifft_filter", _ptr(self.wsB), _ptr(V), nb, self.C, int(self.has_clash), L,
+                 _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2), self.b2, self.HP, has_clip, clip, self.threshold, st)
+            mark("k3_zifft_filter")
         return V[:nb]
 
     def reset_top(self):

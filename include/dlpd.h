@@ -97,11 +97,19 @@ int dlpd_filter_mask(const float* conv0, int C0, int N0, const float* conv1, int
 
 /* Same with strided layouts and weights padded to HP = dlpd_hidden_pad(H): 4 voxels per thread,
  * float4 traffic.  conv0 (nb, *, N0^3) uses its first C0 channels (batch stride conv0_bstride);
- * mask_norm has batch stride mask_bstride (so it may be a channel of conv0). */
+ * mask_norm has batch stride mask_bstride (so it may be a channel of conv0).
+ * conv1_is_preact: conv1 is (nb, HP, N1^3) from dlpd_filter_preact instead of (nb, C1, N1^3). */
 int dlpd_filter_volumes(const float* conv0, int C0, long long conv0_bstride, int N0, const float* conv1, int C1,
-                        int N1, const float* mask_norm, long long mask_bstride, float thr, int has_clash,
+                        int N1, int conv1_is_preact, const float* mask_norm, long long mask_bstride, float thr, int has_clash,
                         const float* W1t, const float* b1, const float* W2, float b2, int HP, float* V, int nb,
                         void* stream);
+
+/* The coarse-resolution half of SimpleFilter's first layer (DockingModels.py:28, after the concat of
+ * :77) evaluated on the coarse grid: pre (nb, HP, N1^3) = b1 + W1rows^T conv1, W1rows (C1, HP) = the
+ * rows of W1t that belong to the coarse channels.  The first layer is linear, so upsampling these
+ * HP planes by index equals applying it to the upsampled channels (8x fewer multiply-adds). */
+int dlpd_filter_preact(const float* conv1, int C1, int N1, const float* W1rows, const float* b1, int HP,
+                       float* pre, int nb, void* stream);
 
 /* dlpd_zifft_real with the clamp restricted to channels [0, nclip). */
 int dlpd_zifft_real_part(const void* wsB, float* out, int nb, int CT, int nclip, int L, int has_clip, float clip,

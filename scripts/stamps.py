@@ -8,7 +8,7 @@ from deeplocalproteindocking_amd.engine import DockingEngine
 from deeplocalproteindocking_amd._lib import get_lib
 K3 = ["dma_wait", "zbuild", "dma_issue", "fft", "barrierA", "accumulate", "barrierB", "-"]
 K2 = ["A->LDS", "barriers", "fwd_y", "columns", "inv_y", "copy_out", "-", "loop_top"]
-C, L, nb = 48, 64, 16
+C, L, nb = (48, 64, 16) if len(sys.argv) < 2 else (16, 80, 16)       # any argument: the N = 160 grid
 rec, lig, recf, ligf, filt = bench.synthetic_pair(C, L)
 eng = DockingEngine(L, C, *filt.parameters_tuple(), clip=5.0, threshold_clash=bench.clash_threshold(recf, ligf),
                     max_conf=2000, batch=nb, device="cuda:0")

@@ -227,6 +227,7 @@ static inline dlpd_pair_t dlpd_load_pair(const float* p) { dlpd_pair_t r; r.x = 
 #define DLPD_STORE_STREAM(p, v) (*(p) = (v))
 #define DLPD_CLAMP(v, c) fminf(fmaxf((v), -(c)), (c))
 #define DLPD_SCHED_FENCE() ((void)0)
+#define DLPD_OPAQUE(x) ((void)(x))
 struct dlpd_f2v { float x, y; };
 static inline dlpd_f2v dlpd_f2_make(float a, float b) { dlpd_f2v r = {a, b}; return r; }
 static inline dlpd_f2v dlpd_f2_splat(float a) { dlpd_f2v r = {a, a}; return r; }

@@ -61,6 +61,27 @@ def test_fused_pipeline_radix5_grid(emu):
     assert ((V[0] - Vo).abs()[sure]).max() <= 1e-4 * Vo.abs().max()
 
 
+def test_pipeline_real_box_size(emu):
+    """L = 80 (N = 160, the reference's box_size): the slab does not fit LDS, so K2 runs the
+    decimation-in-frequency kernel (two half-width passes, G0 parked in registers) and the filter is
+    unfused; two rotations exercise the persistent loop's register prefetch of the next A slab."""
+    L, C = 80, 1
+    rec, lig, recf, ligf, W1, b1, W2, b2 = _pair(L, 4, seed=9)
+    rec, lig, W1 = rec[:C], lig[:C], W1[:, :C]
+    thr = 0.125 * L ** 3
+    R = orc.euler_to_matrix([0.9, -0.3], [0.7, 1.9], [-1.4, 0.2])
+    eng = DockingEngine(L, C, W1, b1, W2, b2, clip=5.0, threshold_clash=thr, max_conf=16, batch=2, device="cpu", lib=emu)
+    eng.set_receptor(rec, recf)
+    eng.set_ligand(lig, ligf)
+    V = eng.score_batch(torch.from_numpy(R).float().contiguous()).clone()
+    for i in range(2):
+        Rb = torch.from_numpy(R[i:i + 1]).float()
+        mask, norm = orc.clash_mask(recf[None, None], orc.rotate_volume(ligf[None, None], Rb), thr)
+        Vo = (mask * orc.score_volumes([rec[None]], [orc.rotate_volume(lig[None], Rb)], W1, b1, W2, b2, clip=5.0))[0]
+        sure = (norm[0] - thr).abs() > 1e-3 * thr
+        assert ((V[i] - Vo).abs()[sure]).max() <= 1e-4 * Vo.abs().max()
+
+
 def test_search_with_odd_tail_matches_oracle_list(emu):
     L, C, K = 32, 4, 40
     rec, lig, recf, ligf, W1, b1, W2, b2 = _pair(L, C, seed=1)
