@@ -15,23 +15,44 @@
 typedef float2 cplx;
 
 DLPD_HD cplx c_make(float a, float b) { cplx r; r.x = a; r.y = b; return r; }
+DLPD_HD cplx c_conj(cplx a) { return c_make(a.x, -a.y); }
+#if defined(DLPD_PK) && DLPD_PK && defined(__HIP_DEVICE_COMPILE__)
+// packed forms (dlpd_platform.h): one VOP3P instruction per complex add, two per multiply
+DLPD_D cplx c_add(cplx a, cplx b) { return dlpd_c_add(a, b); }
+DLPD_D cplx c_sub(cplx a, cplx b) { return dlpd_c_sub(a, b); }
+DLPD_D cplx c_mul(cplx a, cplx b) { return dlpd_c_mul(a, b); }
+DLPD_D cplx c_mulc(cplx a, cplx b) { return dlpd_c_mulc(a, b); }
+DLPD_D cplx c_scale(cplx a, float s) { return dlpd_c_scale(a, s); }
+DLPD_D cplx c_axpy(cplx a, float s, cplx b) { return dlpd_c_axpy(a, s, b); }
+// a + exp(DIR*i*pi/2) * b   and   a - exp(DIR*i*pi/2) * b
+template <int DIR> DLPD_D cplx c_add_rot(cplx a, cplx b) { return DIR < 0 ? dlpd_c_add_mi(a, b) : dlpd_c_add_pi(a, b); }
+template <int DIR> DLPD_D cplx c_sub_rot(cplx a, cplx b) { return DIR < 0 ? dlpd_c_add_pi(a, b) : dlpd_c_add_mi(a, b); }
+template <int DIR> DLPD_D cplx c_rot90(cplx a) { return c_add_rot<DIR>(c_make(0.f, 0.f), a); }
+// multiply by (c + DIR*i*s): c*a + s * (DIR*i*a)
+template <int DIR> DLPD_D cplx c_rotcs(cplx a, float c, float s) {
+  return DIR < 0 ? dlpd_c_rotcs_m(a, c, s) : dlpd_c_rotcs_p(a, c, s);
+}
+#else
 DLPD_HD cplx c_add(cplx a, cplx b) { return c_make(a.x + b.x, a.y + b.y); }
 DLPD_HD cplx c_sub(cplx a, cplx b) { return c_make(a.x - b.x, a.y - b.y); }
 DLPD_HD cplx c_mul(cplx a, cplx b) { return c_make(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 // a * conj(b)
 DLPD_HD cplx c_mulc(cplx a, cplx b) { return c_make(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
-DLPD_HD cplx c_conj(cplx a) { return c_make(a.x, -a.y); }
 DLPD_HD cplx c_scale(cplx a, float s) { return c_make(a.x * s, a.y * s); }
+DLPD_HD cplx c_axpy(cplx a, float s, cplx b) { return c_make(a.x + s * b.x, a.y + s * b.y); }
 
 // multiply by exp(DIR * i * pi/2):  DIR=-1 (forward) -> -i*a ; DIR=+1 (inverse) -> +i*a
 template <int DIR> DLPD_HD cplx c_rot90(cplx a) {
   return DIR < 0 ? c_make(a.y, -a.x) : c_make(-a.y, a.x);
 }
+template <int DIR> DLPD_HD cplx c_add_rot(cplx a, cplx b) { return c_add(a, c_rot90<DIR>(b)); }
+template <int DIR> DLPD_HD cplx c_sub_rot(cplx a, cplx b) { return c_sub(a, c_rot90<DIR>(b)); }
 // multiply by (c + DIR*i*s) i.e. exp(DIR*i*phi) with c=cos(phi), s=sin(phi)
 template <int DIR> DLPD_HD cplx c_rotcs(cplx a, float c, float s) {
   return DIR < 0 ? c_make(a.x * c + a.y * s, a.y * c - a.x * s)
                  : c_make(a.x * c - a.y * s, a.y * c + a.x * s);
 }
+#endif
 
 #define DLPD_SQRT1_2 0.70710678118654752440f
 #define DLPD_COS_PI_8 0.92387953251128675613f
@@ -51,31 +72,26 @@ template <int DIR> DLPD_HD void dft2(cplx& a, cplx& b) {
 }
 template <int DIR> DLPD_HD void dft4(cplx& a0, cplx& a1, cplx& a2, cplx& a3) {
   cplx t0 = c_add(a0, a2), t1 = c_sub(a0, a2);
-  cplx t2 = c_add(a1, a3), t3 = c_rot90<DIR>(c_sub(a1, a3));
+  cplx t2 = c_add(a1, a3), t3 = c_sub(a1, a3);
   a0 = c_add(t0, t2);
-  a1 = c_add(t1, t3);
+  a1 = c_add_rot<DIR>(t1, t3);
   a2 = c_sub(t0, t2);
-  a3 = c_sub(t1, t3);
+  a3 = c_sub_rot<DIR>(t1, t3);
 }
 template <int DIR> DLPD_HD void dft5(cplx& a0, cplx& a1, cplx& a2, cplx& a3, cplx& a4) {
   cplx s1 = c_add(a1, a4), d1 = c_sub(a1, a4);
   cplx s2 = c_add(a2, a3), d2 = c_sub(a2, a3);
   cplx x0 = c_add(a0, c_add(s1, s2));
-  cplx p1 = c_make(a0.x + DLPD_COS_2PI_5 * s1.x + DLPD_COS_4PI_5 * s2.x,
-                   a0.y + DLPD_COS_2PI_5 * s1.y + DLPD_COS_4PI_5 * s2.y);
-  cplx p2 = c_make(a0.x + DLPD_COS_4PI_5 * s1.x + DLPD_COS_2PI_5 * s2.x,
-                   a0.y + DLPD_COS_4PI_5 * s1.y + DLPD_COS_2PI_5 * s2.y);
+  cplx p1 = c_axpy(c_axpy(a0, DLPD_COS_2PI_5, s1), DLPD_COS_4PI_5, s2);
+  cplx p2 = c_axpy(c_axpy(a0, DLPD_COS_4PI_5, s1), DLPD_COS_2PI_5, s2);
   // q1 = i*DIR*(s1*d1 + s2*d2), q2 = i*DIR*(s2*d1 - s1*d2) with s1=sin(2pi/5), s2=sin(4pi/5)
-  cplx u1 = c_make(DLPD_SIN_2PI_5 * d1.x + DLPD_SIN_4PI_5 * d2.x,
-                   DLPD_SIN_2PI_5 * d1.y + DLPD_SIN_4PI_5 * d2.y);
-  cplx u2 = c_make(DLPD_SIN_4PI_5 * d1.x - DLPD_SIN_2PI_5 * d2.x,
-                   DLPD_SIN_4PI_5 * d1.y - DLPD_SIN_2PI_5 * d2.y);
-  cplx q1 = c_rot90<DIR>(u1), q2 = c_rot90<DIR>(u2);
+  cplx u1 = c_axpy(c_scale(d1, DLPD_SIN_2PI_5), DLPD_SIN_4PI_5, d2);
+  cplx u2 = c_axpy(c_scale(d1, DLPD_SIN_4PI_5), -DLPD_SIN_2PI_5, d2);
   a0 = x0;
-  a1 = c_add(p1, q1);
-  a4 = c_sub(p1, q1);
-  a2 = c_add(p2, q2);
-  a3 = c_sub(p2, q2);
+  a1 = c_add_rot<DIR>(p1, u1);
+  a4 = c_sub_rot<DIR>(p1, u1);
+  a2 = c_add_rot<DIR>(p2, u2);
+  a3 = c_sub_rot<DIR>(p2, u2);
 }
 
 template <int R, int DIR> struct SmallDft;
@@ -96,11 +112,10 @@ template <int DIR> struct SmallDft<8, DIR> {
     dft4<DIR>(e0, e1, e2, e3);
     dft4<DIR>(o0, o1, o2, o3);
     o1 = c_rotcs<DIR>(o1, DLPD_SQRT1_2, DLPD_SQRT1_2);
-    o2 = c_rot90<DIR>(o2);
     o3 = c_rotcs<DIR>(o3, -DLPD_SQRT1_2, DLPD_SQRT1_2);
     v[0] = c_add(e0, o0); v[4] = c_sub(e0, o0);
     v[1] = c_add(e1, o1); v[5] = c_sub(e1, o1);
-    v[2] = c_add(e2, o2); v[6] = c_sub(e2, o2);
+    v[2] = c_add_rot<DIR>(e2, o2); v[6] = c_sub_rot<DIR>(e2, o2);
     v[3] = c_add(e3, o3); v[7] = c_sub(e3, o3);
   }
 };

@@ -43,6 +43,21 @@ extern "C" int dlpd_debug_read_stamps_k2(unsigned long long* host16) {
 #ifndef DLPD_K2_WPS
 #define DLPD_K2_WPS 4                    // threads per block = N * DLPD_K2_WPS
 #endif
+// DLPD_K2_LAUNDER=1 recomputes the swizzled slab offsets per pencil set instead of keeping them in
+// VGPRs (154 instead of 234 VGPRs at N = 128) -- measured slower at 2 waves/SIMD, kept for 1024-thread builds
+#ifndef DLPD_K2_LAUNDER
+#define DLPD_K2_LAUNDER 0
+#endif
+#if DLPD_K2_LAUNDER & 1
+#define DLPD_K2_OPAQUE(x) DLPD_OPAQUE(x)
+#else
+#define DLPD_K2_OPAQUE(x) ((void)(x))
+#endif
+#if DLPD_K2_LAUNDER & 2
+#define DLPD_K2_OPAQUE_T(x) DLPD_OPAQUE(x)
+#else
+#define DLPD_K2_OPAQUE_T(x) ((void)(x))
+#endif
 #define DLPD_K2_THREADS(N) ((N) * DLPD_K2_WPS)   // N*WPS/64 waves; each owns 8 pencils per step (wave-local FFT passes)
 template <int N, int MODE> __global__ void __launch_bounds__(DLPD_K2_THREADS(N))
 k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __restrict__ out,
@@ -74,8 +89,7 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
   const int b_beg = (int)(((long long)nb * part) / nsplit), b_end = (int)(((long long)nb * (part + 1)) / nsplit);
   if (b_beg >= b_end) return;
   // row phase: lane = 8*q + t  (pencil q of the set, thread t); column phase: lane = 8*t + c8
-  const int tr = lane & 7, qr = lane >> 3;
-  const int tc = lane >> 3, c8 = lane & 7;
+  const int qr = lane >> 3, c8 = lane & 7;
   cplx* tw = S + N * RS;
   init_twiddles<N>(tw, tid, NT);
 
@@ -89,9 +103,11 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
   DLPD_STAMP_DECL;
   for (int b = b_beg; b < b_end; b++) {
     DLPD_STAMP(7);
+    int tq = tid;
+    DLPD_K2_OPAQUE_T(tq);                 // slab offsets are recomputed per rotation instead of living in VGPRs
 #pragma unroll
     for (int i = 0; i < NLOAD; i++) {
-      const int e = 2 * (tid + i * NT), x = e / L, y = e % L;
+      const int e = 2 * (tq + i * NT), x = e / L, y = e % L;
       if (e < L * L) {
         S[x * RS + slab_swz(y)] = c_make(apref[i].x, apref[i].y);
         S[x * RS + slab_swz(y + 1)] = c_make(apref[i].z, apref[i].w);
@@ -104,6 +120,8 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
 #pragma unroll 1
     for (int set = wave; set < L / 8; set += W) {
       const RowAddr<RS> ad = {(set * 8 + qr) * RS};
+      int tr = lane & 7;
+      DLPD_K2_OPAQUE(tr);
       {
         FwdP1 ps;
         ps.load(S, ad, tr, nullptr);
@@ -126,6 +144,8 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
     for (int set = wave; set < NSET; set += W) {
       const int col = set * 8 + c8;
       const ColAddr<RS> ad = {slab_swz(col)};
+      int tc = lane >> 3;
+      DLPD_K2_OPAQUE(tc);
       cplx rv[FwdP2::PER][R2];
       auto load_rec = [&]() {
         const cplx* rbase = rec + (size_t)b * rec_bstride + ((size_t)c * NZ + kz) * N * N;
@@ -213,6 +233,8 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
   #pragma unroll 1
     for (int set = wave; set < NSET; set += W) {
         const RowAddr<RS> ad = {(set * 8 + qr) * RS};
+        int tr = lane & 7;
+        DLPD_K2_OPAQUE(tr);
         {
           InvP1 ps;
           ps.load(S, ad, tr, nullptr);
@@ -234,7 +256,8 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
     {
       float4* o = reinterpret_cast<float4*>(out + (((size_t)b * CT + c) * NZ + kz) * N * N);
       const float sc = (MODE == 0) ? scale : 1.0f;
-      for (int i = tid; i < N * N / 2; i += NT) {
+      DLPD_K2_OPAQUE_T(tq);
+      for (int i = tq; i < N * N / 2; i += NT) {
         const int e = 2 * i, x = e / N, y = e % N;
         const cplx u = S[x * RS + slab_swz(y)], w = S[x * RS + slab_swz(y + 1)];
         DLPD_STORE_STREAM(o + i, make_float4(u.x * sc, u.y * sc, w.x * sc, w.y * sc));

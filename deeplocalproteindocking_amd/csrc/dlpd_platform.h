@@ -62,3 +62,68 @@ __device__ __forceinline__ dlpd_f2v dlpd_f2_make(float a, float b) { dlpd_f2v r 
 __device__ __forceinline__ dlpd_f2v dlpd_f2_splat(float a) { dlpd_f2v r = {a, a}; return r; }
 __device__ __forceinline__ float dlpd_f2_get(dlpd_f2v v, int i) { return i ? v.y : v.x; }
 __device__ __forceinline__ dlpd_f2v dlpd_pk_fma(dlpd_f2v a, dlpd_f2v b, dlpd_f2v c) { return __builtin_elementwise_fma(a, b, c); }
+
+// ------------------------------------------------------------------------------------------
+// Packed complex arithmetic: one complex number = one aligned VGPR pair, one VOP3P instruction
+// per complex add / rotate-add and two per complex multiply (FFT butterflies are VALU-issue
+// bound: scalar f32 adds run 16 lanes per clock, v_pk_* twice that).  The +-i rotations and
+// conjugations ride on the op_sel / neg modifiers -- hipcc does not fold those itself (it emits
+// v_xor + v_mov per rotation), hence the inline asm.  Modifier semantics: op_sel[i] / op_sel_hi[i]
+// = 1 makes the LOW / HIGH result lane read the HIGH half of source i; neg_lo / neg_hi negate
+// source i for that lane.
+// ------------------------------------------------------------------------------------------
+#ifndef DLPD_PK
+#define DLPD_PK 1
+#endif
+#if DLPD_PK
+#define DLPD_PKV(a) dlpd_f2_make((a).x, (a).y)
+__device__ __forceinline__ float2 dlpd_pkf(dlpd_f2v v) { return make_float2(v.x, v.y); }
+__device__ __forceinline__ float2 dlpd_c_add(float2 a, float2 b) { return dlpd_pkf(DLPD_PKV(a) + DLPD_PKV(b)); }
+__device__ __forceinline__ float2 dlpd_c_sub(float2 a, float2 b) { return dlpd_pkf(DLPD_PKV(a) - DLPD_PKV(b)); }
+__device__ __forceinline__ float2 dlpd_c_scale(float2 a, float s) { return dlpd_pkf(DLPD_PKV(a) * s); }
+// a + s*b (s real)
+__device__ __forceinline__ float2 dlpd_c_axpy(float2 a, float s, float2 b) {
+  return dlpd_pkf(__builtin_elementwise_fma(dlpd_f2_splat(s), DLPD_PKV(b), DLPD_PKV(a)));
+}
+// a - i*b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ float2 dlpd_c_add_mi(float2 a, float2 b) {
+  dlpd_f2v d;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(DLPD_PKV(a)), "v"(DLPD_PKV(b)));
+  return dlpd_pkf(d);
+}
+// a + i*b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ float2 dlpd_c_add_pi(float2 a, float2 b) {
+  dlpd_f2v d;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(DLPD_PKV(a)), "v"(DLPD_PKV(b)));
+  return dlpd_pkf(d);
+}
+// a * (c - i s) = c*a + s*(a.y, -a.x)   and   a * (c + i s) = c*a + s*(-a.y, a.x); c, s wave-uniform
+__device__ __forceinline__ float2 dlpd_c_rotcs_m(float2 a, float c, float s) {
+  const dlpd_f2v va = DLPD_PKV(a), t = va * c, vs = dlpd_f2_splat(s);
+  dlpd_f2v d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(d) : "v"(va), "s"(vs), "v"(t));
+  return dlpd_pkf(d);
+}
+__device__ __forceinline__ float2 dlpd_c_rotcs_p(float2 a, float c, float s) {
+  const dlpd_f2v va = DLPD_PKV(a), t = va * c, vs = dlpd_f2_splat(s);
+  dlpd_f2v d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(va), "s"(vs), "v"(t));
+  return dlpd_pkf(d);
+}
+// a * w = (a.x w.x - a.y w.y, a.x w.y + a.y w.x)
+__device__ __forceinline__ float2 dlpd_c_mul(float2 a, float2 w) {
+  dlpd_f2v t, d;
+  const dlpd_f2v va = DLPD_PKV(a), vw = DLPD_PKV(w);
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(va), "v"(vw));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "v"(va), "v"(vw), "v"(t));
+  return dlpd_pkf(d);
+}
+// a * conj(w) = (a.x w.x + a.y w.y, a.y w.x - a.x w.y)
+__device__ __forceinline__ float2 dlpd_c_mulc(float2 a, float2 w) {
+  dlpd_f2v t, d;
+  const dlpd_f2v va = DLPD_PKV(a), vw = DLPD_PKV(w);
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(va), "v"(vw));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(d) : "v"(va), "v"(vw), "v"(t));
+  return dlpd_pkf(d);
+}
+#endif
