@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--box", type=int, default=64)
     ap.add_argument("--angle_inc", type=int, default=6)
     ap.add_argument("--max_conf", type=int, default=2000)
-    ap.add_argument("--cpu_rotations", type=int, default=3, help="rotations of the CPU baseline sample (0: skip)")
+    ap.add_argument("--cpu_rotations", type=int, default=8, help="rotations of the CPU baseline sample (0: skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

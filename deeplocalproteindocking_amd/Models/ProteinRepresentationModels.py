@@ -6,7 +6,8 @@ with those two members plugs into GlobalDockingModel / Docker.
 ``SyntheticRepr`` produces seeded synthetic representation volumes for the BASELINE configs
 that have no atoms.  ``E3MultiResRepr4x4`` restates the reference's plain-Conv3d plugin
 (:85-114) in torch (it is a caller of the path, SURVEY.md 8(f) row 2, not a measured kernel).
-``SE3MultiResReprScalar`` needs the third-party se3cnn package (unpinned, absent here).
+``SE3MultiResReprScalar`` keeps the reference's layer plan with build-defined isotropic kernels
+(the third-party se3cnn package is unpinned and absent here).
 """
 import torch
 from torch import nn
@@ -71,12 +72,57 @@ class E3MultiResRepr4x4(Module):
         return [vol1, vol2]
 
 
+class IsotropicConv3d(Module):
+    """Scalar-field (l = 0 -> l = 0) SE(3)-equivariant convolution: every (out, in) kernel is a
+    radial function, K(r) = sum_k w[out, in, k] * phi_k(|r|), phi_k Gaussian shells at radii
+    0 .. size//2.  That is the function class of se3cnn's SE3Convolution([(n,0)], [(m,0)], size)
+    used by the reference (ProteinRepresentationModels.py:38-61); se3cnn itself is absent, so the
+    shell profile (sigma 0.6) and the initialisation are build-defined (parity unpinned)."""
+
+    def __init__(self, cin, cout, size=5, padding=2, stride=1, sigma=0.6):
+        super().__init__()
+        self.padding, self.stride = padding, stride
+        nr = size // 2 + 1
+        ax = torch.arange(size, dtype=torch.float32) - (size - 1) / 2.0
+        r = torch.sqrt(ax[:, None, None] ** 2 + ax[None, :, None] ** 2 + ax[None, None, :] ** 2)
+        shells = torch.stack([torch.exp(-0.5 * ((r - k) / sigma) ** 2) for k in range(nr)])
+        shells = shells * (r <= size // 2 + 0.5)                      # spherical support
+        self.register_buffer("shells", shells / shells.flatten(1).norm(dim=1)[:, None, None, None])
+        self.weight = nn.Parameter(torch.empty(cout, cin, nr))
+        # He-style scale for inputs that vary slowly across the 5^3 window (atom densities are smooth
+        # and non-negative): the gain that matters is the kernel SUM, not its norm; without this the
+        # eight bias-free layers amplify the mean by orders of magnitude each
+        dc2 = float((self.shells.flatten(1).sum(dim=1) ** 2).sum())
+        nn.init.normal_(self.weight, std=(2.0 / (cin * dc2)) ** 0.5)
+
+    def kernel(self):
+        return torch.einsum("oik,kxyz->oixyz", self.weight, self.shells)
+
+    def forward(self, x):
+        return nn.functional.conv3d(x, self.kernel(), padding=self.padding, stride=self.stride)
+
+
 class SE3MultiResReprScalar(Module):
+    """Same layer plan as the reference's SE3MultiResReprScalar (ProteinRepresentationModels.py:23-76):
+    four isotropic 5^3 convolutions with ReLU between them at full resolution, then four more whose
+    first has stride 2; outputs [2m @ L^3, 4m @ (L/2)^3]."""
+
     def __init__(self, num_input_channels=11, multiplier=16):
-        super(SE3MultiResReprScalar, self).__init__()
-        try:
-            import se3cnn  # noqa: F401
-        except Exception as e:
-            raise Exception("SE3MultiResReprScalar needs the se3cnn package (reference README.md:6), "
-                            "which is not part of this build; plug in any module with forward()/get_num_outputs()", e)
-        raise Exception("SE3MultiResReprScalar: se3cnn binding is SURVEY.md 8(f) row 2 (next)")
+        super().__init__()
+        m = multiplier
+        self.num_outputs_res0, self.num_outputs_res1 = 2 * m, 4 * m
+
+        def stack(cin, c, stride):
+            return nn.Sequential(IsotropicConv3d(cin, c, stride=stride), nn.ReLU(),
+                                 IsotropicConv3d(c, c), nn.ReLU(),
+                                 IsotropicConv3d(c, c), nn.ReLU(),
+                                 IsotropicConv3d(c, c))
+        self.sequence_res0 = stack(num_input_channels, 2 * m, 1)
+        self.sequence_res1 = stack(2 * m, 4 * m, 2)
+
+    def get_num_outputs(self):
+        return [self.num_outputs_res0, self.num_outputs_res1]
+
+    def forward(self, volume):
+        vol1 = self.sequence_res0(volume)
+        return [vol1, self.sequence_res1(vol1)]

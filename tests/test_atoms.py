@@ -239,3 +239,32 @@ def test_dockSE3_and_dockE3_on_gpu(tmp_path):
     s = max(abs(t[4]) for t in d1.top_list) + 1e-6
     assert max(abs(a[4] - b[4]) for a, b in zip(d1.top_list, d2.top_list)) <= 1e-4 * s
     assert sum(a[:4] == b[:4] for a, b in zip(d1.top_list, d2.top_list)) >= K - 2
+
+
+@pytest.mark.gpu
+def test_dockSE3_reference_configuration_on_gpu(tmp_path):
+    """BASELINE config 4 geometry end to end: PDB files -> 11-type densities at box 80 / 1.25 A ->
+    SE3MultiResReprScalar(multiplier=8) = [16 @ 80^3, 32 @ 40^3] -> 160^3 search with per-rotation
+    clash re-projection (local_test.py:53-69), against the oracle restatement of the same loop."""
+    import __graft_entry__ as entry
+    entry.build()
+    from deeplocalproteindocking_amd.Docker import Docker
+    from deeplocalproteindocking_amd.Models import GlobalDockingModel, SE3MultiResReprScalar, SimpleFilter
+    dev = torch.device("cuda:0")
+    L, res, K = 80, 1.25, 40
+    frec, _, _, _ = _typed(tmp_path, 40, seed=15)
+    flig, _, _, _ = _typed(tmp_path, 25, seed=16)
+    torch.manual_seed(80)
+    repr_ = SE3MultiResReprScalar(multiplier=8)
+    model = GlobalDockingModel(repr_, SimpleFilter(repr_.get_num_outputs()), threshold_clash=3.0)
+    R = orc.euler_to_matrix([0.3, -1.0], [1.1, 0.4], [-2.0, 2.5])
+    be = CoordsBackend()
+    want, scale = _dock_reference_shape(be, model, frec, flig, R, L, res, K)
+    dk = Docker(model.to(dev), box_size=L, resolution=res, max_conf=K, rotations=R, device=dev, coords_backend=be)
+    assert dk.new_log(str(tmp_path / "pair.dat"))
+    with torch.no_grad():
+        dk.dockSE3(frec, flig, batch_size=2)
+    assert max(abs(a[4] - b[4]) for a, b in zip(dk.top_list, want)) <= 1e-4 * scale
+    assert sum(a[:4] == b[:4] for a, b in zip(dk.top_list, want)) >= K - 2
+    dk.cleanup()
+    assert len(open(tmp_path / "pair.dat").read().strip().splitlines()) == K

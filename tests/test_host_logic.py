@@ -170,3 +170,24 @@ def test_merge_entries_is_deterministic_and_stable():
     b = (np.array([1, 1, 3]), np.array([7, 8, 9]), np.array([-3.0, -1.0, -1.0], np.float32), np.array([0, 1, 0]))
     rot, idx, score, pick = DeviceTopList.merge_entries([b, a], 4)
     assert rot.tolist() == [0, 1, 1, 2] and idx.tolist() == [5, 7, 8, 6]
+
+
+def test_se3_scalar_representation_is_equivariant_and_shaped_like_the_reference():
+    """ProteinRepresentationModels.py:23-76: outputs [2m @ L^3, 4m @ (L/2)^3]; isotropic kernels commute
+    with the grid's exact (90 degree) rotations, the property the volume-rotation search relies on."""
+    from deeplocalproteindocking_amd.Models import SE3MultiResReprScalar
+    torch.manual_seed(3)
+    model = SE3MultiResReprScalar(multiplier=2).eval()
+    assert model.get_num_outputs() == [4, 8]
+    L = 12
+    x = torch.zeros(1, 11, L, L, L)
+    x[:, :, 3:9, 3:9, 3:9] = torch.rand(1, 11, 6, 6, 6)          # support away from the faces
+    with torch.no_grad():
+        v0, v1 = model(x)
+        r0, r1 = model(torch.rot90(x, 1, dims=(2, 3)))
+    assert v0.shape == (1, 4, L, L, L) and v1.shape == (1, 8, L // 2, L // 2, L // 2)
+    assert torch.allclose(torch.rot90(v0, 1, dims=(2, 3)), r0, atol=1e-5)
+    k = model.sequence_res0[0].kernel()
+    assert torch.allclose(k, k.flip(2)) and torch.allclose(k, k.transpose(2, 3))      # radial kernels
+    # even box + stride 2 samples a rotated lattice, so only the full-resolution branch is exactly equivariant
+    assert r1.shape == v1.shape
