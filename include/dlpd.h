@@ -24,7 +24,7 @@ extern "C" {
 #define DLPD_ERR_LAUNCH 3
 
 int dlpd_version(void);
-/* 1 if box size L has a compiled fused pipeline (N = 2L in {64, 128}) */
+/* 1 if box size L has a compiled pipeline: L in {32, 40, 64, 80} (grids N = 2L = 64, 80, 128, 160) */
 int dlpd_grid_supported(int L);
 /* hidden width the filter kernel pads H to (2,4,8,16,24,32), -1 if H > 32 */
 int dlpd_hidden_pad(int H);
