@@ -192,7 +192,8 @@ def main():
     V_first = None
     eng.finish()
     if rank == 0 and world == 1 and args.cpu_rotations > 0:
-        V_first = eng.score_batch(Rd[:nb]).cpu()[:args.cpu_rotations].clone()
+        Rs = R_all[:args.cpu_rotations].to(device=dev, dtype=torch.float32).contiguous()
+        V_first = torch.cat([eng.score_batch(Rs[i:i + nb]).cpu() for i in range(0, Rs.shape[0], nb)])
     timer = StageTimer()
     for i in range(min(args.warmup, 3)):                   # untimed: per-stage launch durations
         step_serial(i, timer.mark)
