@@ -176,14 +176,9 @@ class Docker:
         has_clash = receptor_forbidden is not None
         R_all = self.rot.R
         ids = self.shard(R_all.shape[0]) if rot_indices is None else np.asarray(rot_indices, dtype=np.int64)
-        two_res = len(rec) == 2 and rec[1].shape[-1] * 2 == L and self._library().call("dlpd_grid_supported", L // 2)
-        if len(rec) == 1 or two_res:
-            W1, b1, W2, b2 = model.filter.parameters_tuple()
-            eng = DockingEngine(L, rec[0].shape[0], W1.cpu(), b1.cpu(), W2.cpu(), b2.cpu(),
-                                clip=getattr(model, "clip", 5.0), threshold_clash=model.threshold_clash,
-                                has_clash=has_clash, max_conf=self.max_conf, batch=batch_size, device=self.device,
-                                lib=self._lib, coarse_channels=rec[1].shape[0] if two_res else 0)
-            eng.set_receptor(rec[0], receptor_forbidden, rec[1] if two_res else None)
+        eng = self._make_engine(rec, receptor_forbidden, batch_size)
+        if eng is not None:
+            two_res = eng.C1 > 0
             eng.set_ligand(lig[0], ligand_forbidden if ligand_forbidden is not None else torch.zeros(L, L, L),
                            lig[1] if two_res else None)
             eng.clash_provider = clash_provider
@@ -199,6 +194,22 @@ class Docker:
         if write:
             self.write_conformations()
         return self.top_list
+
+    def _make_engine(self, rec, receptor_forbidden, batch_size):
+        """DockingEngine for one receptor (one resolution, or the reference's [C0 @ L, C1 @ L/2] pair);
+        None when the representation has another shape (generic stand-alone-op path)."""
+        model = self.docking_model
+        L = rec[0].shape[-1]
+        two_res = len(rec) == 2 and rec[1].shape[-1] * 2 == L and self._library().call("dlpd_grid_supported", L // 2)
+        if not (len(rec) == 1 or two_res):
+            return None
+        W1, b1, W2, b2 = model.filter.parameters_tuple()
+        eng = DockingEngine(L, rec[0].shape[0], W1.cpu(), b1.cpu(), W2.cpu(), b2.cpu(),
+                            clip=getattr(model, "clip", 5.0), threshold_clash=model.threshold_clash,
+                            has_clash=receptor_forbidden is not None, max_conf=self.max_conf, batch=batch_size,
+                            device=self.device, lib=self._lib, coarse_channels=rec[1].shape[0] if two_res else 0)
+        eng.set_receptor(rec[0], receptor_forbidden, rec[1] if two_res else None)
+        return eng
 
     def _dock_volumes_multires(self, rec, lig, rec_forb, lig_forb, batch_size, ids, clash_provider=None):
         """Reference-shaped loop on the stand-alone ops (any number of resolutions): rotate,
@@ -315,7 +326,8 @@ class Docker:
 
     def dockE3(self, ureceptor, uligand, batch_size):
         """Docker.py:135-182: the ligand is rotated in coordinate space and re-projected and
-        re-represented every batch (the plugin's cost), then scored by the same kernels."""
+        re-represented every batch (the plugin's cost), then scored by the same kernels: the fused
+        engine takes the batch's volumes as they are (no volume rotation), stand-alone ops otherwise."""
         be = self._need_backend()
         from deeplocalproteindocking_amd.ops import VolumeConvolution, filter_volumes
         self.top_list = []
@@ -327,16 +339,21 @@ class Docker:
         if self.randomize_rot:
             rcoords = be.rotate(rcoords, self.randR, rnatoms)
         rcoords = be.translate(rcoords, self.box_center, rnatoms)
-        conv_noclip = VolumeConvolution()
-        top = DeviceTopList(self.max_conf, batch_size, dev, self._library())
-        top.reset()
-        W1, b1, W2, b2 = model.filter.parameters_tuple()
         ids = self.shard(self.rot.R.shape[0])
         with torch.no_grad():
             receptor = be.project(rcoords, rnat, roff, self.box_size, self.resolution, dev)
             receptor_volumes = model.representation(receptor)
-            receptor_forbidden = receptor.sum(dim=1).unsqueeze(dim=1).contiguous()
             lc, ln, lo = be.to_device(lcoords, lnat, loff, dev)
+            eng = self._make_engine([v.reshape((-1,) + tuple(v.shape[-3:])) for v in receptor_volumes],
+                                    receptor.sum(dim=1)[0], batch_size)
+            if eng is not None:
+                eng.reset_top()
+            else:
+                conv_noclip = VolumeConvolution()
+                top = DeviceTopList(self.max_conf, batch_size, dev, self._library())
+                top.reset()
+                W1, b1, W2, b2 = model.filter.parameters_tuple()
+                receptor_forbidden = receptor.sum(dim=1).unsqueeze(dim=1).contiguous()
             for beg in range(0, len(ids), batch_size):
                 bid = ids[beg:beg + batch_size]
                 nb = len(bid)
@@ -344,6 +361,11 @@ class Docker:
                 # rotate + translate + project in one kernel (Docker.py:163-165)
                 ligand = be.project(lc, ln, lo, self.box_size, self.resolution, dev, R=Rb, shift=self.box_center)
                 ligand_volumes = model.representation(ligand)
+                bid_dev = torch.as_tensor(bid, dtype=torch.int32).to(dev)
+                if eng is not None:
+                    eng.step(None, bid_dev, volumes=(ligand_volumes[0], ligand.sum(dim=1),
+                                                     ligand_volumes[1] if eng.C1 else None))
+                    continue
                 ligand_forbidden = ligand.sum(dim=1).unsqueeze(dim=1).contiguous()
                 norm = conv_noclip(receptor_forbidden.expand(nb, -1, -1, -1, -1).contiguous(), ligand_forbidden)
                 rec_b = [v.expand(nb, -1, -1, -1, -1).contiguous() for v in receptor_volumes]
@@ -351,7 +373,7 @@ class Docker:
                 V = filter_volumes(convolved, W1, b1, W2, float(b2.reshape(-1)[0]),
                                    mask_norm=norm.squeeze(1).contiguous(), threshold=model.threshold_clash)
                 top.select(V.reshape(nb, -1), nb)
-                top.merge(torch.as_tensor(bid, dtype=torch.int32).to(dev), nb)
-        entries = self._gather(top.entries())
+                top.merge(bid_dev, nb)
+        entries = self._gather(eng.top_entries() if eng is not None else top.entries())
         self.top_list = DeviceTopList.to_top_list(entries, 2 * self.box_size)
         self.write_conformations()

@@ -195,10 +195,15 @@ class DockingEngine:
             self.lig[self.C] = torch.as_tensor(lig_forbidden, dtype=torch.float32).reshape(L, L, L).to(self.device)
 
     # ---- hot loop ------------------------------------------------------------------------
-    def score_batch(self, R, mark=None, out=None):
+    def score_batch(self, R, mark=None, out=None, volumes=None):
         """R (nb,3,3) float32 on the device, nb <= batch.  Returns V[:nb] (view of the engine's
         buffer, overwritten by the next call): Docker.py:218-232.  mark(name): optional callback
-        after each stage (timing)."""
+        after each stage (timing).
+        volumes = (lig (nb,C,L,L,L), forbidden (nb,L,L,L) | None, coarse (nb,C1,L/2,..) | None): the
+        batch's ligand volumes are given as they are (dockE3: re-projected and re-represented per
+        rotation, Docker.py:163-172) instead of rotating the stored ligand by R."""
+        if volumes is not None:
+            return self._score_volumes(volumes, mark, out)
         nb = R.shape[0]
         assert nb <= self.batch and R.dtype == torch.float32 and R.is_contiguous()
         has_clip, clip = (0 if self.clip is None else 1), float(self.clip or 0.0)
@@ -228,6 +233,38 @@ class DockingEngine:
         else:
             call("dlpd_zfft", _ptr(self.lig), _ptr(R), _ptr(self.wsA), nb, self.CT, L, 0, 1, self.center, st)
         mark("k1_rotate_zfft")
+        return self._correlate_and_filter(nb, V, mark)
+
+    def _score_volumes(self, volumes, mark, out):
+        vl, vf, vc = volumes
+        nb, L = vl.shape[0], self.L
+        assert nb <= self.batch
+        f32c = lambda t: t.to(device=self.device, dtype=torch.float32).contiguous()
+        call, st = self.lib.call, _stream(self.device)
+        has_clip, clip = (0 if self.clip is None else 1), float(self.clip or 0.0)
+        V = self.V if out is None else out
+        mark = mark or (lambda name: None)
+        mark("begin")
+        if self.C1:
+            L1 = self.L1
+            vc = f32c(vc).reshape(nb, self.C1, L1, L1, L1)
+            call("dlpd_zfft", _ptr(vc), 0, _ptr(self.wsA1), nb, self.C1, L1, self.C1 * L1 ** 3, 0, 0.0, st)
+            call("dlpd_xy_correlate", _ptr(self.wsA1), _ptr(self.recF1), _ptr(self.wsB1), nb, self.C1, L1, 0, st)
+            call("dlpd_zifft_real", _ptr(self.wsB1), _ptr(self.aux), nb, self.C1, L1, has_clip, clip, st)
+            mark("coarse")
+        vl = f32c(vl).reshape(nb, self.C, L, L, L)
+        call("dlpd_zfft_into", _ptr(vl), 0, _ptr(self.wsA), nb, self.C, self.CT, 0, L, self.C * L ** 3, 0, 0.0, st)
+        if self.has_clash:
+            vf = f32c(vf).reshape(nb, L, L, L)
+            call("dlpd_zfft_into", _ptr(vf), 0, _ptr(self.wsA), nb, 1, self.CT, self.C, L, L ** 3, 0, 0.0, st)
+        mark("k1_rotate_zfft")
+        self._keep = (vl, vf, vc)                      # inputs stay alive until the stream has consumed them
+        return self._correlate_and_filter(nb, V, mark)
+
+    def _correlate_and_filter(self, nb, V, mark):
+        """K2 + K3 (+ filter) on whatever K1 left in wsA (and the coarse result in aux)."""
+        has_clip, clip = (0 if self.clip is None else 1), float(self.clip or 0.0)
+        call, st, L = self.lib.call, _stream(self.device), self.L
         call("dlpd_xy_correlate", _ptr(self.wsA), _ptr(self.recF), _ptr(self.wsB), nb, self.CT, L, 0, st)
         mark("k2_xy_corr")
         aux, C1, N1 = (_ptr(self.aux), self.C1, 2 * self.L1) if self.C1 else (0, 0, 0)
@@ -269,13 +306,13 @@ class DockingEngine:
         self.top.merge(rot_ids, nb)
 
     # ---- two-stream pipeline: top-K of batch i overlaps K1/K2 of batch i+1 -----------------
-    def step(self, R, rot_ids, mark=None):
+    def step(self, R, rot_ids, mark=None, volumes=None):
         """One batch: score on the current stream; select + merge on a side stream (they are
         latency-bound one-block kernels that fit beside the FFT blocks).  V is double-buffered;
         call finish() before reading the list."""
-        nb = R.shape[0]
+        nb = R.shape[0] if volumes is None else volumes[0].shape[0]
         if self.device.type != "cuda":
-            V = self.score_batch(R, mark=mark)
+            V = self.score_batch(R, mark=mark, volumes=volumes)
             self.select_batch(V, nb)
             self.merge_batch(rot_ids, nb)
             return
@@ -289,7 +326,7 @@ class DockingEngine:
         main = torch.cuda.current_stream(self.device)
         if self._consumed[k] is not None:
             main.wait_event(self._consumed[k])          # V[k] free again
-        V = self.score_batch(R, mark=mark, out=self._Vbuf[k])
+        V = self.score_batch(R, mark=mark, out=self._Vbuf[k], volumes=volumes)
         ready = torch.cuda.Event()
         ready.record(main)
         with torch.cuda.stream(self._side):

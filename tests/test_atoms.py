@@ -174,6 +174,60 @@ def _dock_reference_shape(be, model, frec, flig, R, L, res, K):
     return top, scale
 
 
+def _dock_reference_shape_e3(be, model, frec, flig, R, L, res, K):
+    """The reference loop of Docker.dockE3 (Docker.py:135-182) restated with the oracle pieces: rotate the
+    ATOMS, project, represent, correlate -- no volume rotation."""
+    centre = torch.full((1, 3), L * res / 2.0, dtype=torch.double)
+
+    def load(f):
+        c, ch, rn, ri, an, nat = be.pdb2coords([f])
+        t, cnt, off = be.assign_types(c, rn, an, nat)
+        a, b = be.get_bbox(t, be.last_num_typed)
+        return be.translate(t, -(a + b) * 0.5, be.last_num_typed), cnt, off
+    rc, rn_, ro = load(frec)
+    lc, ln_, lo = load(flig)
+    rec = torch.from_numpy(orc.project_atoms(rc[0].numpy(), rn_[0].numpy(), ro[0].numpy(), L, res,
+                                             shift=centre[0].numpy())).float()[None]
+    W = [w.cpu() for w in model.filter.parameters_tuple()]
+    top, scale = [], 0.0
+    with torch.no_grad():
+        rv = model.representation(rec)
+        for ri in range(R.shape[0]):
+            lig = torch.from_numpy(orc.project_atoms(lc[0].numpy(), ln_[0].numpy(), lo[0].numpy(), L, res, R=R[ri],
+                                                     shift=centre[0].numpy())).float()[None]
+            lv = model.representation(lig)
+            mask, _ = orc.clash_mask(rec.sum(dim=1, keepdim=True), lig.sum(dim=1, keepdim=True), model.threshold_clash)
+            V = (mask * orc.score_volumes(rv, lv, *W, clip=5.0))[0].contiguous()
+            scale = max(scale, float(V.abs().max()))
+            idx, sc = orc.rotation_picks_fast(V.numpy(), K)
+            x, y, z = orc.flat_to_xyz(idx, 2 * L)
+            top += [(ri, int(x[i]), int(y[i]), int(z[i]), float(sc[i])) for i in range(K)]
+            top.sort(key=lambda t: t[4])
+            top = top[:K]
+    return top, scale
+
+
+def test_dockE3_end_to_end_emulated(emu, tmp_path):
+    """PDB files -> Docker.dockE3 (per-batch re-projection + representation, engine fed with the batch's
+    volumes) -> list, all kernels emulated, vs the oracle restatement of Docker.py:135-182."""
+    from deeplocalproteindocking_amd.Docker import Docker
+    from deeplocalproteindocking_amd.Models import SimpleFilter
+    L, res, K = 32, 1.25, 20
+    frec, _, _, _ = _typed(tmp_path, 14, seed=5)
+    flig, _, _, _ = _typed(tmp_path, 9, seed=6)
+    torch.manual_seed(78)
+    model = _Model(_TinyRepr(4), SimpleFilter([4]), thr=3.0)
+    R = orc.euler_to_matrix([0.3, -1.0, 2.0], [1.1, 0.4, 2.2], [-2.0, 2.5, 0.1])
+    be = CoordsBackend(lib=emu)
+    dk = Docker(model, box_size=L, resolution=res, max_conf=K, rotations=R, device="cpu", coords_backend=be, lib=emu)
+    with torch.no_grad():
+        dk.dockE3(frec, flig, batch_size=2)
+    want, scale = _dock_reference_shape_e3(be, model, frec, flig, R, L, res, K)
+    assert len(dk.top_list) == K
+    assert max(abs(a[4] - b[4]) for a, b in zip(dk.top_list, want)) <= 1e-4 * scale
+    assert sum(a[:4] == b[:4] for a, b in zip(dk.top_list, want)) >= K - 2
+
+
 def test_dockSE3_end_to_end_emulated(emu, tmp_path):
     """PDB files -> Docker.dockSE3 -> .dat, all kernels emulated, vs the oracle restatement."""
     from deeplocalproteindocking_amd.Docker import Docker
@@ -268,3 +322,29 @@ def test_dockSE3_reference_configuration_on_gpu(tmp_path):
     assert sum(a[:4] == b[:4] for a, b in zip(dk.top_list, want)) >= K - 2
     dk.cleanup()
     assert len(open(tmp_path / "pair.dat").read().strip().splitlines()) == K
+
+
+@pytest.mark.gpu
+def test_dockE3_reference_configuration_on_gpu(tmp_path):
+    """BASELINE config 5 geometry: E3MultiResRepr4x4(multiplier=8) = [16 @ 80^3, 32 @ 40^3], the ligand
+    re-projected and re-represented for every rotation (local_test.py:67, Docker.py:135-182), scored by the
+    fused engine from the batch's own volumes."""
+    import __graft_entry__ as entry
+    entry.build()
+    from deeplocalproteindocking_amd.Docker import Docker
+    from deeplocalproteindocking_amd.Models import E3MultiResRepr4x4, GlobalDockingModel, SimpleFilter
+    dev = torch.device("cuda:0")
+    L, res, K = 80, 1.25, 40
+    frec, _, _, _ = _typed(tmp_path, 40, seed=15)
+    flig, _, _, _ = _typed(tmp_path, 25, seed=16)
+    torch.manual_seed(81)
+    repr_ = E3MultiResRepr4x4(multiplier=8)
+    model = GlobalDockingModel(repr_, SimpleFilter(repr_.get_num_outputs()), threshold_clash=3.0)
+    R = orc.euler_to_matrix([0.3, -1.0, 0.7], [1.1, 0.4, 2.0], [-2.0, 2.5, 0.9])
+    be = CoordsBackend()
+    want, scale = _dock_reference_shape_e3(be, model, frec, flig, R, L, res, K)
+    dk = Docker(model.to(dev), box_size=L, resolution=res, max_conf=K, rotations=R, device=dev, coords_backend=be)
+    with torch.no_grad():
+        dk.dockE3(frec, flig, batch_size=2)
+    assert max(abs(a[4] - b[4]) for a, b in zip(dk.top_list, want)) <= 1e-4 * scale
+    assert sum(a[:4] == b[:4] for a, b in zip(dk.top_list, want)) >= K - 2
