@@ -36,7 +36,7 @@ def _inputs():
     return L, rec, lig, recf, ligf, filt, R
 
 
-def _run(rank, world, port, out):
+def _run(rank, world, port, out, nrot=5):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -46,6 +46,7 @@ def _run(rank, world, port, out):
     if world > 1:
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     L, rec, lig, recf, ligf, filt, R = _inputs()
+    R = R[:nrot]
     dk = Docker(_Model(filt), angle_inc=20, box_size=L, resolution=1.25, max_conf=30, rotations=R, device="cpu",
                 rank=rank, world_size=world, lib=emu_lib())
     top = dk.dock_volumes([rec], [lig], recf, ligf, batch_size=2, write=False)
@@ -72,3 +73,22 @@ def test_two_rank_sharded_search_equals_single_process():
     assert list(out2[0]) == single[0]
     rots = {t[0] for t in single[0]}
     assert len(rots) > 1                                     # entries from both shards
+
+
+def test_rank_with_empty_shard_still_joins_the_gather():
+    """Fewer rotations than ranks: rank 1 scores nothing, contributes an empty list to the all-gather,
+    and still ends with the global list."""
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    out2 = mgr.dict()
+    port = 31600 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_run, args=(r, 2, port, out2, 1)) for r in range(2)]
+    for p in procs:
+        p.start()
+    single = {}
+    _run(0, 1, 0, single, 1)
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    assert list(out2[0]) == list(out2[1]) == single[0]
+    assert len(single[0]) == 30 and {t[0] for t in single[0]} == {0}
