@@ -43,23 +43,23 @@ extern "C" int dlpd_debug_read_stamps_k2(unsigned long long* host16) {
 #ifndef DLPD_K2_WPS
 #define DLPD_K2_WPS 4                    // threads per block = N * DLPD_K2_WPS
 #endif
-// DLPD_K2_LAUNDER=1 recomputes the swizzled slab offsets per pencil set instead of keeping them in
-// VGPRs (154 instead of 234 VGPRs at N = 128) -- measured slower at 2 waves/SIMD, kept for 1024-thread builds
+// Laundering (DLPD_OPAQUE) makes the compiler recompute the swizzled slab offsets per pencil set
+// instead of keeping ~80 of them in VGPRs.  At N = 128 (one block per CU anyway) that is slower; at
+// N = 80 it takes the kernel from 240 to <= 168 VGPRs, which lets TWO 5-wave blocks share a CU.
+// DLPD_K2_LAUNDER: bit 0 forces it for the pencil loops of every N, bit 1 for the copy loops.
 #ifndef DLPD_K2_LAUNDER
 #define DLPD_K2_LAUNDER 0
 #endif
-#if DLPD_K2_LAUNDER & 1
-#define DLPD_K2_OPAQUE(x) DLPD_OPAQUE(x)
-#else
-#define DLPD_K2_OPAQUE(x) ((void)(x))
+#ifndef DLPD_K2_N80_DENSE
+#define DLPD_K2_N80_DENSE 0             // 1: N = 80 with launder + late receptor loads + 3 waves/SIMD (two blocks per CU): spills, measured 1.5x slower
 #endif
-#if DLPD_K2_LAUNDER & 2
-#define DLPD_K2_OPAQUE_T(x) DLPD_OPAQUE(x)
-#else
-#define DLPD_K2_OPAQUE_T(x) ((void)(x))
-#endif
+#define DLPD_K2_DENSE(N) (DLPD_K2_N80_DENSE && (N) == 80)
+#define DLPD_K2_OPAQUE(x) do { if ((DLPD_K2_LAUNDER & 1) || DLPD_K2_DENSE(N)) DLPD_OPAQUE(x); } while (0)
+#define DLPD_K2_OPAQUE_T(x) do { if ((DLPD_K2_LAUNDER & 2) || DLPD_K2_DENSE(N)) DLPD_OPAQUE(x); } while (0)
 #define DLPD_K2_THREADS(N) ((N) * DLPD_K2_WPS)   // N*WPS/64 waves; each owns 8 pencils per step (wave-local FFT passes)
-template <int N, int MODE> __global__ void __launch_bounds__(DLPD_K2_THREADS(N))
+// N = 80: two 5-wave blocks per CU need 3 waves on a SIMD, i.e. <= 168 VGPRs (second launch-bounds
+// argument = minimum waves per SIMD)
+template <int N, int MODE> __global__ void __launch_bounds__(DLPD_K2_THREADS(N), (DLPD_K2_DENSE(N) ? 3 : 1))
 k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __restrict__ out,
           int CT, int nb, int nsplit, long long rec_bstride, float scale) {
   constexpr int L = N / 2, NZ = N / 2 + 1, RS = N + 8;
@@ -159,7 +159,7 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
       };
       // receptor values: requested before the first x pass (in flight during it) when registers
       // allow (2 waves/SIMD build), else right before their use
-      if (MODE == 1 && !DLPD_K2_LATE_REC) load_rec();
+      if (MODE == 1 && !(DLPD_K2_LATE_REC || DLPD_K2_DENSE(N))) load_rec();
       {
         FwdP1 ps;
         ps.load(S, ad, tc, nullptr);
@@ -167,7 +167,7 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
         ps.store(S, ad, tc);
         DLPD_WAVE_SYNC();
       }
-      if (MODE == 1 && DLPD_K2_LATE_REC) load_rec();
+      if (MODE == 1 && (DLPD_K2_LATE_REC || DLPD_K2_DENSE(N))) load_rec();
       if (MODE == 0) {
         FwdP2 ps;
         ps.load(S, ad, tc, tw);
