@@ -320,6 +320,7 @@ class DockingEngine:
             self._side = torch.cuda.Stream(device=self.device)
             self._Vbuf = [self.V, torch.empty_like(self.V)]
             self._consumed = [None, None]
+            self._ids_alive = [None, None]
             self._k = 0
         k = self._k
         self._k ^= 1
@@ -327,6 +328,9 @@ class DockingEngine:
         if self._consumed[k] is not None:
             main.wait_event(self._consumed[k])          # V[k] free again
         V = self.score_batch(R, mark=mark, out=self._Vbuf[k], volumes=volumes)
+        # the side stream reads rot_ids later: keep the caller's tensor alive (and its memory out of the
+        # allocator's reach) until this buffer slot comes round again
+        self._ids_alive[k] = rot_ids
         ready = torch.cuda.Event()
         ready.record(main)
         with torch.cuda.stream(self._side):
