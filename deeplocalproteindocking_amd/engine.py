@@ -369,4 +369,4 @@ class DockingEngine:
 
     def top_list(self):
         """[(rotation_index, x, y, z, score)] exactly as Docker.top_list (Docker.py:100-105)."""
-        return DeviceTopList.to_top_list(self.top.entries(), self.N)
+        return DeviceTopList.to_top_list(self.top_entries(), self.N)

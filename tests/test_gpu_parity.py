@@ -336,3 +336,27 @@ def test_full_size_search_is_batch_size_and_order_independent(dev):
     assert lists[1] == ref, "batch size changed the result"
     assert lists[2] == ref, "presentation order changed the result"
     assert lists[3] == ref, "rerun is not bit-identical"
+
+
+def test_full_size_rank_shards_merge_to_the_single_process_list(dev):
+    """SURVEY 8(e) at BASELINE config 2 size on one GPU: the interleaved shards of W = 3 ranks, searched
+    separately and merged with the deterministic (score, rotation, pick) key, give exactly the list of the
+    unsharded search (the all-gather itself is covered by the gloo test)."""
+    import bench
+    from deeplocalproteindocking_amd.engine import DeviceTopList, DockingEngine
+    C, L, K, nrot, W = 48, 64, 2000, 50, 3
+    rec, lig, recf, ligf, filt = bench.synthetic_pair(C, L)
+    thr = bench.clash_threshold(recf, ligf)
+    R = _rots(nrot, seed=78)
+
+    def run(ids):
+        eng = DockingEngine(L, C, *filt.parameters_tuple(), clip=5.0, threshold_clash=thr, max_conf=K, batch=16, device=dev)
+        eng.set_receptor(rec, recf)
+        eng.set_ligand(lig, ligf)
+        eng.reset_top()
+        eng.search(R[ids], rot_ids=ids)
+        return eng.top_entries()
+    whole = run(np.arange(nrot))
+    parts = [run(np.arange(r, nrot, W)) for r in range(W)]
+    merged = DeviceTopList.merge_entries(parts, K)
+    assert DeviceTopList.to_top_list(merged, 2 * L) == DeviceTopList.to_top_list(whole, 2 * L)
