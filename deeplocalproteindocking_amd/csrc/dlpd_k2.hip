@@ -56,6 +56,9 @@ extern "C" int dlpd_debug_read_stamps_k2(unsigned long long* host16) {
 #define DLPD_K2_DENSE(N) (DLPD_K2_N80_DENSE && (N) == 80)
 #define DLPD_K2_OPAQUE(x) do { if ((DLPD_K2_LAUNDER & 1) || DLPD_K2_DENSE(N)) DLPD_OPAQUE(x); } while (0)
 #define DLPD_K2_OPAQUE_T(x) do { if ((DLPD_K2_LAUNDER & 2) || DLPD_K2_DENSE(N)) DLPD_OPAQUE(x); } while (0)
+#ifndef DLPD_K2_DIRECT_OUT
+#define DLPD_K2_DIRECT_OUT 0
+#endif
 #define DLPD_K2_THREADS(N) ((N) * DLPD_K2_WPS)   // N*WPS/64 waves; each owns 8 pencils per step (wave-local FFT passes)
 // N = 80: two 5-wave blocks per CU need 3 waves on a SIMD, i.e. <= 168 VGPRs (second launch-bounds
 // argument = minimum waves per SIMD)
@@ -245,15 +248,30 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
         {
           InvP2 ps;
           ps.load(S, ad, tr, tw);
+#if DLPD_K2_DIRECT_OUT
+          // last pass straight to global memory: lanes t = 0..7 of a pencil write 64 contiguous bytes,
+          // the two butterflies of a thread complete each 128-byte line; saves the LDS store, the
+          // copy-out read and one block barrier per slab
+          cplx* orow = out + (((size_t)b * CT + c) * NZ + kz) * N * N + (size_t)(set * 8 + qr) * N;
+#pragma unroll
+          for (int i = 0; i < InvP2::PER; i++)
+            if (ps.active(i, tr)) {
+#pragma unroll
+              for (int r = 0; r < R2; r++) dlpd_store_stream_c(orow + ps.out_index(i, r, tr), ps.v[i][r]);
+            }
+#else
           DLPD_WAVE_SYNC();
           ps.store(S, ad, tr);
+#endif
         }
       }
       DLPD_STAMP(4);
+#if !DLPD_K2_DIRECT_OUT
       __syncthreads();
+#endif
       DLPD_STAMP(1);
     }
-    {
+    if (MODE == 0 || !DLPD_K2_DIRECT_OUT) {
       float4* o = reinterpret_cast<float4*>(out + (((size_t)b * CT + c) * NZ + kz) * N * N);
       const float sc = (MODE == 0) ? scale : 1.0f;
       DLPD_K2_OPAQUE_T(tq);

@@ -45,6 +45,11 @@ __device__ __forceinline__ void dlpd_store_stream(float4* p, float4 v) {
   const dlpd_f4v q = {v.x, v.y, v.z, v.w};
   __builtin_nontemporal_store(q, reinterpret_cast<dlpd_f4v*>(p));
 }
+__device__ __forceinline__ void dlpd_store_stream_c(float2* p, float2 v) {
+  typedef float dlpd_f2s __attribute__((ext_vector_type(2)));
+  const dlpd_f2s q = {v.x, v.y};
+  __builtin_nontemporal_store(q, reinterpret_cast<dlpd_f2s*>(p));
+}
 #define DLPD_LOAD_STREAM(p) dlpd_load_stream(p)
 #define DLPD_STORE_STREAM(p, v) dlpd_store_stream((p), (v))
 #include <stdlib.h>
