@@ -300,8 +300,8 @@ template <int RS> struct ColAddr {
 };
 
 // all passes of a wave-local transform of one pencil set, in place (ends without a trailing sync)
-template <int N, int DIR, int NNZ, class Addr> DLPD_D void fft_wave(cplx* S, const Addr& ad, int t, const cplx* tw) {
-  typedef FftPlanW<N> P;
+template <int N, int DIR, int NNZ, class Addr, class P = FftPlanW<N>>
+DLPD_D void fft_wave(cplx* S, const Addr& ad, int t, const cplx* tw) {
   {
     FftPassW<N, P::R1, 1, DIR, 8, NNZ> ps;
     ps.load(S, ad, t, tw);

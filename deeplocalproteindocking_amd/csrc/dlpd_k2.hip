@@ -3,6 +3,7 @@
 // faster built with -fno-slp-vectorize (at 248 VGPRs the SLP vectoriser's register pairing costs
 // more moves than its packed adds save), while K3's MLP wants the vectoriser's v_pk_fma_f32.
 #include <dlpd_platform.h>
+#include <type_traits>
 #include "dlpd_fft.h"
 #include "dlpd_internal.h"
 
@@ -457,6 +458,12 @@ template <int N, int MODE> static int launch_k2_split(const cplx* A, const cplx*
 //   grid NZ*CT*nsplit (XCD-aware decode as above), block 4N = 640 threads (10 waves: one column
 //   pencil set each), persistent over the rotations of its part of the batch.
 // ------------------------------------------------------------------------------------------
+// column plan of the DIF kernel: the wave-local default (8 x 4 x 5, three LDS round trips) or 10 x 16
+template <int N> struct FftPlanD2;
+template <> struct FftPlanD2<160> { static constexpr int R1 = 10, R2 = 16, R3 = 1; };
+#ifndef DLPD_K2D_PLAN
+#define DLPD_K2D_PLAN FftPlanW
+#endif
 #ifndef DLPD_K2D_WAVES
 #define DLPD_K2D_WAVES 8                 // waves per block (256-VGPR budget; 10 would match the 10 column sets but spills)
 #endif
@@ -471,11 +478,13 @@ k_xy_corr_dif(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __
   constexpr int NT = 64 * DLPD_K2D_WAVES, W = NT / 64;
   constexpr int NLOAD = (L * L / 2 + NT - 1) / NT;     // float4 (2 complex) per thread of an A slab
   constexpr int NG = (N * H / 2 + NT - 1) / NT;        // float4 per thread of a G slab
-  typedef FftPlanW<N> P;
-  static_assert(P::R3 > 1, "three-pass plan expected");
+  typedef DLPD_K2D_PLAN<N> P;                          // column (length-N) plan; rows use FftPlanW<H>
+  constexpr bool THREE = P::R3 > 1;
   typedef FftPassW<N, P::R1, 1, -1, 8, L> FwdP1;
   typedef FftPassW<N, P::R2, P::R1, -1, 8> FwdP2;
-  typedef FftPassW<N, P::R3, P::R1 * P::R2, -1, 8> FwdP3;
+  typedef FftPassW<N, (THREE ? P::R3 : 2), P::R1 * P::R2, -1, 8> FwdP3;
+  typedef typename std::conditional<THREE, FwdP3, FwdP2>::type FwdLast;   // the pass that meets the receptor
+  constexpr int RL = THREE ? P::R3 : P::R2;
   DLPD_DYN_SHARED(cplx, S);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bid = blockIdx.x;
@@ -546,15 +555,17 @@ k_xy_corr_dif(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __
         int tc = lane >> 3;
         DLPD_OPAQUE(tc);
         // receptor values of this pencil set: requested first, in flight during the forward passes
-        cplx rv[FwdP3::PER][P::R3];
-        {
-          const cplx* rbase = rec + (size_t)b * rec_bstride + ((size_t)c * NZ + kz) * N * N + (2 * col + par);
-          FwdP3 idx;
+        // receptor values of this pencil set: requested first (in flight during the forward passes) when
+        // they fit (three-pass plan: 40 VGPRs), else one butterfly at a time right before their use
+        const cplx* rbase = rec + (size_t)b * rec_bstride + ((size_t)c * NZ + kz) * N * N + (2 * col + par);
+        cplx rv[THREE ? FwdLast::PER : 1][RL];
+        if (THREE) {
+          FwdLast idx;
 #pragma unroll
-          for (int i = 0; i < FwdP3::PER; i++)
+          for (int i = 0; i < FwdLast::PER; i++)
             if (idx.active(i, tc)) {
 #pragma unroll
-              for (int q = 0; q < P::R3; q++) rv[i][q] = rbase[(unsigned)(idx.out_index(i, q, tc) * N)];
+              for (int q = 0; q < RL; q++) rv[i][q] = rbase[(unsigned)(idx.out_index(i, q, tc) * N)];
             }
         }
         {
@@ -564,7 +575,7 @@ k_xy_corr_dif(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __
           ps.store(S, ad, tc);
           DLPD_WAVE_SYNC();
         }
-        {
+        if (THREE) {
           FwdP2 ps;
           ps.load(S, ad, tc, tw);
           DLPD_WAVE_SYNC();
@@ -572,19 +583,23 @@ k_xy_corr_dif(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __
           DLPD_WAVE_SYNC();
         }
         {
-          FwdP3 ps;
+          FwdLast ps;
           ps.load(S, ad, tc, tw);
 #pragma unroll
-          for (int i = 0; i < FwdP3::PER; i++)
+          for (int i = 0; i < FwdLast::PER; i++)
             if (ps.active(i, tc)) {
+              if (!THREE) {
 #pragma unroll
-              for (int q = 0; q < P::R3; q++) ps.v[i][q] = c_mulc(rv[i][q], ps.v[i][q]);
+                for (int q = 0; q < RL; q++) rv[0][q] = rbase[(unsigned)(ps.out_index(i, q, tc) * N)];
+              }
+#pragma unroll
+              for (int q = 0; q < RL; q++) ps.v[i][q] = c_mulc(rv[THREE ? i : 0][q], ps.v[i][q]);
             }
           DLPD_WAVE_SYNC();
           ps.store(S, ad, tc);
           DLPD_WAVE_SYNC();
         }
-        fft_wave<N, +1, N>(S, ad, tc, tw);
+        fft_wave<N, +1, N, ColAddr<RS>, P>(S, ad, tc, tw);
       }
       DLPD_STAMP(3);
       __syncthreads();
