@@ -144,6 +144,9 @@ def main():
                              % (args.gpus, args.gpus))
     import __graft_entry__ as entry
     entry.build()
+    # host threads: the synthetic inputs are generated on the CPU by every rank; never oversubscribe the
+    # cgroup quota (the GPU boxes show 256 logical CPUs behind a 16-core quota)
+    torch.set_num_threads(max(1, usable_cores() // max(1, world)))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
