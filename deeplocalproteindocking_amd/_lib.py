@@ -35,6 +35,8 @@ SIGNATURES = {
     "dlpd_filter_preact": (_i, [_p, _i, _i, _p, _p, _i, _p, _i, _p]),
     "dlpd_filter_volumes": (_i, [_p, _i, _ll, _i, _p, _i, _i, _i, _p, _ll, _f, _i, _p, _p, _p, _f, _i, _p, _i, _p]),
     "dlpd_zifft_real_part": (_i, [_p, _p, _i, _i, _i, _i, _i, _f, _p]),
+    "dlpd_conv3d_supported": (_i, [_i, _i, _i, _i]),
+    "dlpd_conv3d": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "dlpd_topk_workspace_bytes": (_sz, [_i, _i]),
     "dlpd_topk_select": (_i, [_p, _i, _ll, _i, _p, _p, _p, _p]),
     "dlpd_topk_glist_bytes": (_sz, [_i]),
@@ -68,7 +70,7 @@ class DlpdLib:
 
     def call(self, name, *args):
         rc = getattr(self, "_" + name)(*args)
-        if SIGNATURES[name][0] is _i and name not in ("dlpd_version", "dlpd_grid_supported",
+        if SIGNATURES[name][0] is _i and name not in ("dlpd_version", "dlpd_grid_supported", "dlpd_conv3d_supported",
                                                       "dlpd_hidden_pad") and rc != 0:
             raise RuntimeError("dlpd: %s failed: %s" % (name, ERRORS.get(rc, rc)))
         return rc

@@ -132,3 +132,10 @@ __device__ __forceinline__ float2 dlpd_c_mulc(float2 a, float2 w) {
   return dlpd_pkf(d);
 }
 #endif
+
+// f32-input matrix core: D(16x16) += A(16x4) * B(4x16); lane l holds A[l&15][l>>4], B[l>>4][l&15] and
+// D[4*(l>>4) + j][l&15] in element j of the accumulator
+typedef float dlpd_acc4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ dlpd_acc4 dlpd_acc4_zero() { dlpd_acc4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+__device__ __forceinline__ float dlpd_acc4_get(dlpd_acc4 v, int j) { return v[j]; }
+#define DLPD_MFMA_16x16x4(a, b, acc) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (acc), 0, 0, 0)

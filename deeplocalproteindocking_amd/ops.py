@@ -92,3 +92,27 @@ def filter_volumes(conv_list, W1, b1, W2, b2, mask_norm=None, threshold=0.0):
     get_lib().call("dlpd_filter_mask", _ptr(c0), C0, N0, _ptr(c1), C1, N1, _ptr(mask_norm), float(threshold),
                    int(has_clash), _ptr(W1t), _ptr(b1), _ptr(W2), float(b2), H, _ptr(V), B, _stream(dev))
     return V
+
+
+def conv3d_supported(weight, D, lib=None):
+    cout, cin, ks = weight.shape[0], weight.shape[1], weight.shape[2]
+    cubic = weight.dim() == 5 and weight.shape[2] == weight.shape[3] == weight.shape[4]
+    return bool(cubic and (lib or get_lib()).call("dlpd_conv3d_supported", int(cin), int(cout), int(ks), int(D)))
+
+
+def conv3d(x, weight, relu=False, lib=None):
+    """[relu] Conv3d(x, weight, padding=k//2, stride=1, bias=None) of the representation plugins
+    (ProteinRepresentationModels.py:85-114) on the f32 matrix cores (inference only: no autograd).
+    x (B, cin, D, D, D) float32; weight (cout, cin, k, k, k)."""
+    lib = lib or get_lib()
+    x = x.contiguous()
+    if x.dtype != torch.float32 or x.dim() != 5 or not (x.shape[2] == x.shape[3] == x.shape[4]):
+        raise RuntimeError("dlpd: conv3d expects (B, C, D, D, D) float32, got %s %s" % (x.dtype, tuple(x.shape)))
+    B, cin, D = x.shape[0], x.shape[1], x.shape[2]
+    w = weight.detach().to(device=x.device, dtype=torch.float32).contiguous()
+    cout, ks = w.shape[0], w.shape[2]
+    if w.shape[1] != cin:
+        raise RuntimeError("dlpd: conv3d channel mismatch %d vs %d" % (w.shape[1], cin))
+    y = torch.empty(B, cout, D, D, D, dtype=torch.float32, device=x.device)
+    lib.call("dlpd_conv3d", _ptr(x), _ptr(w), _ptr(y), B, cin, cout, D, ks, int(bool(relu)), _stream(x.device))
+    return y

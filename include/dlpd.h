@@ -115,6 +115,14 @@ int dlpd_filter_preact(const float* conv1, int C1, int N1, const float* W1rows, 
 int dlpd_zifft_real_part(const void* wsB, float* out, int nb, int CT, int nclip, int L, int has_clip, float clip,
                          void* stream);
 
+/* Representation-plugin convolution (ProteinRepresentationModels.py:85-114, the per-batch cost of
+ * Docker.dockE3, Docker.py:166-167): y (B, cout, D^3) = [relu] conv3d(x (B, cin, D^3), w (cout, cin, ks^3)),
+ * padding ks/2, stride 1, no bias, exact f32 on the matrix cores.  Supported: ks in {3,5}, cout in {16,32},
+ * D <= 80 (dlpd_conv3d_supported); anything else is the plugin's own torch convolution. */
+int dlpd_conv3d_supported(int cin, int cout, int ks, int D);
+int dlpd_conv3d(const float* x, const float* w, float* y, int B, int cin, int cout, int D, int ks, int relu,
+                void* stream);
+
 /* Docker.update_top pick loop, src/Docker/Docker.py:89-98: per rotation the K picks in pick order
  * (incl. the zero-fill behaviour).  V (nb, nvox); out (nb, K). */
 size_t dlpd_topk_workspace_bytes(int nb, int K);

@@ -1,0 +1,48 @@
+"""Diagnostic: where a dockE3 batch spends its time (projection, representation plugin, engine)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import __graft_entry__ as entry
+entry.build()
+from test_atoms import write_fake_pdb
+from deeplocalproteindocking_amd.Docker import Docker
+from deeplocalproteindocking_amd.Models import E3MultiResRepr4x4, GlobalDockingModel, SimpleFilter
+from deeplocalproteindocking_amd.Utils.FullAtom import CoordsBackend
+write_fake_pdb("/tmp/rec.pdb", 120, 31); write_fake_pdb("/tmp/lig.pdb", 80, 32)
+dev = torch.device("cuda:0")
+repr_ = E3MultiResRepr4x4(multiplier=8)
+model = GlobalDockingModel(repr_, SimpleFilter(repr_.get_num_outputs()), threshold_clash=3.0).to(dev)
+be = CoordsBackend()
+dk = Docker(model, angle_inc=20, box_size=80, resolution=1.25, max_conf=2000, device=dev, coords_backend=be)
+lcoords, lnat, loff, lT, lnatoms = dk.load_batch(["/tmp/lig.pdb"], bbox_center=False)
+lc, ln, lo = be.to_device(lcoords, lnat, loff, dev)
+Rb = dk.rot.R[:16].to(device=dev, dtype=torch.float32).contiguous()
+def t(fn, n=5):
+    fn(); torch.cuda.synchronize(); t0 = time.time()
+    for _ in range(n): r = fn()
+    torch.cuda.synchronize(); return (time.time() - t0) / n * 1e3, r
+with torch.no_grad():
+    ms, lig = t(lambda: be.project(lc, ln, lo, 80, 1.25, dev, R=Rb, shift=dk.box_center)); print("project 16 x 11 x 80^3: %.1f ms" % ms)
+    ms, vols = t(lambda: model.representation(lig)); print("representation: %.1f ms" % ms)
+    ms, _ = t(lambda: lig.sum(dim=1)); print("sum types: %.1f ms" % ms)
+    t0 = time.time(); dk.dockE3("/tmp/rec.pdb", "/tmp/lig.pdb", batch_size=16); torch.cuda.synchronize()
+    print("dockE3 1854 rotations: %.1f s" % (time.time() - t0))
+with torch.no_grad():
+    eng = dk.engine if hasattr(dk, "engine") else None
+    rcoords, rnat, roff, rT, rnatoms = dk.load_batch(["/tmp/rec.pdb"], bbox_center=False)
+    rcoords = be.translate(rcoords, dk.box_center, rnatoms)
+    receptor = be.project(rcoords, rnat, roff, 80, 1.25, dev)
+    rv = model.representation(receptor)
+    eng = dk._make_engine([v.reshape((-1,) + tuple(v.shape[-3:])) for v in rv], receptor.sum(dim=1)[0], 16)
+    eng.reset_top()
+    ids = torch.arange(16, dtype=torch.int32, device=dev)
+    vols = model.representation(lig)
+    forb = lig.sum(dim=1)
+    ms, _ = t(lambda: eng.score_batch(None, volumes=(vols[0], forb, vols[1]))); print("engine score_batch(volumes): %.1f ms" % ms)
+    ms, _ = t(lambda: (eng.step(None, ids, volumes=(vols[0], forb, vols[1])), eng.finish())); print("engine step+finish: %.1f ms" % ms)
+    def body():
+        l = be.project(lc, ln, lo, 80, 1.25, dev, R=Rb, shift=dk.box_center)
+        v = model.representation(l)
+        eng.step(None, ids, volumes=(v[0], l.sum(dim=1), v[1]))
+    ms, _ = t(body, n=10); print("full body: %.1f ms" % ms)

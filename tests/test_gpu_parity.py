@@ -360,3 +360,19 @@ def test_full_size_rank_shards_merge_to_the_single_process_list(dev):
     parts = [run(np.arange(r, nrot, W)) for r in range(W)]
     merged = DeviceTopList.merge_entries(parts, K)
     assert DeviceTopList.to_top_list(merged, 2 * L) == DeviceTopList.to_top_list(whole, 2 * L)
+
+
+@pytest.mark.parametrize("cin,cout,ks,D", [(11, 16, 5, 80), (16, 16, 3, 80), (16, 32, 5, 40), (32, 32, 3, 40), (11, 32, 3, 37)])
+def test_conv3d_matches_torch_at_plugin_shapes(dev, cin, cout, ks, D):
+    """dlpd_conv3d (f32 MFMA implicit GEMM) against torch's conv3d on the layer shapes of the reference's
+    representation plugins (ProteinRepresentationModels.py:85-114) and an awkward size; exact-f32 products,
+    so the difference is summation order only."""
+    from deeplocalproteindocking_amd import ops
+    g = torch.Generator().manual_seed(100 + cin + D)
+    x = torch.randn(2, cin, D, D, D, generator=g).to(dev)
+    w = (torch.randn(cout, cin, ks, ks, ks, generator=g) * 0.05).to(dev)
+    for relu in (False, True):
+        got = ops.conv3d(x, w, relu=relu)
+        want = torch.nn.functional.conv3d(x.cpu(), w.cpu(), padding=ks // 2)
+        want = torch.relu(want) if relu else want
+        assert (got.cpu() - want).abs().max() <= 1e-5 * want.abs().max()

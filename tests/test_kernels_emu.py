@@ -238,3 +238,19 @@ def test_fused_two_resolution_pipeline(emu, unfused):
                                    W1, b1, W2, b2, clip=0.8))[0]
     sure = (norm[0] - thr).abs() > 1e-3 * thr
     assert ((V[0] - Vo).abs()[sure]).max() <= 1e-4 * Vo.abs().max()
+
+
+@pytest.mark.parametrize("cin,cout,ks,D,relu", [(11, 16, 5, 6, True), (16, 32, 3, 9, False), (32, 32, 3, 17, True)])
+def test_conv3d_mfma_kernel_matches_torch(emu, cin, cout, ks, D, relu):
+    """The representation plugin's Conv3d (+ReLU) on the emulated f32 matrix core: channel counts that
+    are not multiples of 4 (zero-padded chunk), box sizes that are not multiples of the 4 x 4 patch or
+    of the 16-voxel z tile, both kernel sizes."""
+    from deeplocalproteindocking_amd import ops
+    g = torch.Generator().manual_seed(5 + cin)
+    x = torch.randn(1, cin, D, D, D, generator=g)
+    w = torch.randn(cout, cin, ks, ks, ks, generator=g) * 0.1
+    assert ops.conv3d_supported(w, D, emu)
+    y = ops.conv3d(x, w, relu=relu, lib=emu)
+    want = torch.nn.functional.conv3d(x, w, padding=ks // 2)
+    want = torch.relu(want) if relu else want
+    assert (y - want).abs().max() <= 2e-5 * want.abs().max()
