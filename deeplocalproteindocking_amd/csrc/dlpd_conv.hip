@@ -45,50 +45,124 @@ k_conv3d_mfma(const float* __restrict__ X, const float* __restrict__ W, float* _
 #pragma unroll
       for (int mt = 0; mt < MT; mt++) acc[r][zt][mt] = dlpd_acc4_zero();
   const int nchunk = (CIN + 3) / 4;
+  // Staging.  One z row per wave and step: the row decode is wave-uniform, the lanes only add their z.
+  // KS = 3 (short compute per chunk): the next chunk's tile and weights are fetched into registers
+  // before the MFMAs of the current one and committed to LDS after them; KS = 5 stages directly (its
+  // 125-tap compute phase dwarfs the fetch, and it has no registers to spare).
+  constexpr int NROW = 4 * C::XS * C::YS, RPW = (NROW + C::NW - 1) / C::NW, ZL = (C::ZS + 63) / 64;
+  constexpr int NWV = (C::WCHUNK / 4 + 511) / 512;
+  constexpr bool PREFETCH = (KS == 3);
+  float treg[PREFETCH ? RPW : 1][PREFETCH ? ZL : 1];
+  float4 wreg[PREFETCH ? NWV : 1];
+  auto row_src = [&](int row, int ch, bool& ok) -> const float* {
+    const int yy = row % C::YS, xx = (row / C::YS) % C::XS, k = row / (C::YS * C::XS);
+    const int gx = x0 + xx - H, gy = y0 + yy - H, ci = 4 * ch + k;
+    ok = row < NROW && ci < CIN && gx >= 0 && gx < D && gy >= 0 && gy < D;
+    return Xb + (size_t)(ok ? ci : 0) * D3 + ((size_t)(ok ? gx : 0) * D + (ok ? gy : 0)) * D - H;
+  };
+  auto row_dst = [&](int row) -> float* {
+    const int yy = row % C::YS, xx = (row / C::YS) % C::XS, k = row / (C::YS * C::XS);
+    return Xs + k * C::PLANE + (xx * C::YS + yy) * C::ZS;
+  };
+  auto fetch = [&](int ch) {                                   // global -> registers
+#pragma unroll
+    for (int j = 0; j < RPW; j++) {
+      bool ok;
+      const float* src = row_src(wave + j * C::NW, ch, ok);
+#pragma unroll
+      for (int q = 0; q < ZL; q++) {
+        const int zz = q * 64 + lane;
+        treg[j][q] = (ok && zz >= H && zz < D + H) ? src[zz] : 0.f;
+      }
+    }
+    const float4* wsrc = reinterpret_cast<const float4*>(W + (size_t)ch * C::WCHUNK);
+#pragma unroll
+    for (int j = 0; j < NWV; j++)
+      if (tid + j * 512 < C::WCHUNK / 4) wreg[j] = wsrc[tid + j * 512];
+  };
+  auto commit = [&]() {                                        // registers -> LDS
+#pragma unroll
+    for (int j = 0; j < RPW; j++) {
+      const int row = wave + j * C::NW;
+      if (row < NROW) {
+        float* dst = row_dst(row);
+#pragma unroll
+        for (int q = 0; q < ZL; q++)
+          if (q * 64 + lane < C::ZS) dst[q * 64 + lane] = treg[j][q];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NWV; j++)
+      if (tid + j * 512 < C::WCHUNK / 4) reinterpret_cast<float4*>(Ws)[tid + j * 512] = wreg[j];
+  };
+  if (PREFETCH) fetch(0);
   for (int ch = 0; ch < nchunk; ch++) {
     __syncthreads();                                           // previous chunk fully consumed
-    // ---- stage the halo tile of channels 4*ch .. 4*ch+3 (zeros outside the volume / beyond CIN)
-    for (int i = tid; i < 4 * C::XS * C::YS * C::ZS; i += 512) {
-      const int zz = i % C::ZS, yy = (i / C::ZS) % C::YS, xx = (i / (C::ZS * C::YS)) % C::XS, k = i / (C::ZS * C::YS * C::XS);
-      const int gx = x0 + xx - H, gy = y0 + yy - H, gz = zz - H, ci = 4 * ch + k;
-      float v = 0.f;
-      if (ci < CIN && gx >= 0 && gx < D && gy >= 0 && gy < D && gz >= 0 && gz < D)
-        v = Xb[(size_t)ci * D3 + ((size_t)gx * D + gy) * D + gz];
-      Xs[k * C::PLANE + (xx * C::YS + yy) * C::ZS + zz] = v;
-    }
-    // ---- this chunk's weights: Ws[tap][k][co] = W[co][4*ch + k][tap]
-    for (int i = tid; i < C::WCHUNK; i += 512) {
-      const int co = i % COUT, k = (i / COUT) % 4, tap = i / (4 * COUT), ci = 4 * ch + k;
-      Ws[i] = ci < CIN ? W[((size_t)co * CIN + ci) * C::NTAP + tap] : 0.f;
-    }
-    __syncthreads();
-    // ---- all taps of the chunk
-#pragma unroll 1
-    for (int dx = 0; dx < KS; dx++)
-#pragma unroll 1
-      for (int dy = 0; dy < KS; dy++) {
-        const float* xr[2];
+    if (PREFETCH) {
+      commit();
+    } else {
+      for (int row = wave; row < NROW; row += C::NW) {
+        bool ok;
+        const float* src = row_src(row, ch, ok);
+        float* dst = row_dst(row);
 #pragma unroll
-        for (int r = 0; r < 2; r++) {
-          const int row = 2 * wave + r, rx = row / C::TY, ry = row % C::TY;
-          xr[r] = Xs + kq * C::PLANE + ((rx + dx) * C::YS + (ry + dy)) * C::ZS + n;
-        }
-        const float* wr = Ws + ((dx * KS + dy) * KS) * 4 * COUT + kq * COUT + n;
-#pragma unroll
-        for (int dz = 0; dz < KS; dz++) {
-          float a[MT];
-#pragma unroll
-          for (int mt = 0; mt < MT; mt++) a[mt] = wr[dz * 4 * COUT + mt * 16];
-#pragma unroll
-          for (int r = 0; r < 2; r++)
-#pragma unroll
-            for (int zt = 0; zt < NZT; zt++) {
-              const float bv = xr[r][zt * 16 + dz];
-#pragma unroll
-              for (int mt = 0; mt < MT; mt++) acc[r][zt][mt] = DLPD_MFMA_16x16x4(a[mt], bv, acc[r][zt][mt]);
-            }
+        for (int q = 0; q < ZL; q++) {
+          const int zz = q * 64 + lane;
+          if (zz < C::ZS) dst[zz] = (ok && zz >= H && zz < D + H) ? src[zz] : 0.f;
         }
       }
+      const float4* wsrc = reinterpret_cast<const float4*>(W + (size_t)ch * C::WCHUNK);
+      for (int i = tid; i < C::WCHUNK / 4; i += 512) reinterpret_cast<float4*>(Ws)[i] = wsrc[i];
+    }
+    __syncthreads();
+    if (PREFETCH && ch + 1 < nchunk) fetch(ch + 1);            // in flight during this chunk's MFMAs
+    // ---- all taps of the chunk.  One step = one (dx, dy) row = KS taps.  The fragments of step t+1 are
+    // requested before the MFMAs of step t run (two register sets), so the matrix pipe never waits for
+    // an LDS round trip; the fences keep the compiler from sinking the reads back next to their use.
+    struct Frag { float a[KS][MT], b[KS][2][NZT]; };
+    auto load_frag = [&](Frag& f, int t2) {
+      const int dx = t2 / KS, dy = t2 % KS;
+      const float* wr = Ws + ((dx * KS + dy) * KS) * 4 * COUT + kq * COUT + n;
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        const int row = 2 * wave + r, rx = row / C::TY, ry = row % C::TY;
+        const float* xr = Xs + kq * C::PLANE + ((rx + dx) * C::YS + (ry + dy)) * C::ZS + n;
+#pragma unroll
+        for (int dz = 0; dz < KS; dz++)
+#pragma unroll
+          for (int zt = 0; zt < NZT; zt++) f.b[dz][r][zt] = xr[zt * 16 + dz];
+      }
+#pragma unroll
+      for (int dz = 0; dz < KS; dz++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) f.a[dz][mt] = wr[dz * 4 * COUT + mt * 16];
+    };
+    auto run_frag = [&](const Frag& f) {
+#pragma unroll
+      for (int dz = 0; dz < KS; dz++)
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+          for (int zt = 0; zt < NZT; zt++)
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+              acc[r][zt][mt] = DLPD_MFMA_16x16x4(f.a[dz][mt], f.b[dz][r][zt], acc[r][zt][mt]);
+    };
+    Frag f0, f1;
+    load_frag(f0, 0);
+#pragma unroll 1
+    for (int t2 = 0; t2 < KS * KS; t2 += 2) {
+      if (t2 + 1 < KS * KS) load_frag(f1, t2 + 1);
+      DLPD_SCHED_FENCE();
+      run_frag(f0);
+      DLPD_SCHED_FENCE();
+      if (t2 + 1 < KS * KS) {
+        if (t2 + 2 < KS * KS) load_frag(f0, t2 + 2);
+        DLPD_SCHED_FENCE();
+        run_frag(f1);
+        DLPD_SCHED_FENCE();
+      }
+    }
   }
   // ---- epilogue: lane holds rows (output channels) 4*kq + j, column (voxel) n of each tile
 #pragma unroll
@@ -128,7 +202,30 @@ template <int KS, int COUT, int NZT> static int launch_conv(const float* X, cons
   return dlpd_check_launch();
 }
 
+// wp[chunk][tap][k][co] = w[co][4*chunk + k][tap] (0 beyond cin): the order the kernel stages and reads
+__global__ void __launch_bounds__(256) k_conv3d_pack(const float* __restrict__ w, float* __restrict__ wp, int cin,
+                                                     int cout, int ntap) {
+  const int total = ((cin + 3) / 4) * ntap * 4 * cout;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int co = i % cout, k = (i / cout) % 4, tap = (i / (4 * cout)) % ntap, ch = i / (4 * cout * ntap);
+    const int ci = 4 * ch + k;
+    wp[i] = ci < cin ? w[((size_t)co * cin + ci) * ntap + tap] : 0.f;
+  }
+}
+
 extern "C" {
+
+size_t dlpd_conv3d_packed_floats(int cin, int cout, int ks) {
+  return (size_t)((cin + 3) / 4) * ks * ks * ks * 4 * cout;
+}
+
+int dlpd_conv3d_pack(const float* w, float* wp, int cin, int cout, int ks, void* stream) {
+  if (!w || !wp || cin <= 0 || cout <= 0 || ks <= 0) return DLPD_ERR_ARG;
+  const int total = (int)dlpd_conv3d_packed_floats(cin, cout, ks);
+  DLPD_LAUNCH(k_conv3d_pack, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, wp, cin, cout,
+              ks * ks * ks);
+  return dlpd_check_launch();
+}
 
 int dlpd_conv3d_supported(int cin, int cout, int ks, int D) {
   if (cin <= 0 || D <= 0 || D > 80) return 0;
@@ -136,13 +233,13 @@ int dlpd_conv3d_supported(int cin, int cout, int ks, int D) {
   return (k && (cout == 16 || cout == 32)) ? 1 : 0;
 }
 
-int dlpd_conv3d(const float* x, const float* w, float* y, int B, int cin, int cout, int D, int ks, int relu,
+int dlpd_conv3d(const float* x, const float* wp, float* y, int B, int cin, int cout, int D, int ks, int relu,
                 void* stream) {
-  if (!x || !w || !y || B <= 0) return DLPD_ERR_ARG;
+  if (!x || !wp || !y || B <= 0) return DLPD_ERR_ARG;
   if (!dlpd_conv3d_supported(cin, cout, ks, D)) return DLPD_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int nzt = (D + 15) / 16;                               // z tiles per row
-#define DLPD_CONV(KS, CO, NZ) if (ks == KS && cout == CO && nzt <= NZ) return launch_conv<KS, CO, NZ>(x, w, y, B, cin, D, relu, st)
+#define DLPD_CONV(KS, CO, NZ) if (ks == KS && cout == CO && nzt <= NZ) return launch_conv<KS, CO, NZ>(x, wp, y, B, cin, D, relu, st)
   DLPD_CONV(3, 16, 3); DLPD_CONV(3, 16, 5); DLPD_CONV(5, 16, 3); DLPD_CONV(5, 16, 5);
   DLPD_CONV(3, 32, 3); DLPD_CONV(3, 32, 5); DLPD_CONV(5, 32, 3); DLPD_CONV(5, 32, 5);
 #undef DLPD_CONV

@@ -113,6 +113,28 @@ def conv3d(x, weight, relu=False, lib=None):
     cout, ks = w.shape[0], w.shape[2]
     if w.shape[1] != cin:
         raise RuntimeError("dlpd: conv3d channel mismatch %d vs %d" % (w.shape[1], cin))
+    wp = _packed_weights(weight, w, lib, x.device)
     y = torch.empty(B, cout, D, D, D, dtype=torch.float32, device=x.device)
-    lib.call("dlpd_conv3d", _ptr(x), _ptr(w), _ptr(y), B, cin, cout, D, ks, int(bool(relu)), _stream(x.device))
+    lib.call("dlpd_conv3d", _ptr(x), _ptr(wp), _ptr(y), B, cin, cout, D, ks, int(bool(relu)), _stream(x.device))
     return y
+
+
+_PACKED = {}
+
+
+def _packed_weights(weight, w, lib, device):
+    """dlpd_conv3d_pack; cached per (parameter, version) for nn.Parameters -- inference weights do not
+    change between batches.  Other tensors (e.g. kernels composed on the fly) are packed per call: their
+    storage may be recycled with new contents under the same address."""
+    cacheable = isinstance(weight, torch.nn.Parameter)
+    key = (id(weight), weight.data_ptr(), weight._version, tuple(weight.shape), str(device), id(lib))
+    if cacheable and key in _PACKED:
+        return _PACKED[key]
+    cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
+    wp = torch.empty(lib.call("dlpd_conv3d_packed_floats", cin, cout, ks), dtype=torch.float32, device=device)
+    lib.call("dlpd_conv3d_pack", _ptr(w), _ptr(wp), cin, cout, ks, _stream(device))
+    if cacheable:
+        if len(_PACKED) > 64:
+            _PACKED.clear()
+        _PACKED[key] = wp
+    return wp

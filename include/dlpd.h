@@ -120,7 +120,10 @@ int dlpd_zifft_real_part(const void* wsB, float* out, int nb, int CT, int nclip,
  * padding ks/2, stride 1, no bias, exact f32 on the matrix cores.  Supported: ks in {3,5}, cout in {16,32},
  * D <= 80 (dlpd_conv3d_supported); anything else is the plugin's own torch convolution. */
 int dlpd_conv3d_supported(int cin, int cout, int ks, int D);
-int dlpd_conv3d(const float* x, const float* w, float* y, int B, int cin, int cout, int D, int ks, int relu,
+/* weights are passed packed: wp = dlpd_conv3d_pack(w (cout, cin, ks^3)), dlpd_conv3d_packed_floats() floats */
+size_t dlpd_conv3d_packed_floats(int cin, int cout, int ks);
+int dlpd_conv3d_pack(const float* w, float* wp, int cin, int cout, int ks, void* stream);
+int dlpd_conv3d(const float* x, const float* wp, float* y, int B, int cin, int cout, int D, int ks, int relu,
                 void* stream);
 
 /* Docker.update_top pick loop, src/Docker/Docker.py:89-98: per rotation the K picks in pick order
