@@ -57,6 +57,9 @@ extern "C" int dlpd_debug_read_stamps_k2(unsigned long long* host16) {
 #define DLPD_K2_DENSE(N) (DLPD_K2_N80_DENSE && (N) == 80)
 #define DLPD_K2_OPAQUE(x) do { if ((DLPD_K2_LAUNDER & 1) || DLPD_K2_DENSE(N)) DLPD_OPAQUE(x); } while (0)
 #define DLPD_K2_OPAQUE_T(x) do { if ((DLPD_K2_LAUNDER & 2) || DLPD_K2_DENSE(N)) DLPD_OPAQUE(x); } while (0)
+#ifndef DLPD_K2_DIRECT_IN
+#define DLPD_K2_DIRECT_IN 0
+#endif
 #ifndef DLPD_K2_DIRECT_OUT
 #define DLPD_K2_DIRECT_OUT 0
 #endif
@@ -97,6 +100,21 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
   cplx* tw = S + N * RS;
   init_twiddles<N>(tw, tid, NT);
 
+#if DLPD_K2_DIRECT_IN
+  // The pruned first y pass takes its L/8 non-zero inputs per thread straight from global memory
+  // (one pencil set per wave: L/8 == W), so the A slab is never staged through LDS: one LDS store
+  // pass and one block barrier less per slab.
+  constexpr int RNZ1 = L / 8;
+  static_assert(FwdP1::PER == 1 && FwdP1::NBF == 8 && L / 8 == W, "one y pencil set per wave");
+  cplx ain[RNZ1];
+  auto fetch_rows = [&](int bb) {
+    const cplx* a = A + (((size_t)bb * CT + c) * NZ + kz) * L * L + (size_t)(wave * 8 + qr) * L + (lane & 7);
+#pragma unroll
+    for (int r = 0; r < RNZ1; r++) ain[r] = dlpd_load_stream_c(a + 8 * r);
+  };
+  fetch_rows(b_beg);
+  __syncthreads();                                       // twiddle table visible
+#else
   float4 apref[NLOAD];
   {
     const float4* a = reinterpret_cast<const float4*>(A + (((size_t)b_beg * CT + c) * NZ + kz) * L * L);
@@ -104,11 +122,13 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
     for (int i = 0; i < NLOAD; i++)
       if (tid + i * NT < L * L / 2) apref[i] = DLPD_LOAD_STREAM(a + tid + i * NT);
   }
+#endif
   DLPD_STAMP_DECL;
   for (int b = b_beg; b < b_end; b++) {
     DLPD_STAMP(7);
     int tq = tid;
     DLPD_K2_OPAQUE_T(tq);                 // slab offsets are recomputed per rotation instead of living in VGPRs
+#if !DLPD_K2_DIRECT_IN
 #pragma unroll
     for (int i = 0; i < NLOAD; i++) {
       const int e = 2 * (tq + i * NT), x = e / L, y = e % L;
@@ -120,6 +140,7 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
     DLPD_STAMP(0);
     __syncthreads();
     DLPD_STAMP(1);
+#endif
     // ---- forward along y on the L non-zero rows: L/8 pencil sets over W waves
 #pragma unroll 1
     for (int set = wave; set < L / 8; set += W) {
@@ -128,8 +149,14 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
       DLPD_K2_OPAQUE(tr);
       {
         FwdP1 ps;
+#if DLPD_K2_DIRECT_IN
+#pragma unroll
+        for (int r = 0; r < R1; r++) ps.v[0][r] = r < RNZ1 ? ain[r < RNZ1 ? r : 0] : c_make(0.f, 0.f);
+        SmallDft<R1, -1>::run(ps.v[0]);
+#else
         ps.load(S, ad, tr, nullptr);
         DLPD_WAVE_SYNC();
+#endif
         ps.store(S, ad, tr);
         DLPD_WAVE_SYNC();
       }
@@ -226,12 +253,16 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
     __syncthreads();
     DLPD_STAMP(1);
     // next rotation's A slab: issued now, consumed at the top of the next iteration
+#if DLPD_K2_DIRECT_IN
+    if (b + 1 < b_end) fetch_rows(b + 1);
+#else
     if (b + 1 < b_end) {
       const float4* a = reinterpret_cast<const float4*>(A + (((size_t)(b + 1) * CT + c) * NZ + kz) * L * L);
 #pragma unroll
       for (int i = 0; i < NLOAD; i++)
         if (tid + i * NT < L * L / 2) apref[i] = DLPD_LOAD_STREAM(a + tid + i * NT);
     }
+#endif
     if (MODE == 1) {
       // ---- inverse along y on all N rows
   #pragma unroll 1

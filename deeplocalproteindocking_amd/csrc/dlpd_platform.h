@@ -50,6 +50,11 @@ __device__ __forceinline__ void dlpd_store_stream_c(float2* p, float2 v) {
   const dlpd_f2s q = {v.x, v.y};
   __builtin_nontemporal_store(q, reinterpret_cast<dlpd_f2s*>(p));
 }
+__device__ __forceinline__ float2 dlpd_load_stream_c(const float2* p) {
+  typedef float dlpd_f2s __attribute__((ext_vector_type(2)));
+  const dlpd_f2s v = __builtin_nontemporal_load(reinterpret_cast<const dlpd_f2s*>(p));
+  return make_float2(v.x, v.y);
+}
 #define DLPD_LOAD_STREAM(p) dlpd_load_stream(p)
 #define DLPD_STORE_STREAM(p, v) dlpd_store_stream((p), (v))
 #include <stdlib.h>

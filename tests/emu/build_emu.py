@@ -17,7 +17,7 @@ def build(force=False):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) > os.path.getmtime(d) for d in deps):
         return OUT
     cmd = ["g++", "-O2", "-g", "-std=c++17", "-shared", "-fPIC", "-fpermissive", "-w",
-           "-I", HERE, "-I", CSRC, "-o", OUT]
+           "-I", HERE, "-I", CSRC, "-o", OUT] + os.environ.get("DLPD_EMU_FLAGS", "").split()
     for s in srcs:
         cmd += ["-x", "c++", s]
     subprocess.check_call(cmd)

@@ -224,6 +224,7 @@ struct dlpd_pair_t { float x, y; };
 #define DLPD_PAIR dlpd_pair_t
 static inline dlpd_pair_t dlpd_load_pair(const float* p) { dlpd_pair_t r; r.x = p[0]; r.y = p[1]; return r; }
 static inline void dlpd_store_stream_c(float2* p, float2 v) { *p = v; }
+static inline float2 dlpd_load_stream_c(const float2* p) { return *p; }
 #define DLPD_LOAD_STREAM(p) (*(p))
 #define DLPD_STORE_STREAM(p, v) (*(p) = (v))
 #define DLPD_CLAMP(v, c) fminf(fmaxf((v), -(c)), (c))
