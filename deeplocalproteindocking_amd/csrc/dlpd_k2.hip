@@ -501,12 +501,12 @@ template <> struct FftPlanD2<160> { static constexpr int R1 = 10, R2 = 16, R3 = 
 #ifndef DLPD_K2D_G0REG
 #define DLPD_K2D_G0REG 0                 // 1: G0 waits in registers (spills at 8 waves); 0: in the output slab, re-read from L2
 #endif
-template <int N> __global__ void __launch_bounds__(64 * DLPD_K2D_WAVES)
+template <int N, int WV> __global__ void __launch_bounds__(64 * WV)
 k_xy_corr_dif(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __restrict__ out,
               int CT, int nb, int nsplit, long long rec_bstride) {
   constexpr int L = N / 2, H = N / 2, NZ = N / 2 + 1, RS = H + 8;
   static_assert(RS % 16 == 8, "row stride must be an odd multiple of 8 elements (bank spreading)");
-  constexpr int NT = 64 * DLPD_K2D_WAVES, W = NT / 64;
+  constexpr int NT = 64 * WV, W = WV;
   constexpr int NLOAD = (L * L / 2 + NT - 1) / NT;     // float4 (2 complex) per thread of an A slab
   constexpr int NG = (N * H / 2 + NT - 1) / NT;        // float4 per thread of a G slab
   typedef DLPD_K2D_PLAN<N> P;                          // column (length-N) plan; rows use FftPlanW<H>
@@ -685,16 +685,16 @@ k_xy_corr_dif(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __
   DLPD_STAMP_FLUSH(dlpd_stamps_k2, DLPD_STAMPS);
 }
 
-template <int N> static int launch_k2_dif(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, long long rbs,
+template <int N, int WV> static int launch_k2_dif(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, long long rbs,
                                           hipStream_t st) {
   constexpr int NZ = N / 2 + 1, H = N / 2, RS = H + 8;
   const size_t shmem = (size_t)(N * RS + N + H) * sizeof(cplx);
-  int rc = dlpd_set_max_dyn_shared((const void*)k_xy_corr_dif<N>, shmem);
+  int rc = dlpd_set_max_dyn_shared((const void*)k_xy_corr_dif<N, WV>, shmem);
   if (rc) return rc;
   int nsplit = nb >= 8 ? 2 : 1;
   if (const char* e = getenv("DLPD_K2_NSPLIT")) nsplit = atoi(e) > 0 ? atoi(e) : nsplit;
   const int slabs8 = ((NZ * CT + 7) / 8) * 8;
-  DLPD_LAUNCH((k_xy_corr_dif<N>), dim3(slabs8 * nsplit), dim3(64 * DLPD_K2D_WAVES), shmem, st, A, rec, out, CT, nb, nsplit, rbs);
+  DLPD_LAUNCH((k_xy_corr_dif<N, WV>), dim3(slabs8 * nsplit), dim3(64 * WV), shmem, st, A, rec, out, CT, nb, nsplit, rbs);
   return dlpd_check_launch();
 }
 
@@ -712,9 +712,11 @@ int dlpd_k2_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb,
   switch (L) {
     case 32: return launch_k2<64, 1>(A, rec, out, CT, nb, rbs, 1.f, st);
     case 40: return launch_k2<80, 1>(A, rec, out, CT, nb, rbs, 1.f, st);
-    case 64: return launch_k2<128, 1>(A, rec, out, CT, nb, rbs, 1.f, st);
+    // DLPD_K2_DIF128 (diagnostic): the half-slab kernel at N = 128, two 4-wave blocks per CU
+    case 64: return getenv("DLPD_K2_DIF128") ? launch_k2_dif<128, 4>(A, rec, out, CT, nb, rbs, st)
+                                             : launch_k2<128, 1>(A, rec, out, CT, nb, rbs, 1.f, st);
     case 80: return getenv("DLPD_K2_SPLIT") ? launch_k2_split<160, 1>(A, rec, out, CT, nb, rbs, 1.f, st)
-                                          : launch_k2_dif<160>(A, rec, out, CT, nb, rbs, st);
+                                          : launch_k2_dif<160, DLPD_K2D_WAVES>(A, rec, out, CT, nb, rbs, st);
     default: return DLPD_ERR_UNSUPPORTED;
   }
 }
