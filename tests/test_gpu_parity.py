@@ -376,3 +376,32 @@ def test_conv3d_matches_torch_at_plugin_shapes(dev, cin, cout, ks, D):
         want = torch.nn.functional.conv3d(x.cpu(), w.cpu(), padding=ks // 2)
         want = torch.relu(want) if relu else want
         assert (got.cpu() - want).abs().max() <= 1e-5 * want.abs().max()
+
+
+@pytest.mark.parametrize("L,C,H,has_clash,clip,nb", [(32, 1, 1, True, 5.0, 1), (32, 3, 3, False, None, 2), (32, 5, 6, True, 0.2, 4),
+                                                      (32, 9, 13, False, 5.0, 3), (40, 2, 20, True, None, 2), (32, 7, 32, True, 1.0, 5)])
+def test_scores_match_oracle_odd_shapes(dev, L, C, H, has_clash, clip, nb):
+    """Corner configurations of the fused pipeline: single channel, hidden widths that need zero padding
+    (1, 3, 6, 13, 20 -> 2, 4, 8, 16, 24) or sit at the limit (32), no clash channel, no clip, odd batch sizes."""
+    from deeplocalproteindocking_amd.engine import DockingEngine
+    g = torch.Generator().manual_seed(1000 + 7 * C + H)
+    rec, lig = torch.randn(C, L, L, L, generator=g) * 0.08, torch.randn(C, L, L, L, generator=g) * 0.08
+    recf, ligf = torch.rand(L, L, L, generator=g), torch.rand(L, L, L, generator=g)
+    W1, b1 = torch.randn(H, C, generator=g) * 0.4, torch.randn(H, generator=g) * 0.1
+    W2, b2 = torch.randn(1, H, generator=g), torch.randn(1, generator=g)
+    thr = 0.125 * L ** 3
+    R = _rots(nb, seed=C + H)
+    eng = DockingEngine(L, C, W1, b1, W2, b2, clip=clip, threshold_clash=thr, has_clash=has_clash, max_conf=50,
+                        batch=nb, device=dev)
+    eng.set_receptor(rec, recf if has_clash else None)
+    eng.set_ligand(lig, ligf if has_clash else None)
+    V = eng.score_batch(torch.from_numpy(R).float().to(dev).contiguous()).cpu()
+    for j in range(nb):
+        Rb = torch.from_numpy(R[j:j + 1]).float()
+        S = orc.score_volumes([rec[None]], [orc.rotate_volume(lig[None], Rb)], W1, b1, W2, b2, clip=clip)[0]
+        if has_clash:
+            mask, norm = orc.clash_mask(recf[None, None], orc.rotate_volume(ligf[None, None], Rb), thr)
+            S, sure = mask[0] * S, (norm[0] - thr).abs() > 1e-3 * thr
+        else:
+            sure = torch.ones_like(S, dtype=torch.bool)
+        assert (V[j] - S).abs()[sure].max().item() <= TOL * S.abs().max().item()
