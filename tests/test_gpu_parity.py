@@ -405,3 +405,35 @@ def test_scores_match_oracle_odd_shapes(dev, L, C, H, has_clash, clip, nb):
         else:
             sure = torch.ones_like(S, dtype=torch.bool)
         assert (V[j] - S).abs()[sure].max().item() <= TOL * S.abs().max().item()
+
+
+def test_topk_fuzz_against_faithful_update_top(dev):
+    """The same fuzz as tests/test_kernels_emu.py on the real kernels: ties, signed zeros, too few negatives,
+    no zero at all, K up to the voxel count, several rotations per batch -- tuple-for-tuple equality with the
+    restated reference loop (Docker.py:86-105), including the sign of recorded zeros."""
+    from deeplocalproteindocking_amd._lib import get_lib
+    from deeplocalproteindocking_amd.engine import DeviceTopList
+    rng = np.random.RandomState(777)
+    pools = [np.array([-2.0, -1.0, -1.0, -0.5, 0.0, 0.0, 1.0, 3.0], dtype=np.float32),
+             np.array([-1.0, 0.0, -0.0, 2.0], dtype=np.float32), np.array([0.5, 1.0, 2.0], dtype=np.float32),
+             np.array([-3.0, -3.0, -3.0, 4.0, 0.0], dtype=np.float32)]
+    for trial in range(60):
+        N = int(rng.choice([4, 6, 8, 12]))
+        K = int(rng.randint(1, min(N ** 3, 64) + 1))
+        nrot, batch = int(rng.randint(1, 6)), int(rng.randint(1, 4))
+        pool = pools[trial % len(pools)]
+        Vs = pool[rng.randint(0, len(pool), size=(nrot, N, N, N))]
+        if trial % 5 == 0:
+            Vs = (Vs + rng.randn(*Vs.shape).astype(np.float32) * 0.01).astype(np.float32)
+        want = []
+        for r in range(nrot):
+            want = orc.update_top(want, torch.from_numpy(Vs[r].copy()), r, K)
+        top = DeviceTopList(K, batch, dev, get_lib())
+        top.reset()
+        for beg in range(0, nrot, batch):
+            nb = min(batch, nrot - beg)
+            top.select(torch.from_numpy(Vs[beg:beg + nb].reshape(nb, -1).copy()).to(dev), nb)
+            top.merge(torch.arange(beg, beg + nb, dtype=torch.int32, device=dev), nb)
+        got = DeviceTopList.to_top_list(top.entries(), N)
+        assert got == want, (trial, N, K, nrot, batch)
+        assert [np.signbit(a[4]) for a in got] == [np.signbit(b[4]) for b in want], trial

@@ -254,3 +254,35 @@ def test_conv3d_mfma_kernel_matches_torch(emu, cin, cout, ks, D, relu):
     want = torch.nn.functional.conv3d(x, w, padding=ks // 2)
     want = torch.relu(want) if relu else want
     assert (y - want).abs().max() <= 2e-5 * want.abs().max()
+
+
+def test_topk_kernels_fuzz_against_faithful_update_top(emu):
+    """Randomised small volumes built to provoke every corner of Docker.update_top (Docker.py:86-105): many
+    exact ties, zeros of both signs, fewer negatives than K, no zero at all, K up to the voxel count, batches
+    of several rotations merged into a running list -- the device select + merge must reproduce the reference
+    loop tuple for tuple (including the sign of recorded zeros)."""
+    rng = np.random.RandomState(20240)
+    pools = [np.array([-2.0, -1.0, -1.0, -0.5, 0.0, 0.0, 1.0, 3.0], dtype=np.float32),
+             np.array([-1.0, 0.0, -0.0, 2.0], dtype=np.float32),
+             np.array([0.5, 1.0, 2.0], dtype=np.float32),                      # no zero, no negative
+             np.array([-3.0, -3.0, -3.0, 4.0, 0.0], dtype=np.float32)]
+    for trial in range(24):
+        N = int(rng.choice([4, 5, 8]))
+        K = int(rng.randint(1, min(N ** 3, 40) + 1))
+        nrot, batch = int(rng.randint(1, 5)), int(rng.randint(1, 4))
+        pool = pools[trial % len(pools)]
+        Vs = pool[rng.randint(0, len(pool), size=(nrot, N, N, N))]
+        if trial % 5 == 0:
+            Vs = (Vs + rng.randn(*Vs.shape).astype(np.float32) * 0.01).astype(np.float32)     # mostly distinct values
+        want = []
+        for r in range(nrot):
+            want = orc.update_top(want, torch.from_numpy(Vs[r].copy()), r, K)
+        top = DeviceTopList(K, batch, "cpu", emu)
+        top.reset()
+        for beg in range(0, nrot, batch):
+            nb = min(batch, nrot - beg)
+            top.select(torch.from_numpy(Vs[beg:beg + nb].reshape(nb, -1).copy()), nb)
+            top.merge(torch.arange(beg, beg + nb, dtype=torch.int32), nb)
+        got = DeviceTopList.to_top_list(top.entries(), N)
+        assert got == want, (trial, N, K, nrot, batch)
+        assert [np.signbit(a[4]) for a in got] == [np.signbit(b[4]) for b in want], trial
