@@ -26,7 +26,8 @@ template <int KS, int COUT, int NZT> struct ConvCfg {
 };
 
 template <int KS, int COUT, int NZT, int RELU> __global__ void __launch_bounds__(512)
-k_conv3d_mfma(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ Y, int CIN, int D) {
+k_conv3d_mfma(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ Y, int CIN, int D,
+              int cout_total, int co_base) {
   typedef ConvCfg<KS, COUT, NZT> C;
   constexpr int MT = COUT / 16, H = C::H;
   DLPD_DYN_SHARED(float, S);
@@ -179,36 +180,43 @@ k_conv3d_mfma(const float* __restrict__ X, const float* __restrict__ W, float* _
         for (int j = 0; j < 4; j++) {
           float v = dlpd_acc4_get(acc[r][zt][mt], j);
           if (RELU) v = fmaxf(v, 0.f);
-          Y[((size_t)b * COUT + mt * 16 + 4 * kq + j) * D3 + ((size_t)gx * D + gy) * D + gz] = v;
+          Y[((size_t)b * cout_total + co_base + mt * 16 + 4 * kq + j) * D3 + ((size_t)gx * D + gy) * D + gz] = v;
         }
     }
   }
 }
 
 template <int KS, int COUT, int NZT> static int launch_conv(const float* X, const float* W, float* Y, int B, int CIN,
-                                                            int D, int relu, hipStream_t st) {
+                                                            int D, int relu, int cout_total, int co_base,
+                                                            hipStream_t st) {
   typedef ConvCfg<KS, COUT, NZT> C;
   dim3 grid((D + C::TX - 1) / C::TX, (D + C::TY - 1) / C::TY, B), block(512);
   int rc;
   if (relu) {
     rc = dlpd_set_max_dyn_shared((const void*)k_conv3d_mfma<KS, COUT, NZT, 1>, C::LDS_BYTES);
     if (rc) return rc;
-    DLPD_LAUNCH((k_conv3d_mfma<KS, COUT, NZT, 1>), grid, block, C::LDS_BYTES, st, X, W, Y, CIN, D);
+    DLPD_LAUNCH((k_conv3d_mfma<KS, COUT, NZT, 1>), grid, block, C::LDS_BYTES, st, X, W, Y, CIN, D, cout_total, co_base);
   } else {
     rc = dlpd_set_max_dyn_shared((const void*)k_conv3d_mfma<KS, COUT, NZT, 0>, C::LDS_BYTES);
     if (rc) return rc;
-    DLPD_LAUNCH((k_conv3d_mfma<KS, COUT, NZT, 0>), grid, block, C::LDS_BYTES, st, X, W, Y, CIN, D);
+    DLPD_LAUNCH((k_conv3d_mfma<KS, COUT, NZT, 0>), grid, block, C::LDS_BYTES, st, X, W, Y, CIN, D, cout_total, co_base);
   }
   return dlpd_check_launch();
 }
 
-// wp[chunk][tap][k][co] = w[co][4*chunk + k][tap] (0 beyond cin): the order the kernel stages and reads
+// Output channels are processed in groups of 32 (a last group of 16 if cout % 32 == 16), one launch each.
+// wp[group][chunk][tap][k][co in group] = w[co][4*chunk + k][tap] (0 beyond cin): the order the kernel
+// stages and reads.
+__host__ __device__ inline int conv_group_width(int cout, int g) { return (cout - 32 * g) >= 32 ? 32 : 16; }
 __global__ void __launch_bounds__(256) k_conv3d_pack(const float* __restrict__ w, float* __restrict__ wp, int cin,
                                                      int cout, int ntap) {
-  const int total = ((cin + 3) / 4) * ntap * 4 * cout;
+  const int nch = (cin + 3) / 4;
+  const int total = nch * ntap * 4 * cout;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int co = i % cout, k = (i / cout) % 4, tap = (i / (4 * cout)) % ntap, ch = i / (4 * cout * ntap);
-    const int ci = 4 * ch + k;
+    const int per32 = nch * ntap * 4 * 32;                   // floats of a full group
+    const int g = i / per32, gw = conv_group_width(cout, g), r = i - g * per32;
+    const int col = r % gw, k = (r / gw) % 4, tap = (r / (4 * gw)) % ntap, ch = r / (4 * gw * ntap);
+    const int ci = 4 * ch + k, co = 32 * g + col;
     wp[i] = ci < cin ? w[((size_t)co * cin + ci) * ntap + tap] : 0.f;
   }
 }
@@ -229,8 +237,7 @@ int dlpd_conv3d_pack(const float* w, float* wp, int cin, int cout, int ks, void*
 
 int dlpd_conv3d_supported(int cin, int cout, int ks, int D) {
   if (cin <= 0 || D <= 0 || D > 80) return 0;
-  const bool k = (ks == 3 || ks == 5);
-  return (k && (cout == 16 || cout == 32)) ? 1 : 0;
+  return ((ks == 3 || ks == 5) && cout >= 16 && cout % 16 == 0) ? 1 : 0;
 }
 
 int dlpd_conv3d(const float* x, const float* wp, float* y, int B, int cin, int cout, int D, int ks, int relu,
@@ -239,11 +246,19 @@ int dlpd_conv3d(const float* x, const float* wp, float* y, int B, int cin, int c
   if (!dlpd_conv3d_supported(cin, cout, ks, D)) return DLPD_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int nzt = (D + 15) / 16;                               // z tiles per row
-#define DLPD_CONV(KS, CO, NZ) if (ks == KS && cout == CO && nzt <= NZ) return launch_conv<KS, CO, NZ>(x, wp, y, B, cin, D, relu, st)
-  DLPD_CONV(3, 16, 3); DLPD_CONV(3, 16, 5); DLPD_CONV(5, 16, 3); DLPD_CONV(5, 16, 5);
-  DLPD_CONV(3, 32, 3); DLPD_CONV(3, 32, 5); DLPD_CONV(5, 32, 3); DLPD_CONV(5, 32, 5);
+  const size_t per32 = (size_t)((cin + 3) / 4) * ks * ks * ks * 4 * 32;
+  for (int g = 0; 32 * g < cout; g++) {
+    const int gw = conv_group_width(cout, g), base = 32 * g;
+    const float* wg = wp + per32 * g;
+    int rc = DLPD_ERR_UNSUPPORTED;
+#define DLPD_CONV(KS, CO, NZ) if (rc == DLPD_ERR_UNSUPPORTED && ks == KS && gw == CO && nzt <= NZ) \
+    rc = launch_conv<KS, CO, NZ>(x, wg, y, B, cin, D, relu, cout, base, st)
+    DLPD_CONV(3, 16, 3); DLPD_CONV(3, 16, 5); DLPD_CONV(5, 16, 3); DLPD_CONV(5, 16, 5);
+    DLPD_CONV(3, 32, 3); DLPD_CONV(3, 32, 5); DLPD_CONV(5, 32, 3); DLPD_CONV(5, 32, 5);
 #undef DLPD_CONV
-  return DLPD_ERR_UNSUPPORTED;
+    if (rc) return rc;
+  }
+  return DLPD_OK;
 }
 
 }  // extern "C"

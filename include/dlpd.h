@@ -117,8 +117,8 @@ int dlpd_zifft_real_part(const void* wsB, float* out, int nb, int CT, int nclip,
 
 /* Representation-plugin convolution (ProteinRepresentationModels.py:85-114, the per-batch cost of
  * Docker.dockE3, Docker.py:166-167): y (B, cout, D^3) = [relu] conv3d(x (B, cin, D^3), w (cout, cin, ks^3)),
- * padding ks/2, stride 1, no bias, exact f32 on the matrix cores.  Supported: ks in {3,5}, cout in {16,32},
- * D <= 80 (dlpd_conv3d_supported); anything else is the plugin's own torch convolution. */
+ * padding ks/2, stride 1, no bias, exact f32 on the matrix cores.  Supported: ks in {3,5}, cout a multiple
+ * of 16, D <= 80 (dlpd_conv3d_supported); anything else is the plugin's own torch convolution. */
 int dlpd_conv3d_supported(int cin, int cout, int ks, int D);
 /* weights are passed packed: wp = dlpd_conv3d_pack(w (cout, cin, ks^3)), dlpd_conv3d_packed_floats() floats */
 size_t dlpd_conv3d_packed_floats(int cin, int cout, int ks);

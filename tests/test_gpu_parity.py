@@ -362,7 +362,7 @@ def test_full_size_rank_shards_merge_to_the_single_process_list(dev):
     assert DeviceTopList.to_top_list(merged, 2 * L) == DeviceTopList.to_top_list(whole, 2 * L)
 
 
-@pytest.mark.parametrize("cin,cout,ks,D", [(11, 16, 5, 80), (16, 16, 3, 80), (16, 32, 5, 40), (32, 32, 3, 40), (11, 32, 3, 37)])
+@pytest.mark.parametrize("cin,cout,ks,D", [(11, 16, 5, 80), (16, 16, 3, 80), (16, 32, 5, 40), (32, 32, 3, 40), (11, 32, 3, 37), (32, 64, 5, 40), (11, 48, 3, 21)])
 def test_conv3d_matches_torch_at_plugin_shapes(dev, cin, cout, ks, D):
     """dlpd_conv3d (f32 MFMA implicit GEMM) against torch's conv3d on the layer shapes of the reference's
     representation plugins (ProteinRepresentationModels.py:85-114) and an awkward size; exact-f32 products,

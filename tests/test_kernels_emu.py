@@ -240,7 +240,7 @@ def test_fused_two_resolution_pipeline(emu, unfused):
     assert ((V[0] - Vo).abs()[sure]).max() <= 1e-4 * Vo.abs().max()
 
 
-@pytest.mark.parametrize("cin,cout,ks,D,relu", [(11, 16, 5, 6, True), (16, 32, 3, 9, False), (32, 32, 3, 17, True)])
+@pytest.mark.parametrize("cin,cout,ks,D,relu", [(11, 16, 5, 6, True), (16, 32, 3, 9, False), (32, 32, 3, 17, True), (5, 48, 3, 5, False)])
 def test_conv3d_mfma_kernel_matches_torch(emu, cin, cout, ks, D, relu):
     """The representation plugin's Conv3d (+ReLU) on the emulated f32 matrix core: channel counts that
     are not multiples of 4 (zero-padded chunk), box sizes that are not multiples of the 4 x 4 patch or
