@@ -19,6 +19,15 @@
 #include "dlpd_fft.h"
 #include "dlpd_internal.h"
 
+#ifndef DLPD_K1_TILE
+#define DLPD_K1_TILE 1
+#endif
+#ifndef DLPD_K1_XB
+#define DLPD_K1_XB 1                     // consecutive x-planes per K1 block (2: neutral, 4 and 8: slower -- fewer blocks in flight)
+#endif
+#ifndef DLPD_K1_TILE_Z
+#define DLPD_K1_TILE_Z 8
+#endif
 template <int N> DLPD_D void init_twiddles(cplx* tw, int tid, int nthreads) {
   for (int k = tid; k < N; k += nthreads) {
     double s, c;
@@ -106,12 +115,17 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
   // XCD-aware decode: consecutive block ids are dealt round-robin over the 8 XCDs, so the L
   // x-planes of one (b,c) volume are given ids of equal (id % 8): they run on one XCD and the
   // 1 MiB source volume is fetched into ONE L2 instead of eight.  Speed only, never correctness.
+  // A block walks XB consecutive x-planes: the slanted source slabs of neighbouring planes overlap, so
+  // the second..XB-th plane find most of their lines in this CU's L1 instead of going back to L2.
+  constexpr int XB = DLPD_K1_XB, XG = L / XB;
+  static_assert(L % XB == 0, "planes per block must divide L");
   const int bid = blockIdx.x, jj = bid >> 3;
-  const int grp = (bid & 7) + 8 * (jj / L);
-  const int x = jj % L;
+  const int grp = (bid & 7) + 8 * (jj / XG);
   if (grp >= CT * nb) return;
   const int c = grp % CT, b = grp / CT;
   init_twiddles<N>(tw, tid, NT);
+#pragma unroll 1
+  for (int x = (jj % XG) * XB; x < (jj % XG) * XB + XB; x++) {
   const float* v = vol + (size_t)b * vol_bstride + (size_t)c * L * L * L;
   float* Sf = reinterpret_cast<float*>(S);
   if (do_rotate) {
@@ -119,7 +133,17 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
     const float r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6], r7 = r[7], r8 = r[8];
     const float dx = x - c0;
     for (int s = tid; s < L * L; s += NT) {
+      // 64 consecutive samples form an 8 x 8 (y, z) tile, not a z row: under an oblique rotation a row of
+      // 64 samples crosses up to ~80 source cache lines per gather instruction, a tile ~20 (the TCP serves
+      // about one line per clock, and that is what bounds this kernel); axis-aligned rotations go from
+      // 4 lines to 8 -- measured: K1 over the whole 6-degree set 1.9 ms -> see DESIGN.md
+#if DLPD_K1_TILE
+      constexpr int TZ = DLPD_K1_TILE_Z, TYY = 64 / TZ;        // tile = TYY (y) x TZ (z) samples
+      const int chunk = s >> 6, q = s & 63;
+      const int y = (chunk / (L / TZ)) * TYY + q / TZ, z = (chunk % (L / TZ)) * TZ + q % TZ;
+#else
       const int y = s / L, z = s % L;
+#endif
       const float dy = y - c0, dz = z - c0;
       const float px = c0 + (r0 * dx + r3 * dy + r6 * dz);
       const float py = c0 + (r1 * dx + r4 * dy + r7 * dz);
@@ -162,6 +186,8 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
     o.z = 0.5f * (zk.y + zn.y);
     o.w = 0.5f * (zn.x - zk.x);
     DLPD_STORE_STREAM(reinterpret_cast<float4*>(a + (size_t)k * L * L + 2 * m), o);
+  }
+  __syncthreads();                                   // pencils fully read before the next plane refills them
   }
 }
 
@@ -618,7 +644,7 @@ template <int N> static int launch_k1(const float* vol, const float* R, cplx* A,
                                       int do_rotate, float c0, hipStream_t st, int CT_out = 0, int c_base = 0) {
   constexpr int L = N / 2;
   const int groups = ((CT * nb + 7) / 8) * 8;
-  dim3 grid(groups * L), block((N / 4) * FftPlan<N>::T);
+  dim3 grid(groups * (L / DLPD_K1_XB)), block((N / 4) * FftPlan<N>::T);
   DLPD_LAUNCH((k_rotate_zfft<N>), grid, block, 0, st, vol, R, A, CT, nb, vbs, do_rotate, c0,
               CT_out > 0 ? CT_out : CT, c_base);
   return dlpd_check_launch();
