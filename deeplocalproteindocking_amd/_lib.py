@@ -26,6 +26,10 @@ SIGNATURES = {
     "dlpd_project_atoms": (_i, [_p, _p, _p, _p, _f, _f, _f, _p, _i, _i, _i, _i, _f, _i, _p]),
     "dlpd_rfft3d_padded": (_i, [_p, _p, _p, _i, _i, _f, _p]),
     "dlpd_xy_correlate": (_i, [_p, _p, _p, _i, _i, _i, _ll, _p]),
+    "dlpd_zfft_oriented": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _ll, _i, _f, _i, _p]),
+    "dlpd_xy_correlate_oriented": (_i, [_p, _p, _p, _i, _i, _i, _ll, _i, _p]),
+    "dlpd_score_rotations_oriented": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _f, _i, _i, _f, _f,
+                                           _p, _p, _p, _i, _p]),
     "dlpd_zifft_real": (_i, [_p, _p, _i, _i, _i, _i, _f, _p]),
     "dlpd_zifft_filter": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _i, _f, _f, _p]),
     "dlpd_zifft_filter_aux": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _i, _f, _f, _p, _i, _p]),

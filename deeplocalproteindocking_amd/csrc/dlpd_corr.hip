@@ -105,7 +105,8 @@ __global__ void __launch_bounds__(256) k_rotate(const float* __restrict__ vol, c
 // ------------------------------------------------------------------------------------------
 template <int N> __global__ void __launch_bounds__((N / 4) * FftPlan<N>::T)
 k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* __restrict__ A,
-              int CT, int nb, long long vol_bstride, int do_rotate, float c0, int CT_out, int c_base) {
+              int CT, int nb, long long vol_bstride, int do_rotate, float c0, int CT_out, int c_base,
+              int transposed) {
   constexpr int L = N / 2, NZ = N / 2 + 1, RS = N + 1, NP = L / 2;
   constexpr int T = FftPlan<N>::T, R1 = FftPlan<N>::R1, R2 = FftPlan<N>::R2;
   constexpr int NT = NP * T;
@@ -124,13 +125,22 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
   if (grp >= CT * nb) return;
   const int c = grp % CT, b = grp / CT;
   init_twiddles<N>(tw, tid, NT);
+  // Slab orientation.  When the source z axis lies closer to the output x axis than to the output y axis,
+  // the gather of an x-plane is perpendicular to the contiguous direction of memory (every lane its own
+  // cache line).  The caller groups such rotations into launches with transposed = 1: they are processed
+  // with the roles of x and y exchanged -- blocks are y-planes, the in-plane axis is x -- and the slab is
+  // stored transposed ([kz][y][x]); K2 undoes it while staging (dlpd_k2.hip).
+  const int tr_flag = transposed;
 #pragma unroll 1
   for (int x = (jj % XG) * XB; x < (jj % XG) * XB + XB; x++) {
   const float* v = vol + (size_t)b * vol_bstride + (size_t)c * L * L * L;
   float* Sf = reinterpret_cast<float*>(S);
   if (do_rotate) {
     const float* r = R + (size_t)b * 9;
-    const float r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6], r7 = r[7], r8 = r[8];
+    // transposed processing = the same code with the x and y columns of the sample matrix exchanged
+    const float r0 = r[tr_flag ? 3 : 0], r1 = r[tr_flag ? 4 : 1], r2 = r[tr_flag ? 5 : 2];
+    const float r3 = r[tr_flag ? 0 : 3], r4 = r[tr_flag ? 1 : 4], r5 = r[tr_flag ? 2 : 5];
+    const float r6 = r[6], r7 = r[7], r8 = r[8];
     const float dx = x - c0;
     for (int s = tid; s < L * L; s += NT) {
       // 64 consecutive samples form an 8 x 8 (y, z) tile, not a z row: under an oblique rotation a row of
@@ -151,10 +161,10 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
       Sf[((y >> 1) * RS + z) * 2 + (y & 1)] = trilinear_fetch(v, L, px, py, pz);
     }
   } else {
-    const float* plane = v + (size_t)x * L * L;
     for (int s = tid; s < L * L; s += NT) {
       const int y = s / L, z = s % L;
-      Sf[((y >> 1) * RS + z) * 2 + (y & 1)] = plane[s];
+      // transposed: this block is the plane y_orig = x, its in-plane index runs over x_orig
+      Sf[((y >> 1) * RS + z) * 2 + (y & 1)] = tr_flag ? v[((size_t)y * L + x) * L + z] : v[((size_t)x * L + y) * L + z];
     }
   }
   __syncthreads();
@@ -641,18 +651,20 @@ template <int HP> static int launch_filter_vec(const float* conv0, int C0, long 
 // host-side launchers
 // ------------------------------------------------------------------------------------------
 template <int N> static int launch_k1(const float* vol, const float* R, cplx* A, int CT, int nb, long long vbs,
-                                      int do_rotate, float c0, hipStream_t st, int CT_out = 0, int c_base = 0) {
+                                      int do_rotate, float c0, hipStream_t st, int CT_out = 0, int c_base = 0,
+                                      int transposed = 0) {
   constexpr int L = N / 2;
   const int groups = ((CT * nb + 7) / 8) * 8;
   dim3 grid(groups * (L / DLPD_K1_XB)), block((N / 4) * FftPlan<N>::T);
   DLPD_LAUNCH((k_rotate_zfft<N>), grid, block, 0, st, vol, R, A, CT, nb, vbs, do_rotate, c0,
-              CT_out > 0 ? CT_out : CT, c_base);
+              CT_out > 0 ? CT_out : CT, c_base, transposed ? 1 : 0);
   return dlpd_check_launch();
 }
 
 // K2 lives in dlpd_k2.hip (its own translation unit: it is built with -fno-slp-vectorize)
 int dlpd_k2_forward(const cplx* A, cplx* out, int CT, int nb, int L, float scale, hipStream_t st);
-int dlpd_k2_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, int L, long long rbs, hipStream_t st);
+int dlpd_k2_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, int L, long long rbs, hipStream_t st,
+                      int transposed = 0);
 
 static int k3_group(int CT, int maxg) {
   int ng = (CT + maxg - 1) / maxg;
@@ -724,18 +736,24 @@ int dlpd_rotate_trilinear(const float* vol, const float* R, float* out, int B, i
 
 // vol (nb*CT volumes as (nb, CT, L^3), or one (CT, L^3) set with vol_bstride = 0) -> channels
 // [c_base, c_base + CT) of wsA (nb, CT_out, NZ, L, L)
-int dlpd_zfft_into(const float* vol, const float* R, void* wsA, int nb, int CT, int CT_out, int c_base, int L,
-                   long long vol_bstride, int do_rotate, float center, void* stream) {
+int dlpd_zfft_oriented(const float* vol, const float* R, void* wsA, int nb, int CT, int CT_out, int c_base, int L,
+                       long long vol_bstride, int do_rotate, float center, int transposed, void* stream) {
   if (!vol || !wsA || nb <= 0 || CT <= 0 || c_base < 0 || c_base + CT > CT_out) return DLPD_ERR_ARG;
   if (do_rotate && !R) return DLPD_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
+  cplx* A = (cplx*)wsA;
   switch (L) {
-    case 32: return launch_k1<64>(vol, R, (cplx*)wsA, CT, nb, vol_bstride, do_rotate, center, st, CT_out, c_base);
-    case 40: return launch_k1<80>(vol, R, (cplx*)wsA, CT, nb, vol_bstride, do_rotate, center, st, CT_out, c_base);
-    case 64: return launch_k1<128>(vol, R, (cplx*)wsA, CT, nb, vol_bstride, do_rotate, center, st, CT_out, c_base);
-    case 80: return launch_k1<160>(vol, R, (cplx*)wsA, CT, nb, vol_bstride, do_rotate, center, st, CT_out, c_base);
+    case 32: return launch_k1<64>(vol, R, A, CT, nb, vol_bstride, do_rotate, center, st, CT_out, c_base, transposed);
+    case 40: return launch_k1<80>(vol, R, A, CT, nb, vol_bstride, do_rotate, center, st, CT_out, c_base, transposed);
+    case 64: return launch_k1<128>(vol, R, A, CT, nb, vol_bstride, do_rotate, center, st, CT_out, c_base, transposed);
+    case 80: return launch_k1<160>(vol, R, A, CT, nb, vol_bstride, do_rotate, center, st, CT_out, c_base, transposed);
     default: return DLPD_ERR_UNSUPPORTED;
   }
+}
+
+int dlpd_zfft_into(const float* vol, const float* R, void* wsA, int nb, int CT, int CT_out, int c_base, int L,
+                   long long vol_bstride, int do_rotate, float center, void* stream) {
+  return dlpd_zfft_oriented(vol, R, wsA, nb, CT, CT_out, c_base, L, vol_bstride, do_rotate, center, 0, stream);
 }
 
 int dlpd_zfft(const float* vol, const float* R, void* wsA, int nb, int CT, int L, long long vol_bstride,
@@ -753,11 +771,16 @@ int dlpd_rfft3d_padded(const float* vol, void* spec, void* wsA, int nvol, int L,
 }
 
 // wsA (nb, CT, NZ, L, L) x rec (CT or nb*CT spectra) -> wsB (nb, CT, NZ, N, N)
-int dlpd_xy_correlate(const void* wsA, const void* rec, void* wsB, int nb, int CT, int L, long long rec_bstride,
-                      void* stream) {
+int dlpd_xy_correlate_oriented(const void* wsA, const void* rec, void* wsB, int nb, int CT, int L,
+                               long long rec_bstride, int transposed, void* stream) {
   if (!wsA || !rec || !wsB || nb <= 0 || CT <= 0) return DLPD_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  return dlpd_k2_correlate((const cplx*)wsA, (const cplx*)rec, (cplx*)wsB, CT, nb, L, rec_bstride, st);
+  return dlpd_k2_correlate((const cplx*)wsA, (const cplx*)rec, (cplx*)wsB, CT, nb, L, rec_bstride, st, transposed);
+}
+
+int dlpd_xy_correlate(const void* wsA, const void* rec, void* wsB, int nb, int CT, int L, long long rec_bstride,
+                      void* stream) {
+  return dlpd_xy_correlate_oriented(wsA, rec, wsB, nb, CT, L, rec_bstride, 0, stream);
 }
 
 // wsB -> real correlation volumes out (nb, CT, N^3), optional clamp
@@ -808,13 +831,26 @@ int dlpd_zifft_filter(const void* wsB, float* V, int nb, int C, int has_clash, i
 //   lig (CT, L^3) [score channels then, if has_clash, the ligand forbidden volume]
 //   recF (CT, NZ, N, N) from dlpd_rfft3d_padded(receptor, scale = 1/N^3)
 //   R (nb, 9) -> V (nb, N^3).  wsA: nb*CT*NZ*L*L cplx, wsB: nb*CT*NZ*N*N cplx.
+int dlpd_score_rotations_oriented(const float* lig, const void* recF, const float* R, int nb, int C, int has_clash,
+                                  int L, float center, const float* W1t, const float* b1, const float* W2, float b2,
+                                  int HP, int has_clip, float clip, float thr, void* wsA, void* wsB, float* V,
+                                  int transposed, void* stream);
+
 int dlpd_score_rotations(const float* lig, const void* recF, const float* R, int nb, int C, int has_clash, int L,
                          float center, const float* W1t, const float* b1, const float* W2, float b2, int HP,
                          int has_clip, float clip, float thr, void* wsA, void* wsB, float* V, void* stream) {
+  return dlpd_score_rotations_oriented(lig, recF, R, nb, C, has_clash, L, center, W1t, b1, W2, b2, HP, has_clip, clip,
+                                       thr, wsA, wsB, V, 0, stream);
+}
+
+int dlpd_score_rotations_oriented(const float* lig, const void* recF, const float* R, int nb, int C, int has_clash,
+                                  int L, float center, const float* W1t, const float* b1, const float* W2, float b2,
+                                  int HP, int has_clip, float clip, float thr, void* wsA, void* wsB, float* V,
+                                  int transposed, void* stream) {
   const int CT = C + (has_clash ? 1 : 0);
-  int rc = dlpd_zfft(lig, R, wsA, nb, CT, L, 0, 1, center, stream);
+  int rc = dlpd_zfft_oriented(lig, R, wsA, nb, CT, CT, 0, L, 0, 1, center, transposed, stream);
   if (rc) return rc;
-  rc = dlpd_xy_correlate(wsA, recF, wsB, nb, CT, L, 0, stream);
+  rc = dlpd_xy_correlate_oriented(wsA, recF, wsB, nb, CT, L, 0, transposed, stream);
   if (rc) return rc;
   return dlpd_zifft_filter(wsB, V, nb, C, has_clash, L, W1t, b1, W2, b2, HP, has_clip, clip, thr, stream);
 }

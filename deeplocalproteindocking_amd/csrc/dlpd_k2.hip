@@ -68,7 +68,7 @@ extern "C" int dlpd_debug_read_stamps_k2(unsigned long long* host16) {
 // argument = minimum waves per SIMD)
 template <int N, int MODE> __global__ void __launch_bounds__(DLPD_K2_THREADS(N), (DLPD_K2_DENSE(N) ? 3 : 1))
 k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __restrict__ out,
-          int CT, int nb, int nsplit, long long rec_bstride, float scale) {
+          int CT, int nb, int nsplit, long long rec_bstride, float scale, int transposed) {
   constexpr int L = N / 2, NZ = N / 2 + 1, RS = N + 8;
   constexpr int T = 8, R1 = FftPlanW<N>::R1, R2 = FftPlanW<N>::R2;
   static_assert(RS % 16 == 8, "row stride must be an odd multiple of 8 elements (bank spreading)");
@@ -129,12 +129,17 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
     int tq = tid;
     DLPD_K2_OPAQUE_T(tq);                 // slab offsets are recomputed per rotation instead of living in VGPRs
 #if !DLPD_K2_DIRECT_IN
+    // K1 stores the slabs of a 'transposed' launch as [y][x] (dlpd_corr.hip: slab orientation): undone here
+    const int tr_flag = transposed;
 #pragma unroll
     for (int i = 0; i < NLOAD; i++) {
       const int e = 2 * (tq + i * NT), x = e / L, y = e % L;
       if (e < L * L) {
-        S[x * RS + slab_swz(y)] = c_make(apref[i].x, apref[i].y);
-        S[x * RS + slab_swz(y + 1)] = c_make(apref[i].z, apref[i].w);
+        // (row, col) of the pair's first element and the step to its second one, branch-free in the
+        // wave-uniform flag
+        const int row = tr_flag ? y : x, col = tr_flag ? x : y;
+        S[row * RS + slab_swz(col)] = c_make(apref[i].x, apref[i].y);
+        S[(row + tr_flag) * RS + slab_swz(col + 1 - tr_flag)] = c_make(apref[i].z, apref[i].w);
       }
     }
     DLPD_STAMP(0);
@@ -321,7 +326,7 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
 }
 
 template <int N, int MODE> static int launch_k2(const cplx* A, const cplx* rec, cplx* out, int CT, int nb,
-                                                long long rbs, float scale, hipStream_t st) {
+                                                long long rbs, float scale, hipStream_t st, int transposed = 0) {
   constexpr int NZ = N / 2 + 1, RS = N + 8;
   const size_t shmem = (size_t)(N * RS + N) * sizeof(cplx);
   int rc = dlpd_set_max_dyn_shared((const void*)k_xy_corr<N, MODE>, shmem);
@@ -330,7 +335,7 @@ template <int N, int MODE> static int launch_k2(const cplx* A, const cplx* rec, 
   if (const char* e = getenv("DLPD_K2_NSPLIT")) nsplit = atoi(e) > 0 ? atoi(e) : nsplit;
   const int slabs8 = ((NZ * CT + 7) / 8) * 8;
   dim3 grid(slabs8 * nsplit), block(DLPD_K2_THREADS(N));
-  DLPD_LAUNCH((k_xy_corr<N, MODE>), grid, block, shmem, st, A, rec, out, CT, nb, nsplit, rbs, scale);
+  DLPD_LAUNCH((k_xy_corr<N, MODE>), grid, block, shmem, st, A, rec, out, CT, nb, nsplit, rbs, scale, transposed);
   return dlpd_check_launch();
 }
 
@@ -503,7 +508,7 @@ template <> struct FftPlanD2<160> { static constexpr int R1 = 10, R2 = 16, R3 = 
 #endif
 template <int N, int WV> __global__ void __launch_bounds__(64 * WV)
 k_xy_corr_dif(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __restrict__ out,
-              int CT, int nb, int nsplit, long long rec_bstride) {
+              int CT, int nb, int nsplit, long long rec_bstride, int transposed) {
   constexpr int L = N / 2, H = N / 2, NZ = N / 2 + 1, RS = H + 8;
   static_assert(RS % 16 == 8, "row stride must be an odd multiple of 8 elements (bank spreading)");
   constexpr int NT = 64 * WV, W = WV;
@@ -543,6 +548,7 @@ k_xy_corr_dif(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __
   __syncthreads();                                     // twiddle tables visible
   DLPD_STAMP_DECL;
   for (int b = b_beg; b < b_end; b++) {
+    const int tr_flag = transposed;                          // slabs stored transposed by K1 (dlpd_corr.hip)
 #if DLPD_K2D_G0REG
     float4 g0[NG];
 #endif
@@ -558,9 +564,15 @@ k_xy_corr_dif(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __
         const int e = 2 * (tq + i * NT), x = e / L, y = e % L;
         if (e < L * L) {
           cplx u = c_make(apref[i].x, apref[i].y), v = c_make(apref[i].z, apref[i].w);
-          if (par) { u = c_mul(u, tw[y]); v = c_mul(v, tw[y + 1]); }
-          S[x * RS + slab_swz(y)] = u;
-          S[x * RS + slab_swz(y + 1)] = v;
+          if (tr_flag) {                                     // stored [y][x]: this pair is (x = y, y = x), (x = y + 1, ..)
+            if (par) { u = c_mul(u, tw[x]); v = c_mul(v, tw[x]); }
+            S[y * RS + slab_swz(x)] = u;
+            S[(y + 1) * RS + slab_swz(x)] = v;
+          } else {
+            if (par) { u = c_mul(u, tw[y]); v = c_mul(v, tw[y + 1]); }
+            S[x * RS + slab_swz(y)] = u;
+            S[x * RS + slab_swz(y + 1)] = v;
+          }
         }
       }
       if (par == 1 && b + 1 < b_end) fetch_A(b + 1);   // next rotation's slab, in flight over this parity
@@ -686,7 +698,7 @@ k_xy_corr_dif(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __
 }
 
 template <int N, int WV> static int launch_k2_dif(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, long long rbs,
-                                          hipStream_t st) {
+                                                  hipStream_t st, int transposed = 0) {
   constexpr int NZ = N / 2 + 1, H = N / 2, RS = H + 8;
   const size_t shmem = (size_t)(N * RS + N + H) * sizeof(cplx);
   int rc = dlpd_set_max_dyn_shared((const void*)k_xy_corr_dif<N, WV>, shmem);
@@ -694,7 +706,7 @@ template <int N, int WV> static int launch_k2_dif(const cplx* A, const cplx* rec
   int nsplit = nb >= 8 ? 2 : 1;
   if (const char* e = getenv("DLPD_K2_NSPLIT")) nsplit = atoi(e) > 0 ? atoi(e) : nsplit;
   const int slabs8 = ((NZ * CT + 7) / 8) * 8;
-  DLPD_LAUNCH((k_xy_corr_dif<N, WV>), dim3(slabs8 * nsplit), dim3(64 * WV), shmem, st, A, rec, out, CT, nb, nsplit, rbs);
+  DLPD_LAUNCH((k_xy_corr_dif<N, WV>), dim3(slabs8 * nsplit), dim3(64 * WV), shmem, st, A, rec, out, CT, nb, nsplit, rbs, transposed);
   return dlpd_check_launch();
 }
 
@@ -708,15 +720,17 @@ int dlpd_k2_forward(const cplx* A, cplx* out, int CT, int nb, int L, float scale
   }
 }
 
-int dlpd_k2_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, int L, long long rbs, hipStream_t st) {
+int dlpd_k2_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, int L, long long rbs, hipStream_t st,
+                      int transposed) {
   switch (L) {
-    case 32: return launch_k2<64, 1>(A, rec, out, CT, nb, rbs, 1.f, st);
-    case 40: return launch_k2<80, 1>(A, rec, out, CT, nb, rbs, 1.f, st);
+    case 32: return launch_k2<64, 1>(A, rec, out, CT, nb, rbs, 1.f, st, transposed);
+    case 40: return launch_k2<80, 1>(A, rec, out, CT, nb, rbs, 1.f, st, transposed);
     // DLPD_K2_DIF128 (diagnostic): the half-slab kernel at N = 128, two 4-wave blocks per CU
-    case 64: return getenv("DLPD_K2_DIF128") ? launch_k2_dif<128, 4>(A, rec, out, CT, nb, rbs, st)
-                                             : launch_k2<128, 1>(A, rec, out, CT, nb, rbs, 1.f, st);
-    case 80: return getenv("DLPD_K2_SPLIT") ? launch_k2_split<160, 1>(A, rec, out, CT, nb, rbs, 1.f, st)
-                                          : launch_k2_dif<160, DLPD_K2D_WAVES>(A, rec, out, CT, nb, rbs, st);
+    case 64: return getenv("DLPD_K2_DIF128") ? launch_k2_dif<128, 4>(A, rec, out, CT, nb, rbs, st, transposed)
+                                             : launch_k2<128, 1>(A, rec, out, CT, nb, rbs, 1.f, st, transposed);
+    // (the three-kernel split path has no un-transposing stage: oriented slabs always take the DIF kernel)
+    case 80: return (getenv("DLPD_K2_SPLIT") && !transposed) ? launch_k2_split<160, 1>(A, rec, out, CT, nb, rbs, 1.f, st)
+                                          : launch_k2_dif<160, DLPD_K2D_WAVES>(A, rec, out, CT, nb, rbs, st, transposed);
     default: return DLPD_ERR_UNSUPPORTED;
   }
 }

@@ -251,7 +251,10 @@ k_topk_merge(const float* __restrict__ cs, const int* __restrict__ ci, const int
   if (tid == 0) { s_cnt = 0; s_new = 0; }
   __syncthreads();
   int nnew = 0;                                           // appended, not yet merged (uniform)
-  u64 tau = (count == K) ? (hi[K - 1] >> 32) : ~(u64)0;  // score key of the current K-th
+  // (score key, rotation) of the current K-th entry: a candidate survives iff its own pair sorts before it --
+  // on the score alone when rotations arrive in ascending order (the reference's stable append), on the
+  // rotation id too when a caller visits them in another order (DockingEngine.search groups them)
+  u64 tau = (count == K) ? hi[K - 1] : ~(u64)0;
   for (int r = 0; r < nb; r++) {
     const u64 rot = (u64)(unsigned)rot_ids[r];
     for (int attempt = 0; attempt < 2; attempt++) {
@@ -259,7 +262,7 @@ k_topk_merge(const float* __restrict__ cs, const int* __restrict__ ci, const int
       int local = 0;
       for (int i = tid; i < K; i += nt) {
         const u64 sk = f2key(cs[(size_t)r * K + i]);
-        if (sk < tau) local++;
+        if (((sk << 32) | rot) < tau) local++;
       }
       if (local) atomicAdd(&s_cnt, local);
       __syncthreads();
@@ -274,14 +277,14 @@ k_topk_merge(const float* __restrict__ cs, const int* __restrict__ ci, const int
       for (int i = KP + tid; i < CAP; i += nt) { hi[i] = ~(u64)0; lo[i] = ~(u64)0; }
       for (int i = count + tid; i < KP; i += nt) { hi[i] = ~(u64)0; lo[i] = ~(u64)0; }
       __syncthreads();
-      tau = (count == K) ? (hi[K - 1] >> 32) : ~(u64)0;
+      tau = (count == K) ? hi[K - 1] : ~(u64)0;
       if (tid == 0) s_new = 0;
       __syncthreads();
     }
     for (int i = tid; i < K; i += nt) {
       const float s = cs[(size_t)r * K + i];
       const u64 sk = f2key(s);
-      if (sk < tau) {
+      if (((sk << 32) | rot) < tau) {
         const int slot = KP + atomicAdd(&s_new, 1);
         const u64 negzero = (__float_as_uint(s) == 0x80000000u) ? 1 : 0;
         hi[slot] = (sk << 32) | rot;

@@ -6,6 +6,8 @@ volumes, clash correlation + threshold, GlobalDockingModel.forward, mask multipl
 for a single-resolution representation, without any host synchronisation inside the loop.
 torch is plumbing only (memory + streams); all arithmetic is in libdlpd.so.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -144,6 +146,7 @@ class DockingEngine:
         self.wsA = torch.empty(nb * CT * NZ * L * L * 2, dtype=f32, device=dev)
         self.wsB = torch.empty(nb * CT * NZ * N * N * 2, dtype=f32, device=dev)
         self.V = torch.empty(nb, N, N, N, dtype=f32, device=dev)
+        self.orient = os.environ.get("DLPD_NO_ORIENT", "") == ""      # diagnostic switch (slab orientation)
         if self.C1:
             L1 = self.L // 2
             if self.L % 2 or not lib.call("dlpd_grid_supported", L1):
@@ -194,46 +197,60 @@ class DockingEngine:
         if self.has_clash:
             self.lig[self.C] = torch.as_tensor(lig_forbidden, dtype=torch.float32).reshape(L, L, L).to(self.device)
 
+    @staticmethod
+    def prefers_transposed(R):
+        """(n,3,3) rotation matrices -> bool (n,): the source z axis is closer to the output x axis than to
+        the output y axis, i.e. the x-plane gather of K1 would run across memory rows (include/dlpd.h)."""
+        R = np.asarray(R)
+        return np.abs(R[:, 0, 2]) > np.abs(R[:, 1, 2])
+
     # ---- hot loop ------------------------------------------------------------------------
-    def score_batch(self, R, mark=None, out=None, volumes=None):
+    def score_batch(self, R, mark=None, out=None, volumes=None, transposed=False):
         """R (nb,3,3) float32 on the device, nb <= batch.  Returns V[:nb] (view of the engine's
         buffer, overwritten by the next call): Docker.py:218-232.  mark(name): optional callback
         after each stage (timing).
         volumes = (lig (nb,C,L,L,L), forbidden (nb,L,L,L) | None, coarse (nb,C1,L/2,..) | None): the
         batch's ligand volumes are given as they are (dockE3: re-projected and re-represented per
-        rotation, Docker.py:163-172) instead of rotating the stored ligand by R."""
+        rotation, Docker.py:163-172) instead of rotating the stored ligand by R.
+        transposed: slab orientation for ALL rotations of the batch (include/dlpd.h); search() groups the
+        rotations for which it pays (prefers_transposed) into batches of their own."""
         if volumes is not None:
             return self._score_volumes(volumes, mark, out)
         nb = R.shape[0]
         assert nb <= self.batch and R.dtype == torch.float32 and R.is_contiguous()
+        tr = int(bool(transposed) and self.orient)
         has_clip, clip = (0 if self.clip is None else 1), float(self.clip or 0.0)
         V = self.V if out is None else out
         call, st, L = self.lib.call, _stream(self.device), self.L
         provider = self.clash_provider if self.has_clash else None
         if not (self.C1 or provider or self.fine_unfused or mark):
-            call("dlpd_score_rotations", _ptr(self.lig), _ptr(self.recF), _ptr(R), nb, self.C,
+            call("dlpd_score_rotations_oriented", _ptr(self.lig), _ptr(self.recF), _ptr(R), nb, self.C,
                  int(self.has_clash), L, self.center, _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2), self.b2,
-                 self.HP, has_clip, clip, self.threshold, _ptr(self.wsA), _ptr(self.wsB), _ptr(V), st)
+                 self.HP, has_clip, clip, self.threshold, _ptr(self.wsA), _ptr(self.wsB), _ptr(V), tr, st)
             return V[:nb]
         mark = mark or (lambda name: None)
         mark("begin")
         if self.C1:
             # coarse resolution first: rotate + correlate + clip -> real volumes the fine filter reads
             L1 = self.L1
-            call("dlpd_zfft", _ptr(self.lig1), _ptr(R), _ptr(self.wsA1), nb, self.C1, L1, 0, 1, float(L1) / 2.0, st)
-            call("dlpd_xy_correlate", _ptr(self.wsA1), _ptr(self.recF1), _ptr(self.wsB1), nb, self.C1, L1, 0, st)
+            call("dlpd_zfft_oriented", _ptr(self.lig1), _ptr(R), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1, 0, 1,
+                 float(L1) / 2.0, tr, st)
+            call("dlpd_xy_correlate_oriented", _ptr(self.wsA1), _ptr(self.recF1), _ptr(self.wsB1), nb, self.C1, L1, 0,
+                 tr, st)
             call("dlpd_zifft_real", _ptr(self.wsB1), _ptr(self.aux), nb, self.C1, L1, has_clip, clip, st)
             mark("coarse")
         if provider is not None:
             # clash channel from re-projected rotated ATOMS (Docker.py:221-224), scores from rotated volumes
             forb = provider(R).reshape(nb, L, L, L).contiguous()
-            call("dlpd_zfft_into", _ptr(self.lig), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0, L, 0, 1,
-                 self.center, st)
-            call("dlpd_zfft_into", _ptr(forb), 0, _ptr(self.wsA), nb, 1, self.CT, self.C, L, L ** 3, 0, 0.0, st)
+            call("dlpd_zfft_oriented", _ptr(self.lig), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0, L, 0, 1,
+                 self.center, tr, st)
+            call("dlpd_zfft_oriented", _ptr(forb), 0, _ptr(self.wsA), nb, 1, self.CT, self.C, L, L ** 3, 0, 0.0,
+                 tr, st)                      # same orientation as the score channels
         else:
-            call("dlpd_zfft", _ptr(self.lig), _ptr(R), _ptr(self.wsA), nb, self.CT, L, 0, 1, self.center, st)
+            call("dlpd_zfft_oriented", _ptr(self.lig), _ptr(R), _ptr(self.wsA), nb, self.CT, self.CT, 0, L, 0, 1,
+                 self.center, tr, st)
         mark("k1_rotate_zfft")
-        return self._correlate_and_filter(nb, V, mark)
+        return self._correlate_and_filter(nb, V, mark, tr)
 
     def _score_volumes(self, volumes, mark, out):
         vl, vf, vc = volumes
@@ -259,13 +276,15 @@ class DockingEngine:
             call("dlpd_zfft_into", _ptr(vf), 0, _ptr(self.wsA), nb, 1, self.CT, self.C, L, L ** 3, 0, 0.0, st)
         mark("k1_rotate_zfft")
         self._keep = (vl, vf, vc)                      # inputs stay alive until the stream has consumed them
-        return self._correlate_and_filter(nb, V, mark)
+        return self._correlate_and_filter(nb, V, mark, 0)
 
-    def _correlate_and_filter(self, nb, V, mark):
-        """K2 + K3 (+ filter) on whatever K1 left in wsA (and the coarse result in aux)."""
+    def _correlate_and_filter(self, nb, V, mark, tr):
+        """K2 + K3 (+ filter) on whatever K1 left in wsA (and the coarse result in aux); tr: the slab
+        orientation K1 used."""
         has_clip, clip = (0 if self.clip is None else 1), float(self.clip or 0.0)
         call, st, L = self.lib.call, _stream(self.device), self.L
-        call("dlpd_xy_correlate", _ptr(self.wsA), _ptr(self.recF), _ptr(self.wsB), nb, self.CT, L, 0, st)
+        call("dlpd_xy_correlate_oriented", _ptr(self.wsA), _ptr(self.recF), _ptr(self.wsB), nb, self.CT, L, 0,
+             tr, st)
         mark("k2_xy_corr")
         aux, C1, N1 = (_ptr(self.aux), self.C1, 2 * self.L1) if self.C1 else (0, 0, 0)
         if self.fine_unfused:
@@ -306,13 +325,13 @@ class DockingEngine:
         self.top.merge(rot_ids, nb)
 
     # ---- two-stream pipeline: top-K of batch i overlaps K1/K2 of batch i+1 -----------------
-    def step(self, R, rot_ids, mark=None, volumes=None):
+    def step(self, R, rot_ids, mark=None, volumes=None, transposed=False):
         """One batch: score on the current stream; select + merge on a side stream (they are
         latency-bound one-block kernels that fit beside the FFT blocks).  V is double-buffered;
         call finish() before reading the list."""
         nb = R.shape[0] if volumes is None else volumes[0].shape[0]
         if self.device.type != "cuda":
-            V = self.score_batch(R, mark=mark, volumes=volumes)
+            V = self.score_batch(R, mark=mark, volumes=volumes, transposed=transposed)
             self.select_batch(V, nb)
             self.merge_batch(rot_ids, nb)
             return
@@ -327,7 +346,7 @@ class DockingEngine:
         main = torch.cuda.current_stream(self.device)
         if self._consumed[k] is not None:
             main.wait_event(self._consumed[k])          # V[k] free again
-        V = self.score_batch(R, mark=mark, out=self._Vbuf[k], volumes=volumes)
+        V = self.score_batch(R, mark=mark, out=self._Vbuf[k], volumes=volumes, transposed=transposed)
         # the side stream reads rot_ids later: keep the caller's tensor alive (and its memory out of the
         # allocator's reach) until this buffer slot comes round again
         self._ids_alive[k] = rot_ids
@@ -347,19 +366,28 @@ class DockingEngine:
 
     def search(self, R_all, rot_ids=None, progress=None):
         """Score every rotation in R_all (nrot,3,3) and fold it into the running top list.
-        rot_ids: global rotation indices (ascending) for this shard; default arange."""
+        rot_ids: global rotation indices (ascending) for this shard; default arange.
+        The rotations are visited in two groups -- ordinary and 'transposed' slab orientation
+        (prefers_transposed) -- because the orientation is a per-launch choice; the ranked list does not
+        depend on the visiting order (merge key = (score, rotation, pick))."""
         dev = self.device
-        R_all = torch.as_tensor(R_all).to(device=dev, dtype=torch.float32).contiguous()
-        nrot = R_all.shape[0]
-        if rot_ids is None:
-            rot_ids = torch.arange(nrot, dtype=torch.int32)
-        rot_ids = torch.as_tensor(rot_ids).to(device=dev, dtype=torch.int32).contiguous()
-        for beg in range(0, nrot, self.batch):
-            end = min(beg + self.batch, nrot)
-            nb = end - beg
-            self.step(R_all[beg:end], rot_ids[beg:end])
-            if progress is not None:
-                progress(end)
+        R_host = torch.as_tensor(R_all).detach().cpu().numpy()
+        nrot = R_host.shape[0]
+        ids_host = np.arange(nrot) if rot_ids is None else torch.as_tensor(rot_ids).detach().cpu().numpy()
+        flags = self.prefers_transposed(R_host) if (self.orient and nrot) else np.zeros(nrot, dtype=bool)
+        done = 0
+        for tr in (False, True):
+            sel = np.nonzero(flags == tr)[0]
+            if len(sel) == 0:
+                continue
+            R_grp = torch.from_numpy(np.ascontiguousarray(R_host[sel])).to(device=dev, dtype=torch.float32).contiguous()
+            ids_grp = torch.from_numpy(np.ascontiguousarray(ids_host[sel]).astype(np.int32)).to(dev)
+            for beg in range(0, len(sel), self.batch):
+                end = min(beg + self.batch, len(sel))
+                self.step(R_grp[beg:end], ids_grp[beg:end], transposed=tr)
+                done += end - beg
+                if progress is not None:
+                    progress(done)
         self.finish()
 
     # ---- results ------------------------------------------------------------------------

@@ -47,6 +47,17 @@ int dlpd_zfft(const float* vol, const float* R, void* wsA, int nb, int CT, int L
 int dlpd_zfft_into(const float* vol, const float* R, void* wsA, int nb, int CT, int CT_out, int c_base, int L,
                    long long vol_bstride, int do_rotate, float center, void* stream);
 
+/* Slab orientation (speed only, results identical).  With transposed = 1 every rotation of the call is
+ * processed with the roles of x and y exchanged and its slabs are stored as [kz][y][x]: the caller groups the
+ * rotations whose sample matrix has |R[0][2]| > |R[1][2]| (source z axis closer to the output x axis) into such
+ * calls, so that the gather of Docker.py:218 runs along contiguous memory for them as well.  Channels written
+ * by separate calls (e.g. the re-projected clash volume) must use the same value.
+ * dlpd_xy_correlate_oriented undoes the transposition while it stages each slab. */
+int dlpd_zfft_oriented(const float* vol, const float* R, void* wsA, int nb, int CT, int CT_out, int c_base, int L,
+                       long long vol_bstride, int do_rotate, float center, int transposed, void* stream);
+int dlpd_xy_correlate_oriented(const void* wsA, const void* rec, void* wsB, int nb, int CT, int L,
+                               long long rec_bstride, int transposed, void* stream);
+
 /* CoordsRotate + CoordsTranslate + TypedCoords2Volume (+ channel sum) of src/Docker/Docker.py:204,
  * 208,221-224 in one kernel: p' = R_b p + shift, density exp(-|r - p'|^2 / 2) on the 5^3 voxels
  * around each atom (build-defined shape).  coords (B, 3*stride_atoms) ordered by type,
@@ -88,6 +99,12 @@ int dlpd_score_rotations(const float* lig, const void* recF, const float* R, int
                          int L, float center, const float* W1t, const float* b1, const float* W2, float b2,
                          int HP, int has_clip, float clip, float thr, void* wsA, void* wsB, float* V,
                          void* stream);
+
+/* dlpd_score_rotations with oriented slabs (see dlpd_zfft_oriented). */
+int dlpd_score_rotations_oriented(const float* lig, const void* recF, const float* R, int nb, int C, int has_clash,
+                                  int L, float center, const float* W1t, const float* b1, const float* W2, float b2,
+                                  int HP, int has_clip, float clip, float thr, void* wsA, void* wsB, float* V,
+                                  int transposed, void* stream);
 
 /* Per-voxel filter over materialised correlation volumes incl. nearest upsample of a second,
  * coarser resolution (DockingModels.py:74-83) and mask multiply (Docker.py:232). */

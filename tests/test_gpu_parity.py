@@ -98,14 +98,14 @@ def test_full_search_ranked_list_matches_oracle(dev):
     eng.reset_top()
     eng2 = []
     Rd = torch.from_numpy(R).float().to(dev).contiguous()
-    for beg in range(0, nrot, 7):
-        V = eng.score_batch(Rd[beg:beg + 7]).cpu()
-        for j in range(V.shape[0]):
-            idx, sc = orc.rotation_picks_fast(V[j].numpy(), K)
-            x, y, z = orc.flat_to_xyz(idx, 2 * L)
-            eng2 += [(beg + j, int(x[i]), int(y[i]), int(z[i]), float(sc[i])) for i in range(K)]
-            eng2.sort(key=lambda t: t[4])
-            eng2 = eng2[:K]
+    flags = DockingEngine.prefers_transposed(R)          # search() scores each rotation in this slab orientation
+    for r in range(nrot):
+        V = eng.score_batch(Rd[r:r + 1], transposed=bool(flags[r])).cpu()
+        idx, sc = orc.rotation_picks_fast(V[0].numpy(), K)
+        x, y, z = orc.flat_to_xyz(idx, 2 * L)
+        eng2 += [(r, int(x[i]), int(y[i]), int(z[i]), float(sc[i])) for i in range(K)]
+        eng2.sort(key=lambda t: t[4])
+        eng2 = eng2[:K]
     assert got == eng2
 
 
@@ -321,11 +321,14 @@ def test_full_size_search_is_batch_size_and_order_independent(dev):
         eng.reset_top()
         if order[0] == 0:
             eng.search(R[order], rot_ids=order)
-        else:   # descending presentation: rot_ids must ascend inside a batch, so feed reversed batches
-            for beg in range(0, nrot, nb):
-                ids = np.sort(order[beg:beg + nb])
-                eng.step(torch.from_numpy(R[ids]).float().to(dev).contiguous(),
-                         torch.from_numpy(ids.astype(np.int32)).to(dev))
+        else:   # another visiting order: the 'transposed' group first, each group in descending set order
+            flags = DockingEngine.prefers_transposed(R)
+            for tr in (True, False):
+                grp = order[flags[order] == tr]
+                for beg in range(0, len(grp), nb):
+                    ids = np.sort(grp[beg:beg + nb])
+                    eng.step(torch.from_numpy(R[ids]).float().to(dev).contiguous(),
+                             torch.from_numpy(ids.astype(np.int32)).to(dev), transposed=tr)
             eng.finish()
         lists.append(eng.top_list())
         del eng
@@ -437,3 +440,11 @@ def test_topk_fuzz_against_faithful_update_top(dev):
         got = DeviceTopList.to_top_list(top.entries(), N)
         assert got == want, (trial, N, K, nrot, batch)
         assert [np.signbit(a[4]) for a in got] == [np.signbit(b[4]) for b in want], trial
+        order = rng.permutation(nrot)                  # visiting order must not matter, exact ties included
+        top = DeviceTopList(K, batch, dev, get_lib())
+        top.reset()
+        for beg in range(0, nrot, batch):
+            ids = np.sort(order[beg:beg + batch])
+            top.select(torch.from_numpy(Vs[ids].reshape(len(ids), -1).copy()).to(dev), len(ids))
+            top.merge(torch.from_numpy(ids.astype(np.int32)).to(dev), len(ids))
+        assert DeviceTopList.to_top_list(top.entries(), N) == want, (trial, "permuted", order)

@@ -286,6 +286,16 @@ def test_topk_kernels_fuzz_against_faithful_update_top(emu):
         got = DeviceTopList.to_top_list(top.entries(), N)
         assert got == want, (trial, N, K, nrot, batch)
         assert [np.signbit(a[4]) for a in got] == [np.signbit(b[4]) for b in want], trial
+        # the same rotations visited in another order (DockingEngine.search groups them by slab orientation):
+        # exact ties must still go to the lower rotation id
+        order = rng.permutation(nrot)
+        top = DeviceTopList(K, batch, "cpu", emu)
+        top.reset()
+        for beg in range(0, nrot, batch):
+            ids = np.sort(order[beg:beg + batch])
+            top.select(torch.from_numpy(Vs[ids].reshape(len(ids), -1).copy()), len(ids))
+            top.merge(torch.from_numpy(ids.astype(np.int32)), len(ids))
+        assert DeviceTopList.to_top_list(top.entries(), N) == want, (trial, "permuted", order)
 
 
 def test_representation_plugins_route_their_convolutions_through_the_kernel(emu):
@@ -309,3 +319,54 @@ def test_representation_plugins_route_their_convolutions_through_the_kernel(emu)
         layer.hip_lib = emu
         got1 = layer(x)
     assert (got1 - want1).abs().max() <= 1e-5 * want1.abs().max()
+
+
+def _axis_rot(axis, deg):
+    a = np.deg2rad(deg)
+    c, s = np.cos(a), np.sin(a)
+    return {"x": np.array([[1, 0, 0], [0, c, -s], [0, s, c]]), "y": np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]]),
+            "z": np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])}[axis]
+
+
+@pytest.mark.parametrize("L", [32, 40, 80])
+def test_slab_orientation_is_invisible_in_the_scores(emu, L):
+    """A launch may process its rotations with transposed slabs (K1 swaps the roles of x and y, K2
+    un-transposes while staging: include/dlpd.h 'slab orientation'): purely a memory-access choice.  The same
+    two rotations scored both ways, on the plain (N = 64), radix-5 (N = 80) and half-slab (N = 160) K2
+    kernels, must give the oracle's scores; search() picks the orientation per rotation and must return the
+    same list as a search with the switch off."""
+    C = 2 if L < 80 else 1
+    rec, lig, recf, ligf, W1, b1, W2, b2 = _pair(L, 4, seed=21 + L)
+    rec, lig, W1 = rec[:C], lig[:C], W1[:, :C]
+    thr = 0.125 * L ** 3
+    R = np.stack([_axis_rot("x", 77.0) @ _axis_rot("z", 20.0), _axis_rot("y", 80.0) @ _axis_rot("z", -35.0)])
+    assert DockingEngine.prefers_transposed(R).tolist() == [False, True]
+    eng = DockingEngine(L, C, W1, b1, W2, b2, clip=5.0, threshold_clash=thr, max_conf=16, batch=2, device="cpu", lib=emu)
+    eng.set_receptor(rec, recf)
+    eng.set_ligand(lig, ligf)
+    Rt = torch.from_numpy(R).float().contiguous()
+    Vn = eng.score_batch(Rt, transposed=False).clone()
+    Vt = eng.score_batch(Rt, transposed=True).clone()
+    for i in range(2):
+        Rb = torch.from_numpy(R[i:i + 1]).float()
+        mask, norm = orc.clash_mask(recf[None, None], orc.rotate_volume(ligf[None, None], Rb), thr)
+        Vo = (mask * orc.score_volumes([rec[None]], [orc.rotate_volume(lig[None], Rb)], W1, b1, W2, b2, clip=5.0))[0]
+        sure = (norm[0] - thr).abs() > 1e-3 * thr
+        for V in (Vn, Vt):
+            assert ((V[i] - Vo).abs()[sure]).max() <= 1e-4 * Vo.abs().max()
+    # the clash channel supplied separately (dockSE3's re-projection path) follows the same orientation
+    eng.clash_provider = lambda Rq: torch.cat([orc.rotate_volume(ligf[None, None], Rq[i:i + 1]) for i in range(Rq.shape[0])])
+    V2 = eng.score_batch(Rt, transposed=True).clone()
+    assert (V2 - Vt).abs().max() <= 1e-5 * Vt.abs().max()
+    eng.clash_provider = None
+    if L == 32:                                    # search(): mixed set, orientation chosen per rotation
+        eng.reset_top()
+        eng.search(R)
+        got = eng.top_list()
+        eng.orient = False
+        eng.reset_top()
+        eng.search(R)
+        plain = eng.top_list()
+        assert {t[0] for t in got} == {0, 1} or len({t[0] for t in got}) >= 1
+        assert max(abs(a[4] - b[4]) for a, b in zip(got, plain)) <= 1e-4 * float(Vn.abs().max())
+        assert sum(a[:4] == b[:4] for a, b in zip(got, plain)) >= len(got) - 2
