@@ -167,16 +167,21 @@ def main():
     ids = np.arange(rank, nrot_total, world)                 # this rank's interleaved shard
     # visiting order of DockingEngine.search: rotations grouped by slab orientation (a per-launch choice),
     # set order inside a group; a step is one batch of that sequence
-    flags = DockingEngine.prefers_transposed(R_all[ids].numpy())
-    ids = np.concatenate([ids[~flags], ids[flags]])
-    tr_of = np.concatenate([np.zeros((~flags).sum(), dtype=bool), np.ones(flags.sum(), dtype=bool)])
-    nfirst = int((~flags).sum()) // nb * nb                  # keep batches orientation-pure
-    ids, tr_of = np.concatenate([ids[:nfirst], ids[int((~flags).sum()):]]), np.concatenate([tr_of[:nfirst], tr_of[int((~flags).sum()):]])
+    Rn = R_all[ids].numpy()
+    gkey = DockingEngine.prefers_transposed(Rn).astype(int) * 2 + DockingEngine.prefers_quads(Rn).astype(int)
+    parts, keys = [], []
+    for k in range(4):                                         # groups in the engine's order, whole batches only
+        sel = ids[gkey == k]
+        sel = sel[:len(sel) // nb * nb]
+        parts.append(sel)
+        keys.append(np.full(len(sel), k))
+    ids, key_of = np.concatenate(parts), np.concatenate(keys)
+    tr_of, qd_of = key_of >= 2, (key_of % 2) == 1
     shard_batches = len(ids) // nb
     need = (args.steps + args.warmup) * nb
     reps = (need + shard_batches * nb - 1) // (shard_batches * nb)
-    ids_all, tr_all = ids[:shard_batches * nb], tr_of[:shard_batches * nb]
-    ids, tr_of = np.tile(ids_all, reps)[:need], np.tile(tr_all, reps)[:need]   # (wraps only if steps*batch > shard)
+    ids_all, tr_all, qd_all = ids[:shard_batches * nb], tr_of[:shard_batches * nb], qd_of[:shard_batches * nb]
+    ids, tr_of, qd_of = (np.tile(a, reps)[:need] for a in (ids_all, tr_all, qd_all))   # (wraps only if steps*batch > shard)
     Rd = R_all[ids].to(device=dev, dtype=torch.float32).contiguous()
     idd = torch.as_tensor(ids, dtype=torch.int32).to(dev)
 
@@ -189,11 +194,11 @@ def main():
         # K1,K2,K3 on the main stream; select+merge of the same batch on the engine's side stream
         # (overlapping the next batch), see DockingEngine.step
         sl = slice(i * nb, (i + 1) * nb)
-        eng.step(Rd[sl], idd[sl], mark=mark, transposed=bool(tr_of[i * nb]))
+        eng.step(Rd[sl], idd[sl], mark=mark, transposed=bool(tr_of[i * nb]), quads=bool(qd_of[i * nb]))
 
     def step_serial(i, mark):
         sl = slice(i * nb, (i + 1) * nb)
-        V = eng.score_batch(Rd[sl], mark=mark, transposed=bool(tr_of[i * nb]))
+        V = eng.score_batch(Rd[sl], mark=mark, transposed=bool(tr_of[i * nb]), quads=bool(qd_of[i * nb]))
         eng.select_batch(V, nb)
         mark("topk_select")
         eng.merge_batch(idd[sl], nb)
@@ -242,12 +247,13 @@ def main():
     pick = np.linspace(0, shard_batches - 1, nsample).astype(int)
     Rs = R_all[np.concatenate([ids_all[j * nb:(j + 1) * nb] for j in pick])].to(device=dev, dtype=torch.float32).contiguous()
     Is = torch.as_tensor(np.concatenate([ids_all[j * nb:(j + 1) * nb] for j in pick]), dtype=torch.int32).to(dev)
-    eng.step(Rs[:nb], Is[:nb], transposed=bool(tr_all[pick[0] * nb]))
+    eng.step(Rs[:nb], Is[:nb], transposed=bool(tr_all[pick[0] * nb]), quads=bool(qd_all[pick[0] * nb]))
     eng.finish()
     torch.cuda.synchronize()
     ts = time.perf_counter()
     for j in range(nsample):
-        eng.step(Rs[j * nb:(j + 1) * nb], Is[j * nb:(j + 1) * nb], transposed=bool(tr_all[pick[j] * nb]))
+        eng.step(Rs[j * nb:(j + 1) * nb], Is[j * nb:(j + 1) * nb], transposed=bool(tr_all[pick[j] * nb]),
+                 quads=bool(qd_all[pick[j] * nb]))
     eng.finish()
     torch.cuda.synchronize()
     sustained_ms = (time.perf_counter() - ts) / nsample * 1e3

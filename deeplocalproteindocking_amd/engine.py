@@ -147,6 +147,9 @@ class DockingEngine:
         self.wsB = torch.empty(nb * CT * NZ * N * N * 2, dtype=f32, device=dev)
         self.V = torch.empty(nb, N, N, N, dtype=f32, device=dev)
         self.orient = os.environ.get("DLPD_NO_ORIENT", "") == ""      # diagnostic switch (slab orientation)
+        self.use_quads = os.environ.get("DLPD_NO_QUADS", "") == ""    # diagnostic switch (quad-layout gather)
+        if self.use_quads:
+            self.ligq = torch.empty(lib.call("dlpd_quads_floats", CT, int(L)), dtype=f32, device=dev)
         if self.C1:
             L1 = self.L // 2
             if self.L % 2 or not lib.call("dlpd_grid_supported", L1):
@@ -158,6 +161,8 @@ class DockingEngine:
             self.wsA1 = torch.empty(nb * C1 * NZ1 * L1 * L1 * 2, dtype=f32, device=dev)
             self.wsB1 = torch.empty(nb * C1 * NZ1 * N1 * N1 * 2, dtype=f32, device=dev)
             self.aux = torch.empty(nb, C1, N1, N1, N1, dtype=f32, device=dev)      # clipped coarse correlations
+            if self.use_quads:
+                self.ligq1 = torch.empty(lib.call("dlpd_quads_floats", C1, L1), dtype=f32, device=dev)
         # N = 160: the fused z-inverse + MLP kernel does not fit the register file,
         # so that grid materialises its real correlations and a vectorised filter follows
         self.fine_unfused = (N == 160) if fine_unfused is None else bool(fine_unfused)
@@ -196,6 +201,22 @@ class DockingEngine:
         self.lig[: self.C] = torch.as_tensor(lig_volumes, dtype=torch.float32).reshape(self.C, L, L, L).to(self.device)
         if self.has_clash:
             self.lig[self.C] = torch.as_tensor(lig_forbidden, dtype=torch.float32).reshape(L, L, L).to(self.device)
+        # quad layout for the rotation gather (include/dlpd.h), once per pair: 4x the ligand's bytes
+        if self.use_quads:
+            st = _stream(self.device)
+            self.lib.call("dlpd_make_quads", _ptr(self.lig), _ptr(self.ligq), self.CT, L, st)
+            if self.C1:
+                self.lib.call("dlpd_make_quads", _ptr(self.lig1), _ptr(self.ligq1), self.C1, self.L1, st)
+
+    @staticmethod
+    def prefers_quads(R):
+        """(n,3,3) -> bool (n,): after the slab orientation the source z axis is carried by the in-plane
+        x/y axis rather than by the output z axis.  For those rotations the quad-layout gather
+        (include/dlpd.h) is ~1.4x faster; for the others the plain volume (4x fewer bytes, L2 resident)
+        is as good or better inside the full pipeline."""
+        R = np.asarray(R)
+        inplane = np.maximum(np.abs(R[:, 0, 2]), np.abs(R[:, 1, 2]))
+        return inplane > np.abs(R[:, 2, 2])
 
     @staticmethod
     def prefers_transposed(R):
@@ -205,7 +226,7 @@ class DockingEngine:
         return np.abs(R[:, 0, 2]) > np.abs(R[:, 1, 2])
 
     # ---- hot loop ------------------------------------------------------------------------
-    def score_batch(self, R, mark=None, out=None, volumes=None, transposed=False):
+    def score_batch(self, R, mark=None, out=None, volumes=None, transposed=False, quads=False):
         """R (nb,3,3) float32 on the device, nb <= batch.  Returns V[:nb] (view of the engine's
         buffer, overwritten by the next call): Docker.py:218-232.  mark(name): optional callback
         after each stage (timing).
@@ -219,11 +240,12 @@ class DockingEngine:
         nb = R.shape[0]
         assert nb <= self.batch and R.dtype == torch.float32 and R.is_contiguous()
         tr = int(bool(transposed) and self.orient)
+        use_quads = bool(quads) and self.use_quads
         has_clip, clip = (0 if self.clip is None else 1), float(self.clip or 0.0)
         V = self.V if out is None else out
         call, st, L = self.lib.call, _stream(self.device), self.L
         provider = self.clash_provider if self.has_clash else None
-        if not (self.C1 or provider or self.fine_unfused or mark):
+        if not (self.C1 or provider or self.fine_unfused or mark or use_quads):
             call("dlpd_score_rotations_oriented", _ptr(self.lig), _ptr(self.recF), _ptr(R), nb, self.C,
                  int(self.has_clash), L, self.center, _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2), self.b2,
                  self.HP, has_clip, clip, self.threshold, _ptr(self.wsA), _ptr(self.wsB), _ptr(V), tr, st)
@@ -233,8 +255,12 @@ class DockingEngine:
         if self.C1:
             # coarse resolution first: rotate + correlate + clip -> real volumes the fine filter reads
             L1 = self.L1
-            call("dlpd_zfft_oriented", _ptr(self.lig1), _ptr(R), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1, 0, 1,
-                 float(L1) / 2.0, tr, st)
+            if use_quads:
+                call("dlpd_zfft_quads", _ptr(self.ligq1), _ptr(R), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1,
+                     float(L1) / 2.0, tr, st)
+            else:
+                call("dlpd_zfft_oriented", _ptr(self.lig1), _ptr(R), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1, 0, 1,
+                     float(L1) / 2.0, tr, st)
             call("dlpd_xy_correlate_oriented", _ptr(self.wsA1), _ptr(self.recF1), _ptr(self.wsB1), nb, self.C1, L1, 0,
                  tr, st)
             call("dlpd_zifft_real", _ptr(self.wsB1), _ptr(self.aux), nb, self.C1, L1, has_clip, clip, st)
@@ -242,10 +268,17 @@ class DockingEngine:
         if provider is not None:
             # clash channel from re-projected rotated ATOMS (Docker.py:221-224), scores from rotated volumes
             forb = provider(R).reshape(nb, L, L, L).contiguous()
-            call("dlpd_zfft_oriented", _ptr(self.lig), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0, L, 0, 1,
-                 self.center, tr, st)
+            if use_quads:
+                call("dlpd_zfft_quads", _ptr(self.ligq), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0, L,
+                     self.center, tr, st)
+            else:
+                call("dlpd_zfft_oriented", _ptr(self.lig), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0, L, 0, 1,
+                     self.center, tr, st)
             call("dlpd_zfft_oriented", _ptr(forb), 0, _ptr(self.wsA), nb, 1, self.CT, self.C, L, L ** 3, 0, 0.0,
                  tr, st)                      # same orientation as the score channels
+        elif use_quads:
+            call("dlpd_zfft_quads", _ptr(self.ligq), _ptr(R), _ptr(self.wsA), nb, self.CT, self.CT, 0, L,
+                 self.center, tr, st)
         else:
             call("dlpd_zfft_oriented", _ptr(self.lig), _ptr(R), _ptr(self.wsA), nb, self.CT, self.CT, 0, L, 0, 1,
                  self.center, tr, st)
@@ -325,13 +358,13 @@ class DockingEngine:
         self.top.merge(rot_ids, nb)
 
     # ---- two-stream pipeline: top-K of batch i overlaps K1/K2 of batch i+1 -----------------
-    def step(self, R, rot_ids, mark=None, volumes=None, transposed=False):
+    def step(self, R, rot_ids, mark=None, volumes=None, transposed=False, quads=False):
         """One batch: score on the current stream; select + merge on a side stream (they are
         latency-bound one-block kernels that fit beside the FFT blocks).  V is double-buffered;
         call finish() before reading the list."""
         nb = R.shape[0] if volumes is None else volumes[0].shape[0]
         if self.device.type != "cuda":
-            V = self.score_batch(R, mark=mark, volumes=volumes, transposed=transposed)
+            V = self.score_batch(R, mark=mark, volumes=volumes, transposed=transposed, quads=quads)
             self.select_batch(V, nb)
             self.merge_batch(rot_ids, nb)
             return
@@ -346,7 +379,7 @@ class DockingEngine:
         main = torch.cuda.current_stream(self.device)
         if self._consumed[k] is not None:
             main.wait_event(self._consumed[k])          # V[k] free again
-        V = self.score_batch(R, mark=mark, out=self._Vbuf[k], volumes=volumes, transposed=transposed)
+        V = self.score_batch(R, mark=mark, out=self._Vbuf[k], volumes=volumes, transposed=transposed, quads=quads)
         # the side stream reads rot_ids later: keep the caller's tensor alive (and its memory out of the
         # allocator's reach) until this buffer slot comes round again
         self._ids_alive[k] = rot_ids
@@ -367,24 +400,25 @@ class DockingEngine:
     def search(self, R_all, rot_ids=None, progress=None):
         """Score every rotation in R_all (nrot,3,3) and fold it into the running top list.
         rot_ids: global rotation indices (ascending) for this shard; default arange.
-        The rotations are visited in two groups -- ordinary and 'transposed' slab orientation
-        (prefers_transposed) -- because the orientation is a per-launch choice; the ranked list does not
+        The rotations are visited in groups -- slab orientation (prefers_transposed) x gather layout
+        (prefers_quads) -- because both are per-launch choices; the ranked list does not
         depend on the visiting order (merge key = (score, rotation, pick))."""
         dev = self.device
         R_host = torch.as_tensor(R_all).detach().cpu().numpy()
         nrot = R_host.shape[0]
         ids_host = np.arange(nrot) if rot_ids is None else torch.as_tensor(rot_ids).detach().cpu().numpy()
         flags = self.prefers_transposed(R_host) if (self.orient and nrot) else np.zeros(nrot, dtype=bool)
+        qflags = self.prefers_quads(R_host) if (self.use_quads and nrot) else np.zeros(nrot, dtype=bool)
         done = 0
-        for tr in (False, True):
-            sel = np.nonzero(flags == tr)[0]
+        for tr, qd in ((False, False), (False, True), (True, False), (True, True)):
+            sel = np.nonzero((flags == tr) & (qflags == qd))[0]
             if len(sel) == 0:
                 continue
             R_grp = torch.from_numpy(np.ascontiguousarray(R_host[sel])).to(device=dev, dtype=torch.float32).contiguous()
             ids_grp = torch.from_numpy(np.ascontiguousarray(ids_host[sel]).astype(np.int32)).to(dev)
             for beg in range(0, len(sel), self.batch):
                 end = min(beg + self.batch, len(sel))
-                self.step(R_grp[beg:end], ids_grp[beg:end], transposed=tr)
+                self.step(R_grp[beg:end], ids_grp[beg:end], transposed=tr, quads=qd)
                 done += end - beg
                 if progress is not None:
                     progress(done)

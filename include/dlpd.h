@@ -58,6 +58,15 @@ int dlpd_zfft_oriented(const float* vol, const float* R, void* wsA, int nb, int 
 int dlpd_xy_correlate_oriented(const void* wsA, const void* rec, void* wsB, int nb, int CT, int L,
                                long long rec_bstride, int transposed, void* stream);
 
+/* Quad layout of a volume set for the rotation gather: quads[v][x][y][z] (y, z < L-1) = {vol(x,y,z), vol(x,y,z+1),
+ * vol(x,y+1,z), vol(x,y+1,z+1)}: the eight trilinear corners are two 16-byte gathers instead of four 8-byte
+ * ones (the gather is bound by cache lines touched per instruction).  dlpd_zfft_quads = dlpd_zfft_oriented with
+ * do_rotate = 1 on one volume set shared by all rotations; results are bit-identical to the plain path. */
+size_t dlpd_quads_floats(int nvol, int L);
+int dlpd_make_quads(const float* vol, float* quads, int nvol, int L, void* stream);
+int dlpd_zfft_quads(const float* quads, const float* R, void* wsA, int nb, int CT, int CT_out, int c_base, int L,
+                    float center, int transposed, void* stream);
+
 /* CoordsRotate + CoordsTranslate + TypedCoords2Volume (+ channel sum) of src/Docker/Docker.py:204,
  * 208,221-224 in one kernel: p' = R_b p + shift, density exp(-|r - p'|^2 / 2) on the 5^3 voxels
  * around each atom (build-defined shape).  coords (B, 3*stride_atoms) ordered by type,

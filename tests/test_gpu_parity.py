@@ -99,8 +99,9 @@ def test_full_search_ranked_list_matches_oracle(dev):
     eng2 = []
     Rd = torch.from_numpy(R).float().to(dev).contiguous()
     flags = DockingEngine.prefers_transposed(R)          # search() scores each rotation in this slab orientation
+    quads = DockingEngine.prefers_quads(R)               # ... and from this gather layout
     for r in range(nrot):
-        V = eng.score_batch(Rd[r:r + 1], transposed=bool(flags[r])).cpu()
+        V = eng.score_batch(Rd[r:r + 1], transposed=bool(flags[r]), quads=bool(quads[r])).cpu()
         idx, sc = orc.rotation_picks_fast(V[0].numpy(), K)
         x, y, z = orc.flat_to_xyz(idx, 2 * L)
         eng2 += [(r, int(x[i]), int(y[i]), int(z[i]), float(sc[i])) for i in range(K)]
@@ -321,14 +322,14 @@ def test_full_size_search_is_batch_size_and_order_independent(dev):
         eng.reset_top()
         if order[0] == 0:
             eng.search(R[order], rot_ids=order)
-        else:   # another visiting order: the 'transposed' group first, each group in descending set order
-            flags = DockingEngine.prefers_transposed(R)
-            for tr in (True, False):
-                grp = order[flags[order] == tr]
+        else:   # another visiting order: the groups of search() reversed, each group in descending set order
+            flags, quads = DockingEngine.prefers_transposed(R), DockingEngine.prefers_quads(R)
+            for tr, qd in ((True, True), (True, False), (False, True), (False, False)):
+                grp = order[(flags[order] == tr) & (quads[order] == qd)]
                 for beg in range(0, len(grp), nb):
                     ids = np.sort(grp[beg:beg + nb])
                     eng.step(torch.from_numpy(R[ids]).float().to(dev).contiguous(),
-                             torch.from_numpy(ids.astype(np.int32)).to(dev), transposed=tr)
+                             torch.from_numpy(ids.astype(np.int32)).to(dev), transposed=tr, quads=qd)
             eng.finish()
         lists.append(eng.top_list())
         del eng
@@ -448,3 +449,27 @@ def test_topk_fuzz_against_faithful_update_top(dev):
             top.select(torch.from_numpy(Vs[ids].reshape(len(ids), -1).copy()).to(dev), len(ids))
             top.merge(torch.from_numpy(ids.astype(np.int32)).to(dev), len(ids))
         assert DeviceTopList.to_top_list(top.entries(), N) == want, (trial, "permuted", order)
+
+
+def test_quad_gather_equals_plain_gather(dev):
+    """dlpd_zfft_quads (two 16-byte gathers per sample from the quad layout) against dlpd_zfft_oriented (four
+    8-byte gathers from the plain volume): same weights and products, so the z-spectra agree to round-off
+    of the compiler's FMA contraction (<= 1e-6 of the largest coefficient), for both slab orientations."""
+    from deeplocalproteindocking_amd._lib import get_lib
+    from deeplocalproteindocking_amd.engine import _ptr, _stream
+    lib = get_lib()
+    L, CT, nb = 64, 3, 4
+    g = torch.Generator().manual_seed(4)
+    vol = torch.randn(CT, L, L, L, generator=g).to(dev)
+    quads = torch.empty(lib.call("dlpd_quads_floats", CT, L), dtype=torch.float32, device=dev)
+    lib.call("dlpd_make_quads", _ptr(vol), _ptr(quads), CT, L, _stream(dev))
+    q = quads.reshape(CT, L, L - 1, L - 1, 4)
+    assert torch.equal(q[..., 0], vol[:, :, :-1, :-1]) and torch.equal(q[..., 3], vol[:, :, 1:, 1:])
+    assert torch.equal(q[..., 1], vol[:, :, :-1, 1:]) and torch.equal(q[..., 2], vol[:, :, 1:, :-1])
+    R = torch.from_numpy(_rots(nb, seed=5)).float().to(dev).contiguous()
+    n = nb * CT * (L + 1) * L * L * 2
+    for tr in (0, 1):
+        a, b = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        lib.call("dlpd_zfft_oriented", _ptr(vol), _ptr(R), _ptr(a), nb, CT, CT, 0, L, 0, 1, L / 2.0, tr, _stream(dev))
+        lib.call("dlpd_zfft_quads", _ptr(quads), _ptr(R), _ptr(b), nb, CT, CT, 0, L, L / 2.0, tr, _stream(dev))
+        assert (a - b).abs().max() <= 1e-6 * a.abs().max()
