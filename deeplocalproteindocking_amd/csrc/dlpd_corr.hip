@@ -292,15 +292,24 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
 // 8 two-row pencils, and runs the two wave-local FFT passes -- no block barrier involved.  Two
 // block barriers per group separate "all pencils transformed" from the accumulation phase, in
 // which every thread folds all channels of the group into the hidden units of its 4 voxels.
-#define DLPD_K3_TY 16
 // threads per block and number of channel-owning waves (LDS: WC * (8 pencils + raw staging))
 template <int N> struct K3Cfg;
 // HS: the hidden units are processed in HS slices (the transforms are repeated per slice): N = 160
 // needs 10 waves per block, i.e. 3 on one SIMD and a 168-VGPR cap, which 96 accumulators overflow
-template <> struct K3Cfg<64> { static constexpr int NT = 512, WC = 8, HS = 1; };
-template <> struct K3Cfg<128> { static constexpr int NT = 512, WC = 8, HS = 1; };
-template <> struct K3Cfg<80> { static constexpr int NT = 320, WC = 5, HS = 1; };
-template <> struct K3Cfg<160> { static constexpr int NT = 320, WC = 5, HS = 2; };
+// TY: y rows of the tile.  16 = one channel per wave (8 two-row pencils).  8 = two channels per wave (4 pencils
+// each), half the threads and half the LDS per block, so that TWO blocks share a CU and one block's LDS-bound
+// transform phase overlaps the other's FMA-bound accumulation phase (N = 128).
+#ifndef DLPD_K3_TILE8
+#define DLPD_K3_TILE8 0                  // measured: 2.82 ms vs 2.51 ms for the 16-row tile (64-byte DMA runs, twice the blocks)
+#endif
+template <> struct K3Cfg<64> { static constexpr int NT = 512, WC = 8, HS = 1, TY = 16; };
+#if DLPD_K3_TILE8
+template <> struct K3Cfg<128> { static constexpr int NT = 256, WC = 4, HS = 1, TY = 8; };
+#else
+template <> struct K3Cfg<128> { static constexpr int NT = 512, WC = 8, HS = 1, TY = 16; };
+#endif
+template <> struct K3Cfg<80> { static constexpr int NT = 320, WC = 5, HS = 1, TY = 16; };
+template <> struct K3Cfg<160> { static constexpr int NT = 320, WC = 5, HS = 2, TY = 16; };
 // Extra first-layer inputs that are already real volumes: the clipped correlations of a coarser
 // resolution (N/2 grid), nearest-upsampled by index (DockingModels.py:74-76), W1t rows C..C+Caux-1
 struct K3Aux {
@@ -314,16 +323,18 @@ template <int N, int HP, int MODE> __global__ void __launch_bounds__(K3Cfg<N>::N
 k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int C, int has_clash, int G,
                const float* __restrict__ W1t, const float* __restrict__ b1, const float* __restrict__ W2,
                float b2, int has_clip, float clip, float thr, K3Aux aux) {
-  constexpr int NZ = N / 2 + 1, RS = N + 8, TY = DLPD_K3_TY, NPAIR = TY / 2;
+  constexpr int NZ = N / 2 + 1, RS = N + 8, TY = K3Cfg<N>::TY, NPAIR = TY / 2;
   constexpr int NT = K3Cfg<N>::NT, WC = K3Cfg<N>::WC;
-  static_assert(NPAIR == 8 && WC * 64 <= NT, "one wave = 8 pencils x 8 threads = one channel of the tile");
+  constexpr int CPW = 8 / NPAIR;               // channels per wave: its 8 pencils = CPW channels x NPAIR row pairs
+  constexpr int LPK = 64 / NPAIR;              // kz rows per 64-lane DMA instruction
+  static_assert((NPAIR == 8 || NPAIR == 4) && WC * 64 <= NT, "one wave = 8 pencils x 8 threads");
   constexpr int EPT = (NPAIR * N) / NT > 0 ? (NPAIR * N) / NT : 1;   // complex outputs per thread per channel
   constexpr int MSTEP = NT / N;                // pair stride between a thread's outputs
   static_assert((NPAIR * N) % NT == 0 || NPAIR * N < NT, "tile/thread mismatch");
   constexpr int RAWC = ((NZ * NPAIR + 63) / 64) * 64;    // float4 slots per channel (whole waves)
   DLPD_DYN_SHARED(cplx, S);
-  cplx* tw = S + WC * NPAIR * RS;
-  float4* raw = reinterpret_cast<float4*>(tw + N);        // [WC][RAWC] staging of raw spectra
+  cplx* tw = S + WC * 8 * RS;
+  float4* raw = reinterpret_cast<float4*>(tw + N);        // [WC][CPW][RAWC] staging of raw spectra
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int y0 = blockIdx.x * TY, xo = blockIdx.y, b = blockIdx.z;
   init_twiddles<N>(tw, tid, NT);
@@ -339,21 +350,26 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
   const int zz = tid % N, m0 = tid / N;        // output ownership
   const bool owner = (NPAIR * N >= NT) || (m0 < NPAIR);
   const int tr = lane & 7, qr = lane >> 3;     // FFT: lane = 8*pencil + thread
-  const RowAddr<RS> ad = {(wave * NPAIR + qr) * RS};
-  float4* rawg = raw + wave * RAWC;
+  const RowAddr<RS> ad = {(wave * 8 + qr) * RS};
+  float4* rawg = raw + wave * CPW * RAWC;
 
-  // this wave's channel of group `cb`: raw[k][m] <- Bw[b][cb+wave][k][xo][y0+2m .. +1]
-  // (lane = 8*(k&7) + m: eight 128-byte runs per DMA instruction; k = N/2 is the ninth, short one)
-  constexpr int NFULL = N / 16;                // full 64-lane DMA instructions per channel (bins 0..N/2-1)
-  static_assert(NZ * NPAIR == NFULL * 64 + NPAIR, "raw channel = NFULL full DMA instructions + one of 8 lanes");
+  // this wave's channels of group `cb`: raw[k][m] <- Bw[b][cb + wave*CPW + j][k][xo][y0+2m .. +1]
+  // (lane = NPAIR*(k % LPK) + m: LPK runs of NPAIR*16 bytes per DMA instruction; k = N/2 is the last, short one)
+  constexpr int NFULL = (N / 2) / LPK;         // full 64-lane DMA instructions per channel (bins 0..N/2-1)
+  static_assert(NZ * NPAIR == NFULL * 64 + NPAIR, "raw channel = NFULL full DMA instructions + one short one");
   auto issue_channel = [&](int cb) {
-    if (wave < G && cb + wave < CT) {
-      const cplx* src = Bw + (((size_t)b * CT + cb + wave) * NZ * N + xo) * N + y0;
-      const cplx* lane_src = src + (size_t)(lane >> 3) * N * N + 2 * (lane & 7);
 #pragma unroll
-      for (int it = 0; it < NFULL; it++) DLPD_GLDS16(lane_src + (size_t)it * 8 * N * N, rawg + it * 64);
-      const int mt = (lane & 7);                            // tail lanes re-read valid elements
-      DLPD_GLDS16(src + (size_t)(N / 2) * N * N + 2 * mt, rawg + NFULL * 64);
+    for (int j = 0; j < CPW; j++) {
+      const int g = wave * CPW + j;
+      if (g < G && cb + g < CT) {
+        const cplx* src = Bw + (((size_t)b * CT + cb + g) * NZ * N + xo) * N + y0;
+        const cplx* lane_src = src + (size_t)(lane / NPAIR) * N * N + 2 * (lane % NPAIR);
+        float4* rj = rawg + j * RAWC;
+#pragma unroll
+        for (int it = 0; it < NFULL; it++) DLPD_GLDS16(lane_src + (size_t)it * LPK * N * N, rj + it * 64);
+        const int mt = lane % NPAIR;                        // tail lanes re-read valid elements
+        DLPD_GLDS16(src + (size_t)(N / 2) * N * N + 2 * mt, rj + NFULL * 64);
+      }
     }
   };
   DLPD_STAMP_DECL;
@@ -372,24 +388,27 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
 
   for (int cbase = 0; cbase < CT; cbase += G) {
     const int gn = (CT - cbase) < G ? (CT - cbase) : G;
-    if (wave < gn) {
+    if (wave * CPW < gn) {
       DLPD_WAIT_VMEM();                        // this wave's own DMA has landed
       DLPD_WAVE_SYNC();
       DLPD_STAMP(0);
       // pack two rows per complex pencil: Z[k] = A[k] + i B[k], Z[N-k] = conj(A[k]) + i conj(B[k])
-      {
-        const int m = lane & 7, kq = lane >> 3;
-        cplx* P = S + (wave * NPAIR + m) * RS;
+#pragma unroll
+      for (int j = 0; j < CPW; j++) {
+        if (wave * CPW + j >= gn) break;
+        const int m = lane % NPAIR, kq = lane / NPAIR;
+        cplx* P = S + (wave * 8 + j * NPAIR + m) * RS;
+        const float4* rj = rawg + j * RAWC;
         constexpr int PCH = NFULL > 8 ? NFULL / 2 : NFULL;   // raw elements in flight per lane
-        const float4 qh = rawg[NFULL * 64 + m];             // k = N/2
+        const float4 qh = rj[NFULL * 64 + m];               // k = N/2
 #pragma unroll
         for (int it0 = 0; it0 < NFULL; it0 += PCH) {
           float4 q[PCH];
 #pragma unroll
-          for (int u = 0; u < PCH; u++) q[u] = rawg[(it0 + u) * 64 + lane];
+          for (int u = 0; u < PCH; u++) q[u] = rj[(it0 + u) * 64 + lane];
 #pragma unroll
           for (int u = 0; u < PCH; u++) {
-            const int it = it0 + u, k = it * 8 + kq;
+            const int it = it0 + u, k = it * LPK + kq;
             if (it == 0 && kq == 0) {
               P[slab_swz(0)] = c_make(q[u].x, q[u].z);      // purely real bin of both rows
             } else {
@@ -406,7 +425,7 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
     DLPD_STAMP(1);
     issue_channel(cbase + G);                  // next group's channel streams in behind the math
     DLPD_STAMP(2);
-    if (wave < gn) fft_wave<N, +1, N>(S, ad, tr, tw);
+    if (wave * CPW < gn) fft_wave<N, +1, N>(S, ad, tr, tw);
     DLPD_STAMP(3);
     DLPD_LDS_BARRIER();                        // all channels of the group transformed
     DLPD_STAMP(4);
@@ -752,13 +771,13 @@ template <int N, int HP, int MODE> static int launch_k3(const cplx* Bw, float* o
                                                         int nb, const float* W1t, const float* b1, const float* W2,
                                                         float b2, int has_clip, float clip, float thr,
                                                         hipStream_t st, K3Aux aux = K3Aux{nullptr, 0, 0}) {
-  constexpr int RS = N + 8, NZ = N / 2 + 1, W = K3Cfg<N>::WC, NPAIR = DLPD_K3_TY / 2;
+  constexpr int RS = N + 8, NZ = N / 2 + 1, W = K3Cfg<N>::WC, NPAIR = K3Cfg<N>::TY / 2, CPW = 8 / NPAIR;
   constexpr int RAWC = ((NZ * NPAIR + 63) / 64) * 64;
-  const size_t shmem = (size_t)(W * NPAIR * RS + N) * sizeof(cplx) + (size_t)W * RAWC * 16;
+  const size_t shmem = (size_t)(W * 8 * RS + N) * sizeof(cplx) + (size_t)W * CPW * RAWC * 16;
   int rc = dlpd_set_max_dyn_shared((const void*)k_zifft_filter<N, HP, MODE>, shmem);
   if (rc) return rc;
-  const int G = k3_group(CT, W);               // channels per group (one wave each), <= W
-  dim3 grid(N / DLPD_K3_TY, N, nb), block(K3Cfg<N>::NT);
+  const int G = k3_group(CT, W * CPW);         // channels per group (CPW per wave), <= W * CPW
+  dim3 grid(N / K3Cfg<N>::TY, N, nb), block(K3Cfg<N>::NT);
   DLPD_LAUNCH((k_zifft_filter<N, HP, MODE>), grid, block, shmem, st, Bw, out, CT, C, has_clash, G, W1t, b1, W2, b2,
               has_clip, clip, thr, aux);
   return dlpd_check_launch();
