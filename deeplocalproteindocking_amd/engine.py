@@ -217,7 +217,8 @@ class DockingEngine:
         is as good or better inside the full pipeline."""
         R = np.asarray(R)
         inplane = np.maximum(np.abs(R[:, 0, 2]), np.abs(R[:, 1, 2]))
-        return inplane > np.abs(R[:, 2, 2])
+        zmax = float(os.environ.get("DLPD_QUADS_ZMAX", "0"))          # diagnostic: also when |R22| < zmax
+        return (inplane > np.abs(R[:, 2, 2])) | (np.abs(R[:, 2, 2]) < zmax)
 
     @staticmethod
     def prefers_transposed(R):
