@@ -76,28 +76,23 @@ class Docker:
 
     # ------------------------------------------------------------------ logging (Docker.py:63-84)
     def new_log(self, log_file_name, rewrite=True):
-        if not self.log is None:
-            self.log.close()
-        if os.path.exists(log_file_name) and (not rewrite):
-            lines = []
-            with open(log_file_name, 'r') as fin:
-                for line in fin:
-                    if len(line.split()) > 0:
-                        lines.append(line)
-            if len(lines) > 1:
-                self.log = None
+        """Open the .dat of the next target.  Resume rule of Docker.py:63-79: with ``rewrite=False`` a file
+        that already holds more than one non-blank line counts as finished -- no log is opened and False is
+        returned so the caller skips the target; anything else is (re)started from scratch."""
+        self.cleanup()
+        if not rewrite and os.path.exists(log_file_name):
+            with open(log_file_name) as existing:
+                filled = sum(1 for line in existing if line.split())
+            if filled > 1:
                 return False
-            else:
-                self.log = open(log_file_name, "w")
-                return True
-        else:
-            self.log = open(log_file_name, "w")
-            return True
+        self.log = open(log_file_name, "w")
+        return True
 
     def cleanup(self):
-        if not self.log is None:
-            self.log.close()
-            self.log = None
+        """Close the current log, if any (also registered with atexit, Docker.py:46,81-84)."""
+        log, self.log = self.log, None
+        if log is not None:
+            log.close()
 
     # ------------------------------------------------------------------ top list (Docker.py:86-105)
     def _library(self):
@@ -125,30 +120,26 @@ class Docker:
 
     # ------------------------------------------------------------------ output (Docker.py:107-133)
     def write_conformations(self):
-        if not self.log is None:
-            for i, x, y, z, score in self.top_list:
-                r = self.rot.R[i, :, :]
-                t = torch.zeros(3, device='cpu', dtype=torch.double)
-                t[0] = x
-                t[1] = y
-                t[2] = z
-                if x >= self.box_size:
-                    t[0] = -(2 * self.box_size - x)
-                if y >= self.box_size:
-                    t[1] = -(2 * self.box_size - y)
-                if z >= self.box_size:
-                    t[2] = -(2 * self.box_size - z)
-                t = t * self.resolution
-                if self.randomize_rot:
-                    randRT = torch.transpose(self.randR.squeeze(), 0, 1)
-                    t = torch.matmul(randRT, t)
-                    r = torch.matmul(randRT, r)
-                self.log.write("%f\t%f\t%f\t" % (r[0, 0].item(), r[0, 1].item(), r[0, 2].item()))
-                self.log.write("%f\t%f\t%f\t" % (r[1, 0].item(), r[1, 1].item(), r[1, 2].item()))
-                self.log.write("%f\t%f\t%f\t" % (r[2, 0].item(), r[2, 1].item(), r[2, 2].item()))
-                self.log.write("%f\t%f\t%f\t" % (t[0], t[1], t[2]))
-                self.log.write("%f\n" % (score))
-            self.log.flush()
+        """One line per pose: the 9 entries of R row-major, the translation in Angstrom, the score -- 13
+        tab-separated ``%f`` columns (Docker.py:107-133, byte-exact against fixture G4).  Grid indices at
+        or beyond ``box_size`` are negative shifts (index - 2L); with ``randomize_rot`` both R and t are
+        taken back to the receptor's original frame by randR^T."""
+        if self.log is None:
+            return
+        L, N = self.box_size, 2 * self.box_size
+        undo = self.randR.squeeze().t().to(torch.double) if self.randomize_rot else None
+        rows = []
+        for rot_index, x, y, z, score in self.top_list:
+            r = self.rot.R[rot_index].to(torch.double)
+            shift = torch.tensor([v - N if v >= L else v for v in (x, y, z)], dtype=torch.double)
+            t = shift * self.resolution
+            if undo is not None:
+                t, r = undo @ t, undo @ r
+            cols = [float(v) for v in r.reshape(-1)] + [float(v) for v in t] + [score]
+            rows.append("\t".join("%f" % v for v in cols))
+        if rows:
+            self.log.write("\n".join(rows) + "\n")
+        self.log.flush()
 
     # ------------------------------------------------------------------ the search on volumes
     def shard(self, nrot):
