@@ -83,10 +83,17 @@ class E3MultiResRepr4x4(Module):
                    and m.dilation == (1, 1, 1) and m.groups == 1 and m.padding == tuple(k // 2 for k in m.kernel_size)
                    and x.dtype == torch.float32 and x.shape[2] == x.shape[3] == x.shape[4]
                    and ops.conv3d_supported(m.weight, x.shape[2], self.hip_lib))
+            pool = (self.use_hip_conv and isinstance(m, nn.MaxPool3d) and not torch.is_grad_enabled()
+                    and (x.is_cuda or self.hip_lib is not None) and m.kernel_size == 5 and m.stride == 2
+                    and m.padding == 2 and m.dilation == 1 and not m.ceil_mode and not m.return_indices
+                    and x.dtype == torch.float32 and x.shape[2] == x.shape[3] == x.shape[4])
             if hip:
                 relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
                 x = ops.conv3d(x, m.weight, relu=relu, lib=self.hip_lib)
                 i += 2 if relu else 1
+            elif pool:
+                x = ops.maxpool3d_5s2(x, lib=self.hip_lib)
+                i += 1
             else:
                 x = m(x)
                 i += 1

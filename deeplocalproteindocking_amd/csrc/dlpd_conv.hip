@@ -221,7 +221,46 @@ __global__ void __launch_bounds__(256) k_conv3d_pack(const float* __restrict__ w
   }
 }
 
+// MaxPool3d(kernel 5, stride 2, padding 2) of the E3 plugin (ProteinRepresentationModels.py:101): out-of-range
+// taps do not take part (torch pads with -inf).  One thread per output voxel, z fastest; the 125 taps of
+// neighbouring outputs overlap, so the reads are served by L1/L2.
+__global__ void __launch_bounds__(256) k_maxpool3d_5s2(const float* __restrict__ x, float* __restrict__ y, int nvol,
+                                                       int D, int Do) {
+  const size_t total = (size_t)nvol * Do * Do * Do;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int oz = (int)(i % Do), oy = (int)((i / Do) % Do), ox = (int)((i / ((size_t)Do * Do)) % Do);
+    const size_t v = i / ((size_t)Do * Do * Do);
+    const float* src = x + v * (size_t)D * D * D;
+    float m = -INFINITY;
+    for (int dx = -2; dx <= 2; dx++) {
+      const int ix = 2 * ox + dx;
+      if (ix < 0 || ix >= D) continue;
+      for (int dy = -2; dy <= 2; dy++) {
+        const int iy = 2 * oy + dy;
+        if (iy < 0 || iy >= D) continue;
+        const float* row = src + ((size_t)ix * D + iy) * D;
+#pragma unroll
+        for (int dz = -2; dz <= 2; dz++) {
+          const int iz = 2 * oz + dz;
+          if (iz >= 0 && iz < D) m = fmaxf(m, row[iz]);
+        }
+      }
+    }
+    y[i] = m;
+  }
+}
+
 extern "C" {
+
+int dlpd_maxpool3d_5s2(const float* x, float* y, int nvol, int D, void* stream) {
+  if (!x || !y || nvol <= 0 || D < 1) return DLPD_ERR_ARG;
+  const int Do = (D + 4 - 5) / 2 + 1;
+  const size_t total = (size_t)nvol * Do * Do * Do;
+  size_t nblk = (total + 255) / 256;
+  if (nblk > 131072) nblk = 131072;
+  DLPD_LAUNCH(k_maxpool3d_5s2, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x, y, nvol, D, Do);
+  return dlpd_check_launch();
+}
 
 size_t dlpd_conv3d_packed_floats(int cin, int cout, int ks) {
   return (size_t)((cin + 3) / 4) * ks * ks * ks * 4 * cout;

@@ -138,3 +138,14 @@ def _packed_weights(weight, w, lib, device):
             _PACKED.clear()
         _PACKED[key] = wp
     return wp
+
+
+def maxpool3d_5s2(x, lib=None):
+    """MaxPool3d(kernel_size=5, stride=2, padding=2) of the E3 plugin, (B, C, D, D, D) float32 (inference)."""
+    lib = lib or get_lib()
+    x = x.contiguous()
+    B, C, D = x.shape[0], x.shape[1], x.shape[2]
+    Do = (D - 1) // 2 + 1
+    y = torch.empty(B, C, Do, Do, Do, dtype=torch.float32, device=x.device)
+    lib.call("dlpd_maxpool3d_5s2", _ptr(x), _ptr(y), B * C, D, _stream(x.device))
+    return y

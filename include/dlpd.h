@@ -152,6 +152,10 @@ int dlpd_conv3d_pack(const float* w, float* wp, int cin, int cout, int ks, void*
 int dlpd_conv3d(const float* x, const float* wp, float* y, int B, int cin, int cout, int D, int ks, int relu,
                 void* stream);
 
+/* MaxPool3d(kernel 5, stride 2, padding 2) of the E3 plugin (ProteinRepresentationModels.py:101):
+ * x (nvol, D^3) -> y (nvol, Do^3), Do = (D - 1) / 2 + 1. */
+int dlpd_maxpool3d_5s2(const float* x, float* y, int nvol, int D, void* stream);
+
 /* Docker.update_top pick loop, src/Docker/Docker.py:89-98: per rotation the K picks in pick order
  * (incl. the zero-fill behaviour).  V (nb, nvox); out (nb, K). */
 size_t dlpd_topk_workspace_bytes(int nb, int K);

@@ -473,3 +473,12 @@ def test_quad_gather_equals_plain_gather(dev):
         lib.call("dlpd_zfft_oriented", _ptr(vol), _ptr(R), _ptr(a), nb, CT, CT, 0, L, 0, 1, L / 2.0, tr, _stream(dev))
         lib.call("dlpd_zfft_quads", _ptr(quads), _ptr(R), _ptr(b), nb, CT, CT, 0, L, L / 2.0, tr, _stream(dev))
         assert (a - b).abs().max() <= 1e-6 * a.abs().max()
+
+
+@pytest.mark.parametrize("D", [80, 37, 6])
+def test_maxpool3d_matches_torch(dev, D):
+    """dlpd_maxpool3d_5s2 against torch's MaxPool3d(5, stride 2, padding 2) (bit-exact: a max of the same values)."""
+    from deeplocalproteindocking_amd import ops
+    x = torch.randn(2, 3, D, D, D, generator=torch.Generator().manual_seed(D)).to(dev)
+    want = torch.nn.functional.max_pool3d(x.cpu(), kernel_size=5, stride=2, padding=2)
+    assert torch.equal(ops.maxpool3d_5s2(x).cpu(), want)
