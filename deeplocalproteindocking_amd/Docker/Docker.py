@@ -3,19 +3,33 @@ class (/root/reference/src/Docker/Docker.py:17-238): same constructor, ``new_log
 ``update_top``, ``write_conformations``, ``load_batch``, ``dockE3``, ``dockSE3`` and attributes
 (``top_list``, ``rot.R``, ``box_size``, ``resolution``, ``box_length``, ``max_conf``, ``log``).
 
+It is constructed and driven exactly as /root/reference/src/local_test.py:55,65-71 does
+(``Docker(docking_model=..., angle_inc=..., box_size=80, resolution=1.25, max_conf=2000,
+randomize_rot=True)``, ``new_log``, ``dockSE3(rec, lig, batch_size=2)``); every further keyword is
+optional.
+
 What differs underneath:
-  * the hot loop (Docker.py:211-236) runs in libdlpd.so with no host synchronisation: rotations
-    are processed ``batch_size`` (any number, odd tails included) at a time, the clash mask, the
-    filter MLP and the mask multiply are fused into the inverse FFT, and the top list lives on the
-    device until the pair is finished;
+  * the hot loop (Docker.py:211-236) runs in libdlpd.so with no host synchronisation; the clash
+    mask, the filter MLP and the mask multiply are fused into the inverse FFT, and the top list
+    lives on the device until the pair is finished;
+  * the caller's ``batch_size`` does NOT size the launches: the ranked list is independent of how
+    the rotations are batched (merge key (score, rotation, pick); tested), so ``dockSE3`` /
+    ``dockE3`` always score ``launch_batch`` (16) rotations per launch -- the receptor slab in K2 is
+    amortised over the launch batch, and ``batch_size=2`` of local_test.py:69,71 would cost 8x the
+    launches;
+  * the scoring call ``docking_model(receptor_volumes, ligand_volumes_rotated)`` (Docker.py:229) is
+    replaced by the fused kernels only when that is what the model computes -- the reference's
+    ``GlobalDockingModel.forward`` with an MLP ``SimpleFilter`` (``Models.fused_filter_parameters``).
+    Any other model / filter module is CALLED, on volumes rotated and correlated by the stand-alone
+    HIP ops, followed by the device top-K (``_dock_volumes_generic``);
+  * atoms come from ``Utils.FullAtom.CoordsBackend`` (PDB reader, 11-type typing, GPU density
+    projection; TorchProteinLibrary itself is absent, SURVEY.md 8f rows 1,3), created on first use;
+    ``coords_backend=`` swaps in another implementation;
   * ``dock_volumes`` is the volume-level entry (a superset): it takes representation volumes
     directly, which is what the synthetic BASELINE configs use;
   * rotations can be sharded over ranks (``rank``/``world_size``): rank r scores rotations
     r, r+W, r+2W, ... and one all-gather of the per-rank top lists + a deterministic merge by
-    (score, rotation, pick) reproduces the single-process list (SURVEY.md section 8e);
-  * PDB parsing / atom typing / density projection (TorchProteinLibrary) are not part of this
-    build (SURVEY.md 8f rows 1,3): ``dockSE3``/``dockE3``/``load_batch`` need a
-    ``coords_backend`` object providing them and raise otherwise.
+    (score, rotation, pick) reproduces the single-process list.
 """
 import atexit
 import os
@@ -26,6 +40,11 @@ import torch
 from deeplocalproteindocking_amd.engine import DeviceTopList, DockingEngine
 from deeplocalproteindocking_amd._lib import get_lib
 from deeplocalproteindocking_amd.Utils.Rotations import Rotations, euler_to_matrices
+
+
+def fused_filter_parameters(model):
+    from deeplocalproteindocking_amd.Models.DockingModels import fused_filter_parameters as f
+    return f(model)
 
 
 class _FixedRotations(object):
@@ -43,10 +62,13 @@ def random_rotation(generator=None):
     return torch.from_numpy(euler_to_matrices(phi, theta, psi)).reshape(1, 3, 3)
 
 
+LAUNCH_BATCH = 16      # rotations per launch of the fused pipeline
+
+
 class Docker:
     def __init__(self, docking_model, angle_inc=15.0, box_size=80, resolution=1.25, max_conf=1000,
                  randomize_rot=False, rotations=None, device="cuda", coords_backend=None,
-                 rank=0, world_size=1, process_group=None, lib=None):
+                 rank=0, world_size=1, process_group=None, lib=None, launch_batch=None):
         self.docking_model = docking_model
         self.log = None
 
@@ -69,6 +91,7 @@ class Docker:
         self.coords_backend = coords_backend
         self.rank, self.world_size, self.process_group = int(rank), int(world_size), process_group
         self._lib = lib
+        self.launch_batch = int(launch_batch or os.environ.get("DLPD_LAUNCH_BATCH", LAUNCH_BATCH))
         self._top = None            # DeviceTopList behind update_top()
         self.top_list = []
         self.engine = None
@@ -147,14 +170,16 @@ class Docker:
         return np.arange(self.rank, nrot, self.world_size, dtype=np.int64)
 
     def dock_volumes(self, receptor_volumes, ligand_volumes, receptor_forbidden=None, ligand_forbidden=None,
-                     batch_size=8, rot_indices=None, write=True, clash_provider=None):
+                     batch_size=None, rot_indices=None, write=True, clash_provider=None, model_batch=None):
         """Search all rotations for one pair given its representation volumes.
 
         receptor_volumes / ligand_volumes: lists of (1,C_i,L_i,L_i,L_i) (or (C_i,L_i,..)) tensors
         as returned by ``docking_model.representation``; *_forbidden: (L,L,L)-shaped clash
         densities (``None`` -> no clash exclusion).  The ligand forbidden volume is rotated with
-        the same trilinear kernel as the representation (stand-in for the reference's per-rotation
-        atom re-projection, Docker.py:221-224)."""
+        the same trilinear kernel as the representation unless ``clash_provider`` re-projects it
+        from rotated atoms (Docker.py:221-224).
+        batch_size: rotations per launch (None -> ``self.launch_batch``); the list does not depend
+        on it.  model_batch: rotations per call of a model that has to be CALLED (generic path)."""
         model = self.docking_model
         model.eval() if hasattr(model, "eval") else None
         rec = [torch.as_tensor(v, dtype=torch.float32) for v in receptor_volumes]
@@ -164,10 +189,12 @@ class Docker:
         L = rec[0].shape[-1]
         if L != self.box_size:
             raise Exception("Volume size does not match box_size", L, self.box_size)
-        has_clash = receptor_forbidden is not None
+        nb = int(batch_size or self.launch_batch)
         R_all = self.rot.R
         ids = self.shard(R_all.shape[0]) if rot_indices is None else np.asarray(rot_indices, dtype=np.int64)
-        eng = self._make_engine(rec, receptor_forbidden, batch_size)
+        params = fused_filter_parameters(model)
+        eng = self._make_engine(rec, receptor_forbidden, nb, params)
+        self.path = "fused" if eng is not None else ("ops" if self._ops_path_ok(rec, params) else "call")
         if eng is not None:
             two_res = eng.C1 > 0
             eng.set_ligand(lig[0], ligand_forbidden if ligand_forbidden is not None else torch.zeros(L, L, L),
@@ -177,24 +204,36 @@ class Docker:
             eng.search(R_all[ids], rot_ids=ids)
             self.engine = eng
             entries = eng.top_entries()
+        elif self.path == "ops":
+            entries = self._dock_volumes_multires(rec, lig, receptor_forbidden, ligand_forbidden, nb, ids,
+                                                  clash_provider, params)
         else:
-            entries = self._dock_volumes_multires(rec, lig, receptor_forbidden, ligand_forbidden, batch_size, ids,
-                                                  clash_provider)
+            entries = self._dock_volumes_generic(rec, lig, receptor_forbidden, ligand_forbidden,
+                                                 int(model_batch or nb), ids, clash_provider)
         entries = self._gather(entries)
         self.top_list = DeviceTopList.to_top_list(entries, 2 * L)
         if write:
             self.write_conformations()
         return self.top_list
 
-    def _make_engine(self, rec, receptor_forbidden, batch_size):
+    def _make_engine(self, rec, receptor_forbidden, batch_size, params):
         """DockingEngine for one receptor (one resolution, or the reference's [C0 @ L, C1 @ L/2] pair);
-        None when the representation has another shape (generic stand-alone-op path)."""
-        model = self.docking_model
+        None when the fused pipeline has no kernel for the shape (other grids or resolution layouts,
+        hidden width above 32) or the model's scoring is not the MLP it fuses: the stand-alone-op paths
+        take over."""
+        if params is None:
+            return None
+        lib = self._library()
         L = rec[0].shape[-1]
-        two_res = len(rec) == 2 and rec[1].shape[-1] * 2 == L and self._library().call("dlpd_grid_supported", L // 2)
+        if not lib.call("dlpd_grid_supported", int(L)):
+            return None
+        two_res = len(rec) == 2 and rec[1].shape[-1] * 2 == L and bool(lib.call("dlpd_grid_supported", L // 2))
         if not (len(rec) == 1 or two_res):
             return None
-        W1, b1, W2, b2 = model.filter.parameters_tuple()
+        W1, b1, W2, b2 = params
+        if lib.call("dlpd_hidden_pad", int(W1.shape[0])) < 0 or W1.shape[1] != sum(v.shape[0] for v in rec):
+            return None
+        model = self.docking_model
         eng = DockingEngine(L, rec[0].shape[0], W1.cpu(), b1.cpu(), W2.cpu(), b2.cpu(),
                             clip=getattr(model, "clip", 5.0), threshold_clash=model.threshold_clash,
                             has_clash=receptor_forbidden is not None, max_conf=self.max_conf, batch=batch_size,
@@ -202,41 +241,88 @@ class Docker:
         eng.set_receptor(rec[0], receptor_forbidden, rec[1] if two_res else None)
         return eng
 
-    def _dock_volumes_multires(self, rec, lig, rec_forb, lig_forb, batch_size, ids, clash_provider=None):
-        """Reference-shaped loop on the stand-alone ops (any number of resolutions): rotate,
-        clash correlation, model forward, mask multiply, device top-K."""
+    @staticmethod
+    def _ops_path_ok(rec, params):
+        """The stand-alone ops + the HIP per-voxel filter kernel cover an MLP filter of hidden width
+        <= 64 over one or two resolutions (dlpd_filter_mask)."""
+        return params is not None and params[0].shape[0] <= 64 and len(rec) <= 2
+
+    def _batch_inputs(self, rec, lig, rec_forb, lig_forb, clash_provider):
+        dev = self.device
+        L = rec[0].shape[-1]
+        rec_d = [v.to(dev) for v in rec]
+        lig_d = [v.to(dev) for v in lig]
+        rf = lf = None
+        if rec_forb is not None:
+            rf = torch.as_tensor(rec_forb, dtype=torch.float32).reshape(1, 1, L, L, L).to(dev)
+            if clash_provider is None:
+                lf = torch.as_tensor(lig_forb, dtype=torch.float32).reshape(1, 1, L, L, L).to(dev)
+        return rec_d, lig_d, rf, lf
+
+    def _dock_volumes_multires(self, rec, lig, rec_forb, lig_forb, batch_size, ids, clash_provider=None, params=None):
+        """Reference-shaped loop on the stand-alone ops: rotate, clash correlation, per-resolution
+        correlation, HIP filter kernel (upsample + concat + MLP + mask multiply), device top-K."""
         from deeplocalproteindocking_amd.ops import VolumeConvolution, VolumeRotation, filter_volumes
         dev = self.device
         model = self.docking_model
-        rotate, conv_noclip = VolumeRotation(), VolumeConvolution()
-        rec_d = [v.to(dev) for v in rec]
-        lig_d = [v.to(dev) for v in lig]
+        rotate, conv_noclip = VolumeRotation(lib=self._lib), VolumeConvolution(lib=self._lib)
+        convolve = getattr(model, "convolve", None) or VolumeConvolution(clip=getattr(model, "clip", 5.0), lib=self._lib)
+        rec_d, lig_d, rf, lf = self._batch_inputs(rec, lig, rec_forb, lig_forb, clash_provider)
         L = rec[0].shape[-1]
         top = DeviceTopList(self.max_conf, batch_size, dev, self._library())
         top.reset()
         has_clash = rec_forb is not None
-        if has_clash:
-            rf = torch.as_tensor(rec_forb, dtype=torch.float32).reshape(1, 1, L, L, L).to(dev)
-            if clash_provider is None:
-                lf = torch.as_tensor(lig_forb, dtype=torch.float32).reshape(1, 1, L, L, L).to(dev)
         R_all = self.rot.R
-        W1, b1, W2, b2 = model.filter.parameters_tuple()
+        W1, b1, W2, b2 = params if params is not None else fused_filter_parameters(model)
         for beg in range(0, len(ids), batch_size):
             bid = ids[beg:beg + batch_size]
             nb = len(bid)
             Rb = R_all[bid].to(device=dev, dtype=torch.float32).contiguous()
             lig_rot = [rotate(v.unsqueeze(0).expand(nb, -1, -1, -1, -1).contiguous(), Rb) for v in lig_d]
             rec_b = [v.unsqueeze(0).expand(nb, -1, -1, -1, -1).contiguous() for v in rec_d]
-            convolved = [model.convolve(r, l) for r, l in zip(rec_b, lig_rot)]
+            convolved = [convolve(r, l) for r, l in zip(rec_b, lig_rot)]
             norm = None
             if has_clash:
                 lfr = (clash_provider(Rb).reshape(nb, 1, L, L, L).contiguous() if clash_provider is not None
                        else rotate(lf.expand(nb, -1, -1, -1, -1).contiguous(), Rb))
                 norm = conv_noclip(rf.expand(nb, -1, -1, -1, -1).contiguous(), lfr).squeeze(1).contiguous()
             V = filter_volumes(convolved, W1, b1, W2, float(b2.reshape(-1)[0]), mask_norm=norm,
-                               threshold=model.threshold_clash)
+                               threshold=model.threshold_clash, lib=self._lib)
             top.select(V.reshape(nb, -1), nb)
             top.merge(torch.as_tensor(bid, dtype=torch.int32).to(dev), nb)
+        return top.entries()
+
+    def _dock_volumes_generic(self, rec, lig, rec_forb, lig_forb, batch_size, ids, clash_provider=None):
+        """The loop body of Docker.py:218-232 with the scoring model really CALLED --
+        ``V = self.docking_model(receptor_volumes, ligand_volumes_rotated)`` (Docker.py:229), whatever
+        module that is -- between the stand-alone HIP ops (volume rotation, clash correlation) and the
+        device top-K.  This is the path of a user-defined filter / docking model."""
+        from deeplocalproteindocking_amd.ops import VolumeConvolution, VolumeRotation
+        dev = self.device
+        model = self.docking_model
+        rotate, conv_noclip = VolumeRotation(lib=self._lib), VolumeConvolution(lib=self._lib)
+        rec_d, lig_d, rf, lf = self._batch_inputs(rec, lig, rec_forb, lig_forb, clash_provider)
+        L = rec[0].shape[-1]
+        top = DeviceTopList(self.max_conf, batch_size, dev, self._library())
+        top.reset()
+        has_clash = rec_forb is not None
+        R_all = self.rot.R
+        with torch.no_grad():
+            for beg in range(0, len(ids), batch_size):
+                bid = ids[beg:beg + batch_size]
+                nb = len(bid)
+                Rb = R_all[bid].to(device=dev, dtype=torch.float32).contiguous()
+                lig_rot = [rotate(v.unsqueeze(0).expand(nb, -1, -1, -1, -1).contiguous(), Rb) for v in lig_d]
+                rec_b = [v.unsqueeze(0).expand(nb, -1, -1, -1, -1).contiguous() for v in rec_d]
+                V = model(rec_b, lig_rot).reshape(nb, 2 * L, 2 * L, 2 * L).to(torch.float32)
+                if has_clash:
+                    lfr = (clash_provider(Rb).reshape(nb, 1, L, L, L).contiguous() if clash_provider is not None
+                           else rotate(lf.expand(nb, -1, -1, -1, -1).contiguous(), Rb))
+                    norm = conv_noclip(rf.expand(nb, -1, -1, -1, -1).contiguous(), lfr).squeeze(1)
+                    V = torch.lt(norm, model.threshold_clash).to(dtype=torch.float32) * V
+                V = V.contiguous()
+                top.select(V.reshape(nb, -1), nb)
+                top.merge(torch.as_tensor(bid, dtype=torch.int32).to(dev), nb)
         return top.entries()
 
     def _gather(self, entries):
@@ -267,10 +353,12 @@ class Docker:
 
     # ------------------------------------------------------------------ PDB-level entries
     def _need_backend(self):
+        """The atom front end (TorchProteinLibrary's PDB2CoordsUnordered / Coords2TypedCoords /
+        CoordsTranslate / CoordsRotate / TypedCoords2Volume, Docker.py:29-39): this build's
+        ``CoordsBackend`` unless the constructor was given another one."""
         if self.coords_backend is None:
-            raise Exception("PDB parsing, atom typing and density projection (TorchProteinLibrary "
-                            "PDB2CoordsUnordered / Coords2TypedCoords / TypedCoords2Volume, Docker.py:37-38,31) "
-                            "are not part of this build; pass coords_backend=... or call dock_volumes()")
+            from deeplocalproteindocking_amd.Utils.FullAtom import CoordsBackend
+            self.coords_backend = CoordsBackend(lib=self._lib)
         return self.coords_backend
 
     def load_batch(self, filenames, bbox_center=True):
@@ -290,7 +378,9 @@ class Docker:
     def dockSE3(self, ureceptor, uligand, batch_size):
         """Docker.py:184-238: representations computed once, ligand volumes rotated on the GPU, and
         the ligand forbidden volume re-projected from the rotated ATOMS every batch (Docker.py:221-224)
-        -- by one kernel that rotates on the fly, without the reference's per-batch host round trip."""
+        -- by one kernel that rotates on the fly, without the reference's per-batch host round trip.
+        ``batch_size`` (2 in local_test.py:71) only sizes the calls of a model that has to be called
+        (generic path); the fused pipeline always launches ``self.launch_batch`` rotations."""
         be = self._need_backend()
         self.top_list = []
         self.docking_model.eval()
@@ -312,13 +402,14 @@ class Docker:
             def provider(Rb):   # rotate about the origin, translate to the box centre, project, sum types
                 return be.project(lc, ln, lo, L, res, dev, R=Rb, shift=self.box_center, sum_types=True)
 
-            self.dock_volumes(receptor_volumes, ligand_volumes, receptor_forbidden, None, batch_size=batch_size,
-                              clash_provider=provider)
+            self.dock_volumes(receptor_volumes, ligand_volumes, receptor_forbidden, None, batch_size=None,
+                              clash_provider=provider, model_batch=batch_size)
 
     def dockE3(self, ureceptor, uligand, batch_size):
         """Docker.py:135-182: the ligand is rotated in coordinate space and re-projected and
         re-represented every batch (the plugin's cost), then scored by the same kernels: the fused
-        engine takes the batch's volumes as they are (no volume rotation), stand-alone ops otherwise."""
+        engine takes the batch's volumes as they are (no volume rotation); the stand-alone ops, or a
+        call of the model itself, where the engine has no layout for the model (see dock_volumes)."""
         be = self._need_backend()
         from deeplocalproteindocking_amd.ops import VolumeConvolution, filter_volumes
         self.top_list = []
@@ -331,26 +422,31 @@ class Docker:
             rcoords = be.rotate(rcoords, self.randR, rnatoms)
         rcoords = be.translate(rcoords, self.box_center, rnatoms)
         ids = self.shard(self.rot.R.shape[0])
+        L = self.box_size
         with torch.no_grad():
-            receptor = be.project(rcoords, rnat, roff, self.box_size, self.resolution, dev)
+            receptor = be.project(rcoords, rnat, roff, L, self.resolution, dev)
             receptor_volumes = model.representation(receptor)
             lc, ln, lo = be.to_device(lcoords, lnat, loff, dev)
-            eng = self._make_engine([v.reshape((-1,) + tuple(v.shape[-3:])) for v in receptor_volumes],
-                                    receptor.sum(dim=1)[0], batch_size)
+            rec = [v.reshape((-1,) + tuple(v.shape[-3:])) for v in receptor_volumes]
+            params = fused_filter_parameters(model)
+            eng = self._make_engine(rec, receptor.sum(dim=1)[0], self.launch_batch, params)
+            self.path = "fused" if eng is not None else ("ops" if self._ops_path_ok(rec, params) else "call")
+            nbatch = self.launch_batch if self.path != "call" else int(batch_size)
             if eng is not None:
                 eng.reset_top()
             else:
-                conv_noclip = VolumeConvolution()
-                top = DeviceTopList(self.max_conf, batch_size, dev, self._library())
+                conv_noclip = VolumeConvolution(lib=self._lib)
+                convolve = getattr(model, "convolve", None) or VolumeConvolution(clip=getattr(model, "clip", 5.0),
+                                                                                 lib=self._lib)
+                top = DeviceTopList(self.max_conf, nbatch, dev, self._library())
                 top.reset()
-                W1, b1, W2, b2 = model.filter.parameters_tuple()
                 receptor_forbidden = receptor.sum(dim=1).unsqueeze(dim=1).contiguous()
-            for beg in range(0, len(ids), batch_size):
-                bid = ids[beg:beg + batch_size]
+            for beg in range(0, len(ids), nbatch):
+                bid = ids[beg:beg + nbatch]
                 nb = len(bid)
                 Rb = self.rot.R[bid].to(device=dev, dtype=torch.float32).contiguous()
                 # rotate + translate + project in one kernel (Docker.py:163-165)
-                ligand = be.project(lc, ln, lo, self.box_size, self.resolution, dev, R=Rb, shift=self.box_center)
+                ligand = be.project(lc, ln, lo, L, self.resolution, dev, R=Rb, shift=self.box_center)
                 ligand_volumes = model.representation(ligand)
                 bid_dev = torch.as_tensor(bid, dtype=torch.int32).to(dev)
                 if eng is not None:
@@ -359,10 +455,16 @@ class Docker:
                     continue
                 ligand_forbidden = ligand.sum(dim=1).unsqueeze(dim=1).contiguous()
                 norm = conv_noclip(receptor_forbidden.expand(nb, -1, -1, -1, -1).contiguous(), ligand_forbidden)
+                norm = norm.squeeze(1).contiguous()
                 rec_b = [v.expand(nb, -1, -1, -1, -1).contiguous() for v in receptor_volumes]
-                convolved = [model.convolve(r, l) for r, l in zip(rec_b, ligand_volumes)]
-                V = filter_volumes(convolved, W1, b1, W2, float(b2.reshape(-1)[0]),
-                                   mask_norm=norm.squeeze(1).contiguous(), threshold=model.threshold_clash)
+                if self.path == "ops":
+                    W1, b1, W2, b2 = params
+                    convolved = [convolve(r, l) for r, l in zip(rec_b, ligand_volumes)]
+                    V = filter_volumes(convolved, W1, b1, W2, float(b2.reshape(-1)[0]), mask_norm=norm,
+                                       threshold=model.threshold_clash, lib=self._lib)
+                else:                                              # Docker.py:171-175 with the model called
+                    V = model(rec_b, ligand_volumes).reshape(nb, 2 * L, 2 * L, 2 * L).to(torch.float32)
+                    V = (torch.lt(norm, model.threshold_clash).to(dtype=torch.float32) * V).contiguous()
                 top.select(V.reshape(nb, -1), nb)
                 top.merge(bid_dev, nb)
         entries = self._gather(eng.top_entries() if eng is not None else top.entries())

@@ -7,8 +7,10 @@ carry over: ``SimpleFilter(inputs_sizes)`` owns ``fc = [Linear(C, C//2), ReLU, L
 and ``save/load(directory, epoch)`` writing ``<name>_repr_epochN.th`` / ``<name>_filter_epochN.th``.
 
 What differs is where the arithmetic runs: ``forward`` is one VolumeConvolution(clip) per resolution
-(HIP K1+K2+K3) and ONE kernel for nearest-upsample + concat + MLP, instead of interpolate / cat /
-three transposes / two GEMMs (DockingModels.py:74-83).
+(HIP K1+K2+K3) and, for the reference's MLP filter, ONE kernel for nearest-upsample + concat + MLP
+instead of interpolate / cat / three transposes / two GEMMs (DockingModels.py:74-83).  ``filter`` may
+be ANY module mapping (voxels, channels) -> (voxels, 1) (DockingModels.py:82): a filter that is not
+that MLP is called on the reference's own channels-last layout.
 """
 import os
 
@@ -44,17 +46,50 @@ class SimpleFilter(nn.Module):
         return tuple(t.detach() for t in (first.weight, first.bias, last.weight, last.bias))
 
 
+def mlp_parameters(filt):
+    """(W1 (H,C), b1 (H), W2 (1,H), b2 (1)) when ``filt`` is the reference's SimpleFilter
+    (DockingModels.py:23-37: ``fc = [Linear(C,H), ReLU, Linear(H,1)]`` applied as is) -- this build's
+    class or a same-named class of the same structure, e.g. the reference's own; None for any other
+    module, which then has to be called."""
+    if hasattr(filt, "parameters_tuple"):
+        return filt.parameters_tuple()
+    fc = getattr(filt, "fc", None)
+    if (type(filt).__name__ == "SimpleFilter" and isinstance(fc, nn.Sequential) and len(fc) == 3
+            and isinstance(fc[0], nn.Linear) and isinstance(fc[1], nn.ReLU) and isinstance(fc[2], nn.Linear)
+            and fc[2].out_features == 1 and fc[0].bias is not None and fc[2].bias is not None):
+        return tuple(t.detach() for t in (fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias))
+    return None
+
+
+def fused_filter_parameters(model):
+    """Filter parameters when ``model(receptor_volumes, ligand_volumes)`` (Docker.py:229) IS the
+    reference's ``GlobalDockingModel.forward`` (DockingModels.py:63-84: per-channel correlation,
+    nearest upsample, concat) followed by an MLP filter -- what the fused kernels compute; None when
+    the model brings a forward of its own or another filter, and therefore must be called."""
+    cls = type(model)
+    fwd = getattr(cls, "forward", None)
+    has_own_call = (isinstance(model, nn.Module) and fwd is not None and fwd is not nn.Module.forward
+                    and fwd is not getattr(nn.Module, "_forward_unimplemented", None)) or \
+                   (not isinstance(model, nn.Module) and callable(model))
+    if has_own_call and fwd is not GlobalDockingModel.forward:
+        return None
+    filt = getattr(model, "filter", None)
+    return None if filt is None else mlp_parameters(filt)
+
+
 class GlobalDockingModel(nn.Module):
     FILES = ("%s_repr_epoch%d.th", "%s_filter_epoch%d.th")
 
     def __init__(self, representation, filter, threshold_clash=300, normalize=False, rotate_ligand=False,
-                 exclude_clashes=True, clip=5.0):
+                 exclude_clashes=True, clip=5.0, lib=None):
+        """lib: None -> the product library (GPU); the test-suite passes the emulated one."""
         super().__init__()
         self.representation, self.filter = representation, filter
         self.threshold_clash, self.clip = threshold_clash, clip
         self.normalize, self.rotate_ligand, self.exclude = normalize, rotate_ligand, exclude_clashes
-        self.convolve = VolumeConvolution(clip=clip)
-        self.vol_rotate = VolumeRotation()
+        self.convolve = VolumeConvolution(clip=clip, lib=lib)
+        self.vol_rotate = VolumeRotation(lib=lib)
+        self._lib = lib
 
     def _paths(self, directory, epoch, model_name):
         return [os.path.join(directory, pattern % (model_name, epoch)) for pattern in self.FILES]
@@ -70,5 +105,12 @@ class GlobalDockingModel(nn.Module):
     def forward(self, receptor_volumes, ligand_volumes):
         """Lists of (B, C_i, L_i, L_i, L_i) per resolution -> scores (B, 2L_0, 2L_0, 2L_0)."""
         correlations = [self.convolve(rec, lig) for rec, lig in zip(receptor_volumes, ligand_volumes)]
-        W1, b1, W2, b2 = self.filter.parameters_tuple()
-        return filter_volumes(correlations, W1, b1, W2, float(b2.reshape(-1)[0]))
+        params = mlp_parameters(self.filter)
+        if params is not None and params[0].shape[0] <= 64 and len(correlations) <= 2:
+            W1, b1, W2, b2 = params
+            return filter_volumes(correlations, W1, b1, W2, float(b2.reshape(-1)[0]), lib=self._lib)
+        # any other filter module: the reference's data movement (DockingModels.py:74-83), then the module
+        B, N = correlations[0].shape[0], correlations[0].shape[2]
+        same = [c if c.shape[2] == N else nn.functional.interpolate(c, size=(N, N, N)) for c in correlations]
+        V = torch.cat(same, dim=1).permute(0, 2, 3, 4, 1).reshape(B * N * N * N, -1)
+        return self.filter(V).reshape(B, N, N, N)

@@ -6,15 +6,20 @@ superset:
     ``oim06.eul`` (what the reference actually ships in data/), so angle_inc 6 and 8 load;
   * N comes from the file's line count, not from the table at Rotations.py:42-55;
   * the matrix fill is vectorised (the reference writes 9 tensor elements per row from Python);
-  * when no file exists for ``angle_inc`` (e.g. 4 degrees: data/oim04.eul is absent from the
-    reference, .MISSING_LARGE_BLOBS:1) a deterministic substitute set is generated with the
-    same structure and size as the SOI files: round(41253/inc^2) Fibonacci-sphere directions
-    (theta, psi) x (360/inc) uniform in-plane angles phi.  ``self.source`` says which was used.
+  * when no file exists for ``angle_inc`` the loader raises "Can't find rotation angles" exactly
+    like Rotations.py:41,55 -- UNLESS the caller opts in (``allow_generated=True``, or
+    ``DLPD_ALLOW_GENERATED_ROTATIONS=1`` in the environment): then a deterministic substitute set
+    is generated with the same structure and size as the SOI files (round(41253/inc^2)
+    Fibonacci-sphere directions (theta, psi) x (360/inc) uniform in-plane angles phi; e.g. 4
+    degrees, whose data/oim04.eul is absent from the reference, .MISSING_LARGE_BLOBS:1), a
+    warning is issued and ``self.source`` is "generated".  Poses of a generated set are not
+    comparable with the reference's rotation indices, hence never silently.
 The SOI data files carry MitchellLab's licence (reference README.md:63) and are not
 redistributed here: point ``DLPD_ROTATIONS_DIR`` at a directory holding them.
 """
 import math
 import os
+import warnings
 
 import numpy as np
 import torch
@@ -83,14 +88,16 @@ def find_rotation_file(angle_inc):
 
 
 class Rotations(object):
-    def __init__(self, angle_inc=12, allow_generated=True, verbose=True):
+    def __init__(self, angle_inc=12, allow_generated=None, verbose=True):
         self.angle_inc = angle_inc
+        if allow_generated is None:
+            allow_generated = os.environ.get("DLPD_ALLOW_GENERATED_ROTATIONS", "") not in ("", "0")
         self.loadSOI(angle_inc, allow_generated)
         if verbose:
             print("Angle increment:", angle_inc)
             print("Number of rotations:", self.R.size(0), "(%s)" % self.source)
 
-    def loadSOI(self, angle_inc, allow_generated=True):
+    def loadSOI(self, angle_inc, allow_generated=False):
         filename = find_rotation_file(angle_inc)
         if filename is not None:
             ang = np.loadtxt(filename, dtype=np.float64).reshape(-1, 3)
@@ -98,6 +105,9 @@ class Rotations(object):
         elif allow_generated:
             ang = generate_angles(angle_inc)
             self.source = "generated"
+            warnings.warn("dlpd: no SOI rotation file for angle_inc=%s (DLPD_ROTATIONS_DIR / data/): using a GENERATED "
+                          "substitute set of %d rotations -- rotation indices are not the reference's" %
+                          (angle_inc, ang.shape[0]))
         else:
             raise Exception("Can't find rotation angles:", angle_inc)
         self.angles = ang

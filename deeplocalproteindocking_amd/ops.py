@@ -17,25 +17,28 @@ from ._lib import get_lib
 from .engine import _ptr, _stream
 
 
-def _check(t, name):
-    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32):
+def _check(t, name, lib=None):
+    """lib: None -> the product library, GPU tensors only (no CPU path); the test-suite passes the
+    emulated library, which takes host pointers."""
+    if not (isinstance(t, torch.Tensor) and (t.is_cuda or lib is not None) and t.dtype == torch.float32):
         raise RuntimeError("dlpd: %s must be a float32 CUDA (ROCm) tensor; there is no CPU path" % name)
     return t.contiguous()
 
 
 class VolumeRotation(nn.Module):
-    def __init__(self, center=None):
+    def __init__(self, center=None, lib=None):
         super().__init__()
         self.center = center
+        self.lib = lib
 
     def forward(self, volume, R):
-        volume, R = _check(volume, "volume"), _check(R, "R")
+        volume, R = _check(volume, "volume", self.lib), _check(R, "R", self.lib)
         B, C, L = volume.shape[0], volume.shape[1], volume.shape[2]
         if R.shape[0] != B:
             raise RuntimeError("dlpd: VolumeRotation batch mismatch: volume %d vs R %d" % (B, R.shape[0]))
         out = torch.empty_like(volume)
         c0 = float(L) / 2.0 if self.center is None else float(self.center)
-        get_lib().call("dlpd_rotate_trilinear", _ptr(volume), _ptr(R), _ptr(out), B, C, L, C * L ** 3, c0,
+        (self.lib or get_lib()).call("dlpd_rotate_trilinear", _ptr(volume), _ptr(R), _ptr(out), B, C, L, C * L ** 3, c0,
                        _stream(volume.device))
         return out
 
@@ -44,16 +47,17 @@ class VolumeConvolution(nn.Module):
     """Per-channel circular cross-correlation on the 2L zero-padded grid:
     out[b,c,t mod 2L] = sum_r v1[b,c,r+t] * v2[b,c,r]  (semantics: MultiplyVolumes.py:13-47)."""
 
-    def __init__(self, clip=None):
+    def __init__(self, clip=None, lib=None):
         super().__init__()
         self.clip = clip
+        self.lib = lib
 
     def forward(self, input_volume1, input_volume2):
-        v1, v2 = _check(input_volume1, "volume1"), _check(input_volume2, "volume2")
+        v1, v2 = _check(input_volume1, "volume1", self.lib), _check(input_volume2, "volume2", self.lib)
         if v1.shape != v2.shape:
             raise RuntimeError("dlpd: VolumeConvolution shape mismatch %s vs %s" % (tuple(v1.shape), tuple(v2.shape)))
         B, C, L = v1.shape[0], v1.shape[1], v1.shape[2]
-        lib = get_lib()
+        lib = self.lib or get_lib()
         if not lib.call("dlpd_grid_supported", L):
             raise RuntimeError("dlpd: VolumeConvolution box size %d not compiled (supported: 32, 40, 64, 80)" % L)
         N, NZ, nvol = 2 * L, L + 1, B * C
@@ -70,15 +74,15 @@ class VolumeConvolution(nn.Module):
         return out
 
 
-def filter_volumes(conv_list, W1, b1, W2, b2, mask_norm=None, threshold=0.0):
+def filter_volumes(conv_list, W1, b1, W2, b2, mask_norm=None, threshold=0.0, lib=None):
     """Nearest-upsample + concat + SimpleFilter MLP (+ optional clash mask) on materialised
     correlation volumes -- DockingModels.py:74-83, Docker.py:226,232.  conv_list: one or two
     tensors (B,C_i,N_i,N_i,N_i), N_0 the finest."""
-    c0 = _check(conv_list[0], "conv0")
+    c0 = _check(conv_list[0], "conv0", lib)
     B, C0, N0 = c0.shape[0], c0.shape[1], c0.shape[2]
     if len(conv_list) > 2:
         raise RuntimeError("dlpd: at most two resolutions are supported")
-    c1 = _check(conv_list[1], "conv1") if len(conv_list) == 2 else None
+    c1 = _check(conv_list[1], "conv1", lib) if len(conv_list) == 2 else None
     C1, N1 = (c1.shape[1], c1.shape[2]) if c1 is not None else (0, 0)
     dev = c0.device
     H = W1.shape[0]
@@ -88,8 +92,8 @@ def filter_volumes(conv_list, W1, b1, W2, b2, mask_norm=None, threshold=0.0):
     V = torch.empty(B, N0, N0, N0, dtype=torch.float32, device=dev)
     has_clash = mask_norm is not None
     if has_clash:
-        mask_norm = _check(mask_norm, "mask_norm")
-    get_lib().call("dlpd_filter_mask", _ptr(c0), C0, N0, _ptr(c1), C1, N1, _ptr(mask_norm), float(threshold),
+        mask_norm = _check(mask_norm, "mask_norm", lib)
+    (lib or get_lib()).call("dlpd_filter_mask", _ptr(c0), C0, N0, _ptr(c1), C1, N1, _ptr(mask_norm), float(threshold),
                    int(has_clash), _ptr(W1t), _ptr(b1), _ptr(W2), float(b2), H, _ptr(V), B, _stream(dev))
     return V
 

@@ -319,6 +319,29 @@ def project_atoms(coords, num_atoms_of_type, offsets, L, resolution, R=None, shi
     return out
 
 
+def project_atoms_fast(coords, num_atoms_of_type, offsets, L, resolution, R=None, shift=None, sum_types=False):
+    """Same definition as project_atoms, vectorised over atoms (numpy, float64) for protein-sized
+    inputs; tests/test_oracle_golden.py checks it against the loop on a small case."""
+    T = len(num_atoms_of_type)
+    out = np.zeros((1 if sum_types else T, L * L * L), dtype=np.float64)
+    xyz = np.asarray(coords, dtype=np.float64).reshape(-1, 3)
+    R = np.eye(3) if R is None else np.asarray(R, dtype=np.float64)
+    shift = np.zeros(3) if shift is None else np.asarray(shift, dtype=np.float64).reshape(3)
+    off = np.arange(-2, 3)
+    di, dj, dk = (a.reshape(-1) for a in np.meshgrid(off, off, off, indexing="ij"))
+    for t in range(T):
+        a0, n = int(offsets[t]), int(num_atoms_of_type[t])
+        if n == 0:
+            continue
+        p = xyz[a0:a0 + n] @ R.T + shift                        # (n,3)
+        c = np.floor(p / resolution).astype(np.int64)
+        i, j, k = c[:, 0:1] + di[None], c[:, 1:2] + dj[None], c[:, 2:3] + dk[None]      # (n,125)
+        ok = (i >= 0) & (i < L) & (j >= 0) & (j < L) & (k >= 0) & (k < L)
+        d2 = (p[:, 0:1] - i * resolution) ** 2 + (p[:, 1:2] - j * resolution) ** 2 + (p[:, 2:3] - k * resolution) ** 2
+        np.add.at(out[0 if sum_types else t], ((i * L + j) * L + k)[ok], np.exp(-0.5 * d2)[ok])
+    return out.reshape(-1, L, L, L)
+
+
 # --------------------------------------------------------------------------------------
 # Whole search (Docker.dockSE3 loop, Docker.py:211-238) on volumes
 # --------------------------------------------------------------------------------------

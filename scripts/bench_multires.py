@@ -16,7 +16,7 @@ model = GlobalDockingModel(repr_, SimpleFilter(repr_.get_num_outputs()), thresho
 rec, lig = repr_.make(L, "rec"), repr_.make(L, "lig")
 g = torch.Generator().manual_seed(2)
 recf, ligf = torch.rand(L, L, L, generator=g), torch.rand(L, L, L, generator=g)
-R = Rotations(15, verbose=False).R.numpy()[:nrot]
+R = Rotations(15, allow_generated=True, verbose=False).R.numpy()[:nrot]
 dk = Docker(model, box_size=L, max_conf=K, rotations=R, device=dev)
 dk.dock_volumes(rec, lig, recf, ligf, batch_size=nb, write=False, rot_indices=np.arange(nb))
 torch.cuda.synchronize(); t = time.time()

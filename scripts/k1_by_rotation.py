@@ -14,7 +14,7 @@ g = torch.Generator().manual_seed(0)
 eng = DockingEngine(L, C, torch.randn(24, C, generator=g), torch.randn(24, generator=g), torch.randn(1, 24, generator=g),
                     torch.randn(1, generator=g), max_conf=2000, batch=nb, device=dev)
 eng.set_ligand(torch.randn(C, L, L, L, generator=g), torch.rand(L, L, L, generator=g))
-R = Rotations(6, verbose=False).R.numpy()
+R = Rotations(6, allow_generated=True, verbose=False).R.numpy()
 tr = DockingEngine.prefers_transposed(R)
 inplane = np.maximum(np.where(tr, np.abs(R[:, 0, 2]), np.abs(R[:, 1, 2])), np.abs(R[:, 2, 2]))   # best in-plane |source z|
 zdom = np.abs(R[:, 2, 2]) >= np.where(tr, np.abs(R[:, 0, 2]), np.abs(R[:, 1, 2]))

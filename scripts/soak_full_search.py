@@ -13,7 +13,7 @@ dev = torch.device("cuda:0")
 C, L, K = 48, 64, 2000
 rec, lig, recf, ligf, filt = bench.synthetic_pair(C, L)
 thr = bench.clash_threshold(recf, ligf)
-R = Rotations(6, verbose=False).R
+R = Rotations(6, allow_generated=True, verbose=False).R
 lists = []
 for nb in (16, 16, 12):
     eng = DockingEngine(L, C, *filt.parameters_tuple(), clip=5.0, threshold_clash=thr, max_conf=K, batch=nb, device=dev)

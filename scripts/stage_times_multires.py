@@ -18,7 +18,7 @@ eng = DockingEngine(L, C0, torch.randn(H, C0 + C1, generator=g), torch.randn(H, 
 coarse = lambda: torch.randn(C1, 40, 40, 40, generator=g) if C1 else None
 eng.set_receptor(torch.randn(C0, L, L, L, generator=g), torch.rand(L, L, L, generator=g), coarse())
 eng.set_ligand(torch.randn(C0, L, L, L, generator=g), torch.rand(L, L, L, generator=g), coarse())
-R = Rotations(15, verbose=False).R[:nb].to(device=dev, dtype=torch.float32).contiguous()
+R = Rotations(15, allow_generated=True, verbose=False).R[:nb].to(device=dev, dtype=torch.float32).contiguous()
 ids = torch.arange(nb, dtype=torch.int32, device=dev)
 tm = StageTimer()
 for it in range(6):

@@ -117,6 +117,56 @@ def test_projection_kernel_matches_oracle(emu, tmp_path):
     assert np.abs(plain[0].numpy() - want).max() < 1e-4
 
 
+def _protein_typed(tmp_path, nres, seed, nchains=2):
+    from synth_pdb import write_protein_like_pdb
+    f = str(tmp_path / ("prot%d.pdb" % seed))
+    kept = write_protein_like_pdb(f, nres, seed, nchains=nchains)
+    be = CoordsBackend()
+    coords, ch, rn, ri, an, nat = be.pdb2coords([f])
+    typed, counts, offs = be.assign_types(coords, rn, an, nat)
+    assert int(counts.sum()) == kept and len(set(ch[0])) == nchains      # H / HETATM / altloc B / MODEL 2 dropped
+    a, b = be.get_bbox(typed, be.last_num_typed)
+    return f, be.translate(typed, -(a + b) * 0.5, be.last_num_typed), counts, offs
+
+
+def test_reader_on_a_protein_sized_file(tmp_path):
+    """Thousands of atoms, two chains, negative residue numbers, insertion codes, ANISOU, altloc,
+    HETATM, a second MODEL: only first-model heavy ATOM records with altloc ' '/'A' are typed."""
+    f, coords, counts, offs = _protein_typed(tmp_path, 260, seed=11)
+    assert int(counts.sum()) > 2000 and (counts > 0).all()
+    xyz, chains, resn, resi, atn = read_pdb_atoms(f)
+    assert min(resi) < 0 and "HOH" not in resn and "ZN" not in [r.strip() for r in resn]
+    assert np.abs(xyz).max() < 45.0                                  # MODEL 2 (at +50 A) not read
+
+
+@pytest.mark.gpu
+def test_projection_kernel_matches_oracle_on_gpu_protein_sized(tmp_path):
+    """dlpd_project_atoms on the device, directly against the oracle (not through ranked lists): a
+    2,200-atom two-chain globule at the reference's box (80 / 1.25 A), rotated on the fly, per type and
+    summed; plus bit-identical repeat runs (fixed-point accumulation)."""
+    import __graft_entry__ as entry
+    entry.build()
+    dev = torch.device("cuda:0")
+    L, res = 80, 1.25
+    _, coords, counts, offs = _protein_typed(tmp_path, 260, seed=12)
+    be = CoordsBackend()
+    centre = torch.full((1, 3), L * res / 2.0, dtype=torch.double)
+    R = torch.from_numpy(orc.euler_to_matrix([0.0, 0.4, -2.0], [0.0, 1.0, 0.3], [0.0, -0.7, 1.9])).float()
+    vol = be.project(coords, counts, offs, L, res, dev, R=R.to(dev), shift=centre)
+    assert vol.shape == (3, NUM_ATOM_TYPES, L, L, L)
+    for b in range(3):
+        want = orc.project_atoms_fast(coords[0].numpy(), counts[0].numpy(), offs[0].numpy(), L, res,
+                                      R=R[b].double().numpy(), shift=centre[0].numpy())
+        err = np.abs(vol[b].cpu().numpy() - want).max()
+        assert err < 2e-5 * max(1.0, want.max()), err                 # f32 expf + 2^-24 fixed point vs f64
+        assert want.sum() > 1000 and want.max() < 4.0
+    s = be.project(coords, counts, offs, L, res, dev, R=R.to(dev), shift=centre, sum_types=True)
+    assert (s[:, 0] - vol.sum(dim=1)).abs().max() < 1e-5
+    for _ in range(3):                                               # run-to-run: bit-identical
+        again = be.project(coords, counts, offs, L, res, dev, R=R.to(dev), shift=centre)
+        assert torch.equal(again, vol)
+
+
 class _TinyRepr(torch.nn.Module):
     """single-resolution stand-in for a representation plugin: fixed random 11 -> C 3x3x3 conv"""
 
@@ -239,7 +289,8 @@ def test_dockSE3_end_to_end_emulated(emu, tmp_path):
     model = _Model(_TinyRepr(4), SimpleFilter([4]), thr=3.0)
     R = orc.euler_to_matrix([0.3, -1.0, 2.0], [1.1, 0.4, 2.2], [-2.0, 2.5, 0.1])
     be = CoordsBackend(lib=emu)
-    dk = Docker(model, box_size=L, resolution=res, max_conf=K, rotations=R, device="cpu", coords_backend=be, lib=emu)
+    # no coords_backend argument, as in the reference's constructor: Docker creates its own
+    dk = Docker(model, box_size=L, resolution=res, max_conf=K, rotations=R, device="cpu", lib=emu)
     log = str(tmp_path / "out.dat")
     assert dk.new_log(log)
     with torch.no_grad():
@@ -252,6 +303,135 @@ def test_dockSE3_end_to_end_emulated(emu, tmp_path):
     lines = open(log).read().strip().split("\n")
     assert len(lines) == K and all(len(l.split("\t")) == 13 for l in lines)
     assert dk.new_log(log, rewrite=False) is False              # finished target is skipped on resume
+
+
+class _GatedFilter(torch.nn.Module):
+    """A user-defined filter (NOT the reference's Linear-ReLU-Linear): any module mapping
+    (voxels, channels) -> (voxels, 1) must work as ``docking_model.filter`` (DockingModels.py:82)."""
+
+    def __init__(self, C):
+        super().__init__()
+        self.a, self.b = torch.nn.Linear(C, 3), torch.nn.Linear(C, 3)
+
+    def forward(self, x):
+        return (torch.tanh(self.a(x)) * self.b(x)).sum(dim=-1, keepdim=True)
+
+
+def _oracle_list_with_filter(rv, lv, recf, ligf, R, filt, thr, K, clip=5.0):
+    """Reference loop (Docker.py:211-236) with GlobalDockingModel.forward's data movement
+    (DockingModels.py:70-83) and an arbitrary filter module."""
+    top, scale = [], 0.0
+    L = rv[0].shape[-1]
+    N = 2 * L
+    for ri in range(R.shape[0]):
+        Rb = torch.from_numpy(R[ri:ri + 1]).float()
+        conv = []
+        for r, l in zip(rv, lv):
+            c = orc.correlate_fft(r, orc.rotate_volume(l, Rb), clip=clip)
+            if c.shape[2] < N:
+                s = N // c.shape[2]
+                c = c.repeat_interleave(s, 2).repeat_interleave(s, 3).repeat_interleave(s, 4)
+            conv.append(c)
+        feat = torch.cat(conv, dim=1).permute(0, 2, 3, 4, 1).reshape(N * N * N, -1)
+        with torch.no_grad():
+            V = filt(feat).reshape(1, N, N, N)
+        mask, _ = orc.clash_mask(recf[None, None], orc.rotate_volume(ligf[None, None], Rb), thr)
+        V = (mask * V)[0].contiguous()
+        scale = max(scale, float(V.abs().max()))
+        idx, sc = orc.rotation_picks_fast(V.numpy(), K)
+        x, y, z = orc.flat_to_xyz(idx, N)
+        top += [(ri, int(x[i]), int(y[i]), int(z[i]), float(sc[i])) for i in range(K)]
+        top.sort(key=lambda t: t[4])
+        top = top[:K]
+    return top, scale
+
+
+def _volume_case(seed, C=4, L=32):
+    g = torch.Generator().manual_seed(seed)
+    rec, lig = torch.randn(1, C, L, L, L, generator=g) * 0.1, torch.randn(1, C, L, L, L, generator=g) * 0.1
+    recf, ligf = torch.rand(L, L, L, generator=g), torch.rand(L, L, L, generator=g)
+    R = orc.euler_to_matrix([0.3, -1.0, 2.0], [1.1, 0.4, 2.2], [-2.0, 2.5, 0.1])
+    return rec, lig, recf, ligf, R
+
+
+def _check_lists(got, want, scale, K):
+    assert len(got) == len(want) == K
+    assert max(abs(a[4] - b[4]) for a, b in zip(got, want)) <= 1e-4 * scale
+    assert sum(a[:4] == b[:4] for a, b in zip(got, want)) >= K - 2
+
+
+def _run_user_filter(lib, device):
+    """Docker.py:229: ``V = self.docking_model(rec, lig_rot)`` really calls the user's module."""
+    from deeplocalproteindocking_amd.Docker import Docker
+    from deeplocalproteindocking_amd.Models import GlobalDockingModel, SyntheticRepr
+    L, C, K, thr = 32, 4, 25, 4000.0
+    rec, lig, recf, ligf, R = _volume_case(31, C, L)
+    torch.manual_seed(5)
+    filt = _GatedFilter(C)
+    model = GlobalDockingModel(SyntheticRepr((C,)), filt, threshold_clash=thr, lib=lib)
+    want, scale = _oracle_list_with_filter([rec], [lig], recf, ligf, R, filt, thr, K)
+    dk = Docker(model.to(device), box_size=L, max_conf=K, rotations=R, device=device, lib=lib)
+    got = dk.dock_volumes([rec], [lig], recf, ligf, write=False, model_batch=2)
+    assert dk.path == "call"
+    _check_lists(got, want, scale, K)
+
+    class OwnForward(torch.nn.Module):                     # a docking model with a forward of its own
+        def __init__(self, inner):
+            super().__init__()
+            self.inner, self.representation, self.filter = inner, inner.representation, inner.filter
+            self.threshold_clash, self.calls = inner.threshold_clash, 0
+
+        def forward(self, receptor_volumes, ligand_volumes):
+            self.calls += 1
+            return 2.0 * self.inner(receptor_volumes, ligand_volumes)
+    own = OwnForward(model)
+    dk2 = Docker(own, box_size=L, max_conf=K, rotations=R, device=device, lib=lib)
+    got2 = dk2.dock_volumes([rec], [lig], recf, ligf, write=False, model_batch=2)
+    assert dk2.path == "call" and own.calls == 2            # 3 rotations, 2 per call
+    assert [t[:4] for t in got2] == [t[:4] for t in got]
+    assert max(abs(a[4] - 2.0 * b[4]) for a, b in zip(got2, got)) <= 1e-5 * scale
+
+
+def test_user_defined_filter_and_model_are_called_emulated(emu):
+    _run_user_filter(emu, "cpu")
+
+
+@pytest.mark.gpu
+def test_user_defined_filter_and_model_are_called_on_gpu():
+    import __graft_entry__ as entry
+    entry.build()
+    _run_user_filter(None, torch.device("cuda:0"))
+
+
+def _run_wide_hidden(lib, device):
+    """Hidden width 40 > 32 (the fused K3 pads to at most 32; the class default multiplier=16 gives
+    48): the search must take the stand-alone ops + HIP filter kernel instead of raising."""
+    from deeplocalproteindocking_amd.Docker import Docker
+    from deeplocalproteindocking_amd.Models import GlobalDockingModel, SimpleFilter, SyntheticRepr
+    L, C, K, thr = 32, 4, 25, 4000.0
+    rec, lig, recf, ligf, R = _volume_case(32, C, L)
+    torch.manual_seed(6)
+    filt = SimpleFilter([C])
+    filt.fc[0], filt.fc[2] = torch.nn.Linear(C, 40), torch.nn.Linear(40, 1)
+    model = GlobalDockingModel(SyntheticRepr((C,)), filt, threshold_clash=thr, lib=lib)
+    W = [w.cpu() for w in filt.parameters_tuple()]
+    want = orc.dock_volumes([rec], [lig], recf[None, None], ligf[None, None], R, *W, thr, K, clip=5.0, return_V=True)
+    scale = max(float(v.abs().max()) for v in want[1])
+    dk = Docker(model.to(device), box_size=L, max_conf=K, rotations=R, device=device, lib=lib)
+    got = dk.dock_volumes([rec], [lig], recf, ligf, write=False)
+    assert dk.path == "ops"
+    _check_lists(got, want[0], scale, K)
+
+
+def test_hidden_width_above_32_takes_the_ops_path_emulated(emu):
+    _run_wide_hidden(emu, "cpu")
+
+
+@pytest.mark.gpu
+def test_hidden_width_above_32_takes_the_ops_path_on_gpu():
+    import __graft_entry__ as entry
+    entry.build()
+    _run_wide_hidden(None, torch.device("cuda:0"))
 
 
 @pytest.mark.gpu

@@ -286,7 +286,7 @@ def test_baseline_config1_full_rotation_set(dev):
     C, L, K = 4, 32, 1000
     rec, lig, recf, ligf, filt = bench.synthetic_pair(C, L)
     thr = bench.clash_threshold(recf, ligf)
-    rot = Rotations(20, verbose=False)
+    rot = Rotations(20, allow_generated=True, verbose=False)
     assert rot.R.shape[0] == 1854
     model = GlobalDockingModel(SyntheticRepr((C,)), filt, threshold_clash=thr).to(dev)
     dk = Docker(model, angle_inc=20, box_size=L, max_conf=K, rotations=rot.R.numpy(), device=dev)

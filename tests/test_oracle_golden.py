@@ -136,3 +136,17 @@ def test_dock_volumes_faithful_equals_fast():
     a = orc.dock_volumes([rec], [lig], rf, lf, R, W1, b1, W2, b2, 40.0, 25, faithful_topk=True)
     b = orc.dock_volumes([rec], [lig], rf, lf, R, W1, b1, W2, b2, 40.0, 25, faithful_topk=False)
     assert a == b
+
+
+def test_vectorised_projection_equals_the_loop_definition():
+    """project_atoms_fast (used for protein-sized inputs) against the per-atom loop it restates."""
+    rng = np.random.RandomState(4)
+    counts = np.array([3, 0, 2, 1, 0, 4, 1, 0, 2, 3, 5])
+    offs = np.cumsum(counts) - counts
+    xyz = rng.uniform(-9.0, 9.0, size=(int(counts.sum()), 3))
+    xyz[0] = [-14.9, 0.0, 14.9]                                     # splats clipped by the box faces
+    R = orc.euler_to_matrix(0.4, 1.0, -0.7)
+    for kw in (dict(), dict(R=R, shift=[15.0, 15.0, 15.0]), dict(R=R, shift=[15.0, 15.0, 15.0], sum_types=True)):
+        a = orc.project_atoms(xyz.reshape(-1), counts, offs, 24, 1.25, **kw)
+        b = orc.project_atoms_fast(xyz.reshape(-1), counts, offs, 24, 1.25, **kw)
+        assert a.shape == b.shape and np.abs(a - b).max() < 1e-12 and a.sum() > 1.0
