@@ -1,25 +1,40 @@
 #!/usr/bin/env python3
 """Benchmark of the rotation x translation correlation search (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of `--batch` rotations of a synthetic
-48-channel 64^3 pair (BASELINE config 2: oim06-sized rotation set, max_conf=2000): trilinear
-rotation + z R2C (K1), per-slab 2-D FFT / conj-multiply / 2-D inverse (K2), z C2R + clip + filter MLP
-+ clash mask (K3), per-rotation top-K select and the running global merge.  Inputs are resident in
-HBM before the timed region.  With N ranks every rank scores its own interleaved shard of the
-rotation set (weak scaling: per-GPU work fixed) and the timed region ends with the single all-gather
-of the per-rank top lists and the deterministic merge.
+With N > 1 and no torch.distributed environment this process only SPAWNS the N ranks
+(``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`` as a
+child process, before anything here has touched a GPU), passes their output through and exits with
+their code; started by torch.distributed.run itself (RANK / WORLD_SIZE set) it is one rank.
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" for the dominant kernel (algorithmic
-bytes per launch / its average launch duration measured with HIP events on the launch stream),
-"stages" (ms per launch of every stage), "pipeline" (whole step against SURVEY.md 8(d)'s
-3,080.3 MB/rotation stage-boundary model) and "cpu_baseline" (the CPU oracle = restated reference
-path, timed on this box's host cores on a bounded sample; N=1 only).
+A "step" is one pass of the hot path over one batch of ``--batch`` rotations of a synthetic pair:
+trilinear rotation + z R2C (K1), per-slab 2-D FFT / conj-multiply / 2-D inverse (K2), z C2R + clip +
+filter MLP + clash mask (K3), per-rotation top-K select and the running global merge.  Inputs are
+resident in HBM before the timed region.  The K timed steps are batches SPREAD EVENLY over the rank's
+whole visiting sequence of the rotation set (all four slab-orientation x gather-layout groups, in the
+engine's order), because K1's gather cost depends on the rotation: ``value`` is the sustained
+whole-set rate, the cheaper head of the set is reported beside it (``head_of_set``).  With N ranks
+every rank scores its own interleaved shard (weak scaling: per-GPU work fixed) and the timed region
+ends with the single all-gather of the per-rank top lists and the deterministic merge.
+
+Workloads (``--workload``): ``config2`` (default; BASELINE config 2: 48 ch x 64^3, the configuration
+the metric is quoted on), ``real`` (the reference model's shapes [16 @ 80^3, 32 @ 40^3] -> 160^3,
+configs 4/5), ``c48l80`` (config 5's literal 48 ch x 80^3), ``config1`` (4 ch x 32^3).
+
+Prints ONE JSON line (rank 0): the contract keys plus "roofline" (dominant kernel: algorithmic bytes
+per launch / its average launch duration from HIP events on the launch stream inside the timed
+region), "rooflines" (the same for every stage), "step" (whole step against the bytes the pipeline
+really moves, SURVEY 8(d)'s compulsory floor and its stage-boundary model), "head_of_set",
+"real_shapes" (a short measurement of the N = 160 pipeline, default workload only) and
+"cpu_baseline" (the CPU oracle = restated reference path on this box's host cores, bounded sample,
+N = 1 only, with the parity of the GPU scores on the same rotations).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,38 +42,93 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-STAGE_BOUNDARY_MB_PER_ROT = {(48, 64): 3080.3, (4, 32): 41.6}
+
+# SURVEY.md section 8(d), MB per rotation: stage-boundary model and compulsory floor
+SURVEY_MB_PER_ROT = {"config2": (3080.3, 468.9), "config1": (41.6, 6.1), "c48l80": (6003.7, 913.2),
+                     "real": (3054.6, 392.2)}
+WORKLOADS = {   # name: (C fine, L, C coarse, rotation-set angle, description)
+    "config2": (48, 64, 0, 6, "BASELINE config 2: single synthetic 48-channel 64^3 pair"),
+    "config1": (4, 32, 0, 20, "BASELINE config 1: single synthetic 4-channel 32^3 pair"),
+    "c48l80": (48, 80, 0, 6, "BASELINE config 5 shape: synthetic 48-channel 80^3 pair (grid 160^3)"),
+    "real": (16, 80, 32, 6, "reference model shapes (configs 4/5): synthetic [16 @ 80^3, 32 @ 40^3] pair (grid 160^3)"),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="rotations per step")
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--channels", type=int, default=None, help="override the workload's channel count")
+    ap.add_argument("--box", type=int, default=None, help="override the workload's box size")
+    ap.add_argument("--angle_inc", type=int, default=None)
+    ap.add_argument("--max_conf", type=int, default=2000)
+    ap.add_argument("--cpu_rotations", type=int, default=16,
+                    help="rotations of the CPU baseline sample, spread over the four search groups (0: skip)")
+    ap.add_argument("--no_real_shapes", action="store_true", help="skip the short N = 160 measurement")
+    ap.add_argument("--dry_run", action="store_true",
+                    help="launch plumbing only (gloo, no GPU): every rank joins the group, rank 0 prints a JSON line")
+    return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """Plain ``python bench.py --gpus N``: start the N ranks as a CHILD process tree (never exec from
+    a process that may have initialised the GPU; this one has not), relay the rank-0 JSON line."""
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
 
 
 def synthetic_pair(C, L, seed=0):
     """SURVEY.md 8(d) synthetic inputs: N(0,1) x smooth radial envelope representation volumes,
     relu-blob forbidden volumes, SimpleFilter([C]) after manual_seed(1)."""
+    import torch
     from deeplocalproteindocking_amd.Models import SimpleFilter
-    g = torch.Generator().manual_seed(seed)
-    ar = (torch.arange(L, dtype=torch.float32) - (L - 1) / 2.0) / (L / 2.0)
-    r2 = ar[:, None, None] ** 2 + ar[None, :, None] ** 2 + ar[None, None, :] ** 2
-    env = torch.exp(-1.5 * r2)
-    amp = 206.0 / L ** 1.5              # per-channel correlation std ~2: the +-5 clip bites on the tails only
-    rec = torch.randn(C, L, L, L, generator=g) * env * amp
-    lig = torch.randn(C, L, L, L, generator=g) * env * amp
-
-    def blob(shift):
-        c = torch.tensor(shift, dtype=torch.float32)
-        d2 = (ar[:, None, None] - c[0]) ** 2 + (ar[None, :, None] - c[1]) ** 2 + (ar[None, None, :] - c[2]) ** 2
-        return torch.relu(torch.exp(-2.0 * d2) - 0.2)
-    recf, ligf = blob((0.1, -0.05, 0.0)), blob((-0.05, 0.1, 0.05))
+    rec, lig = synthetic_volumes(C, L, seed)
+    recf, ligf = synthetic_forbidden(L)
     torch.manual_seed(1)
     filt = SimpleFilter([C])
     return rec, lig, recf, ligf, filt
 
 
+def synthetic_volumes(C, L, seed=0):
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    ar = (torch.arange(L, dtype=torch.float32) - (L - 1) / 2.0) / (L / 2.0)
+    r2 = ar[:, None, None] ** 2 + ar[None, :, None] ** 2 + ar[None, None, :] ** 2
+    env = torch.exp(-1.5 * r2)
+    amp = 206.0 / L ** 1.5              # per-channel correlation std ~2-4: the +-5 clip bites on the tails only
+    rec = torch.randn(C, L, L, L, generator=g) * env * amp
+    lig = torch.randn(C, L, L, L, generator=g) * env * amp
+    return rec, lig
+
+
+def synthetic_forbidden(L):
+    import torch
+    ar = (torch.arange(L, dtype=torch.float32) - (L - 1) / 2.0) / (L / 2.0)
+
+    def blob(shift):
+        c = torch.tensor(shift, dtype=torch.float32)
+        d2 = (ar[:, None, None] - c[0]) ** 2 + (ar[None, :, None] - c[1]) ** 2 + (ar[None, None, :] - c[2]) ** 2
+        return torch.relu(torch.exp(-2.0 * d2) - 0.2)
+    return blob((0.1, -0.05, 0.0)), blob((-0.05, 0.1, 0.05))
+
+
 def clash_threshold(recf, ligf):
     """Median of the (unrotated) clash correlation (about half of the grid masked), floored at
     1e-3 of its maximum so the mask never depends on FFT round-off around an exact zero overlap."""
+    import torch
     L = recf.shape[0]
     N = 2 * L
     f = torch.fft.irfftn(torch.fft.rfftn(recf, s=(N, N, N)) * torch.conj(torch.fft.rfftn(ligf, s=(N, N, N))),
@@ -71,6 +141,7 @@ class StageTimer:
         self.events = []
 
     def mark(self, name):
+        import torch
         e = torch.cuda.Event(enable_timing=True)
         e.record()                               # torch's current stream == the launch stream
         self.events.append((name, e))
@@ -98,50 +169,135 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(rec, lig, recf, ligf, W, R, thr, K, nrot_sample, V_gpu=None):
-    """The oracle (restated reference path incl. the reference's update_top loop) on the host."""
+def cpu_baseline(rec, lig, recf, ligf, W, R_sample, group_of, thr, K, V_gpu=None):
+    """The oracle (restated reference path incl. the reference's update_top loop) on the host, on
+    rotations taken from all four search groups; parity of the GPU scores on the same rotations."""
+    import torch
     from oracle import docking_oracle as orc
-    L = rec.shape[-1]
+    L = rec[0].shape[-1]
+    n = R_sample.shape[0]
     torch.set_num_threads(usable_cores())
     t0 = time.time()
-    top, Vs = orc.dock_volumes([rec[None]], [lig[None]], recf[None, None], ligf[None, None], R[:nrot_sample],
-                               *W, thr, K, clip=5.0, faithful_topk=True, return_V=True)
+    top, Vs = orc.dock_volumes([r[None] for r in rec], [l[None] for l in lig], recf[None, None], ligf[None, None],
+                               R_sample, *W, thr, K, clip=5.0, faithful_topk=True, return_V=True)
     dt = time.time() - t0
-    out = {"value": nrot_sample * (2 * L) ** 3 / dt, "unit": "pose scores/s", "cores": torch.get_num_threads(),
-           "kind": "port", "sample": "first %d rotations of the same rotation set and pair, %.1f s" % (nrot_sample, dt)}
+    out = {"value": n * (2 * L) ** 3 / dt, "unit": "pose scores/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": "%d rotations of the same rotation set and pair, %d from each of the four search groups "
+                     "(slab orientation x gather layout), %.1f s; SURVEY 8(d)'s 32 rotations would take about twice "
+                     "the 10-30 s the bench contract allots to this leg" % (n, n // 4, dt)}
     if V_gpu is not None:
-        # parity of the GPU scores on the same rotations: voxels whose clash mask differs (clash
-        # correlation within FFT round-off of the threshold) are counted, not compared
-        errs, flips = [], 0
-        for i in range(nrot_sample):
+        # voxels whose clash mask differs (clash correlation within FFT round-off of the threshold)
+        # are counted, not compared
+        errs, flips, per_group = [], 0, {}
+        for i in range(n):
             same = (V_gpu[i] == 0) == (Vs[i] == 0)
             flips += int((~same).sum())
-            errs.append(float((V_gpu[i] - Vs[i]).abs()[same].max() / Vs[i].abs().max()))
+            e = float((V_gpu[i] - Vs[i]).abs()[same].max() / Vs[i].abs().max())
+            errs.append(e)
+            per_group[group_of[i]] = max(per_group.get(group_of[i], 0.0), e)
         out["parity"] = {"max_err_rel_to_max_abs_score": max(errs), "tolerance": 1e-4,
-                         "mask_flips_at_threshold": flips, "voxels": nrot_sample * (2 * L) ** 3}
+                         "max_err_by_group": per_group, "mask_flips_at_threshold": flips, "voxels": n * (2 * L) ** 3}
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="rotations per step")
-    ap.add_argument("--channels", type=int, default=48)
-    ap.add_argument("--box", type=int, default=64)
-    ap.add_argument("--angle_inc", type=int, default=6)
-    ap.add_argument("--max_conf", type=int, default=2000)
-    ap.add_argument("--cpu_rotations", type=int, default=8, help="rotations of the CPU baseline sample (0: skip)")
-    args = ap.parse_args()
+GROUP_NAMES = ("plain", "quads", "transposed", "transposed+quads")
 
+
+def visiting_sequence(engine_cls, R_all, ids, nb):
+    """This rank's rotations in the order DockingEngine.search visits them: grouped by slab orientation x
+    gather layout (per-launch choices), set order inside a group, whole batches only."""
+    import numpy as np
+    Rn = R_all[ids].numpy()
+    gkey = engine_cls.prefers_transposed(Rn).astype(int) * 2 + engine_cls.prefers_quads(Rn).astype(int)
+    parts, keys = [], []
+    for k in range(4):
+        sel = ids[gkey == k]
+        sel = sel[:len(sel) // nb * nb]
+        parts.append(sel)
+        keys.append(np.full(len(sel), k))
+    return np.concatenate(parts), np.concatenate(keys)
+
+
+def algorithmic_bytes(C, L, C1, nb, K, has_clash=True, unfused=False):
+    """Per-launch algorithmic bytes of every stage (each kernel's compulsory input + output, f32):
+    DESIGN.md section 4."""
+    N, NZ, CT = 2 * L, L + 1, C + (1 if has_clash else 0)
+    alg = {
+        "k1_rotate_zfft": CT * L ** 3 * 4 + nb * CT * NZ * L * L * 8,
+        "k2_xy_corr": nb * CT * NZ * L * L * 8 + CT * NZ * N * N * 8 + nb * CT * NZ * N * N * 8,
+        "topk_select": nb * N ** 3 * 4 + nb * K * 8,
+        "topk_merge": nb * K * 8 + K * 16,
+    }
+    if unfused:
+        alg["k3_zifft"] = nb * CT * NZ * N * N * 8 + nb * CT * N ** 3 * 4
+        alg["filter"] = nb * CT * N ** 3 * 4 + nb * N ** 3 * 4
+        if C1:
+            HP = 24
+            alg["filter"] += nb * C1 * L ** 3 * 4 + 2 * nb * HP * L ** 3 * 4     # pre-activations written + read
+    else:
+        alg["k3_zifft_filter"] = nb * CT * NZ * N * N * 8 + nb * N ** 3 * 4 + (nb * C1 * L ** 3 * 4 if C1 else 0)
+    if C1:
+        L1, N1, NZ1 = L // 2, L, L // 2 + 1
+        alg["coarse"] = (C1 * L1 ** 3 * 4 + 2 * nb * C1 * NZ1 * L1 * L1 * 8 + C1 * NZ1 * N1 * N1 * 8 +
+                         2 * nb * C1 * NZ1 * N1 * N1 * 8 + nb * C1 * N1 ** 3 * 4)
+    return alg
+
+
+def build_workload(name, args, dev):
+    """-> engine (receptor + ligand resident), host copies for the CPU baseline, metadata."""
+    import torch
+    from deeplocalproteindocking_amd.engine import DockingEngine
+    from deeplocalproteindocking_amd.Models import SimpleFilter
+    C, L, C1, angle, desc = WORKLOADS[name]
+    if name == args.workload:
+        C, L = args.channels or C, args.box or L
+    rec0, lig0 = synthetic_volumes(C, L, 0)
+    recf, ligf = synthetic_forbidden(L)
+    rec, lig = [rec0], [lig0]
+    if C1:
+        r1, l1 = synthetic_volumes(C1, L // 2, 1)
+        rec.append(r1)
+        lig.append(l1)
+    torch.manual_seed(1)
+    filt = SimpleFilter([C] + ([C1] if C1 else []))
+    thr = clash_threshold(recf, ligf)
+    W = filt.parameters_tuple()
+    eng = DockingEngine(L, C, *W, clip=5.0, threshold_clash=thr, has_clash=True, max_conf=args.max_conf,
+                        batch=args.batch, device=dev, coarse_channels=C1)
+    eng.set_receptor(rec[0], recf, rec[1] if C1 else None)
+    eng.set_ligand(lig[0], ligf, lig[1] if C1 else None)
+    return eng, dict(C=C, L=L, C1=C1, angle=angle, desc=desc, rec=rec, lig=lig, recf=recf, ligf=ligf, W=W, thr=thr)
+
+
+def time_steps(eng, Rd, idd, tr_of, qd_of, nb, first, count, mark=None):
+    for i in range(first, first + count):
+        sl = slice(i * nb, (i + 1) * nb)
+        eng.step(Rd[sl], idd[sl], mark=mark, transposed=bool(tr_of[i * nb]), quads=bool(qd_of[i * nb]))
+
+
+def dry_run(args):
+    """The launch path without a GPU (CPU test of `python bench.py --gpus N`): rendezvous, one all-reduce."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        assert float(t) == world * (world + 1) / 2
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_rank(args):
+    import numpy as np
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
-                             % (args.gpus, args.gpus))
     import __graft_entry__ as entry
     entry.build()
     # host threads: the synthetic inputs are generated on the CPU by every rank; never oversubscribe the
@@ -149,85 +305,76 @@ def main():
     torch.set_num_threads(max(1, usable_cores() // max(1, world)))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", device_id=dev)
 
-    from deeplocalproteindocking_amd.engine import DeviceTopList, DockingEngine
+    from deeplocalproteindocking_amd.engine import DockingEngine
     from deeplocalproteindocking_amd.Utils.Rotations import Rotations
-    C, L, K, nb = args.channels, args.box, args.max_conf, args.batch
+    K, nb = args.max_conf, args.batch
+    eng, wl = build_workload(args.workload, args, dev)
+    C, L, C1 = wl["C"], wl["L"], wl["C1"]
     N = 2 * L
-    rec, lig, recf, ligf, filt = synthetic_pair(C, L)
-    thr = clash_threshold(recf, ligf)
-    W = filt.parameters_tuple()
-    rot = Rotations(args.angle_inc, verbose=False)
+    angle = args.angle_inc or wl["angle"]
+    # the SOI files carry MitchellLab's licence and are not redistributed: read them when DLPD_ROTATIONS_DIR /
+    # data/ has them, otherwise the SOI-sized generated set -- and the JSON line says which
+    rot = Rotations(angle, allow_generated=True, verbose=False)
     R_all = rot.R
     nrot_total = R_all.shape[0]
-    ids = np.arange(rank, nrot_total, world)                 # this rank's interleaved shard
-    # visiting order of DockingEngine.search: rotations grouped by slab orientation (a per-launch choice),
-    # set order inside a group; a step is one batch of that sequence
-    Rn = R_all[ids].numpy()
-    gkey = DockingEngine.prefers_transposed(Rn).astype(int) * 2 + DockingEngine.prefers_quads(Rn).astype(int)
-    parts, keys = [], []
-    for k in range(4):                                         # groups in the engine's order, whole batches only
-        sel = ids[gkey == k]
-        sel = sel[:len(sel) // nb * nb]
-        parts.append(sel)
-        keys.append(np.full(len(sel), k))
-    ids, key_of = np.concatenate(parts), np.concatenate(keys)
+    generated = rot.source == "generated"
+    shard = np.arange(rank, nrot_total, world)                # this rank's interleaved shard
+    seq_ids, seq_key = visiting_sequence(DockingEngine, R_all, shard, nb)
+    shard_batches = len(seq_ids) // nb
+    # K timed + W warm-up steps = batches spread evenly over the whole sequence (K > shard_batches repeats batches)
+    def spread(n):
+        return (np.arange(n) * shard_batches // max(n, 1)) % shard_batches if n > shard_batches \
+            else np.linspace(0, shard_batches - 1, n).astype(int)
+    warm_pick, time_pick = spread(max(args.warmup, 1)), spread(args.steps)
+    head_n = min(20, shard_batches)
+    pick = np.concatenate([warm_pick, time_pick, np.arange(head_n)])
+    rows = np.concatenate([np.arange(j * nb, (j + 1) * nb) for j in pick])
+    ids, key_of = seq_ids[rows], seq_key[rows]
     tr_of, qd_of = key_of >= 2, (key_of % 2) == 1
-    shard_batches = len(ids) // nb
-    need = (args.steps + args.warmup) * nb
-    reps = (need + shard_batches * nb - 1) // (shard_batches * nb)
-    ids_all, tr_all, qd_all = ids[:shard_batches * nb], tr_of[:shard_batches * nb], qd_of[:shard_batches * nb]
-    ids, tr_of, qd_of = (np.tile(a, reps)[:need] for a in (ids_all, tr_all, qd_all))   # (wraps only if steps*batch > shard)
     Rd = R_all[ids].to(device=dev, dtype=torch.float32).contiguous()
     idd = torch.as_tensor(ids, dtype=torch.int32).to(dev)
+    w0, t_first, h_first = 0, len(warm_pick), len(warm_pick) + len(time_pick)
 
-    eng = DockingEngine(L, C, *W, clip=5.0, threshold_clash=thr, has_clash=True, max_conf=K, batch=nb, device=dev)
-    eng.set_receptor(rec, recf)
-    eng.set_ligand(lig, ligf)
     eng.reset_top()
-
-    def step(i, mark=None):
-        # K1,K2,K3 on the main stream; select+merge of the same batch on the engine's side stream
-        # (overlapping the next batch), see DockingEngine.step
-        sl = slice(i * nb, (i + 1) * nb)
-        eng.step(Rd[sl], idd[sl], mark=mark, transposed=bool(tr_of[i * nb]), quads=bool(qd_of[i * nb]))
-
-    def step_serial(i, mark):
-        sl = slice(i * nb, (i + 1) * nb)
-        V = eng.score_batch(Rd[sl], mark=mark, transposed=bool(tr_of[i * nb]), quads=bool(qd_of[i * nb]))
-        eng.select_batch(V, nb)
-        mark("topk_select")
-        eng.merge_batch(idd[sl], nb)
-        mark("topk_merge")
-
-    for i in range(args.warmup):
-        step(i)
-    V_first = None
+    time_steps(eng, Rd, idd, tr_of, qd_of, nb, w0, args.warmup)
     eng.finish()
+
+    # CPU-baseline sample: cpu_rotations / 4 rotations from the head of each search group; their GPU scores
+    # (each through the K1/K2 variant the search uses for it) are kept for the parity figure
+    V_first = R_cpu = grp_cpu = None
     if rank == 0 and world == 1 and args.cpu_rotations > 0:
-        Rs = R_all[:args.cpu_rotations].to(device=dev, dtype=torch.float32).contiguous()
-        V_first = torch.cat([eng.score_batch(Rs[i:i + nb]).cpu() for i in range(0, Rs.shape[0], nb)])
-    timer = StageTimer()
-    for i in range(min(args.warmup, 3)):                   # untimed: per-stage launch durations
-        step_serial(i, timer.mark)
-    torch.cuda.synchronize()
-    stages = timer.summary()
-    eng.reset_top()
+        per = max(1, args.cpu_rotations // 4)
+        sel, grp_cpu = [], []
+        for k in range(4):
+            g = seq_ids[seq_key == k][:per]
+            sel.append(g)
+            grp_cpu += [GROUP_NAMES[k]] * len(g)
+        sel = np.concatenate(sel)
+        R_cpu = R_all[sel].numpy()
+        Vs = []
+        for j, rid in enumerate(sel):
+            k = GROUP_NAMES.index(grp_cpu[j])
+            Rj = R_all[rid:rid + 1].to(device=dev, dtype=torch.float32).contiguous()
+            Vs.append(eng.score_batch(Rj, transposed=k >= 2, quads=(k % 2) == 1).cpu())
+        V_first = torch.cat(Vs)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    eng.reset_top()
     barrier()
     t0 = time.perf_counter()
     timer = StageTimer()
-    for i in range(args.warmup, args.warmup + args.steps):
-        step(i, mark=timer.mark)
+    time_steps(eng, Rd, idd, tr_of, qd_of, nb, t_first, args.steps, mark=timer.mark)
     entries = eng.top_entries()                              # waits for the side stream; D2H of this rank's list
     if world > 1:                                            # single all-gather + deterministic merge
         from deeplocalproteindocking_amd.Docker import Docker
@@ -240,83 +387,175 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    stages = timer.summary()                                 # K1/K2/K3 as measured inside the timed region
 
-    # untimed extra: the rotation-dependent part (K1's gather) makes the head of the set cheaper than its
-    # bulk, so also time batches spaced evenly over the WHOLE search sequence of this rank
-    nsample = min(48, shard_batches)
-    pick = np.linspace(0, shard_batches - 1, nsample).astype(int)
-    Rs = R_all[np.concatenate([ids_all[j * nb:(j + 1) * nb] for j in pick])].to(device=dev, dtype=torch.float32).contiguous()
-    Is = torch.as_tensor(np.concatenate([ids_all[j * nb:(j + 1) * nb] for j in pick]), dtype=torch.int32).to(dev)
-    eng.step(Rs[:nb], Is[:nb], transposed=bool(tr_all[pick[0] * nb]), quads=bool(qd_all[pick[0] * nb]))
+    # untimed extras: (i) the head of the set (the z-dominant rotations, cheapest K1 gather); (ii) the top-K
+    # kernels, which run on the side stream inside the timed region, serially on the main stream
+    time_steps(eng, Rd, idd, tr_of, qd_of, nb, h_first, 1)
     eng.finish()
     torch.cuda.synchronize()
     ts = time.perf_counter()
-    for j in range(nsample):
-        eng.step(Rs[j * nb:(j + 1) * nb], Is[j * nb:(j + 1) * nb], transposed=bool(tr_all[pick[j] * nb]),
-                 quads=bool(qd_all[pick[j] * nb]))
+    time_steps(eng, Rd, idd, tr_of, qd_of, nb, h_first, head_n)
     eng.finish()
     torch.cuda.synchronize()
-    sustained_ms = (time.perf_counter() - ts) / nsample * 1e3
+    head_ms = (time.perf_counter() - ts) / head_n * 1e3
+    tk = StageTimer()
+    for i in range(h_first, h_first + min(3, head_n)):
+        sl = slice(i * nb, (i + 1) * nb)
+        V = eng.score_batch(Rd[sl], transposed=bool(tr_of[i * nb]), quads=bool(qd_of[i * nb]))
+        tk.mark("begin")
+        eng.select_batch(V, nb)
+        tk.mark("topk_select")
+        eng.merge_batch(idd[sl], nb)
+        tk.mark("topk_merge")
+    torch.cuda.synchronize()
+    stages.update(tk.summary())
+
+    real_shapes = None
+    if rank == 0 and world == 1 and args.workload == "config2" and not args.no_real_shapes:
+        del eng
+        torch.cuda.empty_cache()
+        real_shapes = short_measurement("real", args, dev, R_all, nb)
 
     if rank == 0:
         poses = float(args.steps) * nb * N ** 3 * world
-        stages.update(timer.summary())                      # K1/K2/K3 as measured inside the timed region
-        CT, NZ = C + 1, L + 1
-        alg = {   # algorithmic bytes per launch (each kernel's compulsory input + output, fp32)
-            "k1_rotate_zfft": CT * L ** 3 * 4 + nb * CT * NZ * L * L * 8,
-            "k2_xy_corr": nb * CT * NZ * L * L * 8 + CT * NZ * N * N * 8 + nb * CT * NZ * N * N * 8,
-            "k3_zifft_filter": nb * CT * NZ * N * N * 8 + nb * N ** 3 * 4,
-            "topk_select": nb * N ** 3 * 4 + nb * K * 8,
-            "topk_merge": nb * K * 8 + K * 16,
-        }
-        dom = max((k for k in stages if k in alg), key=lambda k: stages[k])
-        ach = alg[dom] / (stages[dom] * 1e-3) / 1e9
-        traffic = None           # PMC-measured bytes per launch of the same command (profiles/)
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if pmc["config"] == {"channels": C, "box": L, "batch": nb} and dom in pmc["bytes_per_launch"]:
-                t = pmc["bytes_per_launch"][dom]
-                traffic = (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0
-        except Exception:
-            traffic = None
+        alg = algorithmic_bytes(C, L, C1, nb, K, unfused=(N == 160))
+        main_stages = [k for k in stages if k in alg and not k.startswith("topk")]
+        dom = max(main_stages, key=lambda k: stages[k])
+        traffic, traffic_src = pmc_traffic(args.workload, C, L, nb, dom)
+
+        def roof(k):
+            ach = alg[k] / (stages[k] * 1e-3) / 1e9
+            return {"bound": "hbm", "kernel": k, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg[k], "avg_launch_ms": stages[k]}
+        roofline = roof(dom)
+        roofline.update({"traffic": traffic, "traffic_source": traffic_src})
+        rot_src = "generated SOI-sized substitute set" if generated else os.path.basename(rot.source)
+        if (C, L, C1) == (48, 64, 0):
+            metric = "pose correlations/sec (48ch x 64^3 pair, %s)" % (
+                "%d-degree SOI-sized generated rotation set" % angle if generated else os.path.basename(rot.source))
+        else:
+            metric = "pose correlations/sec (%s pair)" % (("[%dch x %d^3, %dch x %d^3]" % (C, L, C1, L // 2)) if C1
+                                                         else "%dch x %d^3" % (C, L))
+        ms_step = elapsed / args.steps * 1e3
+        moved = sum(alg[k] for k in main_stages)
+        sb_mb, floor_mb = SURVEY_MB_PER_ROT.get(args.workload, (None, None)) if (args.channels, args.box) == (None, None) \
+            else (None, None)
+        step = {"ms_per_step": ms_step, "bytes_moved_per_step": moved,
+                "achieved_GBps": moved / (ms_step * 1e-3) / 1e9, "frac_of_peak_on_bytes_moved": moved / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "bytes_moved = sum of the stage kernels' algorithmic input + output (K1 + K2 + K3 ...), what the fused "
+                        "pipeline really transfers per batch; the compulsory floor and the stage-boundary model are SURVEY 8(d)'s"}
+        if sb_mb:
+            rps = args.steps * nb / elapsed
+            step.update({"compulsory_floor_MB_per_rotation": floor_mb,
+                         "frac_of_peak_on_compulsory_floor": rps * floor_mb * 1e6 / 1e9 / HBM_PEAK_GBS,
+                         "stage_boundary_model_MB_per_rotation": sb_mb,
+                         "stage_boundary_model_GBps_nominal": rps * sb_mb * 1e6 / 1e9})
         out = {
-            "metric": "pose correlations/sec (48ch x 64^3 pair, oim06.eul)" if (C, L) == (48, 64)
-                      else "pose correlations/sec (%dch x %d^3 pair)" % (C, L),
-            "value": poses / elapsed, "unit": "pose scores/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "metric": metric, "value": poses / elapsed, "unit": "pose scores/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: single synthetic %d-channel %d^3 pair, %d-degree SOI-sized "
-                                   "rotation set (%d rotations, %s), max_conf=%d" %
-                                   (C, L, args.angle_inc, nrot_total,
-                                    "generated substitute" if rot.source == "generated" else os.path.basename(rot.source), K),
+            "config": {"workload": "%s, %d-degree SOI-sized rotation set (%d rotations, %s), max_conf=%d" %
+                                   (wl["desc"] if (args.channels, args.box) == (None, None) else
+                                    "synthetic %d-channel %d^3 pair" % (C, L), angle, nrot_total, rot_src, K),
                        "rotations_per_step": nb, "rotations_timed_per_gpu": args.steps * nb,
+                       "timed_steps": "batches spread evenly over the rank's whole %d-batch visiting sequence "
+                                      "(all four search groups)" % shard_batches,
                        "translations_per_rotation": N ** 3, "sharding": "rotations interleaved over %d rank(s)" % world,
-                       "clip": 5.0, "threshold_clash": thr,
+                       "world_size_seen_by_the_collective": (dist.get_world_size() if world > 1 else 1),
+                       "collective_backend": (dist.get_backend() if world > 1 else None),
+                       "clip": 5.0, "threshold_clash": wl["thr"],
                        "masked_fraction": None if V_first is None else float((V_first == 0).float().mean())},
             "rot_per_s": args.steps * nb * world / elapsed,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": None if traffic is None else "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per gfx950 note)",
-                         "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": stages[dom]},
-            "stages": {k: {"ms_per_launch": v, "alg_GBps": alg[k] / (v * 1e-3) / 1e9} for k, v in stages.items()},
+            "roofline": roofline,
+            "rooflines": {k: roof(k) for k in stages if k in alg},
+            "stages": {k: {"ms_per_launch": v, "alg_GBps": (alg[k] / (v * 1e-3) / 1e9 if k in alg else None)}
+                       for k, v in stages.items()},
+            "step": step,
+            "head_of_set": {"value": nb * N ** 3 * world / (head_ms * 1e-3), "unit": "pose scores/s", "ms_per_step": head_ms,
+                            "sample": "the first %d batches of the visiting sequence (rotations about z, cheapest K1 gather); "
+                                      "untimed extra, NOT the headline" % head_n},
+            "top_entries": int(len(entries[0])),
         }
-        sb = STAGE_BOUNDARY_MB_PER_ROT.get((C, L))
-        if sb:
-            gbs = out["rot_per_s"] / world * sb * 1e6 / 1e9
-            out["pipeline"] = {"model": "SURVEY 8(d) stage-boundary %.1f MB/rotation" % sb, "achieved_GBps_per_gpu": gbs,
-                               "frac_of_8TBps": gbs / HBM_PEAK_GBS}
-        out["whole_set"] = {"value": nb * N ** 3 * world / (sustained_ms * 1e-3), "unit": "pose scores/s",
-                            "ms_per_step": sustained_ms,
-                            "sample": "%d batches evenly spaced over the %d-batch search sequence of a rank (untimed "
-                                      "extra; the timed steps are the first batches of that sequence)" % (nsample, shard_batches)}
-        out["top_entries"] = int(len(entries[0]))
-        if world == 1 and args.cpu_rotations > 0:
-            out["cpu_baseline"] = cpu_baseline(rec, lig, recf, ligf, [w.cpu() for w in W], R_all.numpy(), thr, K,
-                                               args.cpu_rotations, V_first)
+        if real_shapes is not None:
+            out["real_shapes"] = real_shapes
+        if world == 1 and args.cpu_rotations > 0 and V_first is not None:
+            out["cpu_baseline"] = cpu_baseline(wl["rec"], wl["lig"], wl["recf"], wl["ligf"], [w.cpu() for w in wl["W"]],
+                                               R_cpu, grp_cpu, wl["thr"], K, V_first)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def short_measurement(name, args, dev, R_all, nb, nsteps=24):
+    """A short stratified measurement of another workload (the N = 160 pipeline of the reference's real
+    shapes), reported as an extra object of the default line so that it has a driver-run number."""
+    import numpy as np
+    import torch
+    from deeplocalproteindocking_amd.engine import DockingEngine
+    eng, wl = build_workload(name, args, dev)
+    L, C, C1 = wl["L"], wl["C"], wl["C1"]
+    N = 2 * L
+    seq_ids, seq_key = visiting_sequence(DockingEngine, R_all, np.arange(R_all.shape[0]), nb)
+    nbat = len(seq_ids) // nb
+    pick = np.linspace(0, nbat - 1, nsteps + 2).astype(int)
+    rows = np.concatenate([np.arange(j * nb, (j + 1) * nb) for j in pick])
+    ids, key_of = seq_ids[rows], seq_key[rows]
+    tr_of, qd_of = key_of >= 2, (key_of % 2) == 1
+    Rd = R_all[ids].to(device=dev, dtype=torch.float32).contiguous()
+    idd = torch.as_tensor(ids, dtype=torch.int32).to(dev)
+    eng.reset_top()
+    time_steps(eng, Rd, idd, tr_of, qd_of, nb, 0, 2)
+    eng.finish()
+    torch.cuda.synchronize()
+    timer = StageTimer()
+    t0 = time.perf_counter()
+    time_steps(eng, Rd, idd, tr_of, qd_of, nb, 2, nsteps, mark=timer.mark)
+    eng.finish()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / nsteps * 1e3
+    stages = timer.summary()
+    alg = algorithmic_bytes(C, L, C1, nb, args.max_conf, unfused=(N == 160))
+    sb_mb, floor_mb = SURVEY_MB_PER_ROT[name]
+    rps = nb / (ms * 1e-3)
+    del eng
+    torch.cuda.empty_cache()
+    return {"workload": wl["desc"], "steps": nsteps, "ms_per_step": ms, "rot_per_s": rps,
+            "value": rps * N ** 3, "unit": "pose scores/s",
+            "stages": {k: {"ms_per_launch": v, "alg_GBps": (alg[k] / (v * 1e-3) / 1e9 if k in alg else None),
+                           "frac_of_peak": (alg[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS if k in alg else None)}
+                       for k, v in stages.items()},
+            "frac_of_peak_on_compulsory_floor": rps * floor_mb * 1e6 / 1e9 / HBM_PEAK_GBS,
+            "stage_boundary_model_GBps_nominal": rps * sb_mb * 1e6 / 1e9}
+
+
+def pmc_traffic(workload, C, L, nb, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
+    (profiles/*_pmc_traffic.json; FETCH_SIZE doubled per the gfx950 note), newest round first."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            pmc = json.load(open(path))
+            if pmc["config"] == {"channels": C, "box": L, "batch": nb} and kernel in pmc["bytes_per_launch"]:
+                t = pmc["bytes_per_launch"][kernel]
+                return (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0, \
+                    "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per gfx950 note)" % os.path.basename(path)
+        except Exception:
+            continue
+    return None, None
+
+
+def main():
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and (world_env is None or int(world_env) != args.gpus):
+        if world_env is not None and int(world_env) > 1:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s" % (args.gpus, world_env))
+        raise SystemExit(spawn_ranks(args))
+    if args.dry_run:
+        return dry_run(args)
+    run_rank(args)
 
 
 if __name__ == "__main__":

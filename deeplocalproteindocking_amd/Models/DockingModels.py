@@ -71,7 +71,9 @@ def fused_filter_parameters(model):
     has_own_call = (isinstance(model, nn.Module) and fwd is not None and fwd is not nn.Module.forward
                     and fwd is not getattr(nn.Module, "_forward_unimplemented", None)) or \
                    (not isinstance(model, nn.Module) and callable(model))
-    if has_own_call and fwd is not GlobalDockingModel.forward:
+    # (a marker on the function, not a class identity test: the package is importable both as
+    # ``Models`` -- the reference's import path -- and as ``deeplocalproteindocking_amd.Models``)
+    if has_own_call and not getattr(fwd, "dlpd_reference_forward", False):
         return None
     filt = getattr(model, "filter", None)
     return None if filt is None else mlp_parameters(filt)
@@ -114,3 +116,5 @@ class GlobalDockingModel(nn.Module):
         same = [c if c.shape[2] == N else nn.functional.interpolate(c, size=(N, N, N)) for c in correlations]
         V = torch.cat(same, dim=1).permute(0, 2, 3, 4, 1).reshape(B * N * N * N, -1)
         return self.filter(V).reshape(B, N, N, N)
+
+    forward.dlpd_reference_forward = True      # what the fused kernels compute (fused_filter_parameters)

@@ -18,6 +18,7 @@ _sz = ctypes.c_size_t
 # name -> (restype, argtypes); mirrors include/dlpd.h exactly
 SIGNATURES = {
     "dlpd_version": (_i, []),
+    "dlpd_source_hash": (ctypes.c_char_p, []),
     "dlpd_grid_supported": (_i, [_i]),
     "dlpd_hidden_pad": (_i, [_i]),
     "dlpd_rotate_trilinear": (_i, [_p, _p, _p, _i, _i, _i, _ll, _f, _p]),
@@ -77,6 +78,9 @@ class DlpdLib:
             fn.restype = res
             fn.argtypes = args
             setattr(self, "_" + name, fn)
+
+    def source_hash(self):
+        return self._dlpd_source_hash().decode()
 
     def call(self, name, *args):
         rc = getattr(self, "_" + name)(*args)

@@ -808,8 +808,6 @@ int dlpd_debug_read_stamps(unsigned long long* host16) {
 }
 #endif
 
-int dlpd_version(void) { return 100; }
-
 int dlpd_hidden_pad(int H) {
   const int opts[6] = {2, 4, 8, 16, 24, 32};
   for (int i = 0; i < 6; i++)

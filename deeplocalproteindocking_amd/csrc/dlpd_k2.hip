@@ -325,6 +325,12 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
   DLPD_STAMP_FLUSH(dlpd_stamps_k2, DLPD_STAMPS);
 }
 
+// DLPD_K2_NSPLIT (diagnostic override of the batch split): read once, not on every launch
+static int k2_nsplit_override() {
+  static const int v = [] { const char* e = getenv("DLPD_K2_NSPLIT"); return (e && atoi(e) > 0) ? atoi(e) : 0; }();
+  return v;
+}
+
 template <int N, int MODE> static int launch_k2(const cplx* A, const cplx* rec, cplx* out, int CT, int nb,
                                                 long long rbs, float scale, hipStream_t st, int transposed = 0) {
   constexpr int NZ = N / 2 + 1, RS = N + 8;
@@ -332,7 +338,7 @@ template <int N, int MODE> static int launch_k2(const cplx* A, const cplx* rec, 
   int rc = dlpd_set_max_dyn_shared((const void*)k_xy_corr<N, MODE>, shmem);
   if (rc) return rc;
   int nsplit = (MODE == 1 && nb >= 8) ? 2 : 1;
-  if (const char* e = getenv("DLPD_K2_NSPLIT")) nsplit = atoi(e) > 0 ? atoi(e) : nsplit;
+  if (k2_nsplit_override()) nsplit = k2_nsplit_override();
   const int slabs8 = ((NZ * CT + 7) / 8) * 8;
   dim3 grid(slabs8 * nsplit), block(DLPD_K2_THREADS(N));
   DLPD_LAUNCH((k_xy_corr<N, MODE>), grid, block, shmem, st, A, rec, out, CT, nb, nsplit, rbs, scale, transposed);
@@ -704,7 +710,7 @@ template <int N, int WV> static int launch_k2_dif(const cplx* A, const cplx* rec
   int rc = dlpd_set_max_dyn_shared((const void*)k_xy_corr_dif<N, WV>, shmem);
   if (rc) return rc;
   int nsplit = nb >= 8 ? 2 : 1;
-  if (const char* e = getenv("DLPD_K2_NSPLIT")) nsplit = atoi(e) > 0 ? atoi(e) : nsplit;
+  if (k2_nsplit_override()) nsplit = k2_nsplit_override();
   const int slabs8 = ((NZ * CT + 7) / 8) * 8;
   DLPD_LAUNCH((k_xy_corr_dif<N, WV>), dim3(slabs8 * nsplit), dim3(64 * WV), shmem, st, A, rec, out, CT, nb, nsplit, rbs, transposed);
   return dlpd_check_launch();
@@ -725,12 +731,8 @@ int dlpd_k2_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb,
   switch (L) {
     case 32: return launch_k2<64, 1>(A, rec, out, CT, nb, rbs, 1.f, st, transposed);
     case 40: return launch_k2<80, 1>(A, rec, out, CT, nb, rbs, 1.f, st, transposed);
-    // DLPD_K2_DIF128 (diagnostic): the half-slab kernel at N = 128, two 4-wave blocks per CU
-    case 64: return getenv("DLPD_K2_DIF128") ? launch_k2_dif<128, 4>(A, rec, out, CT, nb, rbs, st, transposed)
-                                             : launch_k2<128, 1>(A, rec, out, CT, nb, rbs, 1.f, st, transposed);
-    // (the three-kernel split path has no un-transposing stage: oriented slabs always take the DIF kernel)
-    case 80: return (getenv("DLPD_K2_SPLIT") && !transposed) ? launch_k2_split<160, 1>(A, rec, out, CT, nb, rbs, 1.f, st)
-                                          : launch_k2_dif<160, DLPD_K2D_WAVES>(A, rec, out, CT, nb, rbs, st, transposed);
+    case 64: return launch_k2<128, 1>(A, rec, out, CT, nb, rbs, 1.f, st, transposed);
+    case 80: return launch_k2_dif<160, DLPD_K2D_WAVES>(A, rec, out, CT, nb, rbs, st, transposed);
     default: return DLPD_ERR_UNSUPPORTED;
   }
 }

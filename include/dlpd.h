@@ -24,6 +24,9 @@ extern "C" {
 #define DLPD_ERR_LAUNCH 3
 
 int dlpd_version(void);
+/* sha256 (64 hex digits) of the sources, headers and flags this library was built from; the build
+ * script refuses a library whose hash differs from the sources next to it */
+const char* dlpd_source_hash(void);
 /* 1 if box size L has a compiled pipeline: L in {32, 40, 64, 80} (grids N = 2L = 64, 80, 128, 160) */
 int dlpd_grid_supported(int L);
 /* hidden width the filter kernel pads H to (2,4,8,16,24,32), -1 if H > 32 */

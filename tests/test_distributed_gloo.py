@@ -92,3 +92,25 @@ def test_rank_with_empty_shard_still_joins_the_gather():
         assert p.exitcode == 0
     assert list(out2[0]) == list(out2[1]) == single[0]
     assert len(single[0]) == 30 and {t[0] for t in single[0]} == {0}
+
+
+def test_bench_spawns_its_own_ranks_when_started_as_plain_python():
+    """The driver runs `python bench.py --gpus N` for its scaling sweep: the process must start the N ranks itself
+    (child torch.distributed.run, 127.0.0.1 rendezvous, free port), relay rank 0's single JSON line and its exit
+    code.  --dry_run keeps the GPU out of it (gloo)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--dry_run"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out == {"dry_run": True, "n_gpus": 2, "steps": 3, "warmup": 1}
+    # a rank that fails makes the launcher's exit code non-zero
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry_run"],
+                         env=dict(env, WORLD_SIZE="3"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0

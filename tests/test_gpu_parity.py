@@ -482,3 +482,106 @@ def test_maxpool3d_matches_torch(dev, D):
     x = torch.randn(2, 3, D, D, D, generator=torch.Generator().manual_seed(D)).to(dev)
     want = torch.nn.functional.max_pool3d(x.cpu(), kernel_size=5, stride=2, padding=2)
     assert torch.equal(ops.maxpool3d_5s2(x).cpu(), want)
+
+
+def _rotations_by_group(need_each=1, seed=2024):
+    """Rotations drawn at random and sorted into the four search groups of DockingEngine.search
+    (slab orientation x gather layout): ``need_each`` per group."""
+    from deeplocalproteindocking_amd.engine import DockingEngine
+    R = _rots(400, seed=seed)
+    tr, qd = DockingEngine.prefers_transposed(R), DockingEngine.prefers_quads(R)
+    out = {}
+    for t in (False, True):
+        for q in (False, True):
+            sel = np.nonzero((tr == t) & (qd == q))[0][:need_each]
+            assert len(sel) == need_each
+            out[(t, q)] = R[sel]
+    return out
+
+
+def _assert_scores_match(V, Vo, norm, thr):
+    sure = (norm - thr).abs() > 1e-3 * thr
+    assert 0.2 < (Vo != 0).float().mean() <= 1.0
+    err = (V - Vo).abs()[sure].max().item()
+    assert err <= TOL * Vo.abs().max().item(), (err, Vo.abs().max().item())
+    return err / Vo.abs().max().item()
+
+
+def test_all_four_search_paths_match_oracle_at_baseline_config2_size(dev):
+    """BASELINE config 2 (48 ch, 64^3 -> 128^3) through every K1/K2 variant the search actually runs:
+    slab orientation (transposed: K1 swaps x/y, K2 un-transposes while staging, N = 128 template) x gather
+    layout (quads).  Each variant is fed (i) a rotation the search WOULD route to it and (ii) one it would
+    not (the flags are speed-only: any rotation must give the same scores), and compared with the oracle
+    under the stated rule |V_hip - V_oracle| <= 1e-4 max|V| (Docker.py:211-236)."""
+    import bench
+    from deeplocalproteindocking_amd.engine import DockingEngine
+    C, L = 48, 64
+    rec, lig, recf, ligf, filt = bench.synthetic_pair(C, L)
+    thr = bench.clash_threshold(recf, ligf)
+    W = [w.cpu() for w in filt.parameters_tuple()]
+    groups = _rotations_by_group(1)
+    eng = DockingEngine(L, C, *W, clip=5.0, threshold_clash=thr, max_conf=100, batch=2, device=dev)
+    eng.set_receptor(rec, recf)
+    eng.set_ligand(lig, ligf)
+    oracle = {}
+    for key, Rg in groups.items():
+        oracle[key] = _oracle_V(rec, lig, recf, ligf, W, Rg[0], thr, 5.0)
+    worst = 0.0
+    for (tr, qd) in groups:                                      # the launch variant under test
+        prefers, other = groups[(tr, qd)][0], groups[(not tr, not qd)][0]
+        Rd = torch.from_numpy(np.stack([prefers, other])).float().to(dev).contiguous()
+        V = eng.score_batch(Rd, transposed=tr, quads=qd).cpu()
+        for j, key in enumerate(((tr, qd), (not tr, not qd))):
+            worst = max(worst, _assert_scores_match(V[j], oracle[key][0], oracle[key][1], thr))
+    print("config 2, four K1/K2 variants x preferred/non-preferred rotations: worst error %.2e of max|V|" % worst)
+
+
+def test_baseline_config5_shape_48ch_80cube_matches_oracle(dev):
+    """BASELINE config 5's literal shape: 48 channels at 80^3, single resolution -> 160^3 (DIF K2 with 49
+    slabs per kz, dlpd_zifft_real_part, k_filter_vec over 48 channels), clip active, clash channel on;
+    two rotations, one per slab orientation as the search would choose."""
+    import bench
+    from deeplocalproteindocking_amd.engine import DockingEngine
+    C, L = 48, 80
+    rec, lig, recf, ligf, filt = bench.synthetic_pair(C, L)
+    thr = bench.clash_threshold(recf, ligf)
+    W = [w.cpu() for w in filt.parameters_tuple()]
+    groups = _rotations_by_group(1, seed=5)
+    eng = DockingEngine(L, C, *W, clip=5.0, threshold_clash=thr, max_conf=100, batch=2, device=dev)
+    assert eng.fine_unfused and eng.CT == 49
+    eng.set_receptor(rec, recf)
+    eng.set_ligand(lig, ligf)
+    worst = 0.0
+    for key in ((False, False), (True, True)):
+        R1 = groups[key][0]
+        Vo, norm = _oracle_V(rec, lig, recf, ligf, W, R1, thr, 5.0)
+        assert float((Vo.abs() > 0).float().mean()) > 0.2
+        Rd = torch.from_numpy(R1[None]).float().to(dev).contiguous()
+        V = eng.score_batch(Rd, transposed=key[0], quads=key[1]).cpu()
+        worst = max(worst, _assert_scores_match(V[0], Vo, norm, thr))
+    print("config 5 shape (48 ch @ 80^3): worst error %.2e of max|V|" % worst)
+    # the clip must really bite at this amplitude, otherwise the clamp path is not exercised
+    c = orc.correlate_fft(rec[None], orc.rotate_volume(lig[None], torch.from_numpy(groups[(False, False)][0][None]).float()))
+    assert float((c.abs() > 5.0).float().mean()) > 1e-3
+
+
+def test_two_rank_nccl_search_equals_single_process(dev, tmp_path):
+    """SURVEY 8(e) on hardware: two ranks (one per GPU, RCCL) search interleaved shards of the rotation set
+    and all-gather their lists once; the merged list must equal the single-process list.  Needs two GPUs
+    (the driver's multi-GPU node); skipped on the one-GPU boxes."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL all-gather)")
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    out = str(tmp_path / "lists.json")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29641", os.path.join(root, "scripts", "shard_check.py"), "--out", out]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.load(open(out))
+    assert res["world"] == 2 and res["backend"] == "nccl"
+    assert res["sharded"] == res["single"] and len(res["single"]) == res["K"]

@@ -30,7 +30,9 @@ def test_library_exports_every_declared_symbol(built_lib):
     dll = ctypes.CDLL(entry.LIB)
     for n in names:
         assert hasattr(dll, n), n
-    assert built_lib.call("dlpd_version") >= 100
+    assert built_lib.call("dlpd_version") >= 200
+    # the library carries the hash of the sources it was built from; build() rebuilds on mismatch
+    assert built_lib.source_hash() == entry.source_hash() == entry.library_hash() and len(entry.source_hash()) == 64
     assert built_lib.call("dlpd_grid_supported", 64) == 1 and built_lib.call("dlpd_grid_supported", 50) == 0
     assert built_lib.call("dlpd_hidden_pad", 24) == 24 and built_lib.call("dlpd_hidden_pad", 3) == 4
     assert built_lib.call("dlpd_topk_glist_bytes", 2000) == (2 + 4000) * 8

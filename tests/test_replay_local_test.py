@@ -1,0 +1,92 @@
+"""The reference's unchanged caller on this build (SURVEY.md 8(b) seam 1, BASELINE north_star: "drops in
+under local_test.py unchanged"): scripts/replay_local_test.py issues local_test.py:5-14,44-71 call for
+call -- reference constructor kwargs only, ``select_model``, ``GlobalDockingModel(...).cuda()``,
+``.load``, ``new_log``, ``dockSE3(rec, lig, batch_size=2)`` -- on a synthetic DockingBenchmark directory
+with protein-sized two-chain structures.  Runs in fresh processes (the package reads its directories
+from the environment at import)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def make_benchmark(root, targets=(("1SYN", 230, 120, 21),)):
+    """DATA_DIR/DebugDockingBenchmark in the layout SplitComplexBenchmark.py:20-46 reads with
+    struct_folder='Matched' (local_test.py:46): Table.csv + Matched/<pdb>_{r_u,l_u,r_b,l_b}.pdb, <pdb>_b.pdb."""
+    from synth_pdb import write_protein_like_pdb
+    bench = os.path.join(root, "data", "DebugDockingBenchmark")
+    os.makedirs(os.path.join(bench, "Matched"))
+    rows = ["Complex\tCat.\tPDB ID 1\tProtein 1\tPDB ID 2\tProtein 2\tI-RMSD\tdASA", "Rigid-body (1)"]
+    for name, nrec, nlig, seed in targets:
+        rows.append("%s_A:B\tOX\t%s_A\tsynthetic receptor\t%s_B\tsynthetic ligand\t1.0\t1500" % (name, name, name))
+        for suffix, nres, sd, off in (("_r_u", nrec, seed, (30.0, -12.0, 5.0)), ("_l_u", nlig, seed + 1, (-40.0, 8.0, 60.0)),
+                                      ("_r_b", nrec, seed, (0.0, 0.0, 0.0)), ("_l_b", nlig, seed + 1, (25.0, 0.0, 0.0))):
+            write_protein_like_pdb(os.path.join(bench, "Matched", name + suffix + ".pdb"), nres, sd, offset=off)
+        write_protein_like_pdb(os.path.join(bench, "Matched", name + "_b.pdb"), nrec + nlig, seed + 2)
+    rows += ["Medium Difficulty (0)", "Difficult (0)"]
+    with open(os.path.join(bench, "Table.csv"), "w") as f:
+        f.write("\n".join(rows[:2] + rows[2:]) + "\n")
+    return bench
+
+
+def _replay(root, log_name, extra_env=None, extra_args=()):
+    env = dict(os.environ)
+    env.update({"DLPD_DATA_DIR": os.path.join(root, "data"), "DLPD_MODELS_DIR": os.path.join(root, "models"),
+                "DLPD_LOG_DIR": os.path.join(root, log_name), "DLPD_ALLOW_GENERATED_ROTATIONS": "1",
+                "PYTHONDONTWRITEBYTECODE": "1"})
+    env.pop("DLPD_LAUNCH_BATCH", None)
+    env.update(extra_env or {})
+    os.makedirs(env["DLPD_LOG_DIR"], exist_ok=True)
+    os.makedirs(os.path.join(env["DLPD_LOG_DIR"], "LocalDebugSE3"), exist_ok=True)
+    os.makedirs(os.path.join(env["DLPD_LOG_DIR"], "LocalDebugE3"), exist_ok=True)
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "replay_local_test.py"), "-angle_inc", "20", "-seed", "7",
+           "-init_weights", "1", "-report", "1", "-threshold_clash", "40.0"] + list(extra_args)
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    rep = [l for l in out.stdout.splitlines() if l.startswith("REPLAY ")]
+    return json.loads(rep[-1][len("REPLAY "):]), out.stdout
+
+
+@pytest.mark.gpu
+def test_reference_driver_replay_dockSE3_and_dockE3(tmp_path):
+    import __graft_entry__ as entry
+    entry.build()
+    root = str(tmp_path)
+    make_benchmark(root)
+    rep, stdout = _replay(root, "logA", extra_args=["-rewrite", "1"])
+    t = rep["targets"][0]
+    assert "Processing 1SYN" in stdout and t["path"] == "fused" and t["launch_batch"] == 16 and t["rotations"] == 1854
+    dat = os.path.join(rep["test_dir"], "1SYN.dat")
+    lines = open(dat).read().strip().split("\n")
+    assert len(lines) == 2000 and all(len(l.split("\t")) == 13 for l in lines)
+    scores = [float(l.split("\t")[12]) for l in lines]
+    assert scores == sorted(scores)                               # ranked, ascending (Docker.py:104)
+    # the same search with launches literally sized by the caller's batch_size=2: byte-identical .dat
+    # (deterministic splat + batch-independent merge), and what decoupling the launch batch buys
+    rep2, _ = _replay(root, "logB", extra_env={"DLPD_LAUNCH_BATCH": "2"}, extra_args=["-rewrite", "1"])
+    t2 = rep2["targets"][0]
+    assert t2["launch_batch"] == 2
+    assert open(os.path.join(rep2["test_dir"], "1SYN.dat")).read() == open(dat).read()
+    print("dockSE3 via the reference's calls (batch_size=2): %.0f rot/s at launch batch 16, %.0f rot/s if the "
+          "launches were sized by the caller (2)" % (t["rot_per_s"], t2["rot_per_s"]))
+    # resume rule (local_test.py:65 with rewrite=0): the finished target is skipped
+    rep3, stdout3 = _replay(root, "logA", extra_args=["-rewrite", "0"])
+    assert "Skipping 1SYN" in stdout3 and rep3["targets"] == []
+    # the E3 branch of the driver (local_test.py:67)
+    rep4, _ = _replay(root, "logA", extra_args=["-rewrite", "1", "-group", "E3", "-model", "E3MultiResRepr4x4",
+                                                "-experiment", "LocalDebugE3"])
+    t4 = rep4["targets"][0]
+    assert t4["path"] == "fused" and t4["poses"] == 2000
+    assert len(open(os.path.join(rep4["test_dir"], "1SYN.dat")).read().strip().split("\n")) == 2000
+
+
+def test_synthetic_benchmark_directory_is_what_the_loader_reads(tmp_path):
+    from deeplocalproteindocking_amd.Dataset import get_benchmark_stream
+    bench = make_benchmark(str(tmp_path), targets=(("1SYN", 30, 20, 3), ("2SYN", 25, 15, 9)))
+    items = list(get_benchmark_stream(bench, struct_folder="Matched", subset="Table.csv", debug=False))
+    assert [i[0][0] for i in items] == ["1SYN", "2SYN"]
+    assert all(os.path.exists(i[k][0]) for i in items for k in (1, 2, 3, 4, 5)) and int(items[0][6][0]) == 1
