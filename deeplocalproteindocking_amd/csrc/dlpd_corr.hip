@@ -393,31 +393,53 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
       DLPD_WAVE_SYNC();
       DLPD_STAMP(0);
       // pack two rows per complex pencil: Z[k] = A[k] + i B[k], Z[N-k] = conj(A[k]) + i conj(B[k])
+      // Lane -> (pencil m, kz row) of the element it packs.  The DMA layout of `raw` is [it][kq][m] (slot =
+      // NPAIR*kq + m inside the 64-slot block of DMA instruction `it`, k = LPK*it + kq).  Packing in that same
+      // lane order makes a 16-lane store group hit 8 pencils x 2 k: the pencil stride (RS = N + 8 complex = 16
+      // dwords mod 32) leaves only 8 distinct banks, a 4-way conflict on every ds_write_b64 (a third of this
+      // kernel's LDS cycles, SQ_LDS_BANK_CONFLICT).  For NPAIR = 8 the lanes are therefore re-dealt so that a
+      // store group covers 4 pencils x 4 consecutive-block k and every lane additionally walks the DMA
+      // instructions rotated by 2m: found by exhaustive search over lane-bit permutations x rotations
+      // (model of the ds_write_b64 / ds_read_b128 lane groups, MI355X_MICROARCH.md LDS table): raw reads stay
+      // conflict-free, stores cost 5.0 instead of 16.25 LDS cycles.
 #pragma unroll
       for (int j = 0; j < CPW; j++) {
         if (wave * CPW + j >= gn) break;
-        const int m = lane % NPAIR, kq = lane / NPAIR;
+        int m, kq;
+        if (NPAIR == 8) {
+          m = (lane & 3) | (((lane >> 4) & 1) << 2);
+          kq = ((lane >> 2) & 1) | (((lane >> 5) & 1) << 1) | (((lane >> 3) & 1) << 2);
+        } else {
+          m = lane % NPAIR;
+          kq = lane / NPAIR;
+        }
+        const int rot = (NPAIR == 8) ? 2 * m : 0;            // lane-dependent start of its walk over the DMA instructions
+        const int slot = NPAIR * kq + m;
         cplx* P = S + (wave * 8 + j * NPAIR + m) * RS;
         const float4* rj = rawg + j * RAWC;
         constexpr int PCH = NFULL > 8 ? NFULL / 2 : NFULL;   // raw elements in flight per lane
-        const float4 qh = rj[NFULL * 64 + m];               // k = N/2
+        const float4 qh = rj[NFULL * 64 + (lane % NPAIR)];  // k = N/2 (lanes with lane / NPAIR == 0 store it)
 #pragma unroll
         for (int it0 = 0; it0 < NFULL; it0 += PCH) {
           float4 q[PCH];
-#pragma unroll
-          for (int u = 0; u < PCH; u++) q[u] = rj[(it0 + u) * 64 + lane];
+          int kk[PCH];
 #pragma unroll
           for (int u = 0; u < PCH; u++) {
-            const int it = it0 + u, k = it * LPK + kq;
-            if (it == 0 && kq == 0) {
-              P[slab_swz(0)] = c_make(q[u].x, q[u].z);      // purely real bin of both rows
-            } else {
-              P[slab_swz(k)] = c_make(q[u].x - q[u].w, q[u].y + q[u].z);
-              P[slab_swz(N - k)] = c_make(q[u].x + q[u].w, q[u].z - q[u].y);
-            }
+            const int it = (it0 + u + rot) % NFULL;
+            kk[u] = it * LPK + kq;
+            q[u] = rj[it * 64 + slot];
+          }
+#pragma unroll
+          for (int u = 0; u < PCH; u++) {
+            const int k = kk[u];
+            // k = 0: the purely real bin of both rows (both stores then write the same value to the same place)
+            const cplx lo = (k == 0) ? c_make(q[u].x, q[u].z) : c_make(q[u].x - q[u].w, q[u].y + q[u].z);
+            const cplx hi = (k == 0) ? c_make(q[u].x, q[u].z) : c_make(q[u].x + q[u].w, q[u].z - q[u].y);
+            P[slab_swz(k)] = lo;
+            P[slab_swz((N - k) & (k == 0 ? 0 : ~0))] = hi;
           }
         }
-        if (kq == 0) P[slab_swz(N / 2)] = c_make(qh.x, qh.z);
+        if (lane / NPAIR == 0) S[(wave * 8 + j * NPAIR + lane % NPAIR) * RS + slab_swz(N / 2)] = c_make(qh.x, qh.z);
       }
       DLPD_WAIT_LDS();                         // raw fully read before it is refilled
       DLPD_WAVE_SYNC();

@@ -154,12 +154,27 @@ def test_projection_kernel_matches_oracle_on_gpu_protein_sized(tmp_path):
     R = torch.from_numpy(orc.euler_to_matrix([0.0, 0.4, -2.0], [0.0, 1.0, 0.3], [0.0, -0.7, 1.9])).float()
     vol = be.project(coords, counts, offs, L, res, dev, R=R.to(dev), shift=centre)
     assert vol.shape == (3, NUM_ATOM_TYPES, L, L, L)
+    n = int(counts.sum())
+    xyz = coords[0, :3 * n].reshape(n, 3).numpy()
     for b in range(3):
         want = orc.project_atoms_fast(coords[0].numpy(), counts[0].numpy(), offs[0].numpy(), L, res,
                                       R=R[b].double().numpy(), shift=centre[0].numpy())
-        err = np.abs(vol[b].cpu().numpy() - want).max()
-        assert err < 2e-5 * max(1.0, want.max()), err                 # f32 expf + 2^-24 fixed point vs f64
-        assert want.sum() > 1000 and want.max() < 4.0
+        diff = np.abs(vol[b].cpu().numpy() - want).max(axis=0)       # (L,L,L), worst over types
+        # The 5^3 window makes the density a discontinuous function of the position: an atom whose p'/res sits
+        # within float32 round-off of an integer may be binned one cell over by the f32 kernel (up to
+        # exp(-(2*1.25)^2/2) = 0.044 on the window's faces).  Such atoms are identified from the f64 positions;
+        # everywhere else the kernel must agree to f32 expf + 2^-24 fixed-point accuracy.
+        p = (xyz @ R[b].double().numpy().T + centre[0].numpy()) / res
+        near = np.abs(p - np.round(p)).min(axis=1) < 1e-4
+        allowed = np.zeros((L, L, L), dtype=bool)
+        for c in np.round(p[near]).astype(int):
+            lo, hi = np.maximum(c - 4, 0), np.minimum(c + 5, L)
+            allowed[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] = True
+        assert near.sum() <= 5, near.sum()
+        err = diff[~allowed].max()
+        assert err < 2e-5 * max(1.0, want.max()), (err, int(near.sum()))
+        assert diff.max() < 0.05
+        assert want.sum() > 1000 and want.max() < 50.0                   # (the int32 accumulator holds +-127)
     s = be.project(coords, counts, offs, L, res, dev, R=R.to(dev), shift=centre, sum_types=True)
     assert (s[:, 0] - vol.sum(dim=1)).abs().max() < 1e-5
     for _ in range(3):                                               # run-to-run: bit-identical
