@@ -218,7 +218,7 @@ def visiting_sequence(engine_cls, R_all, ids, nb):
     return np.concatenate(parts), np.concatenate(keys)
 
 
-def algorithmic_bytes(C, L, C1, nb, K, has_clash=True, unfused=False):
+def algorithmic_bytes(C, L, C1, nb, K, has_clash=True, unfused=False, HP=24):
     """Per-launch algorithmic bytes of every stage (each kernel's compulsory input + output, f32):
     DESIGN.md section 4."""
     N, NZ, CT = 2 * L, L + 1, C + (1 if has_clash else 0)
@@ -228,14 +228,13 @@ def algorithmic_bytes(C, L, C1, nb, K, has_clash=True, unfused=False):
         "topk_select": nb * N ** 3 * 4 + nb * K * 8,
         "topk_merge": nb * K * 8 + K * 16,
     }
+    if C1:
+        alg["preact"] = nb * C1 * L ** 3 * 4 + nb * HP * L ** 3 * 4           # coarse correlations in, pre-activations out
     if unfused:
         alg["k3_zifft"] = nb * CT * NZ * N * N * 8 + nb * CT * N ** 3 * 4
-        alg["filter"] = nb * CT * N ** 3 * 4 + nb * N ** 3 * 4
-        if C1:
-            HP = 24
-            alg["filter"] += nb * C1 * L ** 3 * 4 + 2 * nb * HP * L ** 3 * 4     # pre-activations written + read
+        alg["filter"] = nb * CT * N ** 3 * 4 + nb * N ** 3 * 4 + (nb * HP * L ** 3 * 4 if C1 else 0)
     else:
-        alg["k3_zifft_filter"] = nb * CT * NZ * N * N * 8 + nb * N ** 3 * 4 + (nb * C1 * L ** 3 * 4 if C1 else 0)
+        alg["k3_zifft_filter"] = nb * CT * NZ * N * N * 8 + nb * N ** 3 * 4 + (nb * HP * L ** 3 * 4 if C1 else 0)
     if C1:
         L1, N1, NZ1 = L // 2, L, L // 2 + 1
         alg["coarse"] = (C1 * L1 ** 3 * 4 + 2 * nb * C1 * NZ1 * L1 * L1 * 8 + C1 * NZ1 * N1 * N1 * 8 +
@@ -317,6 +316,7 @@ def run_rank(args):
     K, nb = args.max_conf, args.batch
     eng, wl = build_workload(args.workload, args, dev)
     C, L, C1 = wl["C"], wl["L"], wl["C1"]
+    eng_unfused, eng_hp = eng.fine_unfused, eng.HP
     N = 2 * L
     angle = args.angle_inc or wl["angle"]
     # the SOI files carry MitchellLab's licence and are not redistributed: read them when DLPD_ROTATIONS_DIR /
@@ -419,7 +419,7 @@ def run_rank(args):
 
     if rank == 0:
         poses = float(args.steps) * nb * N ** 3 * world
-        alg = algorithmic_bytes(C, L, C1, nb, K, unfused=(N == 160))
+        alg = algorithmic_bytes(C, L, C1, nb, K, unfused=eng_unfused, HP=eng_hp)
         main_stages = [k for k in stages if k in alg and not k.startswith("topk")]
         dom = max(main_stages, key=lambda k: stages[k])
         traffic, traffic_src = pmc_traffic(args.workload, C, L, nb, dom)
@@ -516,7 +516,7 @@ def short_measurement(name, args, dev, R_all, nb, nsteps=24):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / nsteps * 1e3
     stages = timer.summary()
-    alg = algorithmic_bytes(C, L, C1, nb, args.max_conf, unfused=(N == 160))
+    alg = algorithmic_bytes(C, L, C1, nb, args.max_conf, unfused=eng.fine_unfused, HP=eng.HP)
     sb_mb, floor_mb = SURVEY_MB_PER_ROT[name]
     rps = nb / (ms * 1e-3)
     del eng

@@ -293,38 +293,40 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
 // block barriers per group separate "all pencils transformed" from the accumulation phase, in
 // which every thread folds all channels of the group into the hidden units of its 4 voxels.
 // threads per block and number of channel-owning waves (LDS: WC * (8 pencils + raw staging))
-template <int N> struct K3Cfg;
-// HS: the hidden units are processed in HS slices (the transforms are repeated per slice): N = 160
-// needs 10 waves per block, i.e. 3 on one SIMD and a 168-VGPR cap, which 96 accumulators overflow
-// TY: y rows of the tile.  16 = one channel per wave (8 two-row pencils).  8 = two channels per wave (4 pencils
-// each), half the threads and half the LDS per block, so that TWO blocks share a CU and one block's LDS-bound
-// transform phase overlaps the other's FMA-bound accumulation phase (N = 128).
-#ifndef DLPD_K3_TILE8
-#define DLPD_K3_TILE8 0                  // measured: 2.82 ms vs 2.51 ms for the 16-row tile (64-byte DMA runs, twice the blocks)
+// TY: y rows of the tile.  16 = one channel per wave (8 two-row pencils); 8 = two channels per wave (4 pencils
+// each).  N = 160 fused (MODE 1) takes 8-row tiles: 5 waves x 4 voxels per thread keep the 96 accumulators at
+// 2 waves per SIMD (16-row tiles need either 8 voxels per thread or 10 waves, and spill either way).
+// (Measured and rejected at N = 128: 8-row tiles with two blocks per CU, 2.82 vs 2.51 ms; a block that walks
+// several tiles with the next tile's first DMA behind the current tile's last group, 2.51-2.57 vs 2.40 ms --
+// the outer loop costs ~20 VGPRs of hoisted addressing next to the 96 accumulators.)
+template <int N, int MODE> struct K3Cfg { static constexpr int NT = 512, WC = 8, TY = 16; };
+template <int MODE> struct K3Cfg<80, MODE> { static constexpr int NT = 320, WC = 5, TY = 16; };
+template <> struct K3Cfg<160, 0> { static constexpr int NT = 320, WC = 5, TY = 16; };
+#ifndef DLPD_K3_160_NT
+#define DLPD_K3_160_NT 320
 #endif
-template <> struct K3Cfg<64> { static constexpr int NT = 512, WC = 8, HS = 1, TY = 16; };
-#if DLPD_K3_TILE8
-template <> struct K3Cfg<128> { static constexpr int NT = 256, WC = 4, HS = 1, TY = 8; };
-#else
-template <> struct K3Cfg<128> { static constexpr int NT = 512, WC = 8, HS = 1, TY = 16; };
+template <> struct K3Cfg<160, 1> { static constexpr int NT = DLPD_K3_160_NT, WC = 5, TY = 8; };
+#ifndef DLPD_K3_LAUNDER_160
+#define DLPD_K3_LAUNDER_160 1            // N = 160: pencil / pack offsets recomputed per group instead of hoisted (no spills)
 #endif
-template <> struct K3Cfg<80> { static constexpr int NT = 320, WC = 5, HS = 1, TY = 16; };
-template <> struct K3Cfg<160> { static constexpr int NT = 320, WC = 5, HS = 2, TY = 16; };
-// Extra first-layer inputs that are already real volumes: the clipped correlations of a coarser
-// resolution (N/2 grid), nearest-upsampled by index (DockingModels.py:74-76), W1t rows C..C+Caux-1
+// Extra first-layer inputs that are already real volumes on the coarser (N/2) grid, nearest-upsampled by
+// index (DockingModels.py:74-76): either the Caux clipped correlations of that resolution (W1t rows
+// C..C+Caux-1 are applied here), or -- is_preact -- the HP first-layer pre-activations k_filter_preact
+// computed from them once per COARSE voxel (bias included; the first layer is linear): 8x fewer multiply-adds.
 struct K3Aux {
-  const float* p;   // (nb, Caux, Naux^3), Naux = N/2
-  int C, N;
+  const float* p;   // (nb, Caux or HP, Naux^3), Naux = N/2
+  int C, N, is_preact;
 };
 #ifdef DLPD_STAMPS   // diagnostic build only (scripts/stamps.py): where a K3 wave spends its cycles
 __device__ unsigned long long dlpd_stamps[16];
 #endif
-template <int N, int HP, int MODE> __global__ void __launch_bounds__(K3Cfg<N>::NT)
+template <int N, int HP, int MODE> __global__ void __launch_bounds__((K3Cfg<N, MODE>::NT))
 k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int C, int has_clash, int G,
                const float* __restrict__ W1t, const float* __restrict__ b1, const float* __restrict__ W2,
                float b2, int has_clip, float clip, float thr, K3Aux aux) {
-  constexpr int NZ = N / 2 + 1, RS = N + 8, TY = K3Cfg<N>::TY, NPAIR = TY / 2;
-  constexpr int NT = K3Cfg<N>::NT, WC = K3Cfg<N>::WC;
+  typedef K3Cfg<N, MODE> Cfg;
+  constexpr int NZ = N / 2 + 1, RS = N + 8, TY = Cfg::TY, NPAIR = TY / 2;
+  constexpr int NT = Cfg::NT, WC = Cfg::WC;
   constexpr int CPW = 8 / NPAIR;               // channels per wave: its 8 pencils = CPW channels x NPAIR row pairs
   constexpr int LPK = 64 / NPAIR;              // kz rows per 64-lane DMA instruction
   static_assert((NPAIR == 8 || NPAIR == 4) && WC * 64 <= NT, "one wave = 8 pencils x 8 threads");
@@ -337,12 +339,10 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
   float4* raw = reinterpret_cast<float4*>(tw + N);        // [WC][CPW][RAWC] staging of raw spectra
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int y0 = blockIdx.x * TY, xo = blockIdx.y, b = blockIdx.z;
-  init_twiddles<N>(tw, tid, NT);
 
   // hidden pre-activations of the thread's 2*EPT voxels (the SLP vectoriser pairs adjacent
   // hidden units into v_pk_fma_f32 with the weight pair in SGPRs and the voxel value broadcast)
-  constexpr int HS = (MODE == 1 && HP % K3Cfg<N>::HS == 0) ? K3Cfg<N>::HS : 1;
-  constexpr int HPH = HP / HS;                 // hidden units per slice
+  constexpr int HPH = HP;
   float nrm[EPT * 2];
   float total[EPT * 2];
 #pragma unroll
@@ -350,7 +350,6 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
   const int zz = tid % N, m0 = tid / N;        // output ownership
   const bool owner = (NPAIR * N >= NT) || (m0 < NPAIR);
   const int tr = lane & 7, qr = lane >> 3;     // FFT: lane = 8*pencil + thread
-  const RowAddr<RS> ad = {(wave * 8 + qr) * RS};
   float4* rawg = raw + wave * CPW * RAWC;
 
   // this wave's channels of group `cb`: raw[k][m] <- Bw[b][cb + wave*CPW + j][k][xo][y0+2m .. +1]
@@ -373,18 +372,34 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
     }
   };
   DLPD_STAMP_DECL;
-#pragma unroll 1
-  for (int hs = 0; hs < HS; hs++) {
-  const int j0 = hs * HPH;
+  issue_channel(0);                            // first DMA in flight behind the twiddle table and the bias loads
+  init_twiddles<N>(tw, tid, NT);
+  constexpr int j0 = 0;
   float h[EPT * 2][HPH > 0 ? HPH : 1];
   if (MODE == 1) {
+    if (aux.C > 0 && aux.is_preact) {
+      // rows 2m, 2m+1 and columns z, z^1 of the fine grid share one coarse voxel
+      const int Na = aux.N;
+      const size_t cstride = (size_t)Na * Na * Na;
+      const float* ab = aux.p + (size_t)b * HP * cstride + ((size_t)(xo >> 1) * Na + (y0 >> 1)) * Na + (zz >> 1);
+      if (owner) {
 #pragma unroll
-    for (int e = 0; e < EPT * 2; e++)
+        for (int e = 0; e < EPT; e++)
 #pragma unroll
-      for (int j = 0; j < HPH; j++) h[e][j] = b1[j0 + j];
+          for (int j = 0; j < HP; j++) {
+            const float v = ab[(size_t)j * cstride + (size_t)(m0 + e * MSTEP) * Na];
+            h[2 * e][j] = v;
+            h[2 * e + 1][j] = v;
+          }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPT * 2; e++)
+#pragma unroll
+        for (int j = 0; j < HPH; j++) h[e][j] = b1[j0 + j];
+    }
   }
-  issue_channel(0);
-  __syncthreads();                             // twiddle table visible; previous slice fully consumed
+  __syncthreads();                             // twiddle table visible
 
   for (int cbase = 0; cbase < CT; cbase += G) {
     const int gn = (CT - cbase) < G ? (CT - cbase) : G;
@@ -405,13 +420,14 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
 #pragma unroll
       for (int j = 0; j < CPW; j++) {
         if (wave * CPW + j >= gn) break;
-        int m, kq;
+        int m, kq, lq = lane;
+        if (N == 160 && DLPD_K3_LAUNDER_160) DLPD_OPAQUE(lq);
         if (NPAIR == 8) {
-          m = (lane & 3) | (((lane >> 4) & 1) << 2);
-          kq = ((lane >> 2) & 1) | (((lane >> 5) & 1) << 1) | (((lane >> 3) & 1) << 2);
+          m = (lq & 3) | (((lq >> 4) & 1) << 2);
+          kq = ((lq >> 2) & 1) | (((lq >> 5) & 1) << 1) | (((lq >> 3) & 1) << 2);
         } else {
-          m = lane % NPAIR;
-          kq = lane / NPAIR;
+          m = lq % NPAIR;
+          kq = lq / NPAIR;
         }
         const int rot = (NPAIR == 8) ? 2 * m : 0;            // lane-dependent start of its walk over the DMA instructions
         const int slot = NPAIR * kq + m;
@@ -447,7 +463,14 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
     DLPD_STAMP(1);
     issue_channel(cbase + G);                  // next group's channel streams in behind the math
     DLPD_STAMP(2);
-    if (wave * CPW < gn) fft_wave<N, +1, N>(S, ad, tr, tw);
+    if (wave * CPW < gn) {
+      // N = 160 (three passes, 8-row tiles): the lane-dependent pencil offsets are made opaque per group, otherwise
+      // ~60 of them are hoisted out of the group loop and spill next to the 96 accumulators
+      int tq = tr, qq = qr;
+      if (N == 160 && DLPD_K3_LAUNDER_160) { DLPD_OPAQUE(tq); DLPD_OPAQUE(qq); }
+      const RowAddr<RS> adq = {(wave * 8 + qq) * RS};
+      fft_wave<N, +1, N>(S, adq, tq, tw);
+    }
     DLPD_STAMP(3);
     DLPD_LDS_BARRIER();                        // all channels of the group transformed
     DLPD_STAMP(4);
@@ -521,7 +544,7 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
     DLPD_STAMP(6);
   }
   DLPD_STAMP_FLUSH(dlpd_stamps, DLPD_STAMPS);
-  if (MODE == 1 && owner && aux.C > 0) {
+  if (MODE == 1 && owner && aux.C > 0 && !aux.is_preact) {
     // coarse-resolution channels: rows 2m and 2m+1 and columns z, z^1 share one coarse voxel
     const int Na = aux.N;
     const float* ab = aux.p + (size_t)b * aux.C * Na * Na * Na + ((size_t)(xo >> 1) * Na + (y0 >> 1)) * Na + (zz >> 1);
@@ -557,7 +580,6 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
 #pragma unroll
       for (int j = 0; j < HPH; j++) total[e] = fmaf(W2[j0 + j], fmaxf(h[e][j], 0.f), total[e]);
   }
-  }   // hidden slices
   if (MODE == 1 && owner) {
 #pragma unroll
     for (int e = 0; e < EPT; e++) {
@@ -570,6 +592,296 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3 walking several tiles per block (MODE 1 only).  With few channels per tile (the reference's real model:
+// 17 channels = 2 groups at N = 160) a third of a one-tile block is the exposed latency of its first DMA
+// (stamps: dma_wait 33 %); here a block takes `tpb` consecutive tiles (all y-tiles of one x') and the first group
+// of the NEXT tile streams in behind the last group of the current one.  ONE loop over (tile, group) steps, not a
+// tile loop around a group loop, and lane-dependent offsets made opaque per step: otherwise the compiler hoists
+// another ~20 VGPRs of addressing next to the 96 accumulators and spills.  Not used at N <= 128, where 7 groups per
+// tile hide that latency already and the extra register pressure costs more (measured 2.51-2.57 vs 2.40 ms).
+// ------------------------------------------------------------------------------------------
+template <int N, int HP, int MODE> __global__ void __launch_bounds__((K3Cfg<N, MODE>::NT))
+k_zifft_filter_tiles(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int C, int has_clash, int G,
+               const float* __restrict__ W1t, const float* __restrict__ b1, const float* __restrict__ W2,
+               float b2, int has_clip, float clip, float thr, K3Aux aux, int ntiles, int tpb) {
+  typedef K3Cfg<N, MODE> Cfg;
+  constexpr int NZ = N / 2 + 1, RS = N + 8, TY = Cfg::TY, NPAIR = TY / 2;
+  constexpr int NT = Cfg::NT, WC = Cfg::WC, NYT = N / TY;
+  constexpr int CPW = 8 / NPAIR;               // channels per wave: its 8 pencils = CPW channels x NPAIR row pairs
+  constexpr int LPK = 64 / NPAIR;              // kz rows per 64-lane DMA instruction
+  static_assert((NPAIR == 8 || NPAIR == 4) && WC * 64 <= NT, "one wave = 8 pencils x 8 threads");
+  constexpr int EPT = (NPAIR * N) / NT > 0 ? (NPAIR * N) / NT : 1;   // complex outputs per thread per channel
+  constexpr int MSTEP = NT / N;                // pair stride between a thread's outputs
+  static_assert((NPAIR * N) % NT == 0 || NPAIR * N < NT, "tile/thread mismatch");
+  constexpr int RAWC = ((NZ * NPAIR + 63) / 64) * 64;    // float4 slots per channel (whole waves)
+  DLPD_DYN_SHARED(cplx, S);
+  cplx* tw = S + WC * 8 * RS;
+  float4* raw = reinterpret_cast<float4*>(tw + N);        // [WC][CPW][RAWC] staging of raw spectra
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t_beg = blockIdx.x * tpb, t_end = (t_beg + tpb < ntiles) ? t_beg + tpb : ntiles;
+  if (t_beg >= t_end) return;
+  init_twiddles<N>(tw, tid, NT);
+
+  const int zz = tid % N, m0 = tid / N;        // output ownership
+  const bool owner = (NPAIR * N >= NT) || (m0 < NPAIR);
+  const int tr = lane & 7, qr = lane >> 3;     // FFT: lane = 8*pencil + thread
+  float4* rawg = raw + wave * CPW * RAWC;
+
+  // this wave's channels of group `cb` of tile `t`: raw[k][m] <- Bw[b][cb + wave*CPW + j][k][xo][y0+2m .. +1]
+  // (lane = NPAIR*(k % LPK) + m: LPK runs of NPAIR*16 bytes per DMA instruction; k = N/2 is the last, short one)
+  constexpr int NFULL = (N / 2) / LPK;         // full 64-lane DMA instructions per channel (bins 0..N/2-1)
+  static_assert(NZ * NPAIR == NFULL * 64 + NPAIR, "raw channel = NFULL full DMA instructions + one short one");
+  auto issue_channel = [&](int t, int cb) {
+    const int ty0 = (t % NYT) * TY, txo = (t / NYT) % N, tb = t / (NYT * N);
+#pragma unroll
+    for (int j = 0; j < CPW; j++) {
+      const int g = wave * CPW + j;
+      if (g < G && cb + g < CT) {
+        const cplx* src = Bw + (((size_t)tb * CT + cb + g) * NZ * N + txo) * N + ty0;
+        const cplx* lane_src = src + (size_t)(lane / NPAIR) * N * N + 2 * (lane % NPAIR);
+        float4* rj = rawg + j * RAWC;
+#pragma unroll
+        for (int it = 0; it < NFULL; it++) DLPD_GLDS16(lane_src + (size_t)it * LPK * N * N, rj + it * 64);
+        const int mt = lane % NPAIR;                        // tail lanes re-read valid elements
+        DLPD_GLDS16(src + (size_t)(N / 2) * N * N + 2 * mt, rj + NFULL * 64);
+      }
+    }
+  };
+  DLPD_STAMP_DECL;
+  issue_channel(t_beg, 0);
+  __syncthreads();                             // twiddle table visible
+
+  // ONE loop over (tile, channel group) steps -- not a tile loop around a group loop: with a single loop level the
+  // compiler keeps the same values in registers as the one-tile kernel did (an outer tile loop made it hoist
+  // another ~20 VGPRs of addressing and spill next to the 96 accumulators)
+  float nrm[EPT * 2];
+  float h[EPT * 2][HP > 0 ? HP : 1];
+  const int ngroups = (CT + G - 1) / G;
+  int t = t_beg, cbase = 0;
+#pragma unroll 1
+  for (int step = 0, nsteps = (t_end - t_beg) * ngroups; step < nsteps; step++) {
+  const int y0 = (t % NYT) * TY, xo = (t / NYT) % N, b = t / (NYT * N);
+  if (cbase == 0) {
+  // hidden pre-activations of the thread's 2*EPT voxels (the SLP vectoriser pairs adjacent
+  // hidden units into v_pk_fma_f32 with the weight pair in SGPRs and the voxel value broadcast)
+#pragma unroll
+  for (int e = 0; e < EPT * 2; e++) nrm[e] = 0.f;
+  if (MODE == 1) {
+    if (aux.C > 0 && aux.is_preact) {
+      // rows 2m, 2m+1 and columns z, z^1 of the fine grid share one coarse voxel
+      const int Na = aux.N;
+      const size_t cstride = (size_t)Na * Na * Na;
+      const float* ab = aux.p + (size_t)b * HP * cstride + ((size_t)(xo >> 1) * Na + (y0 >> 1)) * Na + (zz >> 1);
+      if (owner) {
+#pragma unroll
+        for (int e = 0; e < EPT; e++)
+#pragma unroll
+          for (int j = 0; j < HP; j++) {
+            const float v = ab[(size_t)j * cstride + (size_t)(m0 + e * MSTEP) * Na];
+            h[2 * e][j] = v;
+            h[2 * e + 1][j] = v;
+          }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPT * 2; e++)
+#pragma unroll
+        for (int j = 0; j < HP; j++) h[e][j] = b1[j];
+    }
+  }
+  }
+
+  {
+    const int gn = (CT - cbase) < G ? (CT - cbase) : G;
+    if (wave * CPW < gn) {
+      DLPD_WAIT_VMEM();                        // this wave's own DMA has landed
+      DLPD_WAVE_SYNC();
+      DLPD_STAMP(0);
+      // pack two rows per complex pencil: Z[k] = A[k] + i B[k], Z[N-k] = conj(A[k]) + i conj(B[k])
+      // Lane -> (pencil m, kz row) of the element it packs.  The DMA layout of `raw` is [it][kq][m] (slot =
+      // NPAIR*kq + m inside the 64-slot block of DMA instruction `it`, k = LPK*it + kq).  Packing in that same
+      // lane order makes a 16-lane store group hit 8 pencils x 2 k: the pencil stride (RS = N + 8 complex = 16
+      // dwords mod 32) leaves only 8 distinct banks, a 4-way conflict on every ds_write_b64 (a third of this
+      // kernel's LDS cycles, SQ_LDS_BANK_CONFLICT).  For NPAIR = 8 the lanes are therefore re-dealt so that a
+      // store group covers 4 pencils x 4 consecutive-block k and every lane additionally walks the DMA
+      // instructions rotated by 2m: found by exhaustive search over lane-bit permutations x rotations
+      // (model of the ds_write_b64 / ds_read_b128 lane groups, MI355X_MICROARCH.md LDS table): raw reads stay
+      // conflict-free, stores cost 5.0 instead of 16.25 LDS cycles.
+#pragma unroll
+      for (int j = 0; j < CPW; j++) {
+        if (wave * CPW + j >= gn) break;
+        int m, kq, lq = lane;
+        if (1) DLPD_OPAQUE(lq);            // (pack offsets recomputed per group, not kept in VGPRs)
+        if (NPAIR == 8) {
+          m = (lq & 3) | (((lq >> 4) & 1) << 2);
+          kq = ((lq >> 2) & 1) | (((lq >> 5) & 1) << 1) | (((lq >> 3) & 1) << 2);
+        } else {
+          m = lq % NPAIR;
+          kq = lq / NPAIR;
+        }
+        const int rot = (NPAIR == 8) ? 2 * m : 0;            // lane-dependent start of its walk over the DMA instructions
+        const int slot = NPAIR * kq + m;
+        cplx* P = S + (wave * 8 + j * NPAIR + m) * RS;
+        const float4* rj = rawg + j * RAWC;
+        constexpr int PCH = NFULL > 8 ? NFULL / 2 : NFULL;   // raw elements in flight per lane
+        const float4 qh = rj[NFULL * 64 + (lane % NPAIR)];  // k = N/2 (lanes with lane / NPAIR == 0 store it)
+#pragma unroll
+        for (int it0 = 0; it0 < NFULL; it0 += PCH) {
+          float4 q[PCH];
+#pragma unroll
+          for (int u = 0; u < PCH; u++) q[u] = rj[((it0 + u + rot) % NFULL) * 64 + slot];
+#pragma unroll
+          for (int u = 0; u < PCH; u++) {
+            const int k = ((it0 + u + rot) % NFULL) * LPK + kq;
+            // k = 0: the purely real bin of both rows (both stores then write the same value to the same place)
+            const cplx lo = (k == 0) ? c_make(q[u].x, q[u].z) : c_make(q[u].x - q[u].w, q[u].y + q[u].z);
+            const cplx hi = (k == 0) ? c_make(q[u].x, q[u].z) : c_make(q[u].x + q[u].w, q[u].z - q[u].y);
+            P[slab_swz(k)] = lo;
+            P[slab_swz((N - k) & (k == 0 ? 0 : ~0))] = hi;
+          }
+        }
+        if (lane / NPAIR == 0) S[(wave * 8 + j * NPAIR + lane % NPAIR) * RS + slab_swz(N / 2)] = c_make(qh.x, qh.z);
+      }
+      DLPD_WAIT_LDS();                         // raw fully read before it is refilled
+      DLPD_WAVE_SYNC();
+    }
+    DLPD_STAMP(1);
+    // the next DMA streams in behind the math: the next group of this tile, or the first group of the next tile
+    if (cbase + G < CT) issue_channel(t, cbase + G);
+    else if (t + 1 < t_end) issue_channel(t + 1, 0);
+    DLPD_STAMP(2);
+    if (wave * CPW < gn) {
+      // lane-dependent offsets made opaque per group: otherwise the ~60 swizzled pencil offsets of the two
+      // passes are hoisted out of the group / tile loops and live in VGPRs next to the 96 accumulators (spills)
+      int tq = tr, qq = qr;
+      if (1) { DLPD_OPAQUE(tq); DLPD_OPAQUE(qq); }
+      const RowAddr<RS> adq = {(wave * 8 + qq) * RS};
+      fft_wave<N, +1, N>(S, adq, tq, tw);
+    }
+    DLPD_STAMP(3);
+    DLPD_LDS_BARRIER();                        // all channels of the group transformed
+    DLPD_STAMP(4);
+    if (owner) {
+      if (MODE == 0) {
+        for (int g = 0; g < gn; g++) {
+          const int c = cbase + g;
+#pragma unroll
+          for (int e = 0; e < EPT; e++) {
+            const int m = m0 + e * MSTEP;
+            const cplx val = S[(g * NPAIR + m) * RS + slab_swz(zz)];
+            float v0 = val.x, v1 = val.y;
+            if (has_clip && c < C) { v0 = DLPD_CLAMP(v0, clip); v1 = DLPD_CLAMP(v1, clip); }
+            float* o = out + ((((size_t)b * CT + c) * N + xo) * N + y0 + 2 * m) * N + zz;
+            o[0] = v0;
+            o[N] = v1;
+          }
+        }
+      } else {
+        // score channels of this group; the clash channel (index C, always last) is peeled off
+        const int gs = (cbase + gn <= C) ? gn : (C - cbase > 0 ? C - cbase : 0);
+        // first-layer weights are wave-uniform (scalar loads): channel g+1's row is requested
+        // before channel g's FMAs so the scalar-load latency hides behind them
+        float wcur[HP > 0 ? HP : 1], wnxt[HP > 0 ? HP : 1];
+        cplx vcur[EPT], vnxt[EPT];
+        if (gs > 0) {
+#pragma unroll
+          for (int j = 0; j < HP; j++) wcur[j] = W1t[(size_t)cbase * HP + j];
+#pragma unroll
+          for (int e = 0; e < EPT; e++) vcur[e] = S[(m0 + e * MSTEP) * RS + slab_swz(zz)];
+        }
+        for (int g = 0; g < gs; g++) {
+          // channel g+1's weights (scalar loads) and values (LDS) are requested here, one
+          // iteration ahead: both share lgkmcnt, so the only wait sits at the top of the next
+          // iteration, behind this channel's 96 FMAs
+          const int gn1 = (g + 1 < gs ? g + 1 : g);
+#pragma unroll
+          for (int j = 0; j < HP; j++) wnxt[j] = W1t[(size_t)(cbase + gn1) * HP + j];
+#pragma unroll
+          for (int e = 0; e < EPT; e++) vnxt[e] = S[(gn1 * NPAIR + m0 + e * MSTEP) * RS + slab_swz(zz)];
+          DLPD_SCHED_FENCE();
+#pragma unroll
+          for (int e = 0; e < EPT; e++) {
+            float v0 = vcur[e].x, v1 = vcur[e].y;
+            if (has_clip) { v0 = DLPD_CLAMP(v0, clip); v1 = DLPD_CLAMP(v1, clip); }
+#pragma unroll
+            for (int j = 0; j < HP; j++) {
+              h[2 * e][j] = fmaf(wcur[j], v0, h[2 * e][j]);
+              h[2 * e + 1][j] = fmaf(wcur[j], v1, h[2 * e + 1][j]);
+            }
+          }
+          DLPD_SCHED_FENCE();
+#pragma unroll
+          for (int j = 0; j < HP; j++) wcur[j] = wnxt[j];
+#pragma unroll
+          for (int e = 0; e < EPT; e++) vcur[e] = vnxt[e];
+        }
+        if (has_clash && cbase + gn > C) {
+          const int g = C - cbase;
+#pragma unroll
+          for (int e = 0; e < EPT; e++) {
+            const cplx v = S[(g * NPAIR + m0 + e * MSTEP) * RS + slab_swz(zz)];
+            nrm[2 * e] = v.x;
+            nrm[2 * e + 1] = v.y;
+          }
+        }
+      }
+    }
+    DLPD_STAMP(5);
+    DLPD_LDS_BARRIER();                        // pencils free for the next group
+    DLPD_STAMP(6);
+  }
+  if (cbase + G < CT) { cbase += G; continue; }          // more channel groups of this tile
+  if (MODE == 1 && owner && aux.C > 0 && !aux.is_preact) {
+    // coarse-resolution channels: rows 2m and 2m+1 and columns z, z^1 share one coarse voxel
+    const int Na = aux.N;
+    const float* ab = aux.p + (size_t)b * aux.C * Na * Na * Na + ((size_t)(xo >> 1) * Na + (y0 >> 1)) * Na + (zz >> 1);
+    constexpr int CH = EPT > 2 ? 4 : 8;       // channels per chunk: EPT*CH loads in flight per thread
+    const size_t cstride = (size_t)Na * Na * Na;
+    for (int cb = 0; cb < aux.C; cb += CH) {
+      float av[CH][EPT];
+#pragma unroll
+      for (int k = 0; k < CH; k++)
+#pragma unroll
+        for (int e = 0; e < EPT; e++)
+          av[k][e] = (cb + k < aux.C) ? ab[(size_t)(cb + k) * cstride + (size_t)(m0 + e * MSTEP) * Na] : 0.f;
+#pragma unroll
+      for (int k = 0; k < CH; k++) {
+        if (cb + k < aux.C) {
+          const float* w = W1t + (size_t)(C + cb + k) * HP;
+#pragma unroll
+          for (int e = 0; e < EPT; e++) {
+            const float v = av[k][e];
+#pragma unroll
+            for (int j = 0; j < HP; j++) {
+              h[2 * e][j] = fmaf(w[j], v, h[2 * e][j]);
+              h[2 * e + 1][j] = fmaf(w[j], v, h[2 * e + 1][j]);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (MODE == 1 && owner) {
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+      const int m = m0 + e * MSTEP;
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        float acc = b2;
+#pragma unroll
+        for (int j = 0; j < HP; j++) acc = fmaf(W2[j], fmaxf(h[2 * e + u][j], 0.f), acc);
+        if (has_clash) acc = acc * ((nrm[2 * e + u] < thr) ? 1.0f : 0.0f);
+        out[(((size_t)b * N + xo) * N + y0 + 2 * m + u) * N + zz] = acc;
+      }
+    }
+  }
+  cbase = 0;
+  t++;
+  }   // (tile, group) steps
+  DLPD_STAMP_FLUSH(dlpd_stamps, DLPD_STAMPS);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -792,23 +1104,52 @@ static int k3_group(int CT, int maxg) {
 template <int N, int HP, int MODE> static int launch_k3(const cplx* Bw, float* out, int CT, int C, int has_clash,
                                                         int nb, const float* W1t, const float* b1, const float* W2,
                                                         float b2, int has_clip, float clip, float thr,
-                                                        hipStream_t st, K3Aux aux = K3Aux{nullptr, 0, 0}) {
-  constexpr int RS = N + 8, NZ = N / 2 + 1, W = K3Cfg<N>::WC, NPAIR = K3Cfg<N>::TY / 2, CPW = 8 / NPAIR;
+                                                        hipStream_t st, K3Aux aux = K3Aux{nullptr, 0, 0, 0}) {
+  typedef K3Cfg<N, MODE> Cfg;
+  constexpr int RS = N + 8, NZ = N / 2 + 1, W = Cfg::WC, NPAIR = Cfg::TY / 2, CPW = 8 / NPAIR;
   constexpr int RAWC = ((NZ * NPAIR + 63) / 64) * 64;
   const size_t shmem = (size_t)(W * 8 * RS + N) * sizeof(cplx) + (size_t)W * CPW * RAWC * 16;
   int rc = dlpd_set_max_dyn_shared((const void*)k_zifft_filter<N, HP, MODE>, shmem);
   if (rc) return rc;
   const int G = k3_group(CT, W * CPW);         // channels per group (CPW per wave), <= W * CPW
-  dim3 grid(N / K3Cfg<N>::TY, N, nb), block(K3Cfg<N>::NT);
+  dim3 grid(N / Cfg::TY, N, nb), block(Cfg::NT);
   DLPD_LAUNCH((k_zifft_filter<N, HP, MODE>), grid, block, shmem, st, Bw, out, CT, C, has_clash, G, W1t, b1, W2, b2,
               has_clip, clip, thr, aux);
+  return dlpd_check_launch();
+}
+
+// fused K3 over several tiles per block (see k_zifft_filter_tiles)
+template <int N, int HP> static int launch_k3_tiles(const cplx* Bw, float* out, int CT, int C, int has_clash, int nb,
+                                                    const float* W1t, const float* b1, const float* W2, float b2,
+                                                    int has_clip, float clip, float thr, hipStream_t st, K3Aux aux) {
+  typedef K3Cfg<N, 1> Cfg;
+  constexpr int RS = N + 8, NZ = N / 2 + 1, W = Cfg::WC, NPAIR = Cfg::TY / 2, CPW = 8 / NPAIR;
+  constexpr int RAWC = ((NZ * NPAIR + 63) / 64) * 64;
+  const size_t shmem = (size_t)(W * 8 * RS + N) * sizeof(cplx) + (size_t)W * CPW * RAWC * 16;
+  int rc = dlpd_set_max_dyn_shared((const void*)k_zifft_filter_tiles<N, HP, 1>, shmem);
+  if (rc) return rc;
+  const int G = k3_group(CT, W * CPW);
+  const int ntiles = (N / Cfg::TY) * N * nb, tpb = N / Cfg::TY;       // one x' plane per block
+  DLPD_LAUNCH((k_zifft_filter_tiles<N, HP, 1>), dim3((ntiles + tpb - 1) / tpb), dim3(Cfg::NT), shmem, st, Bw, out, CT, C,
+              has_clash, G, W1t, b1, W2, b2, has_clip, clip, thr, aux, ntiles, tpb);
   return dlpd_check_launch();
 }
 
 template <int N> static int k3_filter_dispatch(int HP, const cplx* Bw, float* V, int CT, int C, int has_clash, int nb,
                                                const float* W1t, const float* b1, const float* W2, float b2,
                                                int has_clip, float clip, float thr, hipStream_t st,
-                                               K3Aux aux = K3Aux{nullptr, 0, 0}) {
+                                               K3Aux aux = K3Aux{nullptr, 0, 0, 0}) {
+  if constexpr (N == 160) {                    // few groups per tile: the tile-walking kernel
+    switch (HP) {
+      case 2: return launch_k3_tiles<N, 2>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux);
+      case 4: return launch_k3_tiles<N, 4>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux);
+      case 8: return launch_k3_tiles<N, 8>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux);
+      case 16: return launch_k3_tiles<N, 16>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux);
+      case 24: return launch_k3_tiles<N, 24>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux);
+      case 32: return launch_k3_tiles<N, 32>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux);
+      default: return DLPD_ERR_UNSUPPORTED;
+    }
+  }
   switch (HP) {
     case 2: return launch_k3<N, 2, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux);
     case 4: return launch_k3<N, 4, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux);
@@ -950,11 +1291,12 @@ int dlpd_zifft_real(const void* wsB, float* out, int nb, int CT, int L, int has_
 // aux (nb, Caux, (N/2)^3): already-real first-layer inputs of a coarser resolution (may be null)
 int dlpd_zifft_filter_aux(const void* wsB, float* V, int nb, int C, int has_clash, int L, const float* W1t,
                           const float* b1, const float* W2, float b2, int HP, int has_clip, float clip, float thr,
-                          const float* aux, int Caux, void* stream) {
+                          const float* aux, int Caux, int aux_is_preact, void* stream) {
   if (!wsB || !V || !W1t || !b1 || !W2 || nb <= 0 || C <= 0 || Caux < 0 || (Caux > 0 && !aux)) return DLPD_ERR_ARG;
+  if (L % 2) return DLPD_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int CT = C + (has_clash ? 1 : 0);
-  const K3Aux ax = {aux, Caux, L};              // coarse grid N/2 = L
+  const K3Aux ax = {aux, Caux, L, (Caux > 0 && aux_is_preact) ? 1 : 0};              // coarse grid N/2 = L
   switch (L) {
     case 32: return k3_filter_dispatch<64>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, ax);
     case 40: return k3_filter_dispatch<80>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, ax);
@@ -968,7 +1310,7 @@ int dlpd_zifft_filter(const void* wsB, float* V, int nb, int C, int has_clash, i
                       const float* b1, const float* W2, float b2, int HP, int has_clip, float clip, float thr,
                       void* stream) {
   return dlpd_zifft_filter_aux(wsB, V, nb, C, has_clash, L, W1t, b1, W2, b2, HP, has_clip, clip, thr, nullptr, 0,
-                               stream);
+                               0, stream);
 }
 
 // Fused driver for one batch of rotations (single-resolution model):

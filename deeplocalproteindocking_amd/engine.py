@@ -164,13 +164,14 @@ class DockingEngine:
             self.aux = torch.empty(nb, C1, N1, N1, N1, dtype=f32, device=dev)      # clipped coarse correlations
             if self.use_quads:
                 self.ligq1 = torch.empty(lib.call("dlpd_quads_floats", C1, L1), dtype=f32, device=dev)
-        # N = 160: the fused z-inverse + MLP kernel does not fit the register file,
-        # so that grid materialises its real correlations and a vectorised filter follows
-        self.fine_unfused = (N == 160) if fine_unfused is None else bool(fine_unfused)
+        # fine_unfused (diagnostic / A-B): materialise the real correlations of the fine grid and run the
+        # vectorised filter kernel behind a plain z-inverse, instead of the fused z-inverse + MLP (K3)
+        self.fine_unfused = bool(fine_unfused)
         if self.fine_unfused:
             self.conv = torch.empty(nb, CT, N, N, N, dtype=f32, device=dev)
-            if self.C1:
-                self.pre = torch.empty(nb, HP, 2 * self.L1, 2 * self.L1, 2 * self.L1, dtype=f32, device=dev)
+        if self.C1:
+            # first-layer pre-activations of the coarse channels on the coarse grid (dlpd_filter_preact)
+            self.pre = torch.empty(nb, HP, 2 * self.L1, 2 * self.L1, 2 * self.L1, dtype=f32, device=dev)
         self.top = DeviceTopList(self.K, nb, dev, lib)
         # optional: callable(R (nb,3,3) f32 device) -> (nb,L,L,L) f32 device ligand forbidden volumes
         # re-projected from rotated ATOMS (Docker.py:221-224) instead of the rotated volume
@@ -322,16 +323,17 @@ class DockingEngine:
              tr, st)
         mark("k2_xy_corr")
         aux, C1, N1 = (_ptr(self.aux), self.C1, 2 * self.L1) if self.C1 else (0, 0, 0)
+        if C1:
+            # first layer is linear: its coarse half runs once per COARSE voxel (DockingModels.py:74-83)
+            call("dlpd_filter_preact", aux, C1, N1, self.W1t.data_ptr() + self.C * self.HP * 4, _ptr(self.b1),
+                 self.HP, _ptr(self.pre), nb, st)
+            aux = _ptr(self.pre)
+            mark("preact")
         if self.fine_unfused:
             N3 = self.N ** 3
             call("dlpd_zifft_real_part", _ptr(self.wsB), _ptr(self.conv), nb, self.CT, self.C, L, has_clip, clip, st)
             mark("k3_zifft")
             mask = self.conv.data_ptr() + self.C * N3 * 4 if self.has_clash else 0
-            if C1:
-                # first layer is linear: its coarse half runs once per COARSE voxel (DockingModels.py:74-83)
-                call("dlpd_filter_preact", aux, C1, N1, self.W1t.data_ptr() + self.C * self.HP * 4, _ptr(self.b1),
-                     self.HP, _ptr(self.pre), nb, st)
-                aux = _ptr(self.pre)
             call("dlpd_filter_volumes", _ptr(self.conv), self.C, self.CT * N3, self.N, aux, C1, N1, int(C1 > 0), mask,
                  self.CT * N3, self.threshold, int(self.has_clash), _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2),
                  self.b2, self.HP, _ptr(V), nb, st)
@@ -339,7 +341,7 @@ class DockingEngine:
         elif self.C1:
             call("dlpd_zifft_filter_aux", _ptr(self.wsB), _ptr(V), nb, self.C, int(self.has_clash), L,
                  _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2), self.b2, self.HP, has_clip, clip, self.threshold,
-                 aux, C1, st)
+                 aux, C1, 1, st)
             mark("k3_zifft_filter")
         else:
             call("dlpd_zifft_filter", _ptr(self.wsB), _ptr(V), nb, self.C, int(self.has_clash), L,

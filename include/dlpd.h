@@ -101,10 +101,12 @@ int dlpd_zifft_filter(const void* wsB, float* V, int nb, int C, int has_clash, i
 
 /* Same for the reference's two-resolution layout (ProteinRepresentationModels.py:72-76): the Caux
  * channels of the coarser resolution arrive as clipped real correlation volumes aux (nb, Caux, L^3)
- * (grid N/2 = L) and are nearest-upsampled by index (DockingModels.py:74-76); W1t has C + Caux rows. */
+ * (grid N/2 = L) and are nearest-upsampled by index (DockingModels.py:74-76); W1t has C + Caux rows.
+ * aux_is_preact: aux is (nb, HP, L^3) from dlpd_filter_preact -- the coarse half of the (linear) first
+ * layer, bias included, evaluated once per coarse voxel -- and seeds the hidden units instead. */
 int dlpd_zifft_filter_aux(const void* wsB, float* V, int nb, int C, int has_clash, int L, const float* W1t,
                           const float* b1, const float* W2, float b2, int HP, int has_clip, float clip,
-                          float thr, const float* aux, int Caux, void* stream);
+                          float thr, const float* aux, int Caux, int aux_is_preact, void* stream);
 
 /* One batch of the hot loop, Docker.py:211-232 (single-resolution model): K1 + K2 + K3. */
 int dlpd_score_rotations(const float* lig, const void* recF, const float* R, int nb, int C, int has_clash,

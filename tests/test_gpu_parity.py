@@ -538,8 +538,8 @@ def test_all_four_search_paths_match_oracle_at_baseline_config2_size(dev):
 
 def test_baseline_config5_shape_48ch_80cube_matches_oracle(dev):
     """BASELINE config 5's literal shape: 48 channels at 80^3, single resolution -> 160^3 (DIF K2 with 49
-    slabs per kz, dlpd_zifft_real_part, k_filter_vec over 48 channels), clip active, clash channel on;
-    two rotations, one per slab orientation as the search would choose."""
+    slabs per kz, fused K3 on 8-row tiles; and the unfused z-inverse + k_filter_vec pair as a diagnostic
+    variant), clip active, clash channel on; two rotations, one per slab orientation as the search would choose."""
     import bench
     from deeplocalproteindocking_amd.engine import DockingEngine
     C, L = 48, 80
@@ -548,7 +548,7 @@ def test_baseline_config5_shape_48ch_80cube_matches_oracle(dev):
     W = [w.cpu() for w in filt.parameters_tuple()]
     groups = _rotations_by_group(1, seed=5)
     eng = DockingEngine(L, C, *W, clip=5.0, threshold_clash=thr, max_conf=100, batch=2, device=dev)
-    assert eng.fine_unfused and eng.CT == 49
+    assert eng.CT == 49
     eng.set_receptor(rec, recf)
     eng.set_ligand(lig, ligf)
     worst = 0.0
@@ -559,6 +559,12 @@ def test_baseline_config5_shape_48ch_80cube_matches_oracle(dev):
         Rd = torch.from_numpy(R1[None]).float().to(dev).contiguous()
         V = eng.score_batch(Rd, transposed=key[0], quads=key[1]).cpu()
         worst = max(worst, _assert_scores_match(V[0], Vo, norm, thr))
+        if key == (False, False):                            # the unfused pair (engine option) on the same rotation
+            eng2 = DockingEngine(L, C, *W, clip=5.0, threshold_clash=thr, max_conf=100, batch=1, device=dev, fine_unfused=True)
+            eng2.set_receptor(rec, recf)
+            eng2.set_ligand(lig, ligf)
+            worst = max(worst, _assert_scores_match(eng2.score_batch(Rd).cpu()[0], Vo, norm, thr))
+            del eng2
     print("config 5 shape (48 ch @ 80^3): worst error %.2e of max|V|" % worst)
     # the clip must really bite at this amplitude, otherwise the clamp path is not exercised
     c = orc.correlate_fft(rec[None], orc.rotate_volume(lig[None], torch.from_numpy(groups[(False, False)][0][None]).float()))
