@@ -17,7 +17,7 @@ template <int N> DLPD_D void init_twiddles(cplx* tw, int tid, int nthreads) {
 
 // ------------------------------------------------------------------------------------------
 // K2: one block per (c, kz), looping over the nb rotations of the batch (persistent over b).
-//   1-D grid NZ*CT*nsplit, block 4N threads (N/16 waves), dynamic LDS N*(N+8)*8 B (one swizzled N x N slab).
+//   1-D grid NZ*CT*nsplit, block 4N threads (W = N/16 waves), dynamic LDS N*(N+8)*8 B (one swizzled N x N slab).
 //   MODE 0: forward only -> out[(b*CT+c)][kz][kx][ky] = scale * FFT2(pad(A))     (receptor prep)
 //   MODE 1: correlate    -> out = IFFT2( rec * conj(FFT2(pad(A))) )  (unnormalised inverse;
 //                           the 1/N^3 lives in rec)
@@ -25,10 +25,16 @@ template <int N> DLPD_D void init_twiddles(cplx* tw, int tid, int nthreads) {
 // Per slab: y-forward on the L non-zero rows, x-forward on all columns (pruned first passes), the
 // receptor multiply in registers, and -- because the Stockham output of the last forward x pass
 // leaves thread t with exactly the elements {t + 8m} that the first inverse x pass needs -- the
-// inverse x transform starts from those registers without a trip through LDS.  The next
-// rotation's A slab and this slab's receptor values are prefetched into registers while the
-// current passes run (plain global loads stay in flight across barriers).  The FFT passes are
-// wave-local (dlpd_fft.h): 5 block barriers per slab, waves drift apart between them.
+// inverse x transform starts from those registers without a trip through LDS; then y-inverse on all rows.
+//
+// ROW OWNERSHIP.  Wave w owns rows 8w..8w+7 and 8(w+W)..8(w+W)+7 of the slab in every row phase: it stages
+// rows 8w.. of the next rotation's A slab, runs their y-forward, later the y-inverse of both row sets, and copies
+// exactly those rows out to global memory.  Everything between the two column phases of consecutive rotations is
+// therefore wave-local (the FFT passes are wave-local anyway, dlpd_fft.h): TWO block barriers per slab -- before
+// and after the column phase, which needs all rows -- instead of five, and the waves of a block drift apart through
+// the row phases, one wave's global stores and LDS traffic overlapping another's butterflies.
+// The next rotation's A rows and this slab's receptor values are prefetched into registers while the current
+// passes run (plain global loads stay in flight across barriers).
 // ------------------------------------------------------------------------------------------
 #ifdef DLPD_STAMPS
 __device__ unsigned long long dlpd_stamps_k2[16];
@@ -38,35 +44,8 @@ extern "C" int dlpd_debug_read_stamps_k2(unsigned long long* host16) {
   return hipMemcpyToSymbol(HIP_SYMBOL(dlpd_stamps_k2), z, sizeof(z)) == hipSuccess ? 0 : 1;
 }
 #endif
-#ifndef DLPD_K2_LATE_REC
-#define DLPD_K2_LATE_REC 0
-#endif
-#ifndef DLPD_K2_WPS
-#define DLPD_K2_WPS 4                    // threads per block = N * DLPD_K2_WPS
-#endif
-// Laundering (DLPD_OPAQUE) makes the compiler recompute the swizzled slab offsets per pencil set
-// instead of keeping ~80 of them in VGPRs.  At N = 128 (one block per CU anyway) that is slower; at
-// N = 80 it takes the kernel from 240 to <= 168 VGPRs, which lets TWO 5-wave blocks share a CU.
-// DLPD_K2_LAUNDER: bit 0 forces it for the pencil loops of every N, bit 1 for the copy loops.
-#ifndef DLPD_K2_LAUNDER
-#define DLPD_K2_LAUNDER 0
-#endif
-#ifndef DLPD_K2_N80_DENSE
-#define DLPD_K2_N80_DENSE 0             // 1: N = 80 with launder + late receptor loads + 3 waves/SIMD (two blocks per CU): spills, measured 1.5x slower
-#endif
-#define DLPD_K2_DENSE(N) (DLPD_K2_N80_DENSE && (N) == 80)
-#define DLPD_K2_OPAQUE(x) do { if ((DLPD_K2_LAUNDER & 1) || DLPD_K2_DENSE(N)) DLPD_OPAQUE(x); } while (0)
-#define DLPD_K2_OPAQUE_T(x) do { if ((DLPD_K2_LAUNDER & 2) || DLPD_K2_DENSE(N)) DLPD_OPAQUE(x); } while (0)
-#ifndef DLPD_K2_DIRECT_IN
-#define DLPD_K2_DIRECT_IN 0
-#endif
-#ifndef DLPD_K2_DIRECT_OUT
-#define DLPD_K2_DIRECT_OUT 0
-#endif
-#define DLPD_K2_THREADS(N) ((N) * DLPD_K2_WPS)   // N*WPS/64 waves; each owns 8 pencils per step (wave-local FFT passes)
-// N = 80: two 5-wave blocks per CU need 3 waves on a SIMD, i.e. <= 168 VGPRs (second launch-bounds
-// argument = minimum waves per SIMD)
-template <int N, int MODE> __global__ void __launch_bounds__(DLPD_K2_THREADS(N), (DLPD_K2_DENSE(N) ? 3 : 1))
+#define DLPD_K2_THREADS(N) ((N) * 4)               // N/16 waves; each owns 8 pencils per step (wave-local FFT passes)
+template <int N, int MODE> __global__ void __launch_bounds__(DLPD_K2_THREADS(N))
 k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __restrict__ out,
           int CT, int nb, int nsplit, long long rec_bstride, float scale, int transposed) {
   constexpr int L = N / 2, NZ = N / 2 + 1, RS = N + 8;
@@ -74,8 +53,11 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
   static_assert(RS % 16 == 8, "row stride must be an odd multiple of 8 elements (bank spreading)");
   constexpr int NT = DLPD_K2_THREADS(N), W = NT / 64;
   constexpr int NSET = N / 8;                      // pencil sets (8 pencils) per direction
-  constexpr int NLOAD = (L * L / 2 + NT - 1) / NT; // float4 (2 complex) per thread of an A slab
-  static_assert(NSET % W == 0, "shape");
+  static_assert(NSET == 2 * W && L / 8 == W, "row ownership: one forward and two inverse row sets per wave");
+  constexpr int NA4 = 8 * L / 2;                   // float4 (2 complex) in a wave's 8 A rows
+  constexpr int NLD = (NA4 + 63) / 64;             // ... per lane (the last round partly idle when L = 40)
+  constexpr int NST = (8 * N / 2) / 64;            // float4 per lane of 8 output rows
+  static_assert((8 * N / 2) % 64 == 0, "whole waves per output row set");
   typedef FftPassW<N, R1, 1, -1, T, L> FwdP1;      // pruned: only the first L inputs are non-zero
   typedef FftPassW<N, R2, R1, -1, T> FwdP2;
   typedef FftPassW<N, R1, 1, +1, T> InvP1;
@@ -100,90 +82,96 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
   cplx* tw = S + N * RS;
   init_twiddles<N>(tw, tid, NT);
 
-#if DLPD_K2_DIRECT_IN
-  // The pruned first y pass takes its L/8 non-zero inputs per thread straight from global memory
-  // (one pencil set per wave: L/8 == W), so the A slab is never staged through LDS: one LDS store
-  // pass and one block barrier less per slab.
-  constexpr int RNZ1 = L / 8;
-  static_assert(FwdP1::PER == 1 && FwdP1::NBF == 8 && L / 8 == W, "one y pencil set per wave");
-  cplx ain[RNZ1];
+  // this wave's 8 rows of a rotation's A slab (L x L complex, [x][y], or [y][x] when K1 stored it transposed:
+  // dlpd_corr.hip, slab orientation): NLD float4 per lane
+  float4 apref[NLD];
   auto fetch_rows = [&](int bb) {
-    const cplx* a = A + (((size_t)bb * CT + c) * NZ + kz) * L * L + (size_t)(wave * 8 + qr) * L + (lane & 7);
+    const cplx* a = A + (((size_t)bb * CT + c) * NZ + kz) * L * L;
+    if (!transposed) {
+      // rows 8w..8w+7 are 8*L contiguous complex: lane reads float4 number lane + 64 j of that run
+      const float4* a4 = reinterpret_cast<const float4*>(a + (size_t)wave * 8 * L);
 #pragma unroll
-    for (int r = 0; r < RNZ1; r++) ain[r] = dlpd_load_stream_c(a + 8 * r);
+      for (int j = 0; j < NLD; j++)
+        if (NA4 % 64 == 0 || lane + 64 * j < NA4) apref[j] = DLPD_LOAD_STREAM(a4 + lane + 64 * j);
+    } else {
+      // stored [y][x]: the wave's rows x = 8w..8w+7 are a 64-byte run in every y line
+#pragma unroll
+      for (int j = 0; j < NLD; j++) {
+        const int f = lane + 64 * j, y = f >> 2, p = f & 3;
+        if (NA4 % 64 == 0 || f < NA4)
+          apref[j] = DLPD_LOAD_STREAM(reinterpret_cast<const float4*>(a + (size_t)y * L + wave * 8 + 2 * p));
+      }
+    }
   };
-  fetch_rows(b_beg);
-  __syncthreads();                                       // twiddle table visible
-#else
-  float4 apref[NLOAD];
-  {
-    const float4* a = reinterpret_cast<const float4*>(A + (((size_t)b_beg * CT + c) * NZ + kz) * L * L);
+  auto stage_rows = [&]() {                        // apref -> LDS rows 8w..8w+7, columns 0..L-1
+    if (!transposed) {
 #pragma unroll
-    for (int i = 0; i < NLOAD; i++)
-      if (tid + i * NT < L * L / 2) apref[i] = DLPD_LOAD_STREAM(a + tid + i * NT);
-  }
-#endif
+      for (int j = 0; j < NLD; j++) {
+        const int f = lane + 64 * j, row = wave * 8 + f / (L / 2), col = 2 * (f % (L / 2));
+        if (NA4 % 64 == 0 || f < NA4) {
+          S[row * RS + slab_swz(col)] = c_make(apref[j].x, apref[j].y);
+          S[row * RS + slab_swz(col + 1)] = c_make(apref[j].z, apref[j].w);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NLD; j++) {
+        const int f = lane + 64 * j, y = f >> 2, row = wave * 8 + 2 * (f & 3);
+        if (NA4 % 64 == 0 || f < NA4) {
+          S[row * RS + slab_swz(y)] = c_make(apref[j].x, apref[j].y);
+          S[(row + 1) * RS + slab_swz(y)] = c_make(apref[j].z, apref[j].w);
+        }
+      }
+    }
+  };
+  auto forward_rows = [&]() {                      // y-forward of the wave's rows 8w..8w+7 (wave-local)
+    const RowAddr<RS> ad = {(wave * 8 + qr) * RS};
+    const int tr = lane & 7;
+    {
+      FwdP1 ps;
+      ps.load(S, ad, tr, nullptr);
+      DLPD_WAVE_SYNC();
+      ps.store(S, ad, tr);
+      DLPD_WAVE_SYNC();
+    }
+    {
+      FwdP2 ps;
+      ps.load(S, ad, tr, tw);
+      DLPD_WAVE_SYNC();
+      ps.store(S, ad, tr);
+    }
+  };
+  // rows 8*set..8*set+7 of the slab -> global (N contiguous complex each, the 8 rows one contiguous run)
+  auto copy_rows_out = [&](int set, int bb) {
+    float4* o = reinterpret_cast<float4*>(out + (((size_t)bb * CT + c) * NZ + kz) * N * N + (size_t)set * 8 * N);
+    const float sc = (MODE == 0) ? scale : 1.0f;
+#pragma unroll
+    for (int j = 0; j < NST; j++) {
+      const int f = lane + 64 * j, row = set * 8 + f / (N / 2), col = 2 * (f % (N / 2));
+      const cplx u = S[row * RS + slab_swz(col)], w = S[row * RS + slab_swz(col + 1)];
+      DLPD_STORE_STREAM(o + f, make_float4(u.x * sc, u.y * sc, w.x * sc, w.y * sc));
+    }
+  };
+
+  fetch_rows(b_beg);
+  __syncthreads();                                         // twiddle table visible
+  stage_rows();
+  DLPD_WAVE_SYNC();
+  forward_rows();
   DLPD_STAMP_DECL;
   for (int b = b_beg; b < b_end; b++) {
     DLPD_STAMP(7);
-    int tq = tid;
-    DLPD_K2_OPAQUE_T(tq);                 // slab offsets are recomputed per rotation instead of living in VGPRs
-#if !DLPD_K2_DIRECT_IN
-    // K1 stores the slabs of a 'transposed' launch as [y][x] (dlpd_corr.hip: slab orientation): undone here
-    const int tr_flag = transposed;
-#pragma unroll
-    for (int i = 0; i < NLOAD; i++) {
-      const int e = 2 * (tq + i * NT), x = e / L, y = e % L;
-      if (e < L * L) {
-        // (row, col) of the pair's first element and the step to its second one, branch-free in the
-        // wave-uniform flag
-        const int row = tr_flag ? y : x, col = tr_flag ? x : y;
-        S[row * RS + slab_swz(col)] = c_make(apref[i].x, apref[i].y);
-        S[(row + tr_flag) * RS + slab_swz(col + 1 - tr_flag)] = c_make(apref[i].z, apref[i].w);
-      }
-    }
-    DLPD_STAMP(0);
-    __syncthreads();
-    DLPD_STAMP(1);
-#endif
-    // ---- forward along y on the L non-zero rows: L/8 pencil sets over W waves
-#pragma unroll 1
-    for (int set = wave; set < L / 8; set += W) {
-      const RowAddr<RS> ad = {(set * 8 + qr) * RS};
-      int tr = lane & 7;
-      DLPD_K2_OPAQUE(tr);
-      {
-        FwdP1 ps;
-#if DLPD_K2_DIRECT_IN
-#pragma unroll
-        for (int r = 0; r < R1; r++) ps.v[0][r] = r < RNZ1 ? ain[r < RNZ1 ? r : 0] : c_make(0.f, 0.f);
-        SmallDft<R1, -1>::run(ps.v[0]);
-#else
-        ps.load(S, ad, tr, nullptr);
-        DLPD_WAVE_SYNC();
-#endif
-        ps.store(S, ad, tr);
-        DLPD_WAVE_SYNC();
-      }
-      {
-        FwdP2 ps;
-        ps.load(S, ad, tr, tw);
-        DLPD_WAVE_SYNC();
-        ps.store(S, ad, tr);
-      }
-    }
-    DLPD_STAMP(2);
-    __syncthreads();
+    __syncthreads();                                       // all rows y-transformed (and the previous slab copied out)
     DLPD_STAMP(1);
     // ---- columns: forward x, receptor multiply, inverse x -- all inside one wave per set
 #pragma unroll 1
     for (int set = wave; set < NSET; set += W) {
       const int col = set * 8 + c8;
       const ColAddr<RS> ad = {slab_swz(col)};
-      int tc = lane >> 3;
-      DLPD_K2_OPAQUE(tc);
+      const int tc = lane >> 3;
       cplx rv[FwdP2::PER][R2];
-      auto load_rec = [&]() {
+      // receptor values: requested before the first x pass, in flight during it
+      if (MODE == 1) {
         const cplx* rbase = rec + (size_t)b * rec_bstride + ((size_t)c * NZ + kz) * N * N;
         FwdP2 idx;
 #pragma unroll
@@ -192,10 +180,7 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
 #pragma unroll
             for (int q = 0; q < R2; q++) rv[i][q] = rbase[(unsigned)(idx.out_index(i, q, tc) * N) + (unsigned)col];
           }
-      };
-      // receptor values: requested before the first x pass (in flight during it) when registers
-      // allow (2 waves/SIMD build), else right before their use
-      if (MODE == 1 && !(DLPD_K2_LATE_REC || DLPD_K2_DENSE(N))) load_rec();
+      }
       {
         FwdP1 ps;
         ps.load(S, ad, tc, nullptr);
@@ -203,7 +188,6 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
         ps.store(S, ad, tc);
         DLPD_WAVE_SYNC();
       }
-      if (MODE == 1 && (DLPD_K2_LATE_REC || DLPD_K2_DENSE(N))) load_rec();
       if (MODE == 0) {
         FwdP2 ps;
         ps.load(S, ad, tc, tw);
@@ -255,26 +239,16 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
       }
     }
     DLPD_STAMP(3);
-    __syncthreads();
+    __syncthreads();                                       // all columns done
     DLPD_STAMP(1);
-    // next rotation's A slab: issued now, consumed at the top of the next iteration
-#if DLPD_K2_DIRECT_IN
+    // ---- the wave's own rows from here to the next column phase: next rotation's A rows requested now,
+    // y-inverse + copy-out of row sets w and w + W, then staging + y-forward of the next slab's rows
     if (b + 1 < b_end) fetch_rows(b + 1);
-#else
-    if (b + 1 < b_end) {
-      const float4* a = reinterpret_cast<const float4*>(A + (((size_t)(b + 1) * CT + c) * NZ + kz) * L * L);
-#pragma unroll
-      for (int i = 0; i < NLOAD; i++)
-        if (tid + i * NT < L * L / 2) apref[i] = DLPD_LOAD_STREAM(a + tid + i * NT);
-    }
-#endif
-    if (MODE == 1) {
-      // ---- inverse along y on all N rows
-  #pragma unroll 1
+#pragma unroll 1
     for (int set = wave; set < NSET; set += W) {
+      if (MODE == 1) {
         const RowAddr<RS> ad = {(set * 8 + qr) * RS};
-        int tr = lane & 7;
-        DLPD_K2_OPAQUE(tr);
+        const int tr = lane & 7;
         {
           InvP1 ps;
           ps.load(S, ad, tr, nullptr);
@@ -285,42 +259,23 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
         {
           InvP2 ps;
           ps.load(S, ad, tr, tw);
-#if DLPD_K2_DIRECT_OUT
-          // last pass straight to global memory: lanes t = 0..7 of a pencil write 64 contiguous bytes,
-          // the two butterflies of a thread complete each 128-byte line; saves the LDS store, the
-          // copy-out read and one block barrier per slab
-          cplx* orow = out + (((size_t)b * CT + c) * NZ + kz) * N * N + (size_t)(set * 8 + qr) * N;
-#pragma unroll
-          for (int i = 0; i < InvP2::PER; i++)
-            if (ps.active(i, tr)) {
-#pragma unroll
-              for (int r = 0; r < R2; r++) dlpd_store_stream_c(orow + ps.out_index(i, r, tr), ps.v[i][r]);
-            }
-#else
           DLPD_WAVE_SYNC();
           ps.store(S, ad, tr);
-#endif
         }
+        DLPD_WAVE_SYNC();
       }
       DLPD_STAMP(4);
-#if !DLPD_K2_DIRECT_OUT
-      __syncthreads();
-#endif
-      DLPD_STAMP(1);
+      copy_rows_out(set, b);
+      DLPD_WAVE_SYNC();
+      DLPD_STAMP(5);
     }
-    if (MODE == 0 || !DLPD_K2_DIRECT_OUT) {
-      float4* o = reinterpret_cast<float4*>(out + (((size_t)b * CT + c) * NZ + kz) * N * N);
-      const float sc = (MODE == 0) ? scale : 1.0f;
-      DLPD_K2_OPAQUE_T(tq);
-      for (int i = tq; i < N * N / 2; i += NT) {
-        const int e = 2 * i, x = e / N, y = e % N;
-        const cplx u = S[x * RS + slab_swz(y)], w = S[x * RS + slab_swz(y + 1)];
-        DLPD_STORE_STREAM(o + i, make_float4(u.x * sc, u.y * sc, w.x * sc, w.y * sc));
-      }
+    if (b + 1 < b_end) {
+      stage_rows();
+      DLPD_WAVE_SYNC();
+      DLPD_STAMP(0);
+      forward_rows();
+      DLPD_STAMP(2);
     }
-    DLPD_STAMP(5);
-    __syncthreads();                                     // slab fully read before it is refilled
-    DLPD_STAMP(1);
   }
   DLPD_STAMP_FLUSH(dlpd_stamps_k2, DLPD_STAMPS);
 }
