@@ -228,8 +228,6 @@ def algorithmic_bytes(C, L, C1, nb, K, has_clash=True, unfused=False, HP=24):
         "topk_select": nb * N ** 3 * 4 + nb * K * 8,
         "topk_merge": nb * K * 8 + K * 16,
     }
-    if C1:
-        alg["preact"] = nb * C1 * L ** 3 * 4 + nb * HP * L ** 3 * 4           # coarse correlations in, pre-activations out
     if unfused:
         alg["k3_zifft"] = nb * CT * NZ * N * N * 8 + nb * CT * N ** 3 * 4
         alg["filter"] = nb * CT * N ** 3 * 4 + nb * N ** 3 * 4 + (nb * HP * L ** 3 * 4 if C1 else 0)
@@ -238,7 +236,7 @@ def algorithmic_bytes(C, L, C1, nb, K, has_clash=True, unfused=False, HP=24):
     if C1:
         L1, N1, NZ1 = L // 2, L, L // 2 + 1
         alg["coarse"] = (C1 * L1 ** 3 * 4 + 2 * nb * C1 * NZ1 * L1 * L1 * 8 + C1 * NZ1 * N1 * N1 * 8 +
-                         2 * nb * C1 * NZ1 * N1 * N1 * 8 + nb * C1 * N1 ** 3 * 4)
+                         2 * nb * C1 * NZ1 * N1 * N1 * 8 + nb * HP * N1 ** 3 * 4)
     return alg
 
 

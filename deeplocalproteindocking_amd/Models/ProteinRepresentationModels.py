@@ -4,14 +4,44 @@
 with those two members plugs into GlobalDockingModel / Docker.
 
 ``SyntheticRepr`` produces seeded synthetic representation volumes for the BASELINE configs
-that have no atoms.  ``E3MultiResRepr4x4`` restates the reference's plain-Conv3d plugin
-(:85-114) in torch (it is a caller of the path, SURVEY.md 8(f) row 2, not a measured kernel).
-``SE3MultiResReprScalar`` keeps the reference's layer plan with build-defined isotropic kernels
-(the third-party se3cnn package is unpinned and absent here).
+that have no atoms.  ``E3MultiResRepr4x4`` is the reference's plain-Conv3d plugin (:85-114, same
+state-dict keys).  ``SE3MultiResReprScalar`` keeps the reference's layer plan with build-defined
+isotropic kernels (the third-party se3cnn package is unpinned and absent here).
+
+Where the convolutions run: on a GPU, in inference (no grad, float32), EVERY Conv3d / max-pool of
+both plugins runs on the HIP kernels (``ops.conv3d`` -- f32 matrix cores, stride 1 and 2 --,
+``ops.maxpool3d_5s2``).  A layer shape those kernels do not cover is an error there, not a silent
+switch to torch/MIOpen: set ``DLPD_ALLOW_TORCH_CONV=1`` to allow it (a warning says which layer).
+On CPU tensors and under autograd the modules are plain torch (the reference implementation the
+tests compare against; training is outside this build).
+
+Loading reference checkpoints: ``E3MultiResRepr4x4`` loads ``*_repr_epochN.th`` of the reference
+as they are (identical module tree: ``conv1.{0,2,4,6,8}.weight``, ``conv2.{1,3,5,7}.weight``).
+``SE3MultiResReprScalar`` cannot: se3cnn stores, per layer, coefficients on ITS radial basis, and
+neither that basis nor its version is in the reference tree.  ``IsotropicConv3d.load_radial_profile``
+documents what a user who has se3cnn supplies instead: the dense kernels it produces.
 """
+import os
+import warnings
+
 import torch
 from torch import nn
 from torch.nn.modules.module import Module
+
+
+def _torch_conv_allowed(what):
+    """GPU inference reached a layer the HIP kernels do not cover: loud by default."""
+    if os.environ.get("DLPD_ALLOW_TORCH_CONV", "") == "1":
+        warnings.warn("dlpd: %s has no HIP kernel -- running it on torch/MIOpen (DLPD_ALLOW_TORCH_CONV=1)" % what)
+        return True
+    raise RuntimeError("dlpd: %s has no HIP kernel (supported: cubic float32 volumes up to 80^3, kernel 3 or 5 with "
+                       "padding k//2, stride 1 or 2, no bias, output channels a multiple of 16; MaxPool3d(5, 2, 2)). "
+                       "Set DLPD_ALLOW_TORCH_CONV=1 to run it on torch/MIOpen instead." % what)
+
+
+def _hip_inference(x, hip_lib):
+    """The HIP kernels are the path: GPU tensors (or the emulated library of the test-suite), no autograd."""
+    return (x.is_cuda or hip_lib is not None) and not torch.is_grad_enabled() and x.dtype == torch.float32
 
 
 class SyntheticRepr(Module):
@@ -71,32 +101,34 @@ class E3MultiResRepr4x4(Module):
     use_hip_conv = True
 
     def _run(self, seq, x):
-        """The Sequential, with Conv3d(+ReLU) pairs the HIP kernel supports run by ops.conv3d
-        (exact f32 on the matrix cores; inference only) and everything else by torch."""
+        """The Sequential.  GPU inference: Conv3d(+ReLU) pairs and the max-pool on the HIP kernels (exact f32 on
+        the matrix cores), anything they cannot take is an error unless DLPD_ALLOW_TORCH_CONV=1; CPU / autograd:
+        plain torch."""
         from deeplocalproteindocking_amd import ops
         mods = list(seq)
+        native = self.use_hip_conv and _hip_inference(x, self.hip_lib)
         i = 0
         while i < len(mods):
             m = mods[i]
-            hip = (self.use_hip_conv and isinstance(m, nn.Conv3d) and not torch.is_grad_enabled()
-                   and (x.is_cuda or self.hip_lib is not None) and m.bias is None and m.stride == (1, 1, 1)
-                   and m.dilation == (1, 1, 1) and m.groups == 1 and m.padding == tuple(k // 2 for k in m.kernel_size)
-                   and x.dtype == torch.float32 and x.shape[2] == x.shape[3] == x.shape[4]
-                   and ops.conv3d_supported(m.weight, x.shape[2], self.hip_lib))
-            pool = (self.use_hip_conv and isinstance(m, nn.MaxPool3d) and not torch.is_grad_enabled()
-                    and (x.is_cuda or self.hip_lib is not None) and m.kernel_size == 5 and m.stride == 2
-                    and m.padding == 2 and m.dilation == 1 and not m.ceil_mode and not m.return_indices
-                    and x.dtype == torch.float32 and x.shape[2] == x.shape[3] == x.shape[4])
-            if hip:
-                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-                x = ops.conv3d(x, m.weight, relu=relu, lib=self.hip_lib)
-                i += 2 if relu else 1
-            elif pool:
-                x = ops.maxpool3d_5s2(x, lib=self.hip_lib)
-                i += 1
-            else:
-                x = m(x)
-                i += 1
+            cubic = x.dim() == 5 and x.shape[2] == x.shape[3] == x.shape[4]
+            if native and isinstance(m, nn.Conv3d):
+                ok = (m.bias is None and m.stride in ((1, 1, 1), (2, 2, 2)) and m.dilation == (1, 1, 1) and m.groups == 1
+                      and m.padding == tuple(k // 2 for k in m.kernel_size) and cubic
+                      and ops.conv3d_supported(m.weight, x.shape[2], self.hip_lib))
+                if ok or not _torch_conv_allowed("Conv3d%s on %s" % (tuple(m.weight.shape), tuple(x.shape))):
+                    relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                    x = ops.conv3d(x, m.weight, relu=relu, lib=self.hip_lib, stride=m.stride[0])
+                    i += 2 if relu else 1
+                    continue
+            elif native and isinstance(m, nn.MaxPool3d):
+                ok = (m.kernel_size == 5 and m.stride == 2 and m.padding == 2 and m.dilation == 1 and not m.ceil_mode
+                      and not m.return_indices and cubic)
+                if ok or not _torch_conv_allowed("MaxPool3d(%s, %s, %s)" % (m.kernel_size, m.stride, m.padding)):
+                    x = ops.maxpool3d_5s2(x, lib=self.hip_lib)
+                    i += 1
+                    continue
+            x = m(x)
+            i += 1
         return x
 
     def forward(self, volume):
@@ -133,13 +165,28 @@ class IsotropicConv3d(Module):
 
     hip_lib = None                     # tests: the emulated library
 
+    def load_radial_profile(self, dense_kernels):
+        """For users who have se3cnn: its SE3Convolution([(cin, 0)], [(cout, 0)], size=5) of a reference checkpoint
+        (``sequence_res{0,1}.{0,2,4,6}`` of ``*_repr_epochN.th``, ProteinRepresentationModels.py:38-61) evaluates to a
+        dense (cout, cin, 5, 5, 5) kernel (``module.kernel()`` there).  Pass that tensor: it is projected onto this
+        layer's radial shells by least squares; the residual (returned, relative) says how far se3cnn's radial basis
+        is from the Gaussian shells used here -- 0 for any kernel that is a function of |r| sampled on the shells."""
+        K = torch.as_tensor(dense_kernels, dtype=torch.float32)
+        A = self.shells.flatten(1).t()                                   # (125, nr)
+        sol = torch.linalg.lstsq(A, K.flatten(2).permute(2, 0, 1).reshape(A.shape[0], -1)).solution
+        w = sol.reshape(self.shells.shape[0], K.shape[0], K.shape[1]).permute(1, 2, 0).contiguous()
+        with torch.no_grad():
+            self.weight.copy_(w)
+        return float((torch.einsum("oik,kxyz->oixyz", w, self.shells) - K).norm() / K.norm().clamp_min(1e-30))
+
     def forward(self, x):
         from deeplocalproteindocking_amd import ops
         k = self.kernel()
-        if (self.stride == 1 and not torch.is_grad_enabled() and (x.is_cuda or self.hip_lib is not None)
-                and self.padding == k.shape[2] // 2 and x.dtype == torch.float32
-                and x.shape[2] == x.shape[3] == x.shape[4] and ops.conv3d_supported(k, x.shape[2], self.hip_lib)):
-            return ops.conv3d(x, k, lib=self.hip_lib)          # f32 matrix cores, inference only
+        if _hip_inference(x, self.hip_lib):
+            ok = (self.stride in (1, 2) and self.padding == k.shape[2] // 2 and x.dim() == 5
+                  and x.shape[2] == x.shape[3] == x.shape[4] and ops.conv3d_supported(k, x.shape[2], self.hip_lib))
+            if ok or not _torch_conv_allowed("IsotropicConv3d%s stride %d on %s" % (tuple(k.shape), self.stride, tuple(x.shape))):
+                return ops.conv3d(x, k, lib=self.hip_lib, stride=self.stride)      # f32 matrix cores
         return nn.functional.conv3d(x, k, padding=self.padding, stride=self.stride)
 
 

@@ -42,12 +42,14 @@ SIGNATURES = {
     "dlpd_filter_mask": (_i, [_p, _i, _i, _p, _i, _i, _p, _f, _i, _p, _p, _p, _f, _i, _p, _i, _p]),
     "dlpd_filter_preact": (_i, [_p, _i, _i, _p, _p, _i, _p, _i, _p]),
     "dlpd_filter_volumes": (_i, [_p, _i, _ll, _i, _p, _i, _i, _i, _p, _ll, _f, _i, _p, _p, _p, _f, _i, _p, _i, _p]),
+    "dlpd_zifft_preact": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _f, _p]),
     "dlpd_zifft_real_part": (_i, [_p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "dlpd_maxpool3d_5s2": (_i, [_p, _p, _i, _i, _p]),
     "dlpd_conv3d_supported": (_i, [_i, _i, _i, _i]),
     "dlpd_conv3d_packed_floats": (ctypes.c_size_t, [_i, _i, _i]),
     "dlpd_conv3d_pack": (_i, [_p, _p, _i, _i, _i, _p]),
     "dlpd_conv3d": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "dlpd_conv3d_strided": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dlpd_topk_workspace_bytes": (_sz, [_i, _i]),
     "dlpd_topk_select": (_i, [_p, _i, _ll, _i, _p, _p, _p, _p]),
     "dlpd_topk_glist_bytes": (_sz, [_i]),

@@ -1,6 +1,7 @@
-// Representation-plugin convolution: Conv3d(cin, cout, k, padding = k/2, stride 1,
-// bias = False) [+ ReLU] as the reference's E3MultiResRepr4x4 stacks them
-//   /root/reference/src/Models/ProteinRepresentationModels.py:85-114
+// Representation-plugin convolution: Conv3d(cin, cout, k, padding = k/2, stride 1 or 2,
+// bias = False) [+ ReLU] as the reference's plugins stack them
+//   /root/reference/src/Models/ProteinRepresentationModels.py:85-114   E3MultiResRepr4x4 (stride 1)
+//   /root/reference/src/Models/ProteinRepresentationModels.py:38-61    SE3MultiResReprScalar (one stride-2 layer, :51)
 // -- the per-batch cost of Docker.dockE3 (Docker.py:166-167) -- as an implicit GEMM on the f32-input
 // matrix cores (v_mfma_f32_16x16x4_f32: exact f32 products, k-ordered fmaf chain):
 //     Y[co][voxel] = sum over (tap, ci)  W[co][ci][tap] * X[ci][voxel + tap - k/2]
@@ -9,6 +10,9 @@
 // LDS four at a time (halo tile + that chunk's weights), each wave owns two rows x NZT z-tiles x
 // COUT/16 accumulator tiles.  A fragment (weights) is read once per tap and reused by all 2*NZT
 // voxel tiles of the wave; the B fragment is one conflict-free ds_read_b32 per MFMA.
+// STRIDE = 2 (one layer per protein, never per rotation): the output voxel o is the stride-1 result at 2o, so the
+// same tile is walked with the rows of odd x or y skipped (wave-uniform) and only the even z written -- 2x the
+// minimal matrix work on that layer instead of a second staging scheme for strided fragments.
 #include <dlpd_platform.h>
 #include "dlpd_internal.h"
 
@@ -25,7 +29,7 @@ template <int KS, int COUT, int NZT> struct ConvCfg {
   static constexpr size_t LDS_BYTES = (size_t)(4 * PLANE + WCHUNK) * sizeof(float);
 };
 
-template <int KS, int COUT, int NZT, int RELU> __global__ void __launch_bounds__(512)
+template <int KS, int COUT, int NZT, int RELU, int STRIDE> __global__ void __launch_bounds__(512)
 k_conv3d_mfma(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ Y, int CIN, int D,
               int cout_total, int co_base) {
   typedef ConvCfg<KS, COUT, NZT> C;
@@ -142,12 +146,14 @@ k_conv3d_mfma(const float* __restrict__ X, const float* __restrict__ W, float* _
 #pragma unroll
       for (int dz = 0; dz < KS; dz++)
 #pragma unroll
-        for (int r = 0; r < 2; r++)
+        for (int r = 0; r < 2; r++) {
+          if (STRIDE == 2 && ((((2 * wave + r) / C::TY) | ((2 * wave + r) % C::TY)) & 1)) continue;   // odd x or y: no output
 #pragma unroll
           for (int zt = 0; zt < NZT; zt++)
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
               acc[r][zt][mt] = DLPD_MFMA_16x16x4(f.a[dz][mt], f.b[dz][r][zt], acc[r][zt][mt]);
+        }
     };
     Frag f0, f1;
     load_frag(f0, 0);
@@ -170,38 +176,46 @@ k_conv3d_mfma(const float* __restrict__ X, const float* __restrict__ W, float* _
   for (int r = 0; r < 2; r++) {
     const int row = 2 * wave + r, gx = x0 + row / C::TY, gy = y0 + row % C::TY;
     if (gx >= D || gy >= D) continue;
+    if (STRIDE == 2 && ((gx | gy) & 1)) continue;
+    const int Do = (STRIDE == 2) ? (D - 1) / 2 + 1 : D;
+    const size_t Do3 = (size_t)Do * Do * Do;
 #pragma unroll
     for (int zt = 0; zt < NZT; zt++) {
       const int gz = zt * 16 + n;
-      if (gz >= D) continue;
+      if (gz >= D || (STRIDE == 2 && (gz & 1))) continue;
 #pragma unroll
       for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           float v = dlpd_acc4_get(acc[r][zt][mt], j);
           if (RELU) v = fmaxf(v, 0.f);
-          Y[((size_t)b * cout_total + co_base + mt * 16 + 4 * kq + j) * D3 + ((size_t)gx * D + gy) * D + gz] = v;
+          Y[((size_t)b * cout_total + co_base + mt * 16 + 4 * kq + j) * Do3 +
+            ((size_t)(gx / STRIDE) * Do + gy / STRIDE) * Do + gz / STRIDE] = v;
         }
     }
   }
 }
 
-template <int KS, int COUT, int NZT> static int launch_conv(const float* X, const float* W, float* Y, int B, int CIN,
-                                                            int D, int relu, int cout_total, int co_base,
-                                                            hipStream_t st) {
+template <int KS, int COUT, int NZT, int RELU, int STRIDE> static int launch_conv_rs(const float* X, const float* W, float* Y,
+                                                                                  int B, int CIN, int D, int cout_total,
+                                                                                  int co_base, hipStream_t st) {
   typedef ConvCfg<KS, COUT, NZT> C;
   dim3 grid((D + C::TX - 1) / C::TX, (D + C::TY - 1) / C::TY, B), block(512);
-  int rc;
-  if (relu) {
-    rc = dlpd_set_max_dyn_shared((const void*)k_conv3d_mfma<KS, COUT, NZT, 1>, C::LDS_BYTES);
-    if (rc) return rc;
-    DLPD_LAUNCH((k_conv3d_mfma<KS, COUT, NZT, 1>), grid, block, C::LDS_BYTES, st, X, W, Y, CIN, D, cout_total, co_base);
-  } else {
-    rc = dlpd_set_max_dyn_shared((const void*)k_conv3d_mfma<KS, COUT, NZT, 0>, C::LDS_BYTES);
-    if (rc) return rc;
-    DLPD_LAUNCH((k_conv3d_mfma<KS, COUT, NZT, 0>), grid, block, C::LDS_BYTES, st, X, W, Y, CIN, D, cout_total, co_base);
-  }
+  int rc = dlpd_set_max_dyn_shared((const void*)k_conv3d_mfma<KS, COUT, NZT, RELU, STRIDE>, C::LDS_BYTES);
+  if (rc) return rc;
+  DLPD_LAUNCH((k_conv3d_mfma<KS, COUT, NZT, RELU, STRIDE>), grid, block, C::LDS_BYTES, st, X, W, Y, CIN, D, cout_total,
+              co_base);
   return dlpd_check_launch();
+}
+
+template <int KS, int COUT, int NZT> static int launch_conv(const float* X, const float* W, float* Y, int B, int CIN,
+                                                            int D, int relu, int stride, int cout_total, int co_base,
+                                                            hipStream_t st) {
+  if (stride == 2)      // (no fused ReLU on the strided form: the plugins have none behind their stride-2 layer's input side)
+    return relu ? launch_conv_rs<KS, COUT, NZT, 1, 2>(X, W, Y, B, CIN, D, cout_total, co_base, st)
+                : launch_conv_rs<KS, COUT, NZT, 0, 2>(X, W, Y, B, CIN, D, cout_total, co_base, st);
+  return relu ? launch_conv_rs<KS, COUT, NZT, 1, 1>(X, W, Y, B, CIN, D, cout_total, co_base, st)
+              : launch_conv_rs<KS, COUT, NZT, 0, 1>(X, W, Y, B, CIN, D, cout_total, co_base, st);
 }
 
 // Output channels are processed in groups of 32 (a last group of 16 if cout % 32 == 16), one launch each.
@@ -279,9 +293,17 @@ int dlpd_conv3d_supported(int cin, int cout, int ks, int D) {
   return ((ks == 3 || ks == 5) && cout >= 16 && cout % 16 == 0) ? 1 : 0;
 }
 
+int dlpd_conv3d_strided(const float* x, const float* wp, float* y, int B, int cin, int cout, int D, int ks, int relu,
+                        int stride, void* stream);
+
 int dlpd_conv3d(const float* x, const float* wp, float* y, int B, int cin, int cout, int D, int ks, int relu,
                 void* stream) {
-  if (!x || !wp || !y || B <= 0) return DLPD_ERR_ARG;
+  return dlpd_conv3d_strided(x, wp, y, B, cin, cout, D, ks, relu, 1, stream);
+}
+
+int dlpd_conv3d_strided(const float* x, const float* wp, float* y, int B, int cin, int cout, int D, int ks, int relu,
+                        int stride, void* stream) {
+  if (!x || !wp || !y || B <= 0 || (stride != 1 && stride != 2)) return DLPD_ERR_ARG;
   if (!dlpd_conv3d_supported(cin, cout, ks, D)) return DLPD_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int nzt = (D + 15) / 16;                               // z tiles per row
@@ -291,7 +313,7 @@ int dlpd_conv3d(const float* x, const float* wp, float* y, int B, int cin, int c
     const float* wg = wp + per32 * g;
     int rc = DLPD_ERR_UNSUPPORTED;
 #define DLPD_CONV(KS, CO, NZ) if (rc == DLPD_ERR_UNSUPPORTED && ks == KS && gw == CO && nzt <= NZ) \
-    rc = launch_conv<KS, CO, NZ>(x, wg, y, B, cin, D, relu, cout, base, st)
+    rc = launch_conv<KS, CO, NZ>(x, wg, y, B, cin, D, relu, stride, cout, base, st)
     DLPD_CONV(3, 16, 3); DLPD_CONV(3, 16, 5); DLPD_CONV(5, 16, 3); DLPD_CONV(5, 16, 5);
     DLPD_CONV(3, 32, 3); DLPD_CONV(3, 32, 5); DLPD_CONV(5, 32, 3); DLPD_CONV(5, 32, 5);
 #undef DLPD_CONV

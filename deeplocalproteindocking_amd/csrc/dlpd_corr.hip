@@ -306,6 +306,7 @@ template <> struct K3Cfg<160, 0> { static constexpr int NT = 320, WC = 5, TY = 1
 #define DLPD_K3_160_NT 320
 #endif
 template <> struct K3Cfg<160, 1> { static constexpr int NT = DLPD_K3_160_NT, WC = 5, TY = 8; };
+template <> struct K3Cfg<160, 2> { static constexpr int NT = DLPD_K3_160_NT, WC = 5, TY = 8; };
 #ifndef DLPD_K3_LAUNDER_160
 #define DLPD_K3_LAUNDER_160 1            // N = 160: pencil / pack offsets recomputed per group instead of hoisted (no spills)
 #endif
@@ -376,8 +377,8 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
   init_twiddles<N>(tw, tid, NT);
   constexpr int j0 = 0;
   float h[EPT * 2][HPH > 0 ? HPH : 1];
-  if (MODE == 1) {
-    if (aux.C > 0 && aux.is_preact) {
+  if (MODE >= 1) {
+    if (MODE == 1 && aux.C > 0 && aux.is_preact) {
       // rows 2m, 2m+1 and columns z, z^1 of the fine grid share one coarse voxel
       const int Na = aux.N;
       const size_t cstride = (size_t)Na * Na * Na;
@@ -579,6 +580,19 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
     for (int e = 0; e < EPT * 2; e++)
 #pragma unroll
       for (int j = 0; j < HPH; j++) total[e] = fmaf(W2[j0 + j], fmaxf(h[e][j], 0.f), total[e]);
+  }
+  if (MODE == 2 && owner) {
+    // first-layer pre-activations of these channels as HP planes (bias included): the coarse resolution's half of
+    // SimpleFilter's first layer, which the fine grid's kernel picks up by index (DockingModels.py:74-83)
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+      const int m = m0 + e * MSTEP;
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int j = 0; j < HP; j++)
+          out[((((size_t)b * HP + j) * N + xo) * N + y0 + 2 * m + u) * N + zz] = h[2 * e + u][j];
+    }
   }
   if (MODE == 1 && owner) {
 #pragma unroll
@@ -1281,6 +1295,27 @@ int dlpd_zifft_real_part(const void* wsB, float* out, int nb, int CT, int nclip,
     case 80: return launch_k3<160, 0, 0>((const cplx*)wsB, out, CT, nclip, 0, nb, nullptr, nullptr, nullptr, 0.f, has_clip, clip, 0.f, st);
     default: return DLPD_ERR_UNSUPPORTED;
   }
+}
+
+// wsB (nb, C, NZ, N, N) -> pre (nb, HP, N^3) = b1 + W1rows^T clamp(correlations): z C2R fused with the (linear) first
+// layer over these C channels, the coarse-resolution half of the filter on its own grid
+int dlpd_zifft_preact(const void* wsB, float* pre, int nb, int C, int L, const float* W1rows, const float* b1, int HP,
+                      int has_clip, float clip, void* stream) {
+  if (!wsB || !pre || !W1rows || !b1 || nb <= 0 || C <= 0) return DLPD_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const cplx* B = (const cplx*)wsB;
+#define DLPD_ZP(NN, H) case H: return launch_k3<NN, H, 2>(B, pre, C, C, 0, nb, W1rows, b1, b1, 0.f, has_clip, clip, 0.f, st)
+#define DLPD_ZPN(NN) switch (HP) { DLPD_ZP(NN, 2); DLPD_ZP(NN, 4); DLPD_ZP(NN, 8); DLPD_ZP(NN, 16); DLPD_ZP(NN, 24); DLPD_ZP(NN, 32); \
+                                   default: return DLPD_ERR_UNSUPPORTED; }
+  switch (L) {
+    case 32: DLPD_ZPN(64)
+    case 40: DLPD_ZPN(80)
+    case 64: DLPD_ZPN(128)
+    case 80: DLPD_ZPN(160)
+    default: return DLPD_ERR_UNSUPPORTED;
+  }
+#undef DLPD_ZPN
+#undef DLPD_ZP
 }
 
 int dlpd_zifft_real(const void* wsB, float* out, int nb, int CT, int L, int has_clip, float clip, void* stream) {

@@ -161,7 +161,6 @@ class DockingEngine:
             self.recF1 = torch.zeros(C1, NZ1, N1, N1, 2, dtype=f32, device=dev)
             self.wsA1 = torch.empty(nb * C1 * NZ1 * L1 * L1 * 2, dtype=f32, device=dev)
             self.wsB1 = torch.empty(nb * C1 * NZ1 * N1 * N1 * 2, dtype=f32, device=dev)
-            self.aux = torch.empty(nb, C1, N1, N1, N1, dtype=f32, device=dev)      # clipped coarse correlations
             if self.use_quads:
                 self.ligq1 = torch.empty(lib.call("dlpd_quads_floats", C1, L1), dtype=f32, device=dev)
         # fine_unfused (diagnostic / A-B): materialise the real correlations of the fine grid and run the
@@ -266,7 +265,7 @@ class DockingEngine:
                      float(L1) / 2.0, tr, st)
             call("dlpd_xy_correlate_oriented", _ptr(self.wsA1), _ptr(self.recF1), _ptr(self.wsB1), nb, self.C1, L1, 0,
                  tr, st)
-            call("dlpd_zifft_real", _ptr(self.wsB1), _ptr(self.aux), nb, self.C1, L1, has_clip, clip, st)
+            self._coarse_preact(nb, has_clip, clip, st)
             mark("coarse")
         if provider is not None:
             # clash channel from re-projected rotated ATOMS (Docker.py:221-224), scores from rotated volumes
@@ -303,7 +302,7 @@ class DockingEngine:
             vc = f32c(vc).reshape(nb, self.C1, L1, L1, L1)
             call("dlpd_zfft", _ptr(vc), 0, _ptr(self.wsA1), nb, self.C1, L1, self.C1 * L1 ** 3, 0, 0.0, st)
             call("dlpd_xy_correlate", _ptr(self.wsA1), _ptr(self.recF1), _ptr(self.wsB1), nb, self.C1, L1, 0, st)
-            call("dlpd_zifft_real", _ptr(self.wsB1), _ptr(self.aux), nb, self.C1, L1, has_clip, clip, st)
+            self._coarse_preact(nb, has_clip, clip, st)
             mark("coarse")
         vl = f32c(vl).reshape(nb, self.C, L, L, L)
         call("dlpd_zfft_into", _ptr(vl), 0, _ptr(self.wsA), nb, self.C, self.CT, 0, L, self.C * L ** 3, 0, 0.0, st)
@@ -314,6 +313,12 @@ class DockingEngine:
         self._keep = (vl, vf, vc)                      # inputs stay alive until the stream has consumed them
         return self._correlate_and_filter(nb, V, mark, 0)
 
+    def _coarse_preact(self, nb, has_clip, clip, st):
+        """Coarse grid, last stage: z-inverse + clip fused with the coarse half of the (linear) first layer
+        (DockingModels.py:74-83): HP pre-activation planes on the coarse grid instead of C1 correlation volumes."""
+        self.lib.call("dlpd_zifft_preact", _ptr(self.wsB1), _ptr(self.pre), nb, self.C1, self.L1,
+                      self.W1t.data_ptr() + self.C * self.HP * 4, _ptr(self.b1), self.HP, has_clip, clip, st)
+
     def _correlate_and_filter(self, nb, V, mark, tr):
         """K2 + K3 (+ filter) on whatever K1 left in wsA (and the coarse result in aux); tr: the slab
         orientation K1 used."""
@@ -322,13 +327,7 @@ class DockingEngine:
         call("dlpd_xy_correlate_oriented", _ptr(self.wsA), _ptr(self.recF), _ptr(self.wsB), nb, self.CT, L, 0,
              tr, st)
         mark("k2_xy_corr")
-        aux, C1, N1 = (_ptr(self.aux), self.C1, 2 * self.L1) if self.C1 else (0, 0, 0)
-        if C1:
-            # first layer is linear: its coarse half runs once per COARSE voxel (DockingModels.py:74-83)
-            call("dlpd_filter_preact", aux, C1, N1, self.W1t.data_ptr() + self.C * self.HP * 4, _ptr(self.b1),
-                 self.HP, _ptr(self.pre), nb, st)
-            aux = _ptr(self.pre)
-            mark("preact")
+        aux, C1, N1 = (_ptr(self.pre), self.C1, 2 * self.L1) if self.C1 else (0, 0, 0)
         if self.fine_unfused:
             N3 = self.N ** 3
             call("dlpd_zifft_real_part", _ptr(self.wsB), _ptr(self.conv), nb, self.CT, self.C, L, has_clip, clip, st)

@@ -104,9 +104,9 @@ def conv3d_supported(weight, D, lib=None):
     return bool(cubic and (lib or get_lib()).call("dlpd_conv3d_supported", int(cin), int(cout), int(ks), int(D)))
 
 
-def conv3d(x, weight, relu=False, lib=None):
-    """[relu] Conv3d(x, weight, padding=k//2, stride=1, bias=None) of the representation plugins
-    (ProteinRepresentationModels.py:85-114) on the f32 matrix cores (inference only: no autograd).
+def conv3d(x, weight, relu=False, lib=None, stride=1):
+    """[relu] Conv3d(x, weight, padding=k//2, stride=1|2, bias=None) of the representation plugins
+    (ProteinRepresentationModels.py:38-61,85-114) on the f32 matrix cores (inference only: no autograd).
     x (B, cin, D, D, D) float32; weight (cout, cin, k, k, k)."""
     lib = lib or get_lib()
     x = x.contiguous()
@@ -118,8 +118,12 @@ def conv3d(x, weight, relu=False, lib=None):
     if w.shape[1] != cin:
         raise RuntimeError("dlpd: conv3d channel mismatch %d vs %d" % (w.shape[1], cin))
     wp = _packed_weights(weight, w, lib, x.device)
-    y = torch.empty(B, cout, D, D, D, dtype=torch.float32, device=x.device)
-    lib.call("dlpd_conv3d", _ptr(x), _ptr(wp), _ptr(y), B, cin, cout, D, ks, int(bool(relu)), _stream(x.device))
+    if stride not in (1, 2):
+        raise RuntimeError("dlpd: conv3d stride %r not supported (1 or 2)" % (stride,))
+    Do = (D - 1) // stride + 1
+    y = torch.empty(B, cout, Do, Do, Do, dtype=torch.float32, device=x.device)
+    lib.call("dlpd_conv3d_strided", _ptr(x), _ptr(wp), _ptr(y), B, cin, cout, D, ks, int(bool(relu)), int(stride),
+             _stream(x.device))
     return y
 
 

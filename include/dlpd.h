@@ -142,6 +142,14 @@ int dlpd_filter_volumes(const float* conv0, int C0, long long conv0_bstride, int
 int dlpd_filter_preact(const float* conv1, int C1, int N1, const float* W1rows, const float* b1, int HP,
                        float* pre, int nb, void* stream);
 
+/* Stage K3 for the COARSER resolution of a two-resolution model: z C2R + clip fused with that resolution's half of
+ * SimpleFilter's first layer (DockingModels.py:28 after the concat of :77, linear): pre (nb, HP, N^3) = b1 +
+ * W1rows^T clamp(corr), W1rows (C, HP) = the rows of W1t that belong to these channels.  The fine grid's
+ * dlpd_zifft_filter_aux(aux = pre, aux_is_preact = 1) picks the planes up by index (nearest upsample, :74-76);
+ * the C real correlation volumes of this resolution are never written. */
+int dlpd_zifft_preact(const void* wsB, float* pre, int nb, int C, int L, const float* W1rows, const float* b1, int HP,
+                      int has_clip, float clip, void* stream);
+
 /* dlpd_zifft_real with the clamp restricted to channels [0, nclip). */
 int dlpd_zifft_real_part(const void* wsB, float* out, int nb, int CT, int nclip, int L, int has_clip, float clip,
                          void* stream);
@@ -156,6 +164,10 @@ size_t dlpd_conv3d_packed_floats(int cin, int cout, int ks);
 int dlpd_conv3d_pack(const float* w, float* wp, int cin, int cout, int ks, void* stream);
 int dlpd_conv3d(const float* x, const float* wp, float* y, int B, int cin, int cout, int D, int ks, int relu,
                 void* stream);
+/* Same with stride 1 or 2 (padding ks/2): the stride-2 layer of SE3MultiResReprScalar
+ * (ProteinRepresentationModels.py:51).  y (B, cout, Do^3), Do = (D - 1) / stride + 1. */
+int dlpd_conv3d_strided(const float* x, const float* wp, float* y, int B, int cin, int cout, int D, int ks, int relu,
+                        int stride, void* stream);
 
 /* MaxPool3d(kernel 5, stride 2, padding 2) of the E3 plugin (ProteinRepresentationModels.py:101):
  * x (nvol, D^3) -> y (nvol, Do^3), Do = (D - 1) / 2 + 1. */

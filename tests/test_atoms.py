@@ -476,7 +476,7 @@ def test_dockSE3_and_dockE3_on_gpu(tmp_path):
     # two-resolution reference-shaped plugin through dockE3 and dockSE3 with the identity rotation:
     # both must give the same list (no rotation -> re-projection == the unrotated volumes)
     torch.manual_seed(79)
-    repr2 = E3MultiResRepr4x4(multiplier=2)
+    repr2 = E3MultiResRepr4x4(multiplier=8)          # 16 / 32 channels: every layer on the HIP kernels
     gm = GlobalDockingModel(repr2, SimpleFilter(repr2.get_num_outputs()), threshold_clash=3.0).to(dev)
     I = np.eye(3)[None]
     L2 = 64                                                   # second resolution 32^3 (16^3 is not compiled)

@@ -382,6 +382,33 @@ def test_conv3d_matches_torch_at_plugin_shapes(dev, cin, cout, ks, D):
         assert (got.cpu() - want).abs().max() <= 1e-5 * want.abs().max()
 
 
+def test_conv3d_stride2_and_se3_plugin_never_touch_torch_convolutions(dev, monkeypatch):
+    """The stride-2 5^3 layer (ProteinRepresentationModels.py:51) on the matrix-core kernel at the reference's
+    size (16 -> 32 channels, 80^3 -> 40^3), and the whole SE3MultiResReprScalar(8) forward with torch's conv3d
+    made to raise: GPU inference of the plugin runs on the HIP kernels only."""
+    from deeplocalproteindocking_amd import ops
+    from deeplocalproteindocking_amd.Models import SE3MultiResReprScalar
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 16, 80, 80, 80, generator=g).to(dev)
+    w = (torch.randn(32, 16, 5, 5, 5, generator=g) * 0.05).to(dev)
+    got = ops.conv3d(x, w, stride=2)
+    want = torch.nn.functional.conv3d(x.cpu(), w.cpu(), padding=2, stride=2)
+    assert got.shape == (2, 32, 40, 40, 40) and (got.cpu() - want).abs().max() <= 1e-5 * want.abs().max()
+    torch.manual_seed(3)
+    model = SE3MultiResReprScalar(multiplier=8).eval()
+    vol = torch.rand(1, 11, 80, 80, 80, generator=g)
+    with torch.no_grad():
+        ref = model(vol)                                          # CPU tensors: the torch reference
+        model = model.to(dev)
+
+        def boom(*a, **k):
+            raise AssertionError("torch conv3d called on the GPU inference path")
+        monkeypatch.setattr(torch.nn.functional, "conv3d", boom)
+        out = model(vol.to(dev))
+    for a, b in zip(out, ref):
+        assert a.shape == b.shape and (a.cpu() - b).abs().max() <= 2e-5 * b.abs().max()
+
+
 @pytest.mark.parametrize("L,C,H,has_clash,clip,nb", [(32, 1, 1, True, 5.0, 1), (32, 3, 3, False, None, 2), (32, 5, 6, True, 0.2, 4),
                                                       (32, 9, 13, False, 5.0, 3), (40, 2, 20, True, None, 2), (32, 7, 32, True, 1.0, 5)])
 def test_scores_match_oracle_odd_shapes(dev, L, C, H, has_clash, clip, nb):

@@ -256,6 +256,51 @@ def test_conv3d_mfma_kernel_matches_torch(emu, cin, cout, ks, D, relu):
     assert (y - want).abs().max() <= 2e-5 * want.abs().max()
 
 
+@pytest.mark.parametrize("cin,cout,ks,D", [(16, 32, 5, 10), (5, 16, 3, 9), (8, 16, 5, 7)])
+def test_conv3d_stride2_matches_torch(emu, cin, cout, ks, D):
+    """The stride-2 layer of SE3MultiResReprScalar (ProteinRepresentationModels.py:51): even and odd box sizes."""
+    from deeplocalproteindocking_amd import ops
+    g = torch.Generator().manual_seed(50 + cin)
+    x = torch.randn(2, cin, D, D, D, generator=g)
+    w = torch.randn(cout, cin, ks, ks, ks, generator=g) * 0.1
+    y = ops.conv3d(x, w, lib=emu, stride=2)
+    want = torch.nn.functional.conv3d(x, w, padding=ks // 2, stride=2)
+    assert y.shape == want.shape and (y - want).abs().max() <= 2e-5 * want.abs().max()
+
+
+def test_plugins_refuse_a_silent_torch_convolution(emu, monkeypatch):
+    """GPU inference (here: the emulated library) must not fall back to torch/MIOpen silently: a layer the HIP
+    kernel cannot take raises, unless DLPD_ALLOW_TORCH_CONV=1 (then it warns and runs on torch)."""
+    from deeplocalproteindocking_amd.Models import E3MultiResRepr4x4
+    torch.manual_seed(2)
+    m = E3MultiResRepr4x4(multiplier=3).eval()                # 6 / 12 output channels: not multiples of 16
+    m.hip_lib = emu
+    x = torch.rand(1, 11, 4, 4, 4)
+    monkeypatch.delenv("DLPD_ALLOW_TORCH_CONV", raising=False)
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match="no HIP kernel"):
+            m(x)
+        monkeypatch.setenv("DLPD_ALLOW_TORCH_CONV", "1")
+        with pytest.warns(UserWarning, match="torch/MIOpen"):
+            got = m(x)
+        m.hip_lib = None
+        want = m(x)
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+
+
+def test_isotropic_layer_takes_dense_radial_kernels():
+    """IsotropicConv3d.load_radial_profile: the hand-over for se3cnn users (dense kernels of a scalar-field
+    SE3Convolution): a kernel that is radial on the shells is reproduced exactly, a non-radial one reports
+    its residual."""
+    from deeplocalproteindocking_amd.Models.ProteinRepresentationModels import IsotropicConv3d
+    torch.manual_seed(4)
+    src, dst = IsotropicConv3d(3, 4), IsotropicConv3d(3, 4)
+    K = src.kernel().detach()
+    assert dst.load_radial_profile(K) < 1e-5
+    assert torch.allclose(dst.kernel(), K, atol=1e-6)
+    assert dst.load_radial_profile(K + 0.05 * torch.randn_like(K)) > 1e-3
+
+
 def test_topk_kernels_fuzz_against_faithful_update_top(emu):
     """Randomised small volumes built to provoke every corner of Docker.update_top (Docker.py:86-105): many
     exact ties, zeros of both signs, fewer negatives than K, no zero at all, K up to the voxel count, batches
@@ -299,8 +344,8 @@ def test_topk_kernels_fuzz_against_faithful_update_top(emu):
 
 
 def test_representation_plugins_route_their_convolutions_through_the_kernel(emu):
-    """E3MultiResRepr4x4 / SE3MultiResReprScalar forward with the (emulated) HIP convolution equals the
-    plain torch modules: Conv3d+ReLU pairs fused, MaxPool3d and the stride-2 layer left to torch."""
+    """E3MultiResRepr4x4 / SE3MultiResReprScalar forward with the (emulated) HIP kernels equals the plain torch
+    modules: Conv3d+ReLU pairs fused, MaxPool3d and the stride-2 layer on their kernels too."""
     from deeplocalproteindocking_amd.Models import E3MultiResRepr4x4
     from deeplocalproteindocking_amd.Models.ProteinRepresentationModels import IsotropicConv3d
     torch.manual_seed(11)
@@ -319,6 +364,13 @@ def test_representation_plugins_route_their_convolutions_through_the_kernel(emu)
         layer.hip_lib = emu
         got1 = layer(x)
     assert (got1 - want1).abs().max() <= 1e-5 * want1.abs().max()
+    strided = IsotropicConv3d(16, 32, stride=2).eval()         # ProteinRepresentationModels.py:51
+    x2 = torch.rand(1, 16, 6, 6, 6)
+    with torch.no_grad():
+        want2 = strided(x2)
+        strided.hip_lib = emu
+        got2 = strided(x2)
+    assert got2.shape == want2.shape == (1, 32, 3, 3, 3) and (got2 - want2).abs().max() <= 1e-5 * want2.abs().max()
 
 
 def _axis_rot(axis, deg):
