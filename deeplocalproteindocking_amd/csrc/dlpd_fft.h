@@ -290,6 +290,18 @@ template <> struct FftPlanW<160> { static constexpr int R1 = 8, R2 = 4, R3 = 5; 
 // lives at row*RS + swz(col), swz(c) = c ^ ((c >> 4) & 15): both the contiguous (row pencil) and
 // the strided (column pencil) Stockham accesses of 8 pencils x 8 threads are LDS-bank-conflict free.
 DLPD_HD int slab_swz(int c) { return c ^ ((c >> 4) & 15); }
+// Elements (col, col + 1), col even, of one slab row as ONE 16-byte LDS access: the swizzle XORs both with the
+// same value, so they stay an aligned pair, exchanged when that value is odd.  (Two 8-byte accesses at a 16-byte
+// lane stride are 2-way bank conflicts; the row base must be 16-byte aligned: RS even.)
+DLPD_D float4 slab_load_pair(const cplx* row, int col) {
+  const int s = slab_swz(col);
+  const float4 v = *reinterpret_cast<const float4*>(row + (s & ~1));
+  return (s & 1) ? make_float4(v.z, v.w, v.x, v.y) : v;
+}
+DLPD_D void slab_store_pair(cplx* row, int col, float4 v) {
+  const int s = slab_swz(col);
+  *reinterpret_cast<float4*>(row + (s & ~1)) = (s & 1) ? make_float4(v.z, v.w, v.x, v.y) : v;
+}
 template <int RS> struct RowAddr {
   int base;   // row * RS
   DLPD_HD int operator()(int e) const { return base + slab_swz(e); }

@@ -108,10 +108,7 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
 #pragma unroll
       for (int j = 0; j < NLD; j++) {
         const int f = lane + 64 * j, row = wave * 8 + f / (L / 2), col = 2 * (f % (L / 2));
-        if (NA4 % 64 == 0 || f < NA4) {
-          S[row * RS + slab_swz(col)] = c_make(apref[j].x, apref[j].y);
-          S[row * RS + slab_swz(col + 1)] = c_make(apref[j].z, apref[j].w);
-        }
+        if (NA4 % 64 == 0 || f < NA4) slab_store_pair(S + row * RS, col, apref[j]);
       }
     } else {
 #pragma unroll
@@ -148,8 +145,8 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
 #pragma unroll
     for (int j = 0; j < NST; j++) {
       const int f = lane + 64 * j, row = set * 8 + f / (N / 2), col = 2 * (f % (N / 2));
-      const cplx u = S[row * RS + slab_swz(col)], w = S[row * RS + slab_swz(col + 1)];
-      DLPD_STORE_STREAM(o + f, make_float4(u.x * sc, u.y * sc, w.x * sc, w.y * sc));
+      const float4 v = slab_load_pair(S + row * RS, col);
+      DLPD_STORE_STREAM(o + f, make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc));
     }
   };
 
