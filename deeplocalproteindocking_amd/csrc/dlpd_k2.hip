@@ -35,6 +35,13 @@ template <int N> DLPD_D void init_twiddles(cplx* tw, int tid, int nthreads) {
 // the row phases, one wave's global stores and LDS traffic overlapping another's butterflies.
 // The next rotation's A rows and this slab's receptor values are prefetched into registers while the current
 // passes run (plain global loads stay in flight across barriers).
+//
+// What bounds it (round-2 measurements, N = 128, 16 rotations x 49 channels): the kernel with the FFT phases
+// removed (staging, barriers, copy-out only) streams its 8.8 GB in 1.35 ms = 6.5 TB/s; the row phases alone add
+// 0.07 ms to that (wave-local, hidden behind the memory stream), the column phase alone 0.67 ms, both together
+// 1.43 ms: LDS instruction throughput at 2 waves per SIMD (reads cost about as much as writes there).  Measured
+// and rejected: the last inverse-y pass written straight to global memory with a DPP lane-pair exchange so that
+// every lane stores 16 bytes and 8 lanes a full 128-byte line (a sixth fewer LDS instructions): 3.02 vs 2.78 ms.
 // ------------------------------------------------------------------------------------------
 #ifdef DLPD_STAMPS
 __device__ unsigned long long dlpd_stamps_k2[16];
