@@ -19,18 +19,7 @@
 #include "dlpd_fft.h"
 #include "dlpd_internal.h"
 
-#ifndef DLPD_K1_TILE
-#define DLPD_K1_TILE 1
-#endif
-#ifndef DLPD_K1_UNROLL
 #define DLPD_K1_UNROLL 2                 // samples per thread whose gathers are issued together (2..16 measured equal: not latency-bound)
-#endif
-#ifndef DLPD_K1_XB
-#define DLPD_K1_XB 1                     // consecutive x-planes per K1 block (2: neutral, 4 and 8: slower -- fewer blocks in flight)
-#endif
-#ifndef DLPD_K1_TILE_Z
-#define DLPD_K1_TILE_Z 8
-#endif
 template <int N> DLPD_D void init_twiddles(cplx* tw, int tid, int nthreads) {
   for (int k = tid; k < N; k += nthreads) {
     double s, c;
@@ -180,12 +169,9 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
   // XCD-aware decode: consecutive block ids are dealt round-robin over the 8 XCDs, so the L
   // x-planes of one (b,c) volume are given ids of equal (id % 8): they run on one XCD and the
   // 1 MiB source volume is fetched into ONE L2 instead of eight.  Speed only, never correctness.
-  // A block walks XB consecutive x-planes: the slanted source slabs of neighbouring planes overlap, so
-  // the second..XB-th plane find most of their lines in this CU's L1 instead of going back to L2.
-  constexpr int XB = DLPD_K1_XB, XG = L / XB;
-  static_assert(L % XB == 0, "planes per block must divide L");
+  // (Walking 2-8 consecutive x-planes per block for L1 reuse was measured neutral to slower: fewer blocks in flight.)
   const int bid = blockIdx.x, jj = bid >> 3;
-  const int grp = (bid & 7) + 8 * (jj / XG);
+  const int grp = (bid & 7) + 8 * (jj / L);
   if (grp >= CT * nb) return;
   const int c = grp % CT, b = grp / CT;
   init_twiddles<N>(tw, tid, NT);
@@ -198,8 +184,8 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
   const int lane = tid & 63, wave = tid >> 6;
   (void)lane; (void)wave;
   DLPD_STAMP_DECL;
-#pragma unroll 1
-  for (int x = (jj % XG) * XB; x < (jj % XG) * XB + XB; x++) {
+  const int x = jj % L;
+  {
   const float* v = vol + (size_t)b * vol_bstride + (size_t)c * L * L * L;
   float* Sf = reinterpret_cast<float*>(S);
   if (do_rotate) {
@@ -217,13 +203,9 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
       // 64 samples crosses up to ~80 source cache lines per gather instruction, a tile ~20 (the TCP serves
       // about one line per clock, and that is what bounds this kernel); axis-aligned rotations go from
       // 4 lines to 8 -- measured: K1 over the whole 6-degree set 1.9 ms -> see DESIGN.md
-#if DLPD_K1_TILE
-      constexpr int TZ = DLPD_K1_TILE_Z, TYY = 64 / TZ;        // tile = TYY (y) x TZ (z) samples
+      constexpr int TZ = 8, TYY = 64 / TZ;                     // tile = TYY (y) x TZ (z) samples (other shapes measured equal)
       const int chunk = s >> 6, q = s & 63;
       const int y = (chunk / (L / TZ)) * TYY + q / TZ, z = (chunk % (L / TZ)) * TZ + q % TZ;
-#else
-      const int y = s / L, z = s % L;
-#endif
       const float dy = y - c0, dz = z - c0;
       const float px = c0 + (r0 * dx + r3 * dy + r6 * dz);
       const float py = c0 + (r1 * dx + r4 * dy + r7 * dz);
@@ -273,7 +255,6 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
     DLPD_STORE_STREAM(reinterpret_cast<float4*>(a + (size_t)k * L * L + 2 * m), o);
   }
   DLPD_STAMP(3);
-  __syncthreads();                                   // pencils fully read before the next plane refills them
   }
   DLPD_STAMP_FLUSH(dlpd_stamps_k1, DLPD_STAMPS);
 }
@@ -1099,7 +1080,7 @@ template <int N> static int launch_k1(const float* vol, const float* R, cplx* A,
                                       int transposed = 0, const float4* quads = nullptr) {
   constexpr int L = N / 2;
   const int groups = ((CT * nb + 7) / 8) * 8;
-  dim3 grid(groups * (L / DLPD_K1_XB)), block((N / 4) * FftPlan<N>::T);
+  dim3 grid(groups * L), block((N / 4) * FftPlan<N>::T);
   DLPD_LAUNCH((k_rotate_zfft<N>), grid, block, 0, st, vol, R, A, CT, nb, vbs, do_rotate, c0,
               CT_out > 0 ? CT_out : CT, c_base, transposed ? 1 : 0, quads);
   return dlpd_check_launch();

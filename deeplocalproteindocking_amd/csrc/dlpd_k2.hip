@@ -459,18 +459,10 @@ template <int N, int MODE> static int launch_k2_split(const cplx* A, const cplx*
 //   grid NZ*CT*nsplit (XCD-aware decode as above), block 4N = 640 threads (10 waves: one column
 //   pencil set each), persistent over the rotations of its part of the batch.
 // ------------------------------------------------------------------------------------------
-// column plan of the DIF kernel: the wave-local default (8 x 4 x 5, three LDS round trips) or 10 x 16
-template <int N> struct FftPlanD2;
-template <> struct FftPlanD2<160> { static constexpr int R1 = 10, R2 = 16, R3 = 1; };
-#ifndef DLPD_K2D_PLAN
-#define DLPD_K2D_PLAN FftPlanW
-#endif
-#ifndef DLPD_K2D_WAVES
-#define DLPD_K2D_WAVES 8                 // waves per block (256-VGPR budget; 10 would match the 10 column sets but spills)
-#endif
-#ifndef DLPD_K2D_G0REG
-#define DLPD_K2D_G0REG 0                 // 1: G0 waits in registers (spills at 8 waves); 0: in the output slab, re-read from L2
-#endif
+// Measured and rejected: a 10 x 16 two-pass column plan (8 % slower than the wave-local 8 x 4 x 5 despite one LDS round
+// trip less); G0 kept in registers instead of parked in the output slab (spills at 8 waves); 5 or 10 waves per block
+// (5.6 / 6.1 ms against 4.0 ms at 8: fewer waves hide less latency, ten spill).
+#define DLPD_K2D_WAVES 8
 template <int N, int WV> __global__ void __launch_bounds__(64 * WV)
 k_xy_corr_dif(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __restrict__ out,
               int CT, int nb, int nsplit, long long rec_bstride, int transposed) {
@@ -479,7 +471,7 @@ k_xy_corr_dif(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __
   constexpr int NT = 64 * WV, W = WV;
   constexpr int NLOAD = (L * L / 2 + NT - 1) / NT;     // float4 (2 complex) per thread of an A slab
   constexpr int NG = (N * H / 2 + NT - 1) / NT;        // float4 per thread of a G slab
-  typedef DLPD_K2D_PLAN<N> P;                          // column (length-N) plan; rows use FftPlanW<H>
+  typedef FftPlanW<N> P;                          // column (length-N) plan; rows use FftPlanW<H>
   constexpr bool THREE = P::R3 > 1;
   typedef FftPassW<N, P::R1, 1, -1, 8, L> FwdP1;
   typedef FftPassW<N, P::R2, P::R1, -1, 8> FwdP2;
@@ -514,9 +506,6 @@ k_xy_corr_dif(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __
   DLPD_STAMP_DECL;
   for (int b = b_beg; b < b_end; b++) {
     const int tr_flag = transposed;                          // slabs stored transposed by K1 (dlpd_corr.hip)
-#if DLPD_K2D_G0REG
-    float4 g0[NG];
-#endif
     float4* o = reinterpret_cast<float4*>(out + (((size_t)b * CT + c) * NZ + kz) * N * N);
 #pragma unroll 1
     for (int par = 0; par < 2; par++) {
@@ -630,11 +619,7 @@ k_xy_corr_dif(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __
           const int e = 2 * (tq + i * NT), x = e / H, y = e % H;
           if (e < N * H) {
             const cplx u = S[x * RS + slab_swz(y)], v = S[x * RS + slab_swz(y + 1)];
-#if DLPD_K2D_G0REG
-            g0[i] = make_float4(u.x, u.y, v.x, v.y);
-#else
             o[(x * N + y) / 2] = make_float4(u.x, u.y, v.x, v.y);
-#endif
           }
         }
       } else {
@@ -644,11 +629,7 @@ k_xy_corr_dif(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __
           if (e < N * H) {
             const cplx u = c_mulc(S[x * RS + slab_swz(y)], tw[y]);          // conj(w^y) * G1
             const cplx v = c_mulc(S[x * RS + slab_swz(y + 1)], tw[y + 1]);
-#if DLPD_K2D_G0REG
-            const float4 g = g0[i];
-#else
             const float4 g = o[(x * N + y) / 2];
-#endif
             DLPD_STORE_STREAM(o + (x * N + y) / 2, make_float4(g.x + u.x, g.y + u.y, g.z + v.x, g.w + v.y));
             DLPD_STORE_STREAM(o + (x * N + y + H) / 2, make_float4(g.x - u.x, g.y - u.y, g.z - v.x, g.w - v.y));
           }

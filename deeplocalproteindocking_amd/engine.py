@@ -148,7 +148,6 @@ class DockingEngine:
         self.V = torch.empty(nb, N, N, N, dtype=f32, device=dev)
         self.orient = os.environ.get("DLPD_NO_ORIENT", "") == ""      # diagnostic switch (slab orientation)
         self.use_quads = os.environ.get("DLPD_NO_QUADS", "") == ""    # diagnostic switch (quad-layout gather)
-        self.topk_after_k1 = os.environ.get("DLPD_TOPK_LATE", "") != ""    # diagnostic switch (see step()): off
         if self.use_quads:
             self.ligq = torch.empty(lib.call("dlpd_quads_floats", CT, int(L)), dtype=f32, device=dev)
         if self.C1:
@@ -217,8 +216,7 @@ class DockingEngine:
         is as good or better inside the full pipeline."""
         R = np.asarray(R)
         inplane = np.maximum(np.abs(R[:, 0, 2]), np.abs(R[:, 1, 2]))
-        zmax = float(os.environ.get("DLPD_QUADS_ZMAX", "0"))          # diagnostic: also when |R22| < zmax
-        return (inplane > np.abs(R[:, 2, 2])) | (np.abs(R[:, 2, 2]) < zmax)
+        return inplane > np.abs(R[:, 2, 2])
 
     @staticmethod
     def prefers_transposed(R):
@@ -382,26 +380,17 @@ class DockingEngine:
         main = torch.cuda.current_stream(self.device)
         if self._consumed[k] is not None:
             main.wait_event(self._consumed[k])          # V[k] free again
-        # DLPD_TOPK_LATE: hold the previous batch's select + merge back until K1 of THIS batch has been issued
-        # (they stream V from HBM/L2 next to the gather-bound K1).  Measured: K1 -0.06 ms, K2 +0.11 ms -- off.
-        late = self.topk_after_k1
-
-        def hook(name):
-            if mark is not None:
-                mark(name)
-            if late and name == "k1_rotate_zfft":
-                self._launch_pending(main)
-        V = self.score_batch(R, mark=hook if (late or mark is not None) else None, out=self._Vbuf[k], volumes=volumes,
-                             transposed=transposed, quads=quads)
-        self._launch_pending(main)                      # (no-op if the hook already did)
+        # (Holding the previous batch's select + merge back until K1 of THIS batch has been issued was measured:
+        # K1 -0.06 ms, K2 +0.11 ms -- not kept.)
+        V = self.score_batch(R, mark=mark, out=self._Vbuf[k], volumes=volumes, transposed=transposed, quads=quads)
+        self._launch_pending(main)
         # the side stream reads rot_ids later: keep the caller's tensor alive (and its memory out of the
         # allocator's reach) until this buffer slot comes round again
         self._ids_alive[k] = rot_ids
         ready = torch.cuda.Event()
         ready.record(main)
         self._pending = (V, nb, rot_ids, ready, k)
-        if not late:
-            self._launch_pending(main)
+        self._launch_pending(main)
 
     def _launch_pending(self, main):
         """Enqueue select + merge of the batch that finished last on the side stream: after its scores are
