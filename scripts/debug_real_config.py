@@ -1,4 +1,5 @@
 """Diagnostic: the reference's real configuration (SE3 repr, box 80) -- GPU V per rotation vs the oracle."""
+import os as _os; _os.environ.setdefault("DLPD_ALLOW_GENERATED_ROTATIONS", "1")   # diagnostic script: SOI-sized generated set when the licensed files are absent
 import os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

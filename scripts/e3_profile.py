@@ -1,4 +1,5 @@
 """Diagnostic: where a dockE3 batch spends its time (projection, representation plugin, engine)."""
+import os as _os; _os.environ.setdefault("DLPD_ALLOW_GENERATED_ROTATIONS", "1")   # diagnostic script: SOI-sized generated set when the licensed files are absent
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,3 +1,4 @@
+import os as _os; _os.environ.setdefault("DLPD_ALLOW_GENERATED_ROTATIONS", "1")   # diagnostic script: SOI-sized generated set when the licensed files are absent
 import os, sys, time
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
