@@ -36,6 +36,7 @@ SIGNATURES = {
                                            _p, _p, _p, _i, _p]),
     "dlpd_zifft_real": (_i, [_p, _p, _i, _i, _i, _i, _f, _p]),
     "dlpd_zifft_filter": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _i, _f, _f, _p]),
+    "dlpd_zifft_filter_mfma": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _i, _f, _f, _p]),
     "dlpd_zifft_filter_aux": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _i, _f, _f, _p, _i, _i, _p]),
     "dlpd_score_rotations": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _f, _i, _i, _f, _f,
                                   _p, _p, _p, _p]),

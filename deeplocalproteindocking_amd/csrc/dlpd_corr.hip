@@ -1086,6 +1086,17 @@ template <int N> static int launch_k1(const float* vol, const float* R, cplx* A,
   return dlpd_check_launch();
 }
 
+// K3 with the MLP on the matrix cores lives in dlpd_k3m.hip
+int dlpd_k3_mfma_supported(int L, int HP);
+int dlpd_k3_mfma(const cplx* Bw, float* V, int CT, int C, int has_clash, int nb, int L, const float* W1t, int HP,
+                 const float* b1, const float* W2, float b2, int has_clip, float clip, float thr, hipStream_t st);
+// DLPD_K3_MFMA=1 routes dlpd_zifft_filter to the matrix-core formulation where it exists (measured slower than the
+// vector-unit K3 so far: 3.0 vs 2.5 ms; off by default), read once
+static int k3_mfma_enabled() {
+  static const int v = [] { const char* e = getenv("DLPD_K3_MFMA"); return (e && e[0] == '1') ? 1 : 0; }();
+  return v;
+}
+
 // K2 lives in dlpd_k2.hip (its own translation unit: it is built with -fno-slp-vectorize)
 int dlpd_k2_forward(const cplx* A, cplx* out, int CT, int nb, int L, float scale, hipStream_t st);
 int dlpd_k2_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, int L, long long rbs, hipStream_t st,
@@ -1313,6 +1324,8 @@ int dlpd_zifft_filter_aux(const void* wsB, float* V, int nb, int C, int has_clas
   hipStream_t st = (hipStream_t)stream;
   const int CT = C + (has_clash ? 1 : 0);
   const K3Aux ax = {aux, Caux, L, (Caux > 0 && aux_is_preact) ? 1 : 0};              // coarse grid N/2 = L
+  if (Caux == 0 && k3_mfma_enabled() && dlpd_k3_mfma_supported(L, HP))
+    return dlpd_k3_mfma((const cplx*)wsB, V, CT, C, has_clash, nb, L, W1t, HP, b1, W2, b2, has_clip, clip, thr, st);
   switch (L) {
     case 32: return k3_filter_dispatch<64>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, ax);
     case 40: return k3_filter_dispatch<80>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, ax);
@@ -1320,6 +1333,15 @@ int dlpd_zifft_filter_aux(const void* wsB, float* V, int nb, int C, int has_clas
     case 80: return k3_filter_dispatch<160>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, ax);
     default: return DLPD_ERR_UNSUPPORTED;
   }
+}
+
+// the matrix-core formulation of dlpd_zifft_filter (dlpd_k3m.hip), explicitly
+int dlpd_zifft_filter_mfma(const void* wsB, float* V, int nb, int C, int has_clash, int L, const float* W1t,
+                           const float* b1, const float* W2, float b2, int HP, int has_clip, float clip, float thr,
+                           void* stream) {
+  if (!wsB || !V || !W1t || !b1 || !W2 || nb <= 0 || C <= 0) return DLPD_ERR_ARG;
+  return dlpd_k3_mfma((const cplx*)wsB, V, C + (has_clash ? 1 : 0), C, has_clash, nb, L, W1t, HP, b1, W2, b2, has_clip,
+                      clip, thr, (hipStream_t)stream);
 }
 
 int dlpd_zifft_filter(const void* wsB, float* V, int nb, int C, int has_clash, int L, const float* W1t,

@@ -27,6 +27,10 @@ __device__ __forceinline__ void dlpd_glds16(const void* g, void* l) {
 // barrier that orders LDS traffic only (leaves global loads / LDS-DMA in flight)
 #define DLPD_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define DLPD_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// all but the three youngest vector-memory operations of this wave
+// keeps three values (targets of loads that are still in flight) allocated up to this point
+#define DLPD_KEEP_ALIVE3(a, b, c) asm volatile("" ::"v"(a), "v"(b), "v"(c))
+#define DLPD_WAIT_VMEM_BUT3() asm volatile("s_waitcnt vmcnt(3)" ::: "memory")
 // ordering point between lanes of ONE wave that exchange data through LDS: the hardware runs a
 // wave's LDS instructions in order, so only the compiler must be kept from reordering them
 #define DLPD_WAVE_SYNC() asm volatile("" ::: "memory")
@@ -143,4 +147,5 @@ __device__ __forceinline__ float2 dlpd_c_mulc(float2 a, float2 w) {
 typedef float dlpd_acc4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ dlpd_acc4 dlpd_acc4_zero() { dlpd_acc4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
 __device__ __forceinline__ float dlpd_acc4_get(dlpd_acc4 v, int j) { return v[j]; }
+__device__ __forceinline__ dlpd_acc4 dlpd_acc4_make(float a, float b, float c, float d) { dlpd_acc4 z = {a, b, c, d}; return z; }
 #define DLPD_MFMA_16x16x4(a, b, acc) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (acc), 0, 0, 0)

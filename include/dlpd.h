@@ -99,6 +99,14 @@ int dlpd_zifft_filter(const void* wsB, float* V, int nb, int C, int has_clash, i
                       const float* b1, const float* W2, float b2, int HP, int has_clip, float clip,
                       float thr, void* stream);
 
+/* The same stage with the MLP on the f32 matrix cores and a wave owning a row pair of all channels (no barrier
+ * between transform and MLP; dlpd_k3m.hip): identical sums, compiled for L = 64 and 17 <= HP <= 32 only
+ * (DLPD_ERR_UNSUPPORTED otherwise).  Measured slower than dlpd_zifft_filter so far;
+ * dlpd_zifft_filter uses it only with DLPD_K3_MFMA=1 in the environment. */
+int dlpd_zifft_filter_mfma(const void* wsB, float* V, int nb, int C, int has_clash, int L, const float* W1t,
+                           const float* b1, const float* W2, float b2, int HP, int has_clip, float clip,
+                           float thr, void* stream);
+
 /* Same for the reference's two-resolution layout (ProteinRepresentationModels.py:72-76): the Caux
  * channels of the coarser resolution arrive as clipped real correlation volumes aux (nb, Caux, L^3)
  * (grid N/2 = L) and are nearest-upsampled by index (DockingModels.py:74-76); W1t has C + Caux rows.

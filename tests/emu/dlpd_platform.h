@@ -218,6 +218,8 @@ static inline int max(int a, int b) { return a > b ? a : b; }
 #define DLPD_GLDS16(g, l) memcpy(reinterpret_cast<char*>(l) + 16 * (emu::S().cur % 64), (const void*)(g), 16)
 #define DLPD_LDS_BARRIER() emu::barrier()
 #define DLPD_WAIT_VMEM() ((void)0)
+#define DLPD_WAIT_VMEM_BUT3() ((void)0)
+#define DLPD_KEEP_ALIVE3(a, b, c) ((void)(a), (void)(b), (void)(c))
 #define DLPD_WAVE_SYNC() emu::wave_sync()
 #define DLPD_WAIT_LDS() ((void)0)
 struct dlpd_pair_t { float x, y; };
@@ -240,6 +242,7 @@ static inline dlpd_f2v dlpd_pk_fma(dlpd_f2v a, dlpd_f2v b, dlpd_f2v c) { dlpd_f2
 struct dlpd_acc4 { float v[4]; };
 static inline dlpd_acc4 dlpd_acc4_zero() { dlpd_acc4 z = {{0.f, 0.f, 0.f, 0.f}}; return z; }
 static inline float dlpd_acc4_get(const dlpd_acc4& a, int j) { return a.v[j]; }
+static inline dlpd_acc4 dlpd_acc4_make(float a, float b, float c, float d) { dlpd_acc4 z = {{a, b, c, d}}; return z; }
 static inline dlpd_acc4 dlpd_emu_mfma_16x16x4(float a, float b, dlpd_acc4 acc) {
   emu::State& s = emu::S();
   const int w = s.cur / 64, l = s.cur % 64;

@@ -618,3 +618,10 @@ def test_two_rank_nccl_search_equals_single_process(dev, tmp_path):
     res = json.load(open(out))
     assert res["world"] == 2 and res["backend"] == "nccl"
     assert res["sharded"] == res["single"] and len(res["single"]) == res["K"]
+
+
+def test_matrix_core_k3_equals_the_vector_k3_at_config2_size(dev):
+    """dlpd_zifft_filter_mfma (opt-in formulation: MLP on v_mfma_f32_16x16x4_f32, waves own row pairs) against the oracle
+    and bit for bit against dlpd_zifft_filter at 48 channels x 64^3 (7 groups, the last one the clash channel alone)."""
+    from test_kernels_emu import _k3_both_formulations
+    _k3_both_formulations(None, dev, 64, 48, 24, 5.0, 5)
