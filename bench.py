@@ -398,11 +398,12 @@ def run_rank(args):
     torch.cuda.synchronize()
     head_ms = (time.perf_counter() - ts) / head_n * 1e3
     tk = StageTimer()
+    cs = eng.top.new_candidate_set() if eng.prefilter else None   # the steady-state path: candidate lists from K3
     for i in range(h_first, h_first + min(3, head_n)):
         sl = slice(i * nb, (i + 1) * nb)
-        V = eng.score_batch(Rd[sl], transposed=bool(tr_of[i * nb]), quads=bool(qd_of[i * nb]))
+        V = eng.score_batch(Rd[sl], transposed=bool(tr_of[i * nb]), quads=bool(qd_of[i * nb]), cset=cs)
         tk.mark("begin")
-        eng.select_batch(V, nb)
+        eng.select_batch(V, nb, eng._cset_used)
         tk.mark("topk_select")
         eng.merge_batch(idd[sl], nb)
         tk.mark("topk_merge")

@@ -37,6 +37,7 @@ SIGNATURES = {
     "dlpd_zifft_real": (_i, [_p, _p, _i, _i, _i, _i, _f, _p]),
     "dlpd_zifft_filter": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _i, _f, _f, _p]),
     "dlpd_zifft_filter_mfma": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _i, _f, _f, _p]),
+    "dlpd_zifft_filter_cand": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _i, _f, _f, _p, _i, _i, _p, _p, _p, _i, _p]),
     "dlpd_zifft_filter_aux": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _i, _f, _f, _p, _i, _i, _p]),
     "dlpd_score_rotations": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _f, _i, _i, _f, _f,
                                   _p, _p, _p, _p]),
@@ -53,6 +54,8 @@ SIGNATURES = {
     "dlpd_conv3d_strided": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dlpd_topk_workspace_bytes": (_sz, [_i, _i]),
     "dlpd_topk_select": (_i, [_p, _i, _ll, _i, _p, _p, _p, _p]),
+    "dlpd_topk_select_cand": (_i, [_p, _i, _ll, _i, _p, _p, _p, _p, _p, _i, _p]),
+    "dlpd_topk_merge_tau": (_i, [_p, _p, _p, _i, _i, _p, _p, _p]),
     "dlpd_topk_glist_bytes": (_sz, [_i]),
     "dlpd_topk_glist_reset": (_i, [_p, _i, _p]),
     "dlpd_topk_merge": (_i, [_p, _p, _p, _i, _i, _p, _p]),

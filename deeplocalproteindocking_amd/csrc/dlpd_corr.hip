@@ -299,13 +299,35 @@ struct K3Aux {
   const float* p;   // (nb, Caux or HP, Naux^3), Naux = N/2
   int C, N, is_preact;
 };
+// Candidate emission for the top-K stage (dlpd_topk.hip, candidate path): every score whose order-preserving key is
+// <= *tau is appended to the rotation's list; *tau == 0 means "no valid filter yet" and flags the rotation for the
+// full radix select.  tau is written by the merge kernel of earlier batches on another stream: a stale (larger) value
+// only lengthens the list.  count: [0, nb) counters, [nb, 2 nb) need-full flags.
+struct K3Cand {
+  const unsigned* tau;
+  unsigned long long* keys;   // (nb, cap)
+  unsigned* count;
+  int cap, nb;
+};
+DLPD_D unsigned k3_score_key(float v) {           // == f2key of dlpd_topk.hip
+  v = v + 0.0f;
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+DLPD_D void k3_emit(const K3Cand& cd, unsigned tau, int b, unsigned flat, float score) {
+  const unsigned key = k3_score_key(score);
+  if (key <= tau) {
+    const unsigned slot = atomicAdd(&cd.count[b], 1u);
+    if (slot < (unsigned)cd.cap) cd.keys[(size_t)b * cd.cap + slot] = ((unsigned long long)key << 32) | flat;
+  }
+}
 #ifdef DLPD_STAMPS   // diagnostic build only (scripts/stamps.py): where a K3 wave spends its cycles
 __device__ unsigned long long dlpd_stamps[16];
 #endif
 template <int N, int HP, int MODE> __global__ void __launch_bounds__((K3Cfg<N, MODE>::NT))
 k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int C, int has_clash, int G,
                const float* __restrict__ W1t, const float* __restrict__ b1, const float* __restrict__ W2,
-               float b2, int has_clip, float clip, float thr, K3Aux aux) {
+               float b2, int has_clip, float clip, float thr, K3Aux aux, K3Cand cd) {
   typedef K3Cfg<N, MODE> Cfg;
   constexpr int NZ = N / 2 + 1, RS = N + 8, TY = Cfg::TY, NPAIR = TY / 2;
   constexpr int NT = Cfg::NT, WC = Cfg::WC;
@@ -329,6 +351,9 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
   float total[EPT * 2];
 #pragma unroll
   for (int e = 0; e < EPT * 2; e++) { nrm[e] = 0.f; total[e] = b2; }
+  // candidate filter of the top-K stage (0: none valid yet -> the rotation is flagged for the full select)
+  const unsigned cand_tau = (MODE == 1 && cd.keys) ? *cd.tau : 0u;
+  if (MODE == 1 && cd.keys && !cand_tau && tid == 0) cd.count[cd.nb + blockIdx.z] = 1u;
   const int zz = tid % N, m0 = tid / N;        // output ownership
   const bool owner = (NPAIR * N >= NT) || (m0 < NPAIR);
   const int tr = lane & 7, qr = lane >> 3;     // FFT: lane = 8*pencil + thread
@@ -584,6 +609,7 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
         float acc = total[2 * e + u];
         if (has_clash) acc = acc * ((nrm[2 * e + u] < thr) ? 1.0f : 0.0f);
         out[(((size_t)b * N + xo) * N + y0 + 2 * m + u) * N + zz] = acc;
+        if (cd.keys && cand_tau) k3_emit(cd, cand_tau, b, (unsigned)((xo * N + y0 + 2 * m + u) * N + zz), acc);
       }
     }
   }
@@ -601,7 +627,7 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
 template <int N, int HP, int MODE> __global__ void __launch_bounds__((K3Cfg<N, MODE>::NT))
 k_zifft_filter_tiles(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int C, int has_clash, int G,
                const float* __restrict__ W1t, const float* __restrict__ b1, const float* __restrict__ W2,
-               float b2, int has_clip, float clip, float thr, K3Aux aux, int ntiles, int tpb) {
+               float b2, int has_clip, float clip, float thr, K3Aux aux, int ntiles, int tpb, K3Cand cd) {
   typedef K3Cfg<N, MODE> Cfg;
   constexpr int NZ = N / 2 + 1, RS = N + 8, TY = Cfg::TY, NPAIR = TY / 2;
   constexpr int NT = Cfg::NT, WC = Cfg::WC, NYT = N / TY;
@@ -620,6 +646,8 @@ k_zifft_filter_tiles(const cplx* __restrict__ Bw, float* __restrict__ out, int C
   if (t_beg >= t_end) return;
   init_twiddles<N>(tw, tid, NT);
 
+  // candidate filter of the top-K stage (0: none valid yet -> the rotation is flagged for the full select)
+  const unsigned cand_tau = (MODE == 1 && cd.keys) ? *cd.tau : 0u;
   const int zz = tid % N, m0 = tid / N;        // output ownership
   const bool owner = (NPAIR * N >= NT) || (m0 < NPAIR);
   const int tr = lane & 7, qr = lane >> 3;     // FFT: lane = 8*pencil + thread
@@ -660,6 +688,7 @@ k_zifft_filter_tiles(const cplx* __restrict__ Bw, float* __restrict__ out, int C
   for (int step = 0, nsteps = (t_end - t_beg) * ngroups; step < nsteps; step++) {
   const int y0 = (t % NYT) * TY, xo = (t / NYT) % N, b = t / (NYT * N);
   if (cbase == 0) {
+  if (cd.keys && !cand_tau && tid == 0) cd.count[cd.nb + b] = 1u;
   // hidden pre-activations of the thread's 2*EPT voxels (the SLP vectoriser pairs adjacent
   // hidden units into v_pk_fma_f32 with the weight pair in SGPRs and the voxel value broadcast)
 #pragma unroll
@@ -870,6 +899,7 @@ k_zifft_filter_tiles(const cplx* __restrict__ Bw, float* __restrict__ out, int C
         for (int j = 0; j < HP; j++) acc = fmaf(W2[j], fmaxf(h[2 * e + u][j], 0.f), acc);
         if (has_clash) acc = acc * ((nrm[2 * e + u] < thr) ? 1.0f : 0.0f);
         out[(((size_t)b * N + xo) * N + y0 + 2 * m + u) * N + zz] = acc;
+        if (cd.keys && cand_tau) k3_emit(cd, cand_tau, b, (unsigned)((xo * N + y0 + 2 * m + u) * N + zz), acc);
       }
     }
   }
@@ -1110,7 +1140,8 @@ static int k3_group(int CT, int maxg) {
 template <int N, int HP, int MODE> static int launch_k3(const cplx* Bw, float* out, int CT, int C, int has_clash,
                                                         int nb, const float* W1t, const float* b1, const float* W2,
                                                         float b2, int has_clip, float clip, float thr,
-                                                        hipStream_t st, K3Aux aux = K3Aux{nullptr, 0, 0, 0}) {
+                                                        hipStream_t st, K3Aux aux = K3Aux{nullptr, 0, 0, 0},
+                                                        K3Cand cd = K3Cand{nullptr, nullptr, nullptr, 0, 0}) {
   typedef K3Cfg<N, MODE> Cfg;
   constexpr int RS = N + 8, NZ = N / 2 + 1, W = Cfg::WC, NPAIR = Cfg::TY / 2, CPW = 8 / NPAIR;
   constexpr int RAWC = ((NZ * NPAIR + 63) / 64) * 64;
@@ -1120,14 +1151,15 @@ template <int N, int HP, int MODE> static int launch_k3(const cplx* Bw, float* o
   const int G = k3_group(CT, W * CPW);         // channels per group (CPW per wave), <= W * CPW
   dim3 grid(N / Cfg::TY, N, nb), block(Cfg::NT);
   DLPD_LAUNCH((k_zifft_filter<N, HP, MODE>), grid, block, shmem, st, Bw, out, CT, C, has_clash, G, W1t, b1, W2, b2,
-              has_clip, clip, thr, aux);
+              has_clip, clip, thr, aux, cd);
   return dlpd_check_launch();
 }
 
 // fused K3 over several tiles per block (see k_zifft_filter_tiles)
 template <int N, int HP> static int launch_k3_tiles(const cplx* Bw, float* out, int CT, int C, int has_clash, int nb,
                                                     const float* W1t, const float* b1, const float* W2, float b2,
-                                                    int has_clip, float clip, float thr, hipStream_t st, K3Aux aux) {
+                                                    int has_clip, float clip, float thr, hipStream_t st, K3Aux aux,
+                                                    K3Cand cd) {
   typedef K3Cfg<N, 1> Cfg;
   constexpr int RS = N + 8, NZ = N / 2 + 1, W = Cfg::WC, NPAIR = Cfg::TY / 2, CPW = 8 / NPAIR;
   constexpr int RAWC = ((NZ * NPAIR + 63) / 64) * 64;
@@ -1137,32 +1169,33 @@ template <int N, int HP> static int launch_k3_tiles(const cplx* Bw, float* out, 
   const int G = k3_group(CT, W * CPW);
   const int ntiles = (N / Cfg::TY) * N * nb, tpb = N / Cfg::TY;       // one x' plane per block
   DLPD_LAUNCH((k_zifft_filter_tiles<N, HP, 1>), dim3((ntiles + tpb - 1) / tpb), dim3(Cfg::NT), shmem, st, Bw, out, CT, C,
-              has_clash, G, W1t, b1, W2, b2, has_clip, clip, thr, aux, ntiles, tpb);
+              has_clash, G, W1t, b1, W2, b2, has_clip, clip, thr, aux, ntiles, tpb, cd);
   return dlpd_check_launch();
 }
 
 template <int N> static int k3_filter_dispatch(int HP, const cplx* Bw, float* V, int CT, int C, int has_clash, int nb,
                                                const float* W1t, const float* b1, const float* W2, float b2,
                                                int has_clip, float clip, float thr, hipStream_t st,
-                                               K3Aux aux = K3Aux{nullptr, 0, 0, 0}) {
+                                               K3Aux aux = K3Aux{nullptr, 0, 0, 0},
+                                               K3Cand cd = K3Cand{nullptr, nullptr, nullptr, 0, 0}) {
   if constexpr (N == 160) {                    // few groups per tile: the tile-walking kernel
     switch (HP) {
-      case 2: return launch_k3_tiles<N, 2>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux);
-      case 4: return launch_k3_tiles<N, 4>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux);
-      case 8: return launch_k3_tiles<N, 8>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux);
-      case 16: return launch_k3_tiles<N, 16>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux);
-      case 24: return launch_k3_tiles<N, 24>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux);
-      case 32: return launch_k3_tiles<N, 32>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux);
+      case 2: return launch_k3_tiles<N, 2>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+      case 4: return launch_k3_tiles<N, 4>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+      case 8: return launch_k3_tiles<N, 8>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+      case 16: return launch_k3_tiles<N, 16>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+      case 24: return launch_k3_tiles<N, 24>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+      case 32: return launch_k3_tiles<N, 32>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
       default: return DLPD_ERR_UNSUPPORTED;
     }
   }
   switch (HP) {
-    case 2: return launch_k3<N, 2, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux);
-    case 4: return launch_k3<N, 4, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux);
-    case 8: return launch_k3<N, 8, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux);
-    case 16: return launch_k3<N, 16, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux);
-    case 24: return launch_k3<N, 24, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux);
-    case 32: return launch_k3<N, 32, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux);
+    case 2: return launch_k3<N, 2, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 4: return launch_k3<N, 4, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 8: return launch_k3<N, 8, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 16: return launch_k3<N, 16, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 24: return launch_k3<N, 24, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 32: return launch_k3<N, 32, 1>(Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
     default: return DLPD_ERR_UNSUPPORTED;
   }
 }
@@ -1316,21 +1349,38 @@ int dlpd_zifft_real(const void* wsB, float* out, int nb, int CT, int L, int has_
 
 // wsB -> V (nb, N^3): z C2R + clip + MLP + clash mask
 // aux (nb, Caux, (N/2)^3): already-real first-layer inputs of a coarser resolution (may be null)
+int dlpd_zifft_filter_cand(const void* wsB, float* V, int nb, int C, int has_clash, int L, const float* W1t,
+                           const float* b1, const float* W2, float b2, int HP, int has_clip, float clip, float thr,
+                           const float* aux, int Caux, int aux_is_preact, const void* tau, void* cand_keys,
+                           void* cand_count, int cap, void* stream);
+
 int dlpd_zifft_filter_aux(const void* wsB, float* V, int nb, int C, int has_clash, int L, const float* W1t,
                           const float* b1, const float* W2, float b2, int HP, int has_clip, float clip, float thr,
                           const float* aux, int Caux, int aux_is_preact, void* stream) {
+  return dlpd_zifft_filter_cand(wsB, V, nb, C, has_clash, L, W1t, b1, W2, b2, HP, has_clip, clip, thr, aux, Caux,
+                                aux_is_preact, nullptr, nullptr, nullptr, 0, stream);
+}
+
+// dlpd_zifft_filter_aux that also feeds the top-K stage's candidate lists (dlpd_topk_select_cand): every score whose
+// key is <= *tau (published by dlpd_topk_merge_tau) is appended to cand_keys (nb, cap); see dlpd_topk.hip.
+int dlpd_zifft_filter_cand(const void* wsB, float* V, int nb, int C, int has_clash, int L, const float* W1t,
+                           const float* b1, const float* W2, float b2, int HP, int has_clip, float clip, float thr,
+                           const float* aux, int Caux, int aux_is_preact, const void* tau, void* cand_keys,
+                           void* cand_count, int cap, void* stream) {
   if (!wsB || !V || !W1t || !b1 || !W2 || nb <= 0 || C <= 0 || Caux < 0 || (Caux > 0 && !aux)) return DLPD_ERR_ARG;
   if (L % 2) return DLPD_ERR_ARG;
+  if (cand_keys && (!tau || !cand_count || cap <= 0)) return DLPD_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int CT = C + (has_clash ? 1 : 0);
   const K3Aux ax = {aux, Caux, L, (Caux > 0 && aux_is_preact) ? 1 : 0};              // coarse grid N/2 = L
-  if (Caux == 0 && k3_mfma_enabled() && dlpd_k3_mfma_supported(L, HP))
+  const K3Cand cd = {(const unsigned*)tau, (unsigned long long*)cand_keys, (unsigned*)cand_count, cap, nb};
+  if (Caux == 0 && !cand_keys && k3_mfma_enabled() && dlpd_k3_mfma_supported(L, HP))
     return dlpd_k3_mfma((const cplx*)wsB, V, CT, C, has_clash, nb, L, W1t, HP, b1, W2, b2, has_clip, clip, thr, st);
   switch (L) {
-    case 32: return k3_filter_dispatch<64>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, ax);
-    case 40: return k3_filter_dispatch<80>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, ax);
-    case 64: return k3_filter_dispatch<128>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, ax);
-    case 80: return k3_filter_dispatch<160>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, ax);
+    case 32: return k3_filter_dispatch<64>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, ax, cd);
+    case 40: return k3_filter_dispatch<80>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, ax, cd);
+    case 64: return k3_filter_dispatch<128>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, ax, cd);
+    case 80: return k3_filter_dispatch<160>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, ax, cd);
     default: return DLPD_ERR_UNSUPPORTED;
   }
 }

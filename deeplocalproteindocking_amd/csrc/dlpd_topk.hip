@@ -123,6 +123,7 @@ __global__ void __launch_bounds__(256) k_topk_scan(TopkState* st, int pass) {
 __global__ void __launch_bounds__(TOPK_HIST_THREADS)
 k_topk_collect(const float* __restrict__ V, long long nvox, TopkState* st, u64* __restrict__ cand, int K) {
   const int b = blockIdx.y;
+  if (st[b].done == 2) return;                       // served from K3's candidate list
   const u64 kth = st[b].kth;
   const float* v = V + (size_t)b * nvox;
   const long long per = (nvox + gridDim.x - 1) / gridDim.x;
@@ -163,6 +164,7 @@ k_topk_sort(const float* __restrict__ V, long long nvox, const TopkState* st, co
   __shared__ int nneg_s;
   __shared__ unsigned pmin_s;
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  if (st[b].done == 2) return;                       // served from K3's candidate list
   int KP = 1;
   while (KP < K) KP <<= 1;
   for (int i = tid; i < KP; i += nt) keys[i] = (i < K) ? cand[(size_t)b * K + i] : ~(u64)0;
@@ -208,6 +210,37 @@ k_topk_sort(const float* __restrict__ V, long long nvox, const TopkState* st, co
 }
 
 // ------------------------------------------------------------------------------------------
+// Candidate path.  Once the running list is full and its K-th score tau is negative, a pick of any later rotation
+// can enter the list only if its score is <= tau (the list is the K smallest (score, rotation, pick) triples; zero-fill
+// entries score 0).  K3 therefore appends every voxel with score <= the tau it saw (a possibly older, i.e. larger
+// one: tau only decreases) to a per-rotation list, and this kernel turns that list straight into the rotation's picks:
+// all voxels of the rotation that score below a candidate are candidates themselves, so a candidate's rank in the
+// sorted list IS its pick order.  Rotations whose list is incomplete -- K3 saw no valid tau (need_full), or more than
+// `cap` candidates -- go through the radix select as before.  ccount: [0, nb) counters, [nb, 2 nb) need_full flags.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_topk_from_cand(TopkState* st, const u64* __restrict__ cbuf, unsigned* __restrict__ ccount, int nb, int cap, int K,
+                 float* __restrict__ out_score, int* __restrict__ out_idx) {
+  DLPD_DYN_SHARED(u64, keys);
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const unsigned n = ccount[b], full = ccount[nb + b];
+  __syncthreads();
+  if (tid == 0) { ccount[b] = 0; ccount[nb + b] = 0; }      // ready for the batch after next
+  if (full || n > (unsigned)cap) return;                    // radix select takes this rotation
+  int NP = 64;
+  while (NP < (int)n) NP <<= 1;
+  for (int i = tid; i < NP; i += nt) keys[i] = (i < (int)n) ? cbuf[(size_t)b * cap + i] : ~(u64)0;
+  bitonic_sort_u64(keys, NP, tid, nt);
+  const float inf = __uint_as_float(0x7f800000u);           // filler: never below tau
+  for (int i = tid; i < K; i += nt) {
+    const bool real = i < (int)n;
+    out_score[(size_t)b * K + i] = real ? key2f((unsigned)(keys[i] >> 32)) : inf;
+    out_idx[(size_t)b * K + i] = real ? (int)(keys[i] & 0xffffffffu) : 0;
+  }
+  if (tid == 0) st[b].done = 2;
+}
+
+// ------------------------------------------------------------------------------------------
 // running global list.  glist: u64 header[2] {count, unused}, u64 hi[K], u64 lo[K]
 //   hi = canonical score key << 32 | rotation ; lo = pick << 32 | negzero << 31 | flat idx
 // ------------------------------------------------------------------------------------------
@@ -232,7 +265,7 @@ DLPD_D void bitonic_sort_pairs(u64* hi, u64* lo, int n, int tid, int nt) {
 
 __global__ void __launch_bounds__(1024)
 k_topk_merge(const float* __restrict__ cs, const int* __restrict__ ci, const int* __restrict__ rot_ids, int nb, int K,
-             u64* __restrict__ glist) {
+             u64* __restrict__ glist, unsigned* __restrict__ tau_out) {
   DLPD_DYN_SHARED(u64, sm);
   const int tid = threadIdx.x, nt = blockDim.x;
   int KP = 1;
@@ -301,7 +334,15 @@ k_topk_merge(const float* __restrict__ cs, const int* __restrict__ ci, const int
   }
   __syncthreads();
   for (int i = tid; i < count; i += nt) { ghi[i] = hi[i]; glo[i] = lo[i]; }
-  if (tid == 0) glist[0] = (u64)count;
+  if (tid == 0) {
+    glist[0] = (u64)count;
+    // score key of the K-th entry for K3's candidate filter: only once the list is full and that score is negative
+    // (0 = no filter yet)
+    if (tau_out) {
+      const unsigned tk = (count == K) ? (unsigned)(hi[K - 1] >> 32) : 0u;
+      *tau_out = (tk != 0u && tk < 0x80000000u) ? tk : 0u;
+    }
+  }
 }
 
 extern "C" {
@@ -317,15 +358,36 @@ int dlpd_topk_glist_reset(void* glist, int K, void* stream) {
                                                                                                 : DLPD_ERR_LAUNCH;
 }
 
+int dlpd_topk_select_cand(const float* V, int nb, long long nvox, int K, float* out_score, int* out_idx, void* ws,
+                          const void* cand_keys, void* cand_count, int cap, void* stream);
+
 // V (nb, nvox) -> per rotation the reference's K picks in pick order: out_score/out_idx (nb, K)
 int dlpd_topk_select(const float* V, int nb, long long nvox, int K, float* out_score, int* out_idx, void* ws,
                      void* stream) {
+  return dlpd_topk_select_cand(V, nb, nvox, K, out_score, out_idx, ws, nullptr, nullptr, 0, stream);
+}
+
+// Same, with the candidate lists K3 filled for this batch (dlpd_zifft_filter_cand): rotations whose list is complete
+// skip the radix select.  cand_keys (nb, cap) u64, cand_count 2*nb u32 (counters, then need-full flags); both are
+// consumed and the counters reset.
+int dlpd_topk_select_cand(const float* V, int nb, long long nvox, int K, float* out_score, int* out_idx, void* ws,
+                          const void* cand_keys, void* cand_count, int cap, void* stream) {
   if (!V || !out_score || !out_idx || !ws || nb <= 0 || nvox <= 0 || K <= 0) return DLPD_ERR_ARG;
   if (K > TOPK_MAXK || (long long)K > nvox || nvox > (1ll << 22)) return DLPD_ERR_UNSUPPORTED;
+  if ((cand_keys != nullptr) != (cand_count != nullptr) || (cand_keys && (cap < 64 || cap > 8192))) return DLPD_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   TopkState* state = (TopkState*)ws;
   u64* cand = (u64*)((char*)ws + (((size_t)nb * sizeof(TopkState) + 255) / 256) * 256);
   DLPD_LAUNCH(k_topk_init, dim3(nb), dim3(256), 0, st, state, nb, (unsigned)K);
+  if (cand_keys) {
+    int NP = 64;
+    while (NP < cap) NP <<= 1;
+    const size_t shmem = (size_t)NP * sizeof(u64);
+    int rc = dlpd_set_max_dyn_shared((const void*)k_topk_from_cand, shmem);
+    if (rc) return rc;
+    DLPD_LAUNCH(k_topk_from_cand, dim3(nb), dim3(256), shmem, st, state, (const u64*)cand_keys, (unsigned*)cand_count, nb,
+                cap, K, out_score, out_idx);
+  }
   for (int pass = 0; pass < 5; pass++) {
     DLPD_LAUNCH(k_topk_hist, dim3(TOPK_HIST_BLOCKS, nb), dim3(TOPK_HIST_THREADS), 0, st, V, nvox, state, pass);
     DLPD_LAUNCH(k_topk_scan, dim3(nb), dim3(256), 0, st, state, pass);
@@ -336,9 +398,19 @@ int dlpd_topk_select(const float* V, int nb, long long nvox, int K, float* out_s
   return dlpd_check_launch();
 }
 
+int dlpd_topk_merge_tau(const float* cand_score, const int* cand_idx, const int* rot_ids, int nb, int K, void* glist,
+                        void* tau_out, void* stream);
+
 // fold nb rotations' picks (rotation ids rot_ids, ascending) into the running global list
 int dlpd_topk_merge(const float* cand_score, const int* cand_idx, const int* rot_ids, int nb, int K, void* glist,
                     void* stream) {
+  return dlpd_topk_merge_tau(cand_score, cand_idx, rot_ids, nb, K, glist, nullptr, stream);
+}
+
+// Same, also publishing the candidate filter of the K3 kernels of LATER batches: *tau_out (u32) = order-preserving key
+// of the list's K-th score once the list is full and that score is negative, else 0 (no filter).
+int dlpd_topk_merge_tau(const float* cand_score, const int* cand_idx, const int* rot_ids, int nb, int K, void* glist,
+                        void* tau_out, void* stream) {
   if (!cand_score || !cand_idx || !rot_ids || !glist || nb <= 0 || K <= 0) return DLPD_ERR_ARG;
   if (K > TOPK_MAXK) return DLPD_ERR_UNSUPPORTED;
   int KP = 1;
@@ -347,7 +419,7 @@ int dlpd_topk_merge(const float* cand_score, const int* cand_idx, const int* rot
   int rc = dlpd_set_max_dyn_shared((const void*)k_topk_merge, shmem);
   if (rc) return rc;
   DLPD_LAUNCH(k_topk_merge, dim3(1), dim3(1024), shmem, (hipStream_t)stream, cand_score, cand_idx, rot_ids, nb, K,
-              (u64*)glist);
+              (u64*)glist, (unsigned*)tau_out);
   return dlpd_check_launch();
 }
 

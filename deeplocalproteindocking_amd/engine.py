@@ -43,21 +43,37 @@ class DeviceTopList:
         self.cand_idx = torch.empty(batch, self.K, dtype=torch.int32, device=dev)
         self.ws = torch.empty(lib.call("dlpd_topk_workspace_bytes", batch, self.K), dtype=torch.uint8, device=dev)
         self.glist = torch.zeros(lib.call("dlpd_topk_glist_bytes", self.K) // 8, dtype=torch.int64, device=dev)
+        # candidate filter of the scoring kernel (include/dlpd.h, dlpd_topk_merge_tau): key of the list's K-th score
+        # once the list is full and that score negative, else 0
+        self.tau = torch.zeros(4, dtype=torch.int32, device=dev)
+
+    CAND_CAP = 4096
+
+    def new_candidate_set(self):
+        """Per-batch candidate lists the scoring kernel fills (dlpd_zifft_filter_cand) and select() consumes."""
+        return {"keys": torch.empty(self.batch * self.CAND_CAP, dtype=torch.int64, device=self.device),
+                "count": torch.zeros(2 * self.batch, dtype=torch.int32, device=self.device), "cap": self.CAND_CAP}
 
     def reset(self):
         self.lib.call("dlpd_topk_glist_reset", _ptr(self.glist), self.K, _stream(self.device))
+        self.tau.zero_()
 
-    def select(self, V, nb):
-        """V (nb, nvox) contiguous -> (scores, flat indices) (nb, K) in the reference's pick order."""
+    def select(self, V, nb, cset=None):
+        """V (nb, nvox) contiguous -> (scores, flat indices) (nb, K) in the reference's pick order.
+        cset: the candidate set the scoring kernel filled for exactly these nb rotations (or None)."""
         nvox = V[0].numel()
-        self.lib.call("dlpd_topk_select", _ptr(V), nb, nvox, self.K, _ptr(self.cand_score), _ptr(self.cand_idx),
-                      _ptr(self.ws), _stream(self.device))
+        if cset is None:
+            self.lib.call("dlpd_topk_select", _ptr(V), nb, nvox, self.K, _ptr(self.cand_score), _ptr(self.cand_idx),
+                          _ptr(self.ws), _stream(self.device))
+        else:
+            self.lib.call("dlpd_topk_select_cand", _ptr(V), nb, nvox, self.K, _ptr(self.cand_score), _ptr(self.cand_idx),
+                          _ptr(self.ws), _ptr(cset["keys"]), _ptr(cset["count"]), cset["cap"], _stream(self.device))
         return self.cand_score[:nb], self.cand_idx[:nb]
 
     def merge(self, rot_ids, nb):
         """rot_ids int32 (nb,) on the device, ascending."""
-        self.lib.call("dlpd_topk_merge", _ptr(self.cand_score), _ptr(self.cand_idx), _ptr(rot_ids), nb, self.K,
-                      _ptr(self.glist), _stream(self.device))
+        self.lib.call("dlpd_topk_merge_tau", _ptr(self.cand_score), _ptr(self.cand_idx), _ptr(rot_ids), nb, self.K,
+                      _ptr(self.glist), _ptr(self.tau), _stream(self.device))
 
     def entries(self, glist=None):
         """-> (rot, flat_idx, score, pick) numpy arrays sorted as the reference's top_list."""
@@ -148,6 +164,7 @@ class DockingEngine:
         self.V = torch.empty(nb, N, N, N, dtype=f32, device=dev)
         self.orient = os.environ.get("DLPD_NO_ORIENT", "") == ""      # diagnostic switch (slab orientation)
         self.use_quads = os.environ.get("DLPD_NO_QUADS", "") == ""    # diagnostic switch (quad-layout gather)
+        self.prefilter = os.environ.get("DLPD_NO_PREFILTER", "") == ""   # diagnostic switch (top-K candidate lists from K3)
         if self.use_quads:
             self.ligq = torch.empty(lib.call("dlpd_quads_floats", CT, int(L)), dtype=f32, device=dev)
         if self.C1:
@@ -226,7 +243,7 @@ class DockingEngine:
         return np.abs(R[:, 0, 2]) > np.abs(R[:, 1, 2])
 
     # ---- hot loop ------------------------------------------------------------------------
-    def score_batch(self, R, mark=None, out=None, volumes=None, transposed=False, quads=False):
+    def score_batch(self, R, mark=None, out=None, volumes=None, transposed=False, quads=False, cset=None):
         """R (nb,3,3) float32 on the device, nb <= batch.  Returns V[:nb] (view of the engine's
         buffer, overwritten by the next call): Docker.py:218-232.  mark(name): optional callback
         after each stage (timing).
@@ -235,8 +252,9 @@ class DockingEngine:
         rotation, Docker.py:163-172) instead of rotating the stored ligand by R.
         transposed: slab orientation for ALL rotations of the batch (include/dlpd.h); search() groups the
         rotations for which it pays (prefers_transposed) into batches of their own."""
+        self._cset_used = None
         if volumes is not None:
-            return self._score_volumes(volumes, mark, out)
+            return self._score_volumes(volumes, mark, out, cset)
         nb = R.shape[0]
         assert nb <= self.batch and R.dtype == torch.float32 and R.is_contiguous()
         tr = int(bool(transposed) and self.orient)
@@ -245,7 +263,7 @@ class DockingEngine:
         V = self.V if out is None else out
         call, st, L = self.lib.call, _stream(self.device), self.L
         provider = self.clash_provider if self.has_clash else None
-        if not (self.C1 or provider or self.fine_unfused or mark or use_quads):
+        if not (self.C1 or provider or self.fine_unfused or mark or use_quads or cset is not None):
             call("dlpd_score_rotations_oriented", _ptr(self.lig), _ptr(self.recF), _ptr(R), nb, self.C,
                  int(self.has_clash), L, self.center, _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2), self.b2,
                  self.HP, has_clip, clip, self.threshold, _ptr(self.wsA), _ptr(self.wsB), _ptr(V), tr, st)
@@ -283,9 +301,9 @@ class DockingEngine:
             call("dlpd_zfft_oriented", _ptr(self.lig), _ptr(R), _ptr(self.wsA), nb, self.CT, self.CT, 0, L, 0, 1,
                  self.center, tr, st)
         mark("k1_rotate_zfft")
-        return self._correlate_and_filter(nb, V, mark, tr)
+        return self._correlate_and_filter(nb, V, mark, tr, cset)
 
-    def _score_volumes(self, volumes, mark, out):
+    def _score_volumes(self, volumes, mark, out, cset=None):
         vl, vf, vc = volumes
         nb, L = vl.shape[0], self.L
         assert nb <= self.batch
@@ -309,7 +327,7 @@ class DockingEngine:
             call("dlpd_zfft_into", _ptr(vf), 0, _ptr(self.wsA), nb, 1, self.CT, self.C, L, L ** 3, 0, 0.0, st)
         mark("k1_rotate_zfft")
         self._keep = (vl, vf, vc)                      # inputs stay alive until the stream has consumed them
-        return self._correlate_and_filter(nb, V, mark, 0)
+        return self._correlate_and_filter(nb, V, mark, 0, cset)
 
     def _coarse_preact(self, nb, has_clip, clip, st):
         """Coarse grid, last stage: z-inverse + clip fused with the coarse half of the (linear) first layer
@@ -317,7 +335,7 @@ class DockingEngine:
         self.lib.call("dlpd_zifft_preact", _ptr(self.wsB1), _ptr(self.pre), nb, self.C1, self.L1,
                       self.W1t.data_ptr() + self.C * self.HP * 4, _ptr(self.b1), self.HP, has_clip, clip, st)
 
-    def _correlate_and_filter(self, nb, V, mark, tr):
+    def _correlate_and_filter(self, nb, V, mark, tr, cset=None):
         """K2 + K3 (+ filter) on whatever K1 left in wsA (and the coarse result in aux); tr: the slab
         orientation K1 used."""
         has_clip, clip = (0 if self.clip is None else 1), float(self.clip or 0.0)
@@ -335,14 +353,14 @@ class DockingEngine:
                  self.CT * N3, self.threshold, int(self.has_clash), _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2),
                  self.b2, self.HP, _ptr(V), nb, st)
             mark("filter")
-        elif self.C1:
-            call("dlpd_zifft_filter_aux", _ptr(self.wsB), _ptr(V), nb, self.C, int(self.has_clash), L,
-                 _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2), self.b2, self.HP, has_clip, clip, self.threshold,
-                 aux, C1, 1, st)
-            mark("k3_zifft_filter")
         else:
-            call("dlpd_zifft_filter", _ptr(self.wsB), _ptr(V), nb, self.C, int(self.has_clash), L,
-                 _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2), self.b2, self.HP, has_clip, clip, self.threshold, st)
+            # fused K3; with a candidate set it also appends every score below the running K-th one to the batch's
+            # candidate lists, which the top-K select then takes instead of a radix select over V
+            tau, ck, cc, cap = (_ptr(self.top.tau), _ptr(cset["keys"]), _ptr(cset["count"]), cset["cap"]) if cset else (0, 0, 0, 0)
+            call("dlpd_zifft_filter_cand", _ptr(self.wsB), _ptr(V), nb, self.C, int(self.has_clash), L,
+                 _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2), self.b2, self.HP, has_clip, clip, self.threshold,
+                 aux, C1, int(C1 > 0), tau, ck, cc, cap, st)
+            self._cset_used = cset
             mark("k3_zifft_filter")
         return V[:nb]
 
@@ -350,9 +368,10 @@ class DockingEngine:
         self.finish()                                   # nothing of the previous pair still in flight
         self.top.reset()
 
-    def select_batch(self, V, nb):
-        """Per-rotation picks of Docker.update_top (Docker.py:89-98) for V (nb, N^3)."""
-        return self.top.select(V.reshape(nb, -1), nb)
+    def select_batch(self, V, nb, cset=None):
+        """Per-rotation picks of Docker.update_top (Docker.py:89-98) for V (nb, N^3); cset: the candidate set the
+        scoring kernel filled for this batch."""
+        return self.top.select(V.reshape(nb, -1), nb, cset)
 
     def merge_batch(self, rot_ids, nb):
         """Docker.py:100-105 on the device-resident list.  rot_ids int32 (nb,) ascending."""
@@ -364,14 +383,18 @@ class DockingEngine:
         latency-bound one-block kernels that fit beside the FFT blocks).  V is double-buffered;
         call finish() before reading the list."""
         nb = R.shape[0] if volumes is None else volumes[0].shape[0]
-        if self.device.type != "cuda":
-            V = self.score_batch(R, mark=mark, volumes=volumes, transposed=transposed, quads=quads)
-            self.select_batch(V, nb)
+        if self.device.type != "cuda":                  # emulated library (tests): same calls, one stream
+            if self.prefilter and not hasattr(self, "_cset_cpu"):
+                self._cset_cpu = self.top.new_candidate_set()
+            V = self.score_batch(R, mark=mark, volumes=volumes, transposed=transposed, quads=quads,
+                                 cset=getattr(self, "_cset_cpu", None))
+            self.select_batch(V, nb, self._cset_used)
             self.merge_batch(rot_ids, nb)
             return
         if not hasattr(self, "_side"):
             self._side = torch.cuda.Stream(device=self.device)
             self._Vbuf = [self.V, torch.empty_like(self.V)]
+            self._csets = [self.top.new_candidate_set(), self.top.new_candidate_set()] if self.prefilter else [None, None]
             self._consumed = [None, None]
             self._ids_alive = [None, None]
             self._k = 0
@@ -382,14 +405,16 @@ class DockingEngine:
             main.wait_event(self._consumed[k])          # V[k] free again
         # (Holding the previous batch's select + merge back until K1 of THIS batch has been issued was measured:
         # K1 -0.06 ms, K2 +0.11 ms -- not kept.)
-        V = self.score_batch(R, mark=mark, out=self._Vbuf[k], volumes=volumes, transposed=transposed, quads=quads)
+        V = self.score_batch(R, mark=mark, out=self._Vbuf[k], volumes=volumes, transposed=transposed, quads=quads,
+                             cset=self._csets[k])
+        cset = self._cset_used
         self._launch_pending(main)
         # the side stream reads rot_ids later: keep the caller's tensor alive (and its memory out of the
         # allocator's reach) until this buffer slot comes round again
         self._ids_alive[k] = rot_ids
         ready = torch.cuda.Event()
         ready.record(main)
-        self._pending = (V, nb, rot_ids, ready, k)
+        self._pending = (V, nb, rot_ids, ready, k, cset)
         self._launch_pending(main)
 
     def _launch_pending(self, main):
@@ -398,14 +423,14 @@ class DockingEngine:
         pend, self._pending = getattr(self, "_pending", None), None
         if pend is None:
             return
-        V, nb, rot_ids, ready, k = pend
+        V, nb, rot_ids, ready, k, cset = pend
         gate = torch.cuda.Event()
         gate.record(main)
         with torch.cuda.stream(self._side):
             self._side.wait_event(ready)
             self._side.wait_event(gate)
             if not os.environ.get("DLPD_DIAG_NO_TOPK"):      # diagnostic: how much the side stream costs the main one
-                self.select_batch(V, nb)
+                self.select_batch(V, nb, cset)
                 self.merge_batch(rot_ids, nb)
             done = torch.cuda.Event()
             done.record(self._side)

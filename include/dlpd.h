@@ -150,6 +150,16 @@ int dlpd_filter_volumes(const float* conv0, int C0, long long conv0_bstride, int
 int dlpd_filter_preact(const float* conv1, int C1, int N1, const float* W1rows, const float* b1, int HP,
                        float* pre, int nb, void* stream);
 
+/* dlpd_zifft_filter_aux that also feeds the candidate lists of the top-K stage (dlpd_topk_select_cand): every score
+ * whose order-preserving key is <= *tau is appended to the rotation's list cand_keys (nb, cap) u64 (key << 32 | flat
+ * index), counted in cand_count[0..nb); *tau == 0 ("no valid filter yet", see dlpd_topk_merge_tau) flags the rotation
+ * in cand_count[nb..2nb) for the full select instead.  tau / cand_keys / cand_count null: plain dlpd_zifft_filter_aux.
+ * Replaces nothing in the reference: it is Docker.update_top's pick loop (Docker.py:89-98) seen from the producer. */
+int dlpd_zifft_filter_cand(const void* wsB, float* V, int nb, int C, int has_clash, int L, const float* W1t,
+                           const float* b1, const float* W2, float b2, int HP, int has_clip, float clip, float thr,
+                           const float* aux, int Caux, int aux_is_preact, const void* tau, void* cand_keys,
+                           void* cand_count, int cap, void* stream);
+
 /* Stage K3 for the COARSER resolution of a two-resolution model: z C2R + clip fused with that resolution's half of
  * SimpleFilter's first layer (DockingModels.py:28 after the concat of :77, linear): pre (nb, HP, N^3) = b1 +
  * W1rows^T clamp(corr), W1rows (C, HP) = the rows of W1t that belong to these channels.  The fine grid's
@@ -187,6 +197,14 @@ size_t dlpd_topk_workspace_bytes(int nb, int K);
 int dlpd_topk_select(const float* V, int nb, long long nvox, int K, float* out_score, int* out_idx,
                      void* ws, void* stream);
 
+/* dlpd_topk_select with the candidate lists K3 filled for this batch (dlpd_zifft_filter_cand).  Once the running list
+ * is full and its K-th score negative, a later pick can enter it only with a score <= that K-th score, and every
+ * voxel of a rotation scoring below a candidate is a candidate too, so a candidate's rank in its sorted list IS its
+ * pick order: rotations with a complete list (flag clear, count <= cap) skip the radix select over V; the others take
+ * it as before.  Consumes the lists and resets cand_count.  cap in [64, 8192]. */
+int dlpd_topk_select_cand(const float* V, int nb, long long nvox, int K, float* out_score, int* out_idx, void* ws,
+                          const void* cand_keys, void* cand_count, int cap, void* stream);
+
 /* Docker.update_top list maintenance, src/Docker/Docker.py:100-105: append, stable sort by score,
  * truncate -- on a device-resident list.  glist: u64 count, u64 pad, u64 hi[K], u64 lo[K] with
  * hi = score_key<<32 | rotation, lo = pick<<32 | negzero<<31 | flat_index. */
@@ -194,6 +212,10 @@ size_t dlpd_topk_glist_bytes(int K);
 int dlpd_topk_glist_reset(void* glist, int K, void* stream);
 int dlpd_topk_merge(const float* cand_score, const int* cand_idx, const int* rot_ids, int nb, int K,
                     void* glist, void* stream);
+/* Same, publishing the candidate filter for the K3 launches of later batches: *tau_out (u32) = order-preserving key of
+ * the list's K-th score once the list holds K entries and that score is negative, else 0. */
+int dlpd_topk_merge_tau(const float* cand_score, const int* cand_idx, const int* rot_ids, int nb, int K,
+                        void* glist, void* tau_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -625,3 +625,11 @@ def test_matrix_core_k3_equals_the_vector_k3_at_config2_size(dev):
     and bit for bit against dlpd_zifft_filter at 48 channels x 64^3 (7 groups, the last one the clash channel alone)."""
     from test_kernels_emu import _k3_both_formulations
     _k3_both_formulations(None, dev, 64, 48, 24, 5.0, 5)
+
+
+def test_topk_candidate_lists_from_k3_equal_the_full_select(dev, monkeypatch):
+    """The candidate path of the top-K stage at BASELINE config 2 size (48 ch, 64^3, K = 2000, 60 rotations in batches
+    of 16) and on the N = 160 tile-walking K3 (16 ch at 80^3): identical ranked lists with and without it."""
+    from test_kernels_emu import _search_with_and_without_candidate_lists
+    _search_with_and_without_candidate_lists(None, dev, 64, 48, 2000, 60, 16, monkeypatch)
+    _search_with_and_without_candidate_lists(None, dev, 80, 16, 500, 20, 8, monkeypatch, seed=4)

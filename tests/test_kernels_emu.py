@@ -464,3 +464,40 @@ def test_k3_on_the_matrix_cores_matches_oracle_and_the_vector_k3(emu):
     8), hidden width 20 (padded to 24, second hidden tile partly empty), clip biting, one rotation."""
     assert emu.call("dlpd_hidden_pad", 20) == 24
     _k3_both_formulations(emu, "cpu", 64, 5, 20, 0.6, 77)
+
+
+def _search_with_and_without_candidate_lists(lib, device, L, C, K, nrot, batch, monkeypatch, seed=3):
+    """The top-K candidate path (K3 appends every score below the running K-th score, the select takes that list
+    instead of a radix select over V) must give exactly the list of the full select path."""
+    from oracle import docking_oracle as orc2
+    g = torch.Generator().manual_seed(seed)
+    rec, lig = torch.randn(C, L, L, L, generator=g) * 0.1, torch.randn(C, L, L, L, generator=g) * 0.1
+    recf, ligf = torch.rand(L, L, L, generator=g), torch.rand(L, L, L, generator=g)
+    H = max(C // 2, 1)
+    W1, b1 = torch.randn(H, C, generator=g) * 0.3, torch.randn(H, generator=g) * 0.1
+    W2, b2 = torch.randn(1, H, generator=g), torch.randn(1, generator=g)
+    ang = np.random.RandomState(seed).uniform(-np.pi, np.pi, size=(nrot, 3))
+    R = orc2.euler_to_matrix(ang[:, 0], np.abs(ang[:, 1]), ang[:, 2])
+    lists, taus = [], []
+    for off in ("", "1"):
+        if off:
+            monkeypatch.setenv("DLPD_NO_PREFILTER", "1")
+        else:
+            monkeypatch.delenv("DLPD_NO_PREFILTER", raising=False)
+        eng = DockingEngine(L, C, W1, b1, W2, b2, clip=5.0, threshold_clash=0.3 * L ** 3, max_conf=K, batch=batch,
+                            device=device, lib=lib)
+        assert eng.prefilter == (off == "")
+        eng.set_receptor(rec, recf)
+        eng.set_ligand(lig, ligf)
+        eng.reset_top()
+        eng.search(R)
+        lists.append(eng.top_list())
+        taus.append(int(eng.top.tau[0].item()))
+    assert len(lists[0]) == K and lists[0][-1][4] < 0.0          # list full, K-th score negative: the filter was live
+    assert 0 < taus[0] < 0x80000000
+    assert lists[0] == lists[1]
+    return lists[0]
+
+
+def test_topk_candidate_lists_from_k3_equal_the_full_select_emulated(emu, monkeypatch):
+    _search_with_and_without_candidate_lists(emu, "cpu", 32, 3, 25, 7, 2, monkeypatch)
