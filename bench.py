@@ -218,14 +218,15 @@ def visiting_sequence(engine_cls, R_all, ids, nb):
     return np.concatenate(parts), np.concatenate(keys)
 
 
-def algorithmic_bytes(C, L, C1, nb, K, has_clash=True, unfused=False, HP=24):
+def algorithmic_bytes(C, L, C1, nb, K, has_clash=True, unfused=False, HP=24, prefilter=True):
     """Per-launch algorithmic bytes of every stage (each kernel's compulsory input + output, f32):
     DESIGN.md section 4."""
     N, NZ, CT = 2 * L, L + 1, C + (1 if has_clash else 0)
     alg = {
         "k1_rotate_zfft": CT * L ** 3 * 4 + nb * CT * NZ * L * L * 8,
         "k2_xy_corr": nb * CT * NZ * L * L * 8 + CT * NZ * N * N * 8 + nb * CT * NZ * N * N * 8,
-        "topk_select": nb * N ** 3 * 4 + nb * K * 8,
+        # candidate path (steady state): the select reads K3's short candidate lists, not V
+        "topk_select": (nb * 4096 * 8 if prefilter else nb * N ** 3 * 4) + nb * K * 8,
         "topk_merge": nb * K * 8 + K * 16,
     }
     if unfused:
@@ -314,7 +315,7 @@ def run_rank(args):
     K, nb = args.max_conf, args.batch
     eng, wl = build_workload(args.workload, args, dev)
     C, L, C1 = wl["C"], wl["L"], wl["C1"]
-    eng_unfused, eng_hp = eng.fine_unfused, eng.HP
+    eng_unfused, eng_hp, eng_prefilter = eng.fine_unfused, eng.HP, eng.prefilter
     N = 2 * L
     angle = args.angle_inc or wl["angle"]
     # the SOI files carry MitchellLab's licence and are not redistributed: read them when DLPD_ROTATIONS_DIR /
@@ -418,7 +419,7 @@ def run_rank(args):
 
     if rank == 0:
         poses = float(args.steps) * nb * N ** 3 * world
-        alg = algorithmic_bytes(C, L, C1, nb, K, unfused=eng_unfused, HP=eng_hp)
+        alg = algorithmic_bytes(C, L, C1, nb, K, unfused=eng_unfused, HP=eng_hp, prefilter=eng_prefilter)
         main_stages = [k for k in stages if k in alg and not k.startswith("topk")]
         dom = max(main_stages, key=lambda k: stages[k])
         traffic, traffic_src = pmc_traffic(args.workload, C, L, nb, dom)

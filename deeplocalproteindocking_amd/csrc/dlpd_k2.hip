@@ -461,7 +461,8 @@ template <int N, int MODE> static int launch_k2_split(const cplx* A, const cplx*
 // ------------------------------------------------------------------------------------------
 // Measured and rejected: a 10 x 16 two-pass column plan (8 % slower than the wave-local 8 x 4 x 5 despite one LDS round
 // trip less); G0 kept in registers instead of parked in the output slab (spills at 8 waves); 5 or 10 waves per block
-// (5.6 / 6.1 ms against 4.0 ms at 8: fewer waves hide less latency, ten spill).
+// (5.6 / 6.1 ms against 4.0 ms at 8: fewer waves hide less latency, ten spill -- also with the receptor values loaded at
+// their use instead of prefetched: 5.75 ms at ten waves, 7.2 ms at five).
 #define DLPD_K2D_WAVES 8
 template <int N, int WV> __global__ void __launch_bounds__(64 * WV)
 k_xy_corr_dif(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __restrict__ out,
