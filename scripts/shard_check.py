@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--nrot", type=int, default=70)
+    ap.add_argument("--same_device", type=int, default=0, help="all ranks on cuda:0 (one-GPU box; gloo backend only)")
     args = ap.parse_args()
     import __graft_entry__ as entry
     entry.build()
@@ -27,7 +28,7 @@ def main():
     from deeplocalproteindocking_amd.Docker import Docker
     from deeplocalproteindocking_amd.Models import GlobalDockingModel, SyntheticRepr
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", 0 if args.same_device else local)
     torch.cuda.set_device(dev)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group(args.backend, device_id=dev if args.backend == "nccl" else None)

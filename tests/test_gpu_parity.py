@@ -598,6 +598,27 @@ def test_baseline_config5_shape_48ch_80cube_matches_oracle(dev):
     assert float((c.abs() > 5.0).float().mean()) > 1e-3
 
 
+def test_two_rank_sharded_search_on_one_gpu_equals_single_process(dev, tmp_path):
+    """SURVEY 8(e) end to end in two PROCESSES on the one GPU of this box: interleaved rotation shards searched by the
+    HIP pipeline in each rank, one all-gather of the per-rank lists (gloo transport here -- RCCL needs one device per
+    rank and is covered by the next test where two GPUs exist), the deterministic merge on every rank; the result must
+    equal the single-process list entry for entry."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    out = str(tmp_path / "lists.json")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29643", os.path.join(root, "scripts", "shard_check.py"), "--out", out,
+           "--backend", "gloo", "--same_device", "1", "--nrot", "50"]
+    r = subprocess.run(cmd, env=dict(os.environ), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.load(open(out))
+    assert res["world"] == 2 and res["backend"] == "gloo"
+    assert res["sharded"] == res["single"] and len(res["single"]) == res["K"]
+
+
 def test_two_rank_nccl_search_equals_single_process(dev, tmp_path):
     """SURVEY 8(e) on hardware: two ranks (one per GPU, RCCL) search interleaved shards of the rotation set
     and all-gather their lists once; the merged list must equal the single-process list.  Needs two GPUs
