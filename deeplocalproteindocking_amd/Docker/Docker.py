@@ -234,10 +234,21 @@ class Docker:
         if lib.call("dlpd_hidden_pad", int(W1.shape[0])) < 0 or W1.shape[1] != sum(v.shape[0] for v in rec):
             return None
         model = self.docking_model
-        eng = DockingEngine(L, rec[0].shape[0], W1.cpu(), b1.cpu(), W2.cpu(), b2.cpu(),
-                            clip=getattr(model, "clip", 5.0), threshold_clash=model.threshold_clash,
-                            has_clash=receptor_forbidden is not None, max_conf=self.max_conf, batch=batch_size,
-                            device=self.device, lib=self._lib, coarse_channels=rec[1].shape[0] if two_res else 0)
+        # one engine (multi-GB workspaces, side stream, top-list buffers) serves every pair of the same shape:
+        # local_test.py docks hundreds of targets with one Docker
+        C, C1, has_clash = rec[0].shape[0], (rec[1].shape[0] if two_res else 0), receptor_forbidden is not None
+        key = (int(L), int(C), int(C1), has_clash, int(lib.call("dlpd_hidden_pad", int(W1.shape[0]))), int(self.max_conf),
+               int(batch_size), str(self.device))
+        eng = self.engine if getattr(self, "_engine_key", None) == key else None
+        if eng is None:
+            eng = DockingEngine(L, C, W1.cpu(), b1.cpu(), W2.cpu(), b2.cpu(), clip=getattr(model, "clip", 5.0),
+                                threshold_clash=model.threshold_clash, has_clash=has_clash, max_conf=self.max_conf,
+                                batch=batch_size, device=self.device, lib=self._lib, coarse_channels=C1)
+            self.engine, self._engine_key = eng, key
+        else:
+            eng.finish()
+            eng.set_filter(W1.cpu(), b1.cpu(), W2.cpu(), b2.cpu())
+            eng.clip, eng.threshold = getattr(model, "clip", 5.0), float(model.threshold_clash)
         eng.set_receptor(rec[0], receptor_forbidden, rec[1] if two_res else None)
         return eng
 

@@ -142,20 +142,7 @@ class DockingEngine:
         dev = self.device
         f32 = torch.float32
         self.C1 = int(coarse_channels)
-        W1 = torch.as_tensor(W1, dtype=f32).reshape(-1, self.C + self.C1)
-        H = W1.shape[0]
-        HP = lib.call("dlpd_hidden_pad", int(H))
-        if HP < 0:
-            raise RuntimeError("dlpd: hidden width %d > 32 unsupported by the fused filter" % H)
-        self.H, self.HP = H, HP
-        W1t = torch.zeros(self.C + self.C1, HP, dtype=f32)
-        W1t[:, :H] = W1.t()
-        b1p = torch.zeros(HP, dtype=f32)
-        b1p[:H] = torch.as_tensor(b1, dtype=f32).reshape(-1)
-        W2p = torch.zeros(HP, dtype=f32)
-        W2p[:H] = torch.as_tensor(W2, dtype=f32).reshape(-1)
-        self.W1t, self.b1, self.W2 = W1t.to(dev), b1p.to(dev), W2p.to(dev)
-        self.b2 = float(torch.as_tensor(b2).reshape(-1)[0])
+        self.set_filter(W1, b1, W2, b2)
         nb, CT, NZ, N = self.batch, self.CT, self.NZ, self.N
         self.lig = torch.zeros(CT, L, L, L, dtype=f32, device=dev)
         self.recF = torch.zeros(CT, NZ, N, N, 2, dtype=f32, device=dev)
@@ -186,13 +173,34 @@ class DockingEngine:
             self.conv = torch.empty(nb, CT, N, N, N, dtype=f32, device=dev)
         if self.C1:
             # first-layer pre-activations of the coarse channels on the coarse grid (dlpd_filter_preact)
-            self.pre = torch.empty(nb, HP, 2 * self.L1, 2 * self.L1, 2 * self.L1, dtype=f32, device=dev)
+            self.pre = torch.empty(nb, self.HP, 2 * self.L1, 2 * self.L1, 2 * self.L1, dtype=f32, device=dev)
         self.top = DeviceTopList(self.K, nb, dev, lib)
         # optional: callable(R (nb,3,3) f32 device) -> (nb,L,L,L) f32 device ligand forbidden volumes
         # re-projected from rotated ATOMS (Docker.py:221-224) instead of the rotated volume
         self.clash_provider = None
 
     # ---- inputs ------------------------------------------------------------------------
+    def set_filter(self, W1, b1, W2, b2):
+        """SimpleFilter parameters (DockingModels.py:28-32) in the kernels' layout: W1 transposed and zero-padded to
+        the hidden width the filter kernel is compiled for.  May be called again on a live engine (same shapes)."""
+        f32, dev, lib = torch.float32, self.device, self.lib
+        W1 = torch.as_tensor(W1, dtype=f32).reshape(-1, self.C + self.C1)
+        H = W1.shape[0]
+        HP = lib.call("dlpd_hidden_pad", int(H))
+        if HP < 0:
+            raise RuntimeError("dlpd: hidden width %d > 32 unsupported by the fused filter" % H)
+        if getattr(self, "HP", HP) != HP:
+            raise RuntimeError("dlpd: a live engine keeps its hidden width (%d), got %d" % (self.HP, HP))
+        self.H, self.HP = H, HP
+        W1t = torch.zeros(self.C + self.C1, HP, dtype=f32)
+        W1t[:, :H] = W1.t()
+        b1p = torch.zeros(HP, dtype=f32)
+        b1p[:H] = torch.as_tensor(b1, dtype=f32).reshape(-1)
+        W2p = torch.zeros(HP, dtype=f32)
+        W2p[:H] = torch.as_tensor(W2, dtype=f32).reshape(-1)
+        self.W1t, self.b1, self.W2 = W1t.to(dev), b1p.to(dev), W2p.to(dev)
+        self.b2 = float(torch.as_tensor(b2).reshape(-1)[0])
+
     def set_receptor(self, rec_volumes, rec_forbidden=None, rec_coarse=None):
         """rec_volumes (C,L,L,L); rec_forbidden (L,L,L); rec_coarse (C1,L/2,..).  Spectra precomputed
         once per pair (the reference recomputes them every batch inside VolumeConvolution,

@@ -318,6 +318,15 @@ def test_dockSE3_end_to_end_emulated(emu, tmp_path):
     lines = open(log).read().strip().split("\n")
     assert len(lines) == K and all(len(l.split("\t")) == 13 for l in lines)
     assert dk.new_log(log, rewrite=False) is False              # finished target is skipped on resume
+    # the next target reuses the engine (workspaces, top-list buffers): nothing of the first pair may survive
+    eng = dk.engine
+    with torch.no_grad():
+        dk.dockSE3(flig, frec, batch_size=2)
+    assert dk.engine is eng
+    fresh = Docker(model, box_size=L, resolution=res, max_conf=K, rotations=R, device="cpu", lib=emu)
+    with torch.no_grad():
+        fresh.dockSE3(flig, frec, batch_size=2)
+    assert dk.top_list == fresh.top_list and fresh.engine is not eng
 
 
 class _GatedFilter(torch.nn.Module):
