@@ -39,9 +39,13 @@ template <int N> DLPD_D void init_twiddles(cplx* tw, int tid, int nthreads) {
 // What bounds it (round-2 measurements, N = 128, 16 rotations x 49 channels): the kernel with the FFT phases
 // removed (staging, barriers, copy-out only) streams its 8.8 GB in 1.35 ms = 6.5 TB/s; the row phases alone add
 // 0.07 ms to that (wave-local, hidden behind the memory stream), the column phase alone 0.67 ms, both together
-// 1.43 ms: LDS instruction throughput at 2 waves per SIMD (reads cost about as much as writes there).  Measured
-// and rejected: the last inverse-y pass written straight to global memory with a DPP lane-pair exchange so that
-// every lane stores 16 bytes and 8 lanes a full 128-byte line (a sixth fewer LDS instructions): 3.02 vs 2.78 ms.
+// 1.43 ms.  With every global access removed the kernel still takes 2.24 ms: the butterflies (about 2.0 MFLOP per
+// slab on a VALU that retires ~110 f32 results per clock and CU, packed or not) and the LDS exchanges (~13 k LDS
+// cycles per slab) add up rather than overlap; the memory stream hides behind them.
+// DIRECT OUT (N = 128): the last inverse-y pass deals its butterflies 2t, 2t+1 to thread t, so a lane ends up with
+// adjacent output pairs (16 bytes) and the 8 lanes of a pencil with a full 128-byte line: the rows go to global
+// memory from the butterfly registers, without the copy-out trip through the slab (2.84 -> 2.74 ms).  The same
+// idea with the standard dealing and a DPP lane-pair exchange was slower (3.02 vs 2.78 ms: the exchange is VALU).
 // ------------------------------------------------------------------------------------------
 #ifdef DLPD_STAMPS
 __device__ unsigned long long dlpd_stamps_k2[16];
@@ -50,6 +54,9 @@ extern "C" int dlpd_debug_read_stamps_k2(unsigned long long* host16) {
   unsigned long long z[16] = {0};
   return hipMemcpyToSymbol(HIP_SYMBOL(dlpd_stamps_k2), z, sizeof(z)) == hipSuccess ? 0 : 1;
 }
+#endif
+#ifndef DLPD_K2_DIRECT_OUT
+#define DLPD_K2_DIRECT_OUT 1
 #endif
 #define DLPD_K2_THREADS(N) ((N) * 4)               // N/16 waves; each owns 8 pencils per step (wave-local FFT passes)
 template <int N, int MODE> __global__ void __launch_bounds__(DLPD_K2_THREADS(N))
@@ -69,6 +76,8 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
   typedef FftPassW<N, R2, R1, -1, T> FwdP2;
   typedef FftPassW<N, R1, 1, +1, T> InvP1;
   typedef FftPassW<N, R2, R1, +1, T> InvP2;
+  typedef FftPassW<N, R2, R1, +1, T, N, 1> InvP2A;
+  constexpr bool DIRECT_OUT = DLPD_K2_DIRECT_OUT && MODE == 1 && InvP2::FULL && InvP2::PER == 2;
   // register hand-over forward-x pass 2 -> inverse-x pass 1 (power-of-two plans only)
   constexpr bool HANDOVER = InvP1::PER == 1 && InvP1::NBF == T && (R1 % T == 0) && FwdP2::NBF <= R1;
   DLPD_DYN_SHARED(cplx, S);
@@ -260,7 +269,20 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
           ps.store(S, ad, tr);
           DLPD_WAVE_SYNC();
         }
-        {
+        if constexpr (DIRECT_OUT) {
+          // last pass straight to global memory: with the butterflies dealt 2t, 2t+1 a lane holds adjacent pairs
+          // (16 bytes) and the 8 lanes of a pencil a full 128-byte line of the output row -- no copy-out trip
+          // through the slab.  The pencils of the set are dealt over the lanes so that the 16-byte reads are
+          // bank-conflict free (lane groups of ds_read_b128, MI355X_MICROARCH.md).
+          const int t2 = lane & 7, q2 = ((lane >> 5) & 1) | (((lane >> 3) & 3) << 1);
+          InvP2A ps;
+          ps.load_pairs(S + (set * 8 + q2) * RS, t2, tw);
+          float4* o = reinterpret_cast<float4*>(out + (((size_t)b * CT + c) * NZ + kz) * N * N + (size_t)(set * 8 + q2) * N);
+#pragma unroll
+          for (int r = 0; r < R2; r++)
+            DLPD_STORE_STREAM(o + t2 + r * (InvP2A::NBF / 2),
+                              make_float4(ps.v[0][r].x, ps.v[0][r].y, ps.v[1][r].x, ps.v[1][r].y));
+        } else {
           InvP2 ps;
           ps.load(S, ad, tr, tw);
           DLPD_WAVE_SYNC();
@@ -269,8 +291,10 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
         DLPD_WAVE_SYNC();
       }
       DLPD_STAMP(4);
-      copy_rows_out(set, b);
-      DLPD_WAVE_SYNC();
+      if constexpr (!DIRECT_OUT) {
+        copy_rows_out(set, b);
+        DLPD_WAVE_SYNC();
+      }
       DLPD_STAMP(5);
     }
     if (b + 1 < b_end) {
@@ -448,37 +472,34 @@ template <int N, int MODE> static int launch_k2_split(const cplx* A, const cplx*
 }
 
 // ------------------------------------------------------------------------------------------
-// K2 for grids whose N x N slab does not fit LDS (N = 160): decimation in frequency along y.
-// With only the first N/2 inputs of a y row non-zero, its even outputs are the N/2-point FFT of the
-// row and its odd outputs the N/2-point FFT of the row times w_N^y; likewise the inverse along y is
-//     out[n'] = G0[n'] + conj(w_N^n') G1[n'],  out[n' + N/2] = G0[n'] - conj(w_N^n') G1[n'],
-// G_p = N/2-point inverse over the parity-p columns.  So one block runs the whole slab as two
-// half-width passes over an N x (N/2) LDS slab (110 KB at N = 160): G0 waits in registers
-// (N*N/4/NT complex per thread) while parity 1 runs, the A slab stays in registers for both
-// parities, and the output is written once, fully coalesced.  Same in/out layout as k_xy_corr.
-//   grid NZ*CT*nsplit (XCD-aware decode as above), block 4N = 640 threads (10 waves: one column
-//   pencil set each), persistent over the rotations of its part of the batch.
+// K2 for grids whose N x N slab does not fit LDS (N = 160, 205 KB), as FOUR N/2 x N/2 problems: decimation in
+// frequency along x AND y.  With kx = 2m + p, ky = 2n + q
+//     F[2m+p][2n+q] = FFT2_{N/2}( a[x][y] w^(p x + q y) )[m][n]                       (w = exp(-2 pi i / N); a is L x L, L = N/2)
+//     out[u + L s][v + L r] = sum_pq (-1)^(p s + q r) conj(w)^(p u + q v) G_pq[u][v],  G_pq = IFFT2_{N/2}( rec[2m+p][2n+q] conj(F_pq) )
+// so every transform is a dense 80-point one (two wave-local passes, one LDS exchange; the length-160 columns of the
+// round-2 half-slab kernel -- decimation along y only, G_0 parked in the output slab -- needed three passes: 3.86 ms
+// against 3.63 ms for 17 channels x 16 rotations) and two sub-problems (q = 0, 1 of one p) sit in LDS side by side: every
+// phase has 20 pencil sets for the block's waves instead of 10.  The q-combination H_p[u][y'] is formed when the pair
+// is done; H_0 waits in registers (L*N/NT complex per thread) for H_1 and the output slab is written once.  The last
+// forward x pass (radix 8, butterfly j holds kx = j + 10 r) hands its registers to the first inverse x pass, which is
+// a radix-8 pass over exactly those inputs when the inverse runs the plan 8 x 10.
+//   grid NZ*CT*nsplit (XCD-aware decode as above), block 64*WV threads, persistent over its part of the batch.
 // ------------------------------------------------------------------------------------------
-// Measured and rejected: a 10 x 16 two-pass column plan (8 % slower than the wave-local 8 x 4 x 5 despite one LDS round
-// trip less); G0 kept in registers instead of parked in the output slab (spills at 8 waves); 5 or 10 waves per block
-// (5.6 / 6.1 ms against 4.0 ms at 8: fewer waves hide less latency, ten spill -- also with the receptor values loaded at
-// their use instead of prefetched: 5.75 ms at ten waves, 7.2 ms at five).
-#define DLPD_K2D_WAVES 8
 template <int N, int WV> __global__ void __launch_bounds__(64 * WV)
-k_xy_corr_dif(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __restrict__ out,
-              int CT, int nb, int nsplit, long long rec_bstride, int transposed) {
+k_xy_corr_quad(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __restrict__ out,
+               int CT, int nb, int nsplit, long long rec_bstride, int transposed) {
   constexpr int L = N / 2, H = N / 2, NZ = N / 2 + 1, RS = H + 8;
   static_assert(RS % 16 == 8, "row stride must be an odd multiple of 8 elements (bank spreading)");
   constexpr int NT = 64 * WV, W = WV;
-  constexpr int NLOAD = (L * L / 2 + NT - 1) / NT;     // float4 (2 complex) per thread of an A slab
-  constexpr int NG = (N * H / 2 + NT - 1) / NT;        // float4 per thread of a G slab
-  typedef FftPlanW<N> P;                          // column (length-N) plan; rows use FftPlanW<H>
-  constexpr bool THREE = P::R3 > 1;
-  typedef FftPassW<N, P::R1, 1, -1, 8, L> FwdP1;
-  typedef FftPassW<N, P::R2, P::R1, -1, 8> FwdP2;
-  typedef FftPassW<N, (THREE ? P::R3 : 2), P::R1 * P::R2, -1, 8> FwdP3;
-  typedef typename std::conditional<THREE, FwdP3, FwdP2>::type FwdLast;   // the pass that meets the receptor
-  constexpr int RL = THREE ? P::R3 : P::R2;
+  constexpr int NP = (L * L / 2 + NT - 1) / NT;        // element pairs (float4) per thread of an L x L slab
+  constexpr int NSET = 2 * (H / 8);                    // pencil sets per phase: both sub-problems
+  typedef FftPlanW<H> P;
+  static_assert(P::R3 == 1, "two-pass plan");
+  typedef FftPassW<H, P::R1, 1, -1, 8> FwdP1;
+  typedef FftPassW<H, P::R2, P::R1, -1, 8> FwdP2;
+  typedef FftPassW<H, P::R2, 1, +1, 8> InvP1;          // inverse columns run R2 x R1: pass 1 consumes FwdP2's registers
+  typedef FftPassW<H, P::R1, P::R2, +1, 8> InvP2;
+  static_assert(FwdP2::PER == InvP1::PER && FwdP2::NBF == InvP1::NBF, "register hand-over forward -> inverse");
   DLPD_DYN_SHARED(cplx, S);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bid = blockIdx.x;
@@ -490,54 +511,61 @@ k_xy_corr_dif(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __
   if (b_beg >= b_end) return;
   const int tr = lane & 7, qr = lane >> 3;             // row phase: lane = 8*pencil + thread
   const int c8 = lane & 7;                             // column phase: lane = 8*thread + column
-  cplx* tw = S + N * RS;                               // exp(-2 pi i k / N)
+  cplx* tw = S + 2 * H * RS;                           // exp(-2 pi i k / N)
   cplx* twh = tw + N;                                  // exp(-2 pi i k / H)
   init_twiddles<N>(tw, tid, NT);
   init_twiddles<H>(twh, tid, NT);
 
-  float4 apref[NLOAD];
+  float4 apref[NP];
   auto fetch_A = [&](int b) {
     const float4* a = reinterpret_cast<const float4*>(A + (((size_t)b * CT + c) * NZ + kz) * L * L);
 #pragma unroll
-    for (int i = 0; i < NLOAD; i++)
+    for (int i = 0; i < NP; i++)
       if (tid + i * NT < L * L / 2) apref[i] = DLPD_LOAD_STREAM(a + tid + i * NT);
   };
+  float4 h0[NP][2];                                    // H_0[u][v..v+1], H_0[u][v+L..]
   fetch_A(b_beg);
   __syncthreads();                                     // twiddle tables visible
   DLPD_STAMP_DECL;
   for (int b = b_beg; b < b_end; b++) {
-    const int tr_flag = transposed;                          // slabs stored transposed by K1 (dlpd_corr.hip)
     float4* o = reinterpret_cast<float4*>(out + (((size_t)b * CT + c) * NZ + kz) * N * N);
 #pragma unroll 1
-    for (int par = 0; par < 2; par++) {
-      // ---- A slab (registers) -> rows 0..L-1, times w_N^y for the odd outputs
+    for (int p = 0; p < 2; p++) {
+      // ---- A slab (registers) times w^(p x) -> sub-slab q = 0, times w^y -> sub-slab q = 1
       DLPD_STAMP(7);
       int tq = tid;
-      DLPD_OPAQUE(tq);               // keeps the ~60 slab offsets below from being hoisted out of the loops and spilled
+      DLPD_OPAQUE(tq);               // keeps the slab offsets below from being hoisted out of the loops and spilled
 #pragma unroll
-      for (int i = 0; i < NLOAD; i++) {
-        const int e = 2 * (tq + i * NT), x = e / L, y = e % L;
+      for (int i = 0; i < NP; i++) {
+        const int e = 2 * (tq + i * NT), r0 = e / L, c0 = e % L;       // memory row / column of the pair
         if (e < L * L) {
           cplx u = c_make(apref[i].x, apref[i].y), v = c_make(apref[i].z, apref[i].w);
-          if (tr_flag) {                                     // stored [y][x]: this pair is (x = y, y = x), (x = y + 1, ..)
-            if (par) { u = c_mul(u, tw[x]); v = c_mul(v, tw[x]); }
-            S[y * RS + slab_swz(x)] = u;
-            S[(y + 1) * RS + slab_swz(x)] = v;
+          if (transposed) {                                  // stored [y][x]: the pair is (x, y) = (c0, r0), (c0 + 1, r0)
+            if (p) { u = c_mul(u, tw[c0]); v = c_mul(v, tw[c0 + 1]); }
+            const cplx wy = tw[r0];
+            cplx* d = S + c0 * RS + slab_swz(r0);
+            d[0] = u;
+            d[RS] = v;
+            d[H * RS] = c_mul(u, wy);
+            d[H * RS + RS] = c_mul(v, wy);
           } else {
-            if (par) { u = c_mul(u, tw[y]); v = c_mul(v, tw[y + 1]); }
-            S[x * RS + slab_swz(y)] = u;
-            S[x * RS + slab_swz(y + 1)] = v;
+            if (p) { const cplx wx = tw[r0]; u = c_mul(u, wx); v = c_mul(v, wx); }
+            cplx* d = S + r0 * RS;
+            d[slab_swz(c0)] = u;
+            d[slab_swz(c0 + 1)] = v;
+            d[H * RS + slab_swz(c0)] = c_mul(u, tw[c0]);
+            d[H * RS + slab_swz(c0 + 1)] = c_mul(v, tw[c0 + 1]);
           }
         }
       }
-      if (par == 1 && b + 1 < b_end) fetch_A(b + 1);   // next rotation's slab, in flight over this parity
+      if (p == 1 && b + 1 < b_end) fetch_A(b + 1);     // next rotation's slab, in flight over this pair
       DLPD_STAMP(0);
       __syncthreads();
       DLPD_STAMP(1);
-      // ---- forward along y: H-point transforms of the L non-zero rows
+      // ---- forward along y: all rows of both sub-slabs
 #pragma unroll 1
-      for (int set = wave; set < L / 8; set += W) {
-        const RowAddr<RS> ad = {(set * 8 + qr) * RS};
+      for (int set = wave; set < NSET; set += W) {
+        const RowAddr<RS> ad = {(set * 8 + qr) * RS};        // sub-slab 1 starts at row H
         int t = tr;
         DLPD_OPAQUE(t);
         fft_wave<H, -1, H>(S, ad, t, twh);
@@ -545,66 +573,57 @@ k_xy_corr_dif(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __
       DLPD_STAMP(2);
       __syncthreads();
       DLPD_STAMP(1);
-      // ---- columns ky = 2m + par: forward x (pruned), receptor multiply, inverse x
+      // ---- columns: forward x, receptor multiply, inverse x (first inverse pass in registers)
 #pragma unroll 1
-      for (int set = wave; set < H / 8; set += W) {
-        const int col = set * 8 + c8;
-        const ColAddr<RS> ad = {slab_swz(col)};
+      for (int set = wave; set < NSET; set += W) {
+        const int q = set / (H / 8), col = (set % (H / 8)) * 8 + c8;
+        const ColAddr<RS> ad = {q * H * RS + slab_swz(col)};
         int tc = lane >> 3;
         DLPD_OPAQUE(tc);
-        // receptor values of this pencil set: requested first, in flight during the forward passes
-        // receptor values of this pencil set: requested first (in flight during the forward passes) when
-        // they fit (three-pass plan: 40 VGPRs), else one butterfly at a time right before their use
-        const cplx* rbase = rec + (size_t)b * rec_bstride + ((size_t)c * NZ + kz) * N * N + (2 * col + par);
-        cplx rv[THREE ? FwdLast::PER : 1][RL];
-        if (THREE) {
-          FwdLast idx;
+        const cplx* rbase = rec + (size_t)b * rec_bstride + (((size_t)c * NZ + kz) * N + p) * N + (2 * col + q);
+        cplx rv[FwdP2::PER][P::R2];
+        {
+          FwdP2 idx;                                   // receptor values: requested first, in flight during the first pass
 #pragma unroll
-          for (int i = 0; i < FwdLast::PER; i++)
+          for (int i = 0; i < FwdP2::PER; i++)
             if (idx.active(i, tc)) {
 #pragma unroll
-              for (int q = 0; q < RL; q++) rv[i][q] = rbase[(unsigned)(idx.out_index(i, q, tc) * N)];
+              for (int r = 0; r < P::R2; r++) rv[i][r] = rbase[(unsigned)(idx.out_index(i, r, tc) * 2 * N)];
             }
         }
         {
           FwdP1 ps;
-          ps.load(S, ad, tc, tw);
+          ps.load(S, ad, tc, twh);
           DLPD_WAVE_SYNC();
           ps.store(S, ad, tc);
           DLPD_WAVE_SYNC();
         }
-        if (THREE) {
-          FwdP2 ps;
-          ps.load(S, ad, tc, tw);
-          DLPD_WAVE_SYNC();
-          ps.store(S, ad, tc);
-          DLPD_WAVE_SYNC();
-        }
+        InvP1 qs;
         {
-          FwdLast ps;
-          ps.load(S, ad, tc, tw);
+          FwdP2 ps;
+          ps.load(S, ad, tc, twh);
 #pragma unroll
-          for (int i = 0; i < FwdLast::PER; i++)
+          for (int i = 0; i < FwdP2::PER; i++)
             if (ps.active(i, tc)) {
-              if (!THREE) {
 #pragma unroll
-                for (int q = 0; q < RL; q++) rv[0][q] = rbase[(unsigned)(ps.out_index(i, q, tc) * N)];
-              }
-#pragma unroll
-              for (int q = 0; q < RL; q++) ps.v[i][q] = c_mulc(rv[THREE ? i : 0][q], ps.v[i][q]);
+              for (int r = 0; r < P::R2; r++) qs.v[i][r] = c_mulc(rv[i][r], ps.v[i][r]);
+              SmallDft<P::R2, +1>::run(qs.v[i]);
             }
-          DLPD_WAVE_SYNC();
-          ps.store(S, ad, tc);
-          DLPD_WAVE_SYNC();
         }
-        fft_wave<N, +1, N, ColAddr<RS>, P>(S, ad, tc, tw);
+        DLPD_WAVE_SYNC();
+        qs.store(S, ad, tc);
+        DLPD_WAVE_SYNC();
+        InvP2 ps;
+        ps.load(S, ad, tc, twh);
+        DLPD_WAVE_SYNC();
+        ps.store(S, ad, tc);
       }
       DLPD_STAMP(3);
       __syncthreads();
       DLPD_STAMP(1);
-      // ---- inverse along y: H-point transforms of all N rows -> G_par
+      // ---- inverse along y -> G_p0, G_p1
 #pragma unroll 1
-      for (int set = wave; set < N / 8; set += W) {
+      for (int set = wave; set < NSET; set += W) {
         const RowAddr<RS> ad = {(set * 8 + qr) * RS};
         int t = tr;
         DLPD_OPAQUE(t);
@@ -613,47 +632,53 @@ k_xy_corr_dif(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __
       DLPD_STAMP(4);
       __syncthreads();
       DLPD_STAMP(1);
+      // ---- H_p[u][v + L r] = G_p0[u][v] + (-1)^r conj(w^v) G_p1[u][v];  out[u + L s][y'] = H_0 + (-1)^s conj(w^u) H_1
       DLPD_OPAQUE(tq);
-      if (par == 0) {
 #pragma unroll
-        for (int i = 0; i < NG; i++) {
-          const int e = 2 * (tq + i * NT), x = e / H, y = e % H;
-          if (e < N * H) {
-            const cplx u = S[x * RS + slab_swz(y)], v = S[x * RS + slab_swz(y + 1)];
-            o[(x * N + y) / 2] = make_float4(u.x, u.y, v.x, v.y);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < NG; i++) {
-          const int e = 2 * (tq + i * NT), x = e / H, y = e % H;
-          if (e < N * H) {
-            const cplx u = c_mulc(S[x * RS + slab_swz(y)], tw[y]);          // conj(w^y) * G1
-            const cplx v = c_mulc(S[x * RS + slab_swz(y + 1)], tw[y + 1]);
-            const float4 g = o[(x * N + y) / 2];
-            DLPD_STORE_STREAM(o + (x * N + y) / 2, make_float4(g.x + u.x, g.y + u.y, g.z + v.x, g.w + v.y));
-            DLPD_STORE_STREAM(o + (x * N + y + H) / 2, make_float4(g.x - u.x, g.y - u.y, g.z - v.x, g.w - v.y));
+      for (int i = 0; i < NP; i++) {
+        const int e = 2 * (tq + i * NT), u = e / H, v = e % H;
+        if (e < H * H) {
+          const cplx* g = S + u * RS;
+          const cplx a0 = g[slab_swz(v)], a1 = g[slab_swz(v + 1)];
+          const cplx b0 = c_mulc(g[H * RS + slab_swz(v)], tw[v]), b1 = c_mulc(g[H * RS + slab_swz(v + 1)], tw[v + 1]);
+          const float4 lo = make_float4(a0.x + b0.x, a0.y + b0.y, a1.x + b1.x, a1.y + b1.y);
+          const float4 hi = make_float4(a0.x - b0.x, a0.y - b0.y, a1.x - b1.x, a1.y - b1.y);
+          if (p == 0) {
+            h0[i][0] = lo;
+            h0[i][1] = hi;
+          } else {
+            const cplx wu = tw[u];
+            const cplx l0 = c_mulc(c_make(lo.x, lo.y), wu), l1 = c_mulc(c_make(lo.z, lo.w), wu);
+            const cplx k0 = c_mulc(c_make(hi.x, hi.y), wu), k1 = c_mulc(c_make(hi.z, hi.w), wu);
+            const float4 f = h0[i][0], k = h0[i][1];
+            DLPD_STORE_STREAM(o + (u * N + v) / 2, make_float4(f.x + l0.x, f.y + l0.y, f.z + l1.x, f.w + l1.y));
+            DLPD_STORE_STREAM(o + (u * N + v + H) / 2, make_float4(k.x + k0.x, k.y + k0.y, k.z + k1.x, k.w + k1.y));
+            DLPD_STORE_STREAM(o + ((u + H) * N + v) / 2, make_float4(f.x - l0.x, f.y - l0.y, f.z - l1.x, f.w - l1.y));
+            DLPD_STORE_STREAM(o + ((u + H) * N + v + H) / 2, make_float4(k.x - k0.x, k.y - k0.y, k.z - k1.x, k.w - k1.y));
           }
         }
       }
       DLPD_STAMP(5);
-      __syncthreads();                                 // slab fully read before it is refilled
+      __syncthreads();                                 // sub-slabs fully read before they are refilled
       DLPD_STAMP(1);
     }
   }
   DLPD_STAMP_FLUSH(dlpd_stamps_k2, DLPD_STAMPS);
 }
 
-template <int N, int WV> static int launch_k2_dif(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, long long rbs,
-                                                  hipStream_t st, int transposed = 0) {
+#ifndef DLPD_K2Q_WAVES
+#define DLPD_K2Q_WAVES 8
+#endif
+template <int N, int WV> static int launch_k2_quad(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, long long rbs,
+                                                   hipStream_t st, int transposed = 0) {
   constexpr int NZ = N / 2 + 1, H = N / 2, RS = H + 8;
-  const size_t shmem = (size_t)(N * RS + N + H) * sizeof(cplx);
-  int rc = dlpd_set_max_dyn_shared((const void*)k_xy_corr_dif<N, WV>, shmem);
+  const size_t shmem = (size_t)(2 * H * RS + N + H) * sizeof(cplx);
+  int rc = dlpd_set_max_dyn_shared((const void*)k_xy_corr_quad<N, WV>, shmem);
   if (rc) return rc;
   int nsplit = nb >= 8 ? 2 : 1;
   if (k2_nsplit_override()) nsplit = k2_nsplit_override();
   const int slabs8 = ((NZ * CT + 7) / 8) * 8;
-  DLPD_LAUNCH((k_xy_corr_dif<N, WV>), dim3(slabs8 * nsplit), dim3(64 * WV), shmem, st, A, rec, out, CT, nb, nsplit, rbs, transposed);
+  DLPD_LAUNCH((k_xy_corr_quad<N, WV>), dim3(slabs8 * nsplit), dim3(64 * WV), shmem, st, A, rec, out, CT, nb, nsplit, rbs, transposed);
   return dlpd_check_launch();
 }
 
@@ -673,7 +698,7 @@ int dlpd_k2_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb,
     case 32: return launch_k2<64, 1>(A, rec, out, CT, nb, rbs, 1.f, st, transposed);
     case 40: return launch_k2<80, 1>(A, rec, out, CT, nb, rbs, 1.f, st, transposed);
     case 64: return launch_k2<128, 1>(A, rec, out, CT, nb, rbs, 1.f, st, transposed);
-    case 80: return launch_k2_dif<160, DLPD_K2D_WAVES>(A, rec, out, CT, nb, rbs, st, transposed);
+    case 80: return launch_k2_quad<160, DLPD_K2Q_WAVES>(A, rec, out, CT, nb, rbs, st, transposed);
     default: return DLPD_ERR_UNSUPPORTED;
   }
 }

@@ -232,6 +232,7 @@ static inline float2 dlpd_load_stream_c(const float2* p) { return *p; }
 #define DLPD_CLAMP(v, c) fminf(fmaxf((v), -(c)), (c))
 #define DLPD_SCHED_FENCE() ((void)0)
 #define DLPD_OPAQUE(x) ((void)(x))
+#define DLPD_SET_PRIO(n) ((void)0)
 struct dlpd_f2v { float x, y; };
 static inline dlpd_f2v dlpd_f2_make(float a, float b) { dlpd_f2v r = {a, b}; return r; }
 static inline dlpd_f2v dlpd_f2_splat(float a) { dlpd_f2v r = {a, a}; return r; }

@@ -161,11 +161,12 @@ def test_rotate_kernel_matches_oracle(emu):
     assert torch.equal(out, vol)
 
 
-def test_volume_convolution_stages_match_oracle_and_definition(emu):
+@pytest.mark.parametrize("L,nvol", [(32, 2), (64, 1)])
+def test_volume_convolution_stages_match_oracle_and_definition(emu, L, nvol):
     """rfft3d_padded + zfft + xy_correlate + zifft_real == VolumeConvolution; spot-checked against
-    the MultiplyVolumes definition (sum_r v1[r+t] v2[r])."""
+    the MultiplyVolumes definition (sum_r v1[r+t] v2[r]).  L = 64: the N = 128 slab kernel of the headline
+    configuration (last inverse pass written straight to global memory)."""
     torch.manual_seed(4)
-    L, nvol = 32, 2
     N, NZ = 2 * L, L + 1
     v1, v2 = torch.randn(nvol, L, L, L), torch.randn(nvol, L, L, L)
     wsA = torch.empty(nvol * NZ * L * L * 2)
@@ -178,7 +179,7 @@ def test_volume_convolution_stages_match_oracle_and_definition(emu):
     emu.call("dlpd_zifft_real", _ptr(wsB), _ptr(out), 1, nvol, L, 0, 0.0, 0)
     ref = orc.correlate_fft(v1[None], v2[None], dtype=torch.float64)[0]
     assert (out.double() - ref).abs().max() < 1e-5 * ref.abs().max()
-    for t in [(0, 0, 0), (3, -2, 5), (-31, 31, 0), (7, 7, -7)]:
+    for t in [(0, 0, 0), (3, -2, 5), (1 - L, L - 1, 0), (7, 7, -7)]:
         sl1 = tuple(slice(max(d, 0), L + min(d, 0)) for d in t)
         sl2 = tuple(slice(max(-d, 0), L + min(-d, 0)) for d in t)
         direct = (v1[(slice(None),) + sl1].double() * v2[(slice(None),) + sl2].double()).sum(dim=(1, 2, 3))
@@ -187,7 +188,7 @@ def test_volume_convolution_stages_match_oracle_and_definition(emu):
     assert out[:, L, :, :].abs().max() < 1e-3          # |t| = L: no overlap
     # clip variant
     emu.call("dlpd_zifft_real", _ptr(wsB), _ptr(out), 1, nvol, L, 1, 2.0, 0)
-    assert (out.double() - ref.clamp(-2.0, 2.0)).abs().max() < 1e-4 and out.abs().max() <= 2.0
+    assert (out.double() - ref.clamp(-2.0, 2.0)).abs().max() < 1e-4 + 1e-6 * ref.abs().max() and out.abs().max() <= 2.0
 
 
 @pytest.mark.parametrize("tag,nres", [("multires", 2), ("single", 1)])
