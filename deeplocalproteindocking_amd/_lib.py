@@ -30,6 +30,9 @@ SIGNATURES = {
     "dlpd_quads_floats": (ctypes.c_size_t, [_i, _i]),
     "dlpd_make_quads": (_i, [_p, _p, _i, _i, _p]),
     "dlpd_zfft_quads": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "dlpd_channels_last_floats": (ctypes.c_size_t, [_i, _i]),
+    "dlpd_make_channels_last": (_i, [_p, _p, _i, _i, _p]),
+    "dlpd_zfft_channels_last": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "dlpd_zfft_oriented": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _ll, _i, _f, _i, _p]),
     "dlpd_xy_correlate_oriented": (_i, [_p, _p, _p, _i, _i, _i, _ll, _i, _p]),
     "dlpd_score_rotations_oriented": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _f, _i, _i, _f, _f,

@@ -260,6 +260,161 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
 }
 
 // ------------------------------------------------------------------------------------------
+// K1 from a CHANNELS-LAST ligand: cl[x][y][z][Cp] (Cp = C rounded up to 16, zero padded).  The rotation is the same
+// for every channel, so one gather address serves all of them: a lane fetches FOUR channels of one corner with one
+// 16-byte load and the four lanes of a voxel a 64-byte run -- the number of cache-line requests per sample no longer
+// depends on how oblique the rotation is (the per-channel kernel above issues one 8-byte request per lane and corner
+// pair and spends 85-90 % of its time in the texture-cache pipeline; slab orientation and the quad layout exist to
+// soften exactly that and are not needed here).  Same corner weights, products and summation order as
+// trilinear_fetch: bit-identical samples.
+//   block = (rotation b, plane x, 8 rows y0..y0+7, 16 channels): 64 two-row pencils; 1-D grid, every XCD takes a
+//   contiguous range of (b, x) so that neighbouring planes -- which share source lines -- meet in one L2.
+//   LDS: 64 pencils x (N + 13) complex; the pencils of channel quad q start 4q elements into their rows, which
+//   puts the 8-byte stores of a voxel's four lanes (four channels 16 pencils apart: same bank otherwise) on
+//   disjoint banks.
+// ------------------------------------------------------------------------------------------
+#define DLPD_K1CL_CC 16                   // channels per block
+#define DLPD_K1CL_YG 8                    // rows per block
+template <int N> __global__ void __launch_bounds__(64 * FftPlan<N>::T)
+k_rotate_zfft_cl(const float4* __restrict__ cl, const float* __restrict__ R, cplx* __restrict__ A,
+                 int C, int Cq, int nb, float c0, int CT_out, int c_base) {
+  constexpr int L = N / 2, NZ = N / 2 + 1, NP = 64, CC = DLPD_K1CL_CC, YG = DLPD_K1CL_YG, NPR = YG / 2;
+  static_assert(CC * NPR == NP && L % YG == 0, "64 pencils per block");
+  constexpr int RS = N + 13;
+  constexpr int T = FftPlan<N>::T, R1 = FftPlan<N>::R1, R2 = FftPlan<N>::R2;
+  constexpr int NT = NP * T;
+  DLPD_DYN_SHARED(cplx, S);
+  cplx* tw = S + NP * RS;
+  const int tid = threadIdx.x;
+  const int nchunk = Cq / (CC / 4), per = (L / YG) * nchunk;
+  const int groups = nb * L, gper = (groups + 7) / 8;
+  const int bid = blockIdx.x, seq = bid >> 3;
+  const int g = (bid & 7) * gper + seq / per;
+  if (seq / per >= gper || g >= groups) return;
+  const int inner = seq % per, yg = inner / nchunk, chunk = inner % nchunk;
+  const int b = g / L, x = g % L;
+  init_twiddles<N>(tw, tid, NT);
+  {
+    const float* r = R + (size_t)b * 9;
+    const float r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6], r7 = r[7], r8 = r[8];
+    const float dx = x - c0;
+    const int hi = L - 1;
+    for (int task = tid; task < NPR * L * 4; task += NT) {
+      const int q = task & 3, z = (task >> 2) % L, m = (task >> 2) / L;
+      const float4* src = cl + chunk * (CC / 4) + q;
+      const float dz = z - c0;
+      float4 acc[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const float dy = (yg * YG + 2 * m + u) - c0;
+        const float px = c0 + (r0 * dx + r3 * dy + r6 * dz);
+        const float py = c0 + (r1 * dx + r4 * dy + r7 * dz);
+        const float pz = c0 + (r2 * dx + r5 * dy + r8 * dz);
+        const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+        const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+        const float ax = px - fx, ay = py - fy, az = pz - fz;
+        const bool x0 = (ix >= 0) & (ix <= hi), x1 = (ix + 1 >= 0) & (ix + 1 <= hi);
+        const bool y0 = (iy >= 0) & (iy <= hi), y1 = (iy + 1 >= 0) & (iy + 1 <= hi);
+        const bool z0 = (iz >= 0) & (iz <= hi), z1 = (iz + 1 >= 0) & (iz + 1 <= hi);
+        const float wx0 = x0 ? 1.f - ax : 0.f, wx1 = x1 ? ax : 0.f;
+        const float wy0 = y0 ? 1.f - ay : 0.f, wy1 = y1 ? ay : 0.f;
+        const float wz0 = z0 ? 1.f - az : 0.f, wz1 = z1 ? az : 0.f;
+        const int cx0 = min(max(ix, 0), hi), cx1 = min(max(ix + 1, 0), hi);
+        const int cy0 = min(max(iy, 0), hi), cy1 = min(max(iy + 1, 0), hi);
+        const int cz0 = min(max(iz, 0), hi), cz1 = min(max(iz + 1, 0), hi);
+        const float4 v000 = src[(size_t)((cx0 * L + cy0) * L + cz0) * Cq], v001 = src[(size_t)((cx0 * L + cy0) * L + cz1) * Cq];
+        const float4 v010 = src[(size_t)((cx0 * L + cy1) * L + cz0) * Cq], v011 = src[(size_t)((cx0 * L + cy1) * L + cz1) * Cq];
+        const float4 v100 = src[(size_t)((cx1 * L + cy0) * L + cz0) * Cq], v101 = src[(size_t)((cx1 * L + cy0) * L + cz1) * Cq];
+        const float4 v110 = src[(size_t)((cx1 * L + cy1) * L + cz0) * Cq], v111 = src[(size_t)((cx1 * L + cy1) * L + cz1) * Cq];
+        const float w000 = wx0 * wy0 * wz0, w001 = wx0 * wy0 * wz1, w010 = wx0 * wy1 * wz0, w011 = wx0 * wy1 * wz1;
+        const float w100 = wx1 * wy0 * wz0, w101 = wx1 * wy0 * wz1, w110 = wx1 * wy1 * wz0, w111 = wx1 * wy1 * wz1;
+#define DLPD_TRI(f)                                                                                               \
+  {                                                                                                               \
+    float a = v000.f * w000;                                                                                      \
+    a += v001.f * w001;                                                                                           \
+    a += v010.f * w010;                                                                                           \
+    a += v011.f * w011;                                                                                           \
+    a += v100.f * w100;                                                                                           \
+    a += v101.f * w101;                                                                                           \
+    a += v110.f * w110;                                                                                           \
+    a += v111.f * w111;                                                                                           \
+    acc[u].f = a;                                                                                                 \
+  }
+        DLPD_TRI(x) DLPD_TRI(y) DLPD_TRI(z) DLPD_TRI(w)
+#undef DLPD_TRI
+      }
+      // rows 2m (real part) and 2m+1 (imaginary part) of the four channels' pencils
+      cplx* P = S + ((4 * q) * NPR + m) * RS + 4 * q + z;
+      P[0] = c_make(acc[0].x, acc[1].x);
+      P[NPR * RS] = c_make(acc[0].y, acc[1].y);
+      P[2 * NPR * RS] = c_make(acc[0].z, acc[1].z);
+      P[3 * NPR * RS] = c_make(acc[0].w, acc[1].w);
+    }
+  }
+  __syncthreads();
+  const int p = tid % NP, t = tid / NP;
+  cplx* Sp = S + p * RS + 4 * (p / (4 * NPR));
+  {
+    FftPass<N, R1, 1, -1, T, L> ps;
+    ps.load(Sp, 1, t, tw);
+    __syncthreads();
+    ps.store(Sp, 1, t);
+    __syncthreads();
+  }
+  {
+    FftPass<N, R2, R1, -1, T> ps;
+    ps.load(Sp, 1, t, tw);
+    __syncthreads();
+    ps.store(Sp, 1, t);
+    __syncthreads();
+  }
+  // untangle the two real rows packed in each complex pencil; write [kz][x][y]
+  for (int s = tid; s < NP * NZ; s += NT) {
+    const int pm = s % NP, k = s / NP;
+    const int c = chunk * CC + pm / NPR, m = pm % NPR;
+    if (c < C) {
+      const cplx* Z = S + pm * RS + 4 * (pm / (4 * NPR));
+      const cplx zk = Z[k];
+      const cplx zn = Z[(N - k) % N];
+      float4 o;
+      o.x = 0.5f * (zk.x + zn.x);
+      o.y = 0.5f * (zk.y - zn.y);
+      o.z = 0.5f * (zk.y + zn.y);
+      o.w = 0.5f * (zn.x - zk.x);
+      cplx* a = A + (((size_t)b * CT_out + c_base + c) * NZ + k) * L * L + (size_t)x * L + yg * YG + 2 * m;
+      DLPD_STORE_STREAM(reinterpret_cast<float4*>(a), o);
+    }
+  }
+}
+
+// (C, L, L, L) -> channels-last (L, L, L, Cp), Cp = 4 Cq >= C, zero padded
+__global__ void __launch_bounds__(256) k_make_channels_last(const float* __restrict__ v, float4* __restrict__ cl, int C, int Cq, int L) {
+  const size_t L3 = (size_t)L * L * L, total = L3 * Cq;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % Cq);
+    const size_t vox = i / Cq;
+    float e[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) e[j] = (4 * c4 + j < C) ? v[(size_t)(4 * c4 + j) * L3 + vox] : 0.f;
+    cl[i] = make_float4(e[0], e[1], e[2], e[3]);
+  }
+}
+
+template <int N> static int launch_k1_cl(const float4* cl, const float* R, cplx* A, int C, int nb, float c0, hipStream_t st,
+                                         int CT_out, int c_base) {
+  constexpr int L = N / 2, RS = N + 13;
+  const int Cq = ((C + DLPD_K1CL_CC - 1) / DLPD_K1CL_CC) * (DLPD_K1CL_CC / 4);
+  const size_t shmem = (size_t)(64 * RS + N) * sizeof(cplx);
+  int rc = dlpd_set_max_dyn_shared((const void*)k_rotate_zfft_cl<N>, shmem);
+  if (rc) return rc;
+  const int per = (L / DLPD_K1CL_YG) * (Cq / (DLPD_K1CL_CC / 4));
+  const int gper = (nb * L + 7) / 8;
+  dim3 grid((unsigned)(8 * gper * per)), block(64 * FftPlan<N>::T);
+  DLPD_LAUNCH((k_rotate_zfft_cl<N>), grid, block, shmem, st, cl, R, A, C, Cq, nb, c0, CT_out, c_base);
+  return dlpd_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------
 // K3: z-axis C2R + (MODE 1) filter MLP + clash mask, or (MODE 0) plain real output.
 //   grid (N/16, N [x'], nb), block 512 threads (8 waves), dynamic LDS: 64 pencils + twiddles + raw staging.
 //   Bw   (nb, CT, NZ, N, N) complex [kz][x'][y']
@@ -1271,6 +1426,36 @@ int dlpd_zfft_quads(const float* quads, const float* R, void* wsA, int nb, int C
     case 40: return launch_k1<80>(dummy, R, A, CT, nb, 0, 1, center, st, CT_out, c_base, transposed, q4);
     case 64: return launch_k1<128>(dummy, R, A, CT, nb, 0, 1, center, st, CT_out, c_base, transposed, q4);
     case 80: return launch_k1<160>(dummy, R, A, CT, nb, 0, 1, center, st, CT_out, c_base, transposed, q4);
+    default: return DLPD_ERR_UNSUPPORTED;
+  }
+}
+
+size_t dlpd_channels_last_floats(int C, int L) {
+  return (size_t)L * L * L * (size_t)(((C + DLPD_K1CL_CC - 1) / DLPD_K1CL_CC) * DLPD_K1CL_CC);
+}
+
+int dlpd_make_channels_last(const float* vol, float* cl, int C, int L, void* stream) {
+  if (!vol || !cl || C <= 0 || L <= 0) return DLPD_ERR_ARG;
+  const int Cq = ((C + DLPD_K1CL_CC - 1) / DLPD_K1CL_CC) * (DLPD_K1CL_CC / 4);
+  const size_t total = (size_t)L * L * L * Cq;
+  size_t nblk = (total + 255) / 256;
+  if (nblk > 65536) nblk = 65536;
+  DLPD_LAUNCH(k_make_channels_last, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, vol, (float4*)cl, C, Cq, L);
+  return dlpd_check_launch();
+}
+
+// rotation + z FFT of the C score channels of ONE ligand shared by all rotations, gathered from its channels-last copy
+int dlpd_zfft_channels_last(const float* cl, const float* R, void* wsA, int nb, int C, int CT_out, int c_base, int L,
+                            float center, void* stream) {
+  if (!cl || !R || !wsA || nb <= 0 || C <= 0 || c_base < 0 || c_base + C > CT_out) return DLPD_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  cplx* A = (cplx*)wsA;
+  const float4* c4 = (const float4*)cl;
+  switch (L) {
+    case 32: return launch_k1_cl<64>(c4, R, A, C, nb, center, st, CT_out, c_base);
+    case 40: return launch_k1_cl<80>(c4, R, A, C, nb, center, st, CT_out, c_base);
+    case 64: return launch_k1_cl<128>(c4, R, A, C, nb, center, st, CT_out, c_base);
+    case 80: return launch_k1_cl<160>(c4, R, A, C, nb, center, st, CT_out, c_base);
     default: return DLPD_ERR_UNSUPPORTED;
   }
 }

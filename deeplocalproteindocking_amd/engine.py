@@ -118,7 +118,7 @@ class DockingEngine:
 
     def __init__(self, L, C, W1, b1, W2, b2, clip=5.0, threshold_clash=300.0, has_clash=True,
                  max_conf=1000, batch=8, device="cuda", lib=None, center=None, coarse_channels=0,
-                 fine_unfused=None):
+                 fine_unfused=None, channels_last=None):
         """coarse_channels > 0: the reference's two-resolution layout -- C channels at L^3 plus
         ``coarse_channels`` at (L/2)^3 (ProteinRepresentationModels.py:72-76); W1 is (H, C+coarse)."""
         self.device = torch.device(device)
@@ -149,8 +149,16 @@ class DockingEngine:
         self.wsA = torch.empty(nb * CT * NZ * L * L * 2, dtype=f32, device=dev)
         self.wsB = torch.empty(nb * CT * NZ * N * N * 2, dtype=f32, device=dev)
         self.V = torch.empty(nb, N, N, N, dtype=f32, device=dev)
-        self.orient = os.environ.get("DLPD_NO_ORIENT", "") == ""      # diagnostic switch (slab orientation)
-        self.use_quads = os.environ.get("DLPD_NO_QUADS", "") == ""    # diagnostic switch (quad-layout gather)
+        # channels-last gather (include/dlpd.h): one 16-byte load serves four channels of a corner, so the rotation
+        # costs the same for every rotation; slab orientation and the quad layout are the per-channel kernel's
+        # remedies and stay for ligands with few channels (and as diagnostic switches)
+        if channels_last is None:
+            channels_last = os.environ.get("DLPD_NO_CHANNELS_LAST", "") == "" and self.C >= 8
+        self.use_cl = bool(channels_last)
+        self.orient = os.environ.get("DLPD_NO_ORIENT", "") == "" and not self.use_cl
+        self.use_quads = os.environ.get("DLPD_NO_QUADS", "") == "" and not self.use_cl
+        if self.use_cl:
+            self.ligcl = torch.empty(lib.call("dlpd_channels_last_floats", self.C, int(L)), dtype=f32, device=dev)
         self.prefilter = os.environ.get("DLPD_NO_PREFILTER", "") == ""   # diagnostic switch (top-K candidate lists from K3)
         if self.use_quads:
             self.ligq = torch.empty(lib.call("dlpd_quads_floats", CT, int(L)), dtype=f32, device=dev)
@@ -166,6 +174,8 @@ class DockingEngine:
             self.wsB1 = torch.empty(nb * C1 * NZ1 * N1 * N1 * 2, dtype=f32, device=dev)
             if self.use_quads:
                 self.ligq1 = torch.empty(lib.call("dlpd_quads_floats", C1, L1), dtype=f32, device=dev)
+            if self.use_cl:
+                self.ligcl1 = torch.empty(lib.call("dlpd_channels_last_floats", C1, L1), dtype=f32, device=dev)
         # fine_unfused (diagnostic / A-B): materialise the real correlations of the fine grid and run the
         # vectorised filter kernel behind a plain z-inverse, instead of the fused z-inverse + MLP (K3)
         self.fine_unfused = bool(fine_unfused)
@@ -226,6 +236,11 @@ class DockingEngine:
         self.lig[: self.C] = torch.as_tensor(lig_volumes, dtype=torch.float32).reshape(self.C, L, L, L).to(self.device)
         if self.has_clash:
             self.lig[self.C] = torch.as_tensor(lig_forbidden, dtype=torch.float32).reshape(L, L, L).to(self.device)
+        if self.use_cl:
+            st = _stream(self.device)
+            self.lib.call("dlpd_make_channels_last", _ptr(self.lig), _ptr(self.ligcl), self.C, L, st)
+            if self.C1:
+                self.lib.call("dlpd_make_channels_last", _ptr(self.lig1), _ptr(self.ligcl1), self.C1, self.L1, st)
         # quad layout for the rotation gather (include/dlpd.h), once per pair: 4x the ligand's bytes
         if self.use_quads:
             st = _stream(self.device)
@@ -271,7 +286,7 @@ class DockingEngine:
         V = self.V if out is None else out
         call, st, L = self.lib.call, _stream(self.device), self.L
         provider = self.clash_provider if self.has_clash else None
-        if not (self.C1 or provider or self.fine_unfused or mark or use_quads or cset is not None):
+        if not (self.C1 or provider or self.fine_unfused or mark or use_quads or self.use_cl or cset is not None):
             call("dlpd_score_rotations_oriented", _ptr(self.lig), _ptr(self.recF), _ptr(R), nb, self.C,
                  int(self.has_clash), L, self.center, _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2), self.b2,
                  self.HP, has_clip, clip, self.threshold, _ptr(self.wsA), _ptr(self.wsB), _ptr(V), tr, st)
@@ -281,7 +296,10 @@ class DockingEngine:
         if self.C1:
             # coarse resolution first: rotate + correlate + clip -> real volumes the fine filter reads
             L1 = self.L1
-            if use_quads:
+            if self.use_cl:
+                call("dlpd_zfft_channels_last", _ptr(self.ligcl1), _ptr(R), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1,
+                     float(L1) / 2.0, st)
+            elif use_quads:
                 call("dlpd_zfft_quads", _ptr(self.ligq1), _ptr(R), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1,
                      float(L1) / 2.0, tr, st)
             else:
@@ -294,7 +312,10 @@ class DockingEngine:
         if provider is not None:
             # clash channel from re-projected rotated ATOMS (Docker.py:221-224), scores from rotated volumes
             forb = provider(R).reshape(nb, L, L, L).contiguous()
-            if use_quads:
+            if self.use_cl:
+                call("dlpd_zfft_channels_last", _ptr(self.ligcl), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0, L,
+                     self.center, st)
+            elif use_quads:
                 call("dlpd_zfft_quads", _ptr(self.ligq), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0, L,
                      self.center, tr, st)
             else:
@@ -302,6 +323,12 @@ class DockingEngine:
                      self.center, tr, st)
             call("dlpd_zfft_oriented", _ptr(forb), 0, _ptr(self.wsA), nb, 1, self.CT, self.C, L, L ** 3, 0, 0.0,
                  tr, st)                      # same orientation as the score channels
+        elif self.use_cl:
+            call("dlpd_zfft_channels_last", _ptr(self.ligcl), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0, L,
+                 self.center, st)
+            if self.has_clash:                # the ligand's forbidden volume: one channel, per-channel kernel
+                call("dlpd_zfft_oriented", self.lig.data_ptr() + self.C * L ** 3 * 4, _ptr(R), _ptr(self.wsA), nb, 1,
+                     self.CT, self.C, L, 0, 1, self.center, 0, st)
         elif use_quads:
             call("dlpd_zfft_quads", _ptr(self.ligq), _ptr(R), _ptr(self.wsA), nb, self.CT, self.CT, 0, L,
                  self.center, tr, st)

@@ -70,6 +70,17 @@ int dlpd_make_quads(const float* vol, float* quads, int nvol, int L, void* strea
 int dlpd_zfft_quads(const float* quads, const float* R, void* wsA, int nb, int CT, int CT_out, int c_base, int L,
                     float center, int transposed, void* stream);
 
+/* Channels-last copy of a ligand's C score volumes for the rotation gather of Docker.py:218: cl[x][y][z][Cp], Cp = C
+ * rounded up to 16 (zero padded).  Every channel is sampled at the same rotated position, so one 16-byte load
+ * serves four channels of a corner and the gather's cache-line requests per sample stop depending on the rotation
+ * (no slab orientation, no quad layout on this path).  dlpd_zfft_channels_last = dlpd_zfft_into with do_rotate = 1
+ * for channels [c_base, c_base + C) of a (nb, CT_out, NZ, L, L) workspace; samples are bit-identical to the plain
+ * path.  A clash channel is written by a separate dlpd_zfft_into call (transposed = 0). */
+size_t dlpd_channels_last_floats(int C, int L);
+int dlpd_make_channels_last(const float* vol, float* cl, int C, int L, void* stream);
+int dlpd_zfft_channels_last(const float* cl, const float* R, void* wsA, int nb, int C, int CT_out, int c_base, int L,
+                            float center, void* stream);
+
 /* CoordsRotate + CoordsTranslate + TypedCoords2Volume (+ channel sum) of src/Docker/Docker.py:204,
  * 208,221-224 in one kernel: p' = R_b p + shift, density exp(-|r - p'|^2 / 2) on the 5^3 voxels
  * around each atom (build-defined shape).  coords (B, 3*stride_atoms) ordered by type,

@@ -547,26 +547,39 @@ def test_all_four_search_paths_match_oracle_at_baseline_config2_size(dev):
     thr = bench.clash_threshold(recf, ligf)
     W = [w.cpu() for w in filt.parameters_tuple()]
     groups = _rotations_by_group(1)
-    eng = DockingEngine(L, C, *W, clip=5.0, threshold_clash=thr, max_conf=100, batch=2, device=dev)
-    eng.set_receptor(rec, recf)
-    eng.set_ligand(lig, ligf)
     oracle = {}
     for key, Rg in groups.items():
         oracle[key] = _oracle_V(rec, lig, recf, ligf, W, Rg[0], thr, 5.0)
     worst = 0.0
+    # the default K1: channels-last gather (one kernel for every rotation), on a rotation of each group
+    eng = DockingEngine(L, C, *W, clip=5.0, threshold_clash=thr, max_conf=100, batch=4, device=dev)
+    assert eng.use_cl and not eng.orient and not eng.use_quads
+    eng.set_receptor(rec, recf)
+    eng.set_ligand(lig, ligf)
+    keys = list(groups)
+    V = eng.score_batch(torch.from_numpy(np.stack([groups[k][0] for k in keys])).float().to(dev).contiguous()).cpu()
+    for j, key in enumerate(keys):
+        worst = max(worst, _assert_scores_match(V[j], oracle[key][0], oracle[key][1], thr))
+    del eng
+    # the per-channel K1 (ligands with few channels, DLPD_NO_CHANNELS_LAST) and its four launch variants
+    eng = DockingEngine(L, C, *W, clip=5.0, threshold_clash=thr, max_conf=100, batch=2, device=dev, channels_last=False)
+    assert eng.orient and eng.use_quads
+    eng.set_receptor(rec, recf)
+    eng.set_ligand(lig, ligf)
     for (tr, qd) in groups:                                      # the launch variant under test
         prefers, other = groups[(tr, qd)][0], groups[(not tr, not qd)][0]
         Rd = torch.from_numpy(np.stack([prefers, other])).float().to(dev).contiguous()
         V = eng.score_batch(Rd, transposed=tr, quads=qd).cpu()
         for j, key in enumerate(((tr, qd), (not tr, not qd))):
             worst = max(worst, _assert_scores_match(V[j], oracle[key][0], oracle[key][1], thr))
-    print("config 2, four K1/K2 variants x preferred/non-preferred rotations: worst error %.2e of max|V|" % worst)
+    print("config 2, channels-last K1 + four per-channel K1/K2 variants x preferred/non-preferred rotations: "
+          "worst error %.2e of max|V|" % worst)
 
 
 def test_baseline_config5_shape_48ch_80cube_matches_oracle(dev):
-    """BASELINE config 5's literal shape: 48 channels at 80^3, single resolution -> 160^3 (DIF K2 with 49
-    slabs per kz, fused K3 on 8-row tiles; and the unfused z-inverse + k_filter_vec pair as a diagnostic
-    variant), clip active, clash channel on; two rotations, one per slab orientation as the search would choose."""
+    """BASELINE config 5's literal shape: 48 channels at 80^3, single resolution -> 160^3 (channels-last K1, the
+    four-sub-problem K2 with 49 slabs per kz, fused K3 on 8-row tiles; the unfused z-inverse + k_filter_vec pair and
+    the per-channel K1 with transposed slabs as variants), clip active, clash channel on; two rotations."""
     import bench
     from deeplocalproteindocking_amd.engine import DockingEngine
     C, L = 48, 80
@@ -592,6 +605,12 @@ def test_baseline_config5_shape_48ch_80cube_matches_oracle(dev):
             eng2.set_ligand(lig, ligf)
             worst = max(worst, _assert_scores_match(eng2.score_batch(Rd).cpu()[0], Vo, norm, thr))
             del eng2
+        else:                                                # the per-channel K1 with transposed slabs + quad layout
+            eng3 = DockingEngine(L, C, *W, clip=5.0, threshold_clash=thr, max_conf=100, batch=1, device=dev, channels_last=False)
+            eng3.set_receptor(rec, recf)
+            eng3.set_ligand(lig, ligf)
+            worst = max(worst, _assert_scores_match(eng3.score_batch(Rd, transposed=True, quads=True).cpu()[0], Vo, norm, thr))
+            del eng3
     print("config 5 shape (48 ch @ 80^3): worst error %.2e of max|V|" % worst)
     # the clip must really bite at this amplitude, otherwise the clamp path is not exercised
     c = orc.correlate_fft(rec[None], orc.rotate_volume(lig[None], torch.from_numpy(groups[(False, False)][0][None]).float()))

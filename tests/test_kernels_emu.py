@@ -161,6 +161,26 @@ def test_rotate_kernel_matches_oracle(emu):
     assert torch.equal(out, vol)
 
 
+@pytest.mark.parametrize("L,C", [(32, 20), (40, 16)])
+def test_channels_last_rotation_equals_the_per_channel_kernel(emu, L, C):
+    """dlpd_zfft_channels_last == dlpd_zfft_into(do_rotate=1), bit for bit, on oblique rotations; channel counts that
+    are not a multiple of the 16-channel block (zero-padded copy) and a workspace with more channels than written."""
+    torch.manual_seed(12)
+    nb, NZ, CT = 2, L + 1, C + 1
+    vol = torch.randn(C, L, L, L)
+    R = torch.from_numpy(orc.euler_to_matrix([0.4, -1.3], [0.9, 2.0], [1.7, -0.2])).float().contiguous()
+    want = torch.zeros(nb * CT * NZ * L * L * 2)
+    got = torch.zeros_like(want)
+    emu.call("dlpd_zfft_into", _ptr(vol), _ptr(R), _ptr(want), nb, C, CT, 0, L, 0, 1, L / 2.0, 0)
+    cl = torch.empty(emu.call("dlpd_channels_last_floats", C, L))
+    emu.call("dlpd_make_channels_last", _ptr(vol), _ptr(cl), C, L, 0)
+    Cp = cl.numel() // L ** 3
+    assert Cp % 16 == 0 and Cp >= C
+    assert torch.equal(cl.view(L, L, L, Cp)[..., :C], vol.permute(1, 2, 3, 0)) and not cl.view(L, L, L, Cp)[..., C:].any()
+    emu.call("dlpd_zfft_channels_last", _ptr(cl), _ptr(R), _ptr(got), nb, C, CT, 0, L, L / 2.0, 0)
+    assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("L,nvol", [(32, 2), (64, 1)])
 def test_volume_convolution_stages_match_oracle_and_definition(emu, L, nvol):
     """rfft3d_padded + zfft + xy_correlate + zifft_real == VolumeConvolution; spot-checked against
