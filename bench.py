@@ -182,8 +182,9 @@ def cpu_baseline(rec, lig, recf, ligf, W, R_sample, group_of, thr, K, V_gpu=None
                                R_sample, *W, thr, K, clip=5.0, faithful_topk=True, return_V=True)
     dt = time.time() - t0
     out = {"value": n * (2 * L) ** 3 / dt, "unit": "pose scores/s", "cores": torch.get_num_threads(), "kind": "port",
-           "sample": "%d rotations of the same rotation set and pair, %d from each of the four search groups "
-                     "(slab orientation x gather layout), %.1f s; SURVEY 8(d)'s 32 rotations would take about twice "
+           "sample": "%d rotations of the same rotation set and pair, %d from each of the four rotation classes "
+                     "(source z axis closest to output x / y / z: the per-channel K1's slab orientation x gather "
+                     "layout groups), %.1f s; SURVEY 8(d)'s 32 rotations would take about twice "
                      "the 10-30 s the bench contract allots to this leg" % (n, n // 4, dt)}
     if V_gpu is not None:
         # voxels whose clash mask differs (clash correlation within FFT round-off of the threshold)
