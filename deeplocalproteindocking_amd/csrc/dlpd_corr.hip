@@ -267,18 +267,22 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
 // pair and spends 85-90 % of its time in the texture-cache pipeline; slab orientation and the quad layout exist to
 // soften exactly that and are not needed here).  Same corner weights, products and summation order as
 // trilinear_fetch: bit-identical samples.
-//   block = (rotation b, plane x, 8 rows y0..y0+7, 16 channels): 64 two-row pencils; 1-D grid, every XCD takes a
-//   contiguous range of (b, x) so that neighbouring planes -- which share source lines -- meet in one L2.
-//   LDS: 64 pencils x (N + 13) complex; the pencils of channel quad q start 4q elements into their rows, which
-//   puts the 8-byte stores of a voxel's four lanes (four channels 16 pencils apart: same bank otherwise) on
-//   disjoint banks.
+//   block = (rotation b, plane x, YG rows, CC channels), YG x CC = 128: 64 two-row pencils (K1ClCfg); 1-D grid,
+//   every XCD takes a contiguous range of (b, x) so that neighbouring planes -- which share source lines -- meet in
+//   one L2.  LDS: 64 pencils x (N + 13) complex; the pencils of channel quad q start SKEW q elements into their
+//   rows, which puts the 8-byte stores of a voxel's lanes (channel quads 4 YG/2 pencils apart: same bank otherwise)
+//   on disjoint banks.
 // ------------------------------------------------------------------------------------------
-#define DLPD_K1CL_CC 16                   // channels per block
-#define DLPD_K1CL_YG 8                    // rows per block
+#define DLPD_K1CL_CC 16                   // channel padding of the channels-last copy
+// rows x channels per block (64 two-row pencils either way).  8 x 16: 64-byte gathers, 64-byte output pieces;
+// 16 x 8: 32-byte gathers, full 128-byte output lines.  Measured: N = 128 (48 channels) 0.83 / 0.75 ms,
+// N = 160 (16 channels) 0.61 / 0.66 ms.
+template <int N> struct K1ClCfg { static constexpr int YG = (N == 128) ? 16 : 8, CC = 128 / YG; };
 template <int N> __global__ void __launch_bounds__(64 * FftPlan<N>::T)
 k_rotate_zfft_cl(const float4* __restrict__ cl, const float* __restrict__ R, cplx* __restrict__ A,
                  int C, int Cq, int nb, float c0, int CT_out, int c_base) {
-  constexpr int L = N / 2, NZ = N / 2 + 1, NP = 64, CC = DLPD_K1CL_CC, YG = DLPD_K1CL_YG, NPR = YG / 2;
+  constexpr int L = N / 2, NZ = N / 2 + 1, NP = 64, CC = K1ClCfg<N>::CC, YG = K1ClCfg<N>::YG, NPR = YG / 2;
+  constexpr int LPV = CC / 4, SKEW = 16 / LPV;         // lanes per voxel; bank skew (complex) between channel quads
   static_assert(CC * NPR == NP && L % YG == 0, "64 pencils per block");
   constexpr int RS = N + 13;
   constexpr int T = FftPlan<N>::T, R1 = FftPlan<N>::R1, R2 = FftPlan<N>::R2;
@@ -299,8 +303,8 @@ k_rotate_zfft_cl(const float4* __restrict__ cl, const float* __restrict__ R, cpl
     const float r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6], r7 = r[7], r8 = r[8];
     const float dx = x - c0;
     const int hi = L - 1;
-    for (int task = tid; task < NPR * L * 4; task += NT) {
-      const int q = task & 3, z = (task >> 2) % L, m = (task >> 2) / L;
+    for (int task = tid; task < NPR * L * LPV; task += NT) {
+      const int q = task % LPV, z = (task / LPV) % L, m = (task / LPV) / L;
       const float4* src = cl + chunk * (CC / 4) + q;
       const float dz = z - c0;
       float4 acc[2];
@@ -344,7 +348,7 @@ k_rotate_zfft_cl(const float4* __restrict__ cl, const float* __restrict__ R, cpl
 #undef DLPD_TRI
       }
       // rows 2m (real part) and 2m+1 (imaginary part) of the four channels' pencils
-      cplx* P = S + ((4 * q) * NPR + m) * RS + 4 * q + z;
+      cplx* P = S + ((4 * q) * NPR + m) * RS + SKEW * q + z;
       P[0] = c_make(acc[0].x, acc[1].x);
       P[NPR * RS] = c_make(acc[0].y, acc[1].y);
       P[2 * NPR * RS] = c_make(acc[0].z, acc[1].z);
@@ -353,7 +357,7 @@ k_rotate_zfft_cl(const float4* __restrict__ cl, const float* __restrict__ R, cpl
   }
   __syncthreads();
   const int p = tid % NP, t = tid / NP;
-  cplx* Sp = S + p * RS + 4 * (p / (4 * NPR));
+  cplx* Sp = S + p * RS + SKEW * (p / (4 * NPR));
   {
     FftPass<N, R1, 1, -1, T, L> ps;
     ps.load(Sp, 1, t, tw);
@@ -373,7 +377,7 @@ k_rotate_zfft_cl(const float4* __restrict__ cl, const float* __restrict__ R, cpl
     const int pm = s % NP, k = s / NP;
     const int c = chunk * CC + pm / NPR, m = pm % NPR;
     if (c < C) {
-      const cplx* Z = S + pm * RS + 4 * (pm / (4 * NPR));
+      const cplx* Z = S + pm * RS + SKEW * (pm / (4 * NPR));
       const cplx zk = Z[k];
       const cplx zn = Z[(N - k) % N];
       float4 o;
@@ -407,7 +411,7 @@ template <int N> static int launch_k1_cl(const float4* cl, const float* R, cplx*
   const size_t shmem = (size_t)(64 * RS + N) * sizeof(cplx);
   int rc = dlpd_set_max_dyn_shared((const void*)k_rotate_zfft_cl<N>, shmem);
   if (rc) return rc;
-  const int per = (L / DLPD_K1CL_YG) * (Cq / (DLPD_K1CL_CC / 4));
+  const int per = (L / K1ClCfg<N>::YG) * (Cq / (K1ClCfg<N>::CC / 4));
   const int gper = (nb * L + 7) / 8;
   dim3 grid((unsigned)(8 * gper * per)), block(64 * FftPlan<N>::T);
   DLPD_LAUNCH((k_rotate_zfft_cl<N>), grid, block, shmem, st, cl, R, A, C, Cq, nb, c0, CT_out, c_base);

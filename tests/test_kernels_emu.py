@@ -161,14 +161,14 @@ def test_rotate_kernel_matches_oracle(emu):
     assert torch.equal(out, vol)
 
 
-@pytest.mark.parametrize("L,C", [(32, 20), (40, 16)])
+@pytest.mark.parametrize("L,C", [(32, 20), (40, 16), (64, 9)])
 def test_channels_last_rotation_equals_the_per_channel_kernel(emu, L, C):
     """dlpd_zfft_channels_last == dlpd_zfft_into(do_rotate=1), bit for bit, on oblique rotations; channel counts that
     are not a multiple of the 16-channel block (zero-padded copy) and a workspace with more channels than written."""
     torch.manual_seed(12)
-    nb, NZ, CT = 2, L + 1, C + 1
+    nb, NZ, CT = (2 if L < 64 else 1), L + 1, C + 1       # L = 64: the 16-row x 8-channel block shape of N = 128
     vol = torch.randn(C, L, L, L)
-    R = torch.from_numpy(orc.euler_to_matrix([0.4, -1.3], [0.9, 2.0], [1.7, -0.2])).float().contiguous()
+    R = torch.from_numpy(orc.euler_to_matrix([0.4, -1.3], [0.9, 2.0], [1.7, -0.2])).float()[:nb].contiguous()
     want = torch.zeros(nb * CT * NZ * L * L * 2)
     got = torch.zeros_like(want)
     emu.call("dlpd_zfft_into", _ptr(vol), _ptr(R), _ptr(want), nb, C, CT, 0, L, 0, 1, L / 2.0, 0)
