@@ -166,7 +166,22 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
     }
   };
 
+  cplx rv[FwdP2::PER][R2];
+  auto fetch_rec = [&](int bb, int set) {
+    const cplx* rbase = rec + (size_t)bb * rec_bstride + ((size_t)c * NZ + kz) * N * N;
+    int col = set * 8 + c8;
+    DLPD_OPAQUE(col);                  // keeps the 16 load addresses from being hoisted out of the batch loop (spills)
+    const int tc = lane >> 3;
+    FwdP2 idx;
+#pragma unroll
+    for (int i = 0; i < FwdP2::PER; i++)
+      if (idx.active(i, tc)) {
+#pragma unroll
+        for (int q = 0; q < R2; q++) rv[i][q] = rbase[(unsigned)(idx.out_index(i, q, tc) * N) + (unsigned)col];
+      }
+  };
   fetch_rows(b_beg);
+  if (MODE == 1) fetch_rec(b_beg, wave);
   __syncthreads();                                         // twiddle table visible
   stage_rows();
   DLPD_WAVE_SYNC();
@@ -182,18 +197,9 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
       const int col = set * 8 + c8;
       const ColAddr<RS> ad = {slab_swz(col)};
       const int tc = lane >> 3;
-      cplx rv[FwdP2::PER][R2];
-      // receptor values: requested before the first x pass, in flight during it
-      if (MODE == 1) {
-        const cplx* rbase = rec + (size_t)b * rec_bstride + ((size_t)c * NZ + kz) * N * N;
-        FwdP2 idx;
-#pragma unroll
-        for (int i = 0; i < FwdP2::PER; i++)
-          if (idx.active(i, tc)) {
-#pragma unroll
-            for (int q = 0; q < R2; q++) rv[i][q] = rbase[(unsigned)(idx.out_index(i, q, tc) * N) + (unsigned)col];
-          }
-      }
+      // receptor values: the first set's were requested in the row phase (ahead of the second row set's output
+      // stores), the second set's are requested here, before its first x pass
+      if (MODE == 1 && set != wave) fetch_rec(b, set);
       {
         FwdP1 ps;
         ps.load(S, ad, tc, nullptr);
@@ -254,11 +260,13 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
     DLPD_STAMP(3);
     __syncthreads();                                       // all columns done
     DLPD_STAMP(1);
-    // ---- the wave's own rows from here to the next column phase: next rotation's A rows requested now,
-    // y-inverse + copy-out of row sets w and w + W, then staging + y-forward of the next slab's rows
-    if (b + 1 < b_end) fetch_rows(b + 1);
-#pragma unroll 1
-    for (int set = wave; set < NSET; set += W) {
+    // ---- the wave's own rows from here to the next column phase.  Order (vmcnt counts loads and stores together, in
+    // issue order): next rotation's A rows requested; y-inverse + output of row set w; staging + y-forward of the next
+    // slab's rows 8w.. (the wait for the A rows has only set w's stores behind it); the receptor values of the next
+    // column phase's first set requested; y-inverse + output of row set w + W.  No load is ever waited for behind
+    // stores younger than one transform phase: with all stores ahead of the receptor loads the column phase used to
+    // wait for the write-back of the whole slab (A loads 0.25 ms, receptor loads 0.15 ms of 2.56: variant builds).
+    auto inverse_rows_out = [&](int set) {
       if (MODE == 1) {
         const RowAddr<RS> ad = {(set * 8 + qr) * RS};
         const int tr = lane & 7;
@@ -296,14 +304,18 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
         DLPD_WAVE_SYNC();
       }
       DLPD_STAMP(5);
-    }
+    };
+    if (b + 1 < b_end) fetch_rows(b + 1);
+    inverse_rows_out(wave);
     if (b + 1 < b_end) {
       stage_rows();
       DLPD_WAVE_SYNC();
       DLPD_STAMP(0);
       forward_rows();
       DLPD_STAMP(2);
+      if (MODE == 1) fetch_rec(b + 1, wave);
     }
+    inverse_rows_out(wave + W);
   }
   DLPD_STAMP_FLUSH(dlpd_stamps_k2, DLPD_STAMPS);
 }
