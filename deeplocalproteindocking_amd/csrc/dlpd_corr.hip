@@ -617,11 +617,11 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
             // k = 0: the purely real bin of both rows (both stores then write the same value to the same place)
             const cplx lo = (k == 0) ? c_make(q[u].x, q[u].z) : c_make(q[u].x - q[u].w, q[u].y + q[u].z);
             const cplx hi = (k == 0) ? c_make(q[u].x, q[u].z) : c_make(q[u].x + q[u].w, q[u].z - q[u].y);
-            P[slab_swz(k)] = lo;
-            P[slab_swz((N - k) & (k == 0 ? 0 : ~0))] = hi;
+            P[pencil_in_pos<N>(k)] = lo;
+            P[pencil_in_pos<N>((N - k) & (k == 0 ? 0 : ~0))] = hi;
           }
         }
-        if (lane / NPAIR == 0) S[(wave * 8 + j * NPAIR + lane % NPAIR) * RS + slab_swz(N / 2)] = c_make(qh.x, qh.z);
+        if (lane / NPAIR == 0) S[(wave * 8 + j * NPAIR + lane % NPAIR) * RS + pencil_in_pos<N>(N / 2)] = c_make(qh.x, qh.z);
       }
       DLPD_WAIT_LDS();                         // raw fully read before it is refilled
       DLPD_WAVE_SYNC();
@@ -634,8 +634,7 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
       // ~60 of them are hoisted out of the group loop and spill next to the 96 accumulators
       int tq = tr, qq = qr;
       if (N == 160 && DLPD_K3_LAUNDER_160) { DLPD_OPAQUE(tq); DLPD_OPAQUE(qq); }
-      const RowAddr<RS> adq = {(wave * 8 + qq) * RS};
-      fft_wave<N, +1, N>(S, adq, tq, tw);
+      fft_wave_pencils<N, +1>(S, wave * 8, RS, qq, tq, tw);
     }
     DLPD_STAMP(3);
     DLPD_LDS_BARRIER();                        // all channels of the group transformed
@@ -647,7 +646,7 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
 #pragma unroll
           for (int e = 0; e < EPT; e++) {
             const int m = m0 + e * MSTEP;
-            const cplx val = S[(g * NPAIR + m) * RS + slab_swz(zz)];
+            const cplx val = S[(g * NPAIR + m) * RS + pencil_out_pos<N>(zz)];
             float v0 = val.x, v1 = val.y;
             if (has_clip && c < C) { v0 = DLPD_CLAMP(v0, clip); v1 = DLPD_CLAMP(v1, clip); }
             float* o = out + ((((size_t)b * CT + c) * N + xo) * N + y0 + 2 * m) * N + zz;
@@ -666,7 +665,7 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
 #pragma unroll
           for (int j = 0; j < HPH; j++) wcur[j] = W1t[(size_t)cbase * HP + j0 + j];
 #pragma unroll
-          for (int e = 0; e < EPT; e++) vcur[e] = S[(m0 + e * MSTEP) * RS + slab_swz(zz)];
+          for (int e = 0; e < EPT; e++) vcur[e] = S[(m0 + e * MSTEP) * RS + pencil_out_pos<N>(zz)];
         }
         for (int g = 0; g < gs; g++) {
           // channel g+1's weights (scalar loads) and values (LDS) are requested here, one
@@ -676,7 +675,7 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
 #pragma unroll
           for (int j = 0; j < HPH; j++) wnxt[j] = W1t[(size_t)(cbase + gn1) * HP + j0 + j];
 #pragma unroll
-          for (int e = 0; e < EPT; e++) vnxt[e] = S[(gn1 * NPAIR + m0 + e * MSTEP) * RS + slab_swz(zz)];
+          for (int e = 0; e < EPT; e++) vnxt[e] = S[(gn1 * NPAIR + m0 + e * MSTEP) * RS + pencil_out_pos<N>(zz)];
           DLPD_SCHED_FENCE();
 #pragma unroll
           for (int e = 0; e < EPT; e++) {
@@ -698,7 +697,7 @@ k_zifft_filter(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int
           const int g = C - cbase;
 #pragma unroll
           for (int e = 0; e < EPT; e++) {
-            const cplx v = S[(g * NPAIR + m0 + e * MSTEP) * RS + slab_swz(zz)];
+            const cplx v = S[(g * NPAIR + m0 + e * MSTEP) * RS + pencil_out_pos<N>(zz)];
             nrm[2 * e] = v.x;
             nrm[2 * e + 1] = v.y;
           }
@@ -922,11 +921,11 @@ k_zifft_filter_tiles(const cplx* __restrict__ Bw, float* __restrict__ out, int C
             // k = 0: the purely real bin of both rows (both stores then write the same value to the same place)
             const cplx lo = (k == 0) ? c_make(q[u].x, q[u].z) : c_make(q[u].x - q[u].w, q[u].y + q[u].z);
             const cplx hi = (k == 0) ? c_make(q[u].x, q[u].z) : c_make(q[u].x + q[u].w, q[u].z - q[u].y);
-            P[slab_swz(k)] = lo;
-            P[slab_swz((N - k) & (k == 0 ? 0 : ~0))] = hi;
+            P[pencil_in_pos<N>(k)] = lo;
+            P[pencil_in_pos<N>((N - k) & (k == 0 ? 0 : ~0))] = hi;
           }
         }
-        if (lane / NPAIR == 0) S[(wave * 8 + j * NPAIR + lane % NPAIR) * RS + slab_swz(N / 2)] = c_make(qh.x, qh.z);
+        if (lane / NPAIR == 0) S[(wave * 8 + j * NPAIR + lane % NPAIR) * RS + pencil_in_pos<N>(N / 2)] = c_make(qh.x, qh.z);
       }
       DLPD_WAIT_LDS();                         // raw fully read before it is refilled
       DLPD_WAVE_SYNC();
@@ -941,8 +940,7 @@ k_zifft_filter_tiles(const cplx* __restrict__ Bw, float* __restrict__ out, int C
       // passes are hoisted out of the group / tile loops and live in VGPRs next to the 96 accumulators (spills)
       int tq = tr, qq = qr;
       if (1) { DLPD_OPAQUE(tq); DLPD_OPAQUE(qq); }
-      const RowAddr<RS> adq = {(wave * 8 + qq) * RS};
-      fft_wave<N, +1, N>(S, adq, tq, tw);
+      fft_wave_pencils<N, +1>(S, wave * 8, RS, qq, tq, tw);
     }
     DLPD_STAMP(3);
     DLPD_LDS_BARRIER();                        // all channels of the group transformed
@@ -954,7 +952,7 @@ k_zifft_filter_tiles(const cplx* __restrict__ Bw, float* __restrict__ out, int C
 #pragma unroll
           for (int e = 0; e < EPT; e++) {
             const int m = m0 + e * MSTEP;
-            const cplx val = S[(g * NPAIR + m) * RS + slab_swz(zz)];
+            const cplx val = S[(g * NPAIR + m) * RS + pencil_out_pos<N>(zz)];
             float v0 = val.x, v1 = val.y;
             if (has_clip && c < C) { v0 = DLPD_CLAMP(v0, clip); v1 = DLPD_CLAMP(v1, clip); }
             float* o = out + ((((size_t)b * CT + c) * N + xo) * N + y0 + 2 * m) * N + zz;
@@ -973,7 +971,7 @@ k_zifft_filter_tiles(const cplx* __restrict__ Bw, float* __restrict__ out, int C
 #pragma unroll
           for (int j = 0; j < HP; j++) wcur[j] = W1t[(size_t)cbase * HP + j];
 #pragma unroll
-          for (int e = 0; e < EPT; e++) vcur[e] = S[(m0 + e * MSTEP) * RS + slab_swz(zz)];
+          for (int e = 0; e < EPT; e++) vcur[e] = S[(m0 + e * MSTEP) * RS + pencil_out_pos<N>(zz)];
         }
         for (int g = 0; g < gs; g++) {
           // channel g+1's weights (scalar loads) and values (LDS) are requested here, one
@@ -983,7 +981,7 @@ k_zifft_filter_tiles(const cplx* __restrict__ Bw, float* __restrict__ out, int C
 #pragma unroll
           for (int j = 0; j < HP; j++) wnxt[j] = W1t[(size_t)(cbase + gn1) * HP + j];
 #pragma unroll
-          for (int e = 0; e < EPT; e++) vnxt[e] = S[(gn1 * NPAIR + m0 + e * MSTEP) * RS + slab_swz(zz)];
+          for (int e = 0; e < EPT; e++) vnxt[e] = S[(gn1 * NPAIR + m0 + e * MSTEP) * RS + pencil_out_pos<N>(zz)];
           DLPD_SCHED_FENCE();
 #pragma unroll
           for (int e = 0; e < EPT; e++) {
@@ -1005,7 +1003,7 @@ k_zifft_filter_tiles(const cplx* __restrict__ Bw, float* __restrict__ out, int C
           const int g = C - cbase;
 #pragma unroll
           for (int e = 0; e < EPT; e++) {
-            const cplx v = S[(g * NPAIR + m0 + e * MSTEP) * RS + slab_swz(zz)];
+            const cplx v = S[(g * NPAIR + m0 + e * MSTEP) * RS + pencil_out_pos<N>(zz)];
             nrm[2 * e] = v.x;
             nrm[2 * e + 1] = v.y;
           }

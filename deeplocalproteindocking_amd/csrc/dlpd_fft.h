@@ -167,6 +167,26 @@ template <int DIR> struct SmallDft<10, DIR> {
   }
 };
 
+template <int DIR> struct SmallDft<20, DIR> {
+  DLPD_HD static void run(cplx* v) {
+    // prime-factor (Good-Thomas) 4 x 5: n = (5 n1 + 4 n2) mod 20, k = (5 k1 + 16 k2) mod 20 -- then
+    // n k = 5 n1 k1 + 4 n2 k2 (mod 20): a 5-point transform over n2 and a 4-point one over n1, NO twiddles between
+    cplx y[4][5];
+#pragma unroll
+    for (int n1 = 0; n1 < 4; n1++) {
+#pragma unroll
+      for (int n2 = 0; n2 < 5; n2++) y[n1][n2] = v[(5 * n1 + 4 * n2) % 20];
+      dft5<DIR>(y[n1][0], y[n1][1], y[n1][2], y[n1][3], y[n1][4]);
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < 5; k2++) {
+      dft4<DIR>(y[0][k2], y[1][k2], y[2][k2], y[3][k2]);
+#pragma unroll
+      for (int k1 = 0; k1 < 4; k1++) v[(5 * k1 + 16 * k2) % 20] = y[k1][k2];
+    }
+  }
+};
+
 // ---- one Stockham pass over one pencil, register-resident between load() and store() ----
 //  N   transform length            R   radix of this pass
 //  NS  product of earlier radices  DIR -1 forward / +1 inverse (unnormalised)
@@ -382,5 +402,54 @@ DLPD_D void fft_wave(cplx* S, const Addr& ad, int t, const cplx* tw) {
     ps.load(S, ad, t, tw);
     DLPD_WAVE_SYNC();
     ps.store(S, ad, t);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Pencil layouts of the wave-local z transforms (K3).  N != 160: element e of a pencil lives at slab_swz(e) before,
+// between and after the passes.  N = 160 runs TWO passes (20 x 8, one LDS exchange; the three-pass 8 x 4 x 5 plan
+// of FftPlanW<160> needs two) and keeps its pencils in "blocks of 21": the input is stored in natural order, the
+// first pass writes its 20 outputs of butterfly t at 21 t + r and the second pass reads / writes j + 21 r -- the
+// stride 21 (42 dwords) puts the 8 threads' 8-byte stores of one r on 8 distinct bank pairs, which stride 20 does not
+// (model of the ds_write_b64 lane groups: 208 -> 80 LDS-array cycles per pencil set).  8 x 21 = 168 = the row stride.
+// ------------------------------------------------------------------------------------------
+template <int N> DLPD_HD int pencil_in_pos(int k) { return N == 160 ? k : slab_swz(k); }
+template <int N> DLPD_HD int pencil_out_pos(int z) { return N == 160 ? z + z / 20 : slab_swz(z); }
+
+// all passes of the wave-local length-N transform of 8 pencils (rows rowbase + 8 more, lane = 8 * pencil + thread),
+// input at pencil_in_pos, output at pencil_out_pos
+template <int N, int DIR> DLPD_D void fft_wave_pencils(cplx* S, int rowbase, int RS, int q, int t, const cplx* tw) {
+  if constexpr (N == 160) {
+    cplx* P = S + (rowbase + q) * RS;
+    {
+      FftPassW<N, 20, 1, DIR, 8> ps;                   // 8 butterflies of radix 20: one per thread
+#pragma unroll
+      for (int r = 0; r < 20; r++) ps.v[0][r] = lds_ld(P + t + 8 * r);
+      ps.twiddle_and_run(0, t, tw);
+      DLPD_WAVE_SYNC();
+#pragma unroll
+      for (int r = 0; r < 20; r++) lds_st(P + 21 * t + r, ps.v[0][r]);
+      DLPD_WAVE_SYNC();
+    }
+    {
+      FftPassW<N, 8, 20, DIR, 8> ps;                   // 20 butterflies of radix 8: three rounds, the last half full
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+        if (t + 8 * i < 20) {
+#pragma unroll
+          for (int r = 0; r < 8; r++) ps.v[i][r] = lds_ld(P + t + 8 * i + 21 * r);
+          ps.twiddle_and_run(i, t + 8 * i, tw);
+        }
+      DLPD_WAVE_SYNC();
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+        if (t + 8 * i < 20) {
+#pragma unroll
+          for (int r = 0; r < 8; r++) lds_st(P + t + 8 * i + 21 * r, ps.v[i][r]);
+        }
+    }
+  } else {
+    const RowAddr<0> ad = {(rowbase + q) * RS};
+    fft_wave<N, DIR, N>(S, ad, t, tw);
   }
 }
