@@ -95,7 +95,14 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
   if (b_beg >= b_end) return;
   // row phase: lane = 8*q + t  (pencil q of the set, thread t); column phase: lane = 8*t + c8
   const int qr = lane >> 3, c8 = lane & 7;
-  cplx* tw = S + N * RS;
+  // Blocked intermediate of the two-pass transforms (FftPassW::store_blk) where it pays: the 10 x 8 plan of N = 80
+  // (first-pass stores 104 / 80 -> 40 LDS-array cycles per pencil set); at N = 128 the column stores would go
+  // 128 -> 64 by the same model, but the kernel measured 0.1 ms SLOWER with it (2.46 -> 2.56 ms), so it keeps the
+  // natural order there.  The slab has 8 spare rows for the column intermediates.
+  constexpr bool BLK = (N == 80);
+#define K2_P1_STORE(ps, t) do { if constexpr (BLK) (ps).store_blk(S, md, t); else (ps).store(S, ad, t); } while (0)
+#define K2_P2_LOAD(ps, t) do { if constexpr (BLK) (ps).load_blk(S, md, t, tw); else (ps).load(S, ad, t, tw); } while (0)
+  cplx* tw = S + (N + (BLK ? 8 : 0)) * RS;
   init_twiddles<N>(tw, tid, NT);
 
   // this wave's 8 rows of a rotation's A slab (L x L complex, [x][y], or [y][x] when K1 stored it transposed:
@@ -139,17 +146,18 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
   };
   auto forward_rows = [&]() {                      // y-forward of the wave's rows 8w..8w+7 (wave-local)
     const RowAddr<RS> ad = {(wave * 8 + qr) * RS};
+    const RowMid<R1 + 1> md = {ad.base};           // blocked intermediate (FftPassW::store_blk)
     const int tr = lane & 7;
     {
       FwdP1 ps;
       ps.load(S, ad, tr, nullptr);
       DLPD_WAVE_SYNC();
-      ps.store(S, ad, tr);
+      K2_P1_STORE(ps, tr);
       DLPD_WAVE_SYNC();
     }
     {
       FwdP2 ps;
-      ps.load(S, ad, tr, tw);
+      K2_P2_LOAD(ps, tr);
       DLPD_WAVE_SYNC();
       ps.store(S, ad, tr);
     }
@@ -200,22 +208,24 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
       // receptor values: the first set's were requested in the row phase (ahead of the second row set's output
       // stores), the second set's are requested here, before its first x pass
       if (MODE == 1 && set != wave) fetch_rec(b, set);
+      // first passes leave their outputs in blocks R1 + 1 rows apart (FftPassW::store_blk), the second passes read them there
+      const ColMid<RS, R1 + 1> md = {ad.base};
       {
         FwdP1 ps;
         ps.load(S, ad, tc, nullptr);
         DLPD_WAVE_SYNC();
-        ps.store(S, ad, tc);
+        K2_P1_STORE(ps, tc);
         DLPD_WAVE_SYNC();
       }
       if (MODE == 0) {
         FwdP2 ps;
-        ps.load(S, ad, tc, tw);
+        K2_P2_LOAD(ps, tc);
         DLPD_WAVE_SYNC();
         ps.store(S, ad, tc);
       } else if (!HANDOVER) {
         {
           FwdP2 ps;
-          ps.load(S, ad, tc, tw);
+          K2_P2_LOAD(ps, tc);
 #pragma unroll
           for (int i = 0; i < FwdP2::PER; i++)
 #pragma unroll
@@ -228,18 +238,18 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
           InvP1 ps;
           ps.load(S, ad, tc, nullptr);
           DLPD_WAVE_SYNC();
-          ps.store(S, ad, tc);
+          K2_P1_STORE(ps, tc);
           DLPD_WAVE_SYNC();
         }
         InvP2 ps;
-        ps.load(S, ad, tc, tw);
+        K2_P2_LOAD(ps, tc);
         DLPD_WAVE_SYNC();
         ps.store(S, ad, tc);
       } else {
         InvP1 qs;
         {
           FwdP2 ps;
-          ps.load(S, ad, tc, tw);
+          K2_P2_LOAD(ps, tc);
           // thread t owns kx = t + i*T + q*R1; the inverse radix-R1 butterfly j = t wants input r1
           // at kx = t + r1*T  ->  r1 = (i*T + q*R1) / T : a pure register renaming
 #pragma unroll
@@ -249,10 +259,10 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
         }
         SmallDft<R1, +1>::run(qs.v[0]);
         DLPD_WAVE_SYNC();
-        qs.store(S, ad, tc);
+        K2_P1_STORE(qs, tc);
         DLPD_WAVE_SYNC();
         InvP2 ps;
-        ps.load(S, ad, tc, tw);
+        K2_P2_LOAD(ps, tc);
         DLPD_WAVE_SYNC();
         ps.store(S, ad, tc);
       }
@@ -270,11 +280,12 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
       if (MODE == 1) {
         const RowAddr<RS> ad = {(set * 8 + qr) * RS};
         const int tr = lane & 7;
+        const RowMid<R1 + 1> md = {ad.base};
         {
           InvP1 ps;
           ps.load(S, ad, tr, nullptr);
           DLPD_WAVE_SYNC();
-          ps.store(S, ad, tr);
+          K2_P1_STORE(ps, tr);
           DLPD_WAVE_SYNC();
         }
         if constexpr (DIRECT_OUT) {
@@ -292,7 +303,7 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
                               make_float4(ps.v[0][r].x, ps.v[0][r].y, ps.v[1][r].x, ps.v[1][r].y));
         } else {
           InvP2 ps;
-          ps.load(S, ad, tr, tw);
+          K2_P2_LOAD(ps, tr);
           DLPD_WAVE_SYNC();
           ps.store(S, ad, tr);
         }
@@ -319,6 +330,8 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
   }
   DLPD_STAMP_FLUSH(dlpd_stamps_k2, DLPD_STAMPS);
 }
+#undef K2_P1_STORE
+#undef K2_P2_LOAD
 
 // DLPD_K2_NSPLIT (diagnostic override of the batch split): read once, not on every launch
 static int k2_nsplit_override() {
@@ -329,7 +342,7 @@ static int k2_nsplit_override() {
 template <int N, int MODE> static int launch_k2(const cplx* A, const cplx* rec, cplx* out, int CT, int nb,
                                                 long long rbs, float scale, hipStream_t st, int transposed = 0) {
   constexpr int NZ = N / 2 + 1, RS = N + 8;
-  const size_t shmem = (size_t)(N * RS + N) * sizeof(cplx);
+  const size_t shmem = (size_t)((N + (N == 80 ? 8 : 0)) * RS + N) * sizeof(cplx);
   int rc = dlpd_set_max_dyn_shared((const void*)k_xy_corr<N, MODE>, shmem);
   if (rc) return rc;
   int nsplit = (MODE == 1 && nb >= 8) ? 2 : 1;
@@ -501,6 +514,8 @@ template <int N, int WV> __global__ void __launch_bounds__(64 * WV)
 k_xy_corr_quad(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __restrict__ out,
                int CT, int nb, int nsplit, long long rec_bstride, int transposed) {
   constexpr int L = N / 2, H = N / 2, NZ = N / 2 + 1, RS = H + 8;
+  constexpr int HR = H + 10, SUB = HR * RS;            // rows per sub-slab (10 spare: blocked intermediates of the column
+                                                       // passes, FftPassW::store_blk: 8 x 11 forward, 10 x 9 inverse)
   static_assert(RS % 16 == 8, "row stride must be an odd multiple of 8 elements (bank spreading)");
   constexpr int NT = 64 * WV, W = WV;
   constexpr int NP = (L * L / 2 + NT - 1) / NT;        // element pairs (float4) per thread of an L x L slab
@@ -523,7 +538,7 @@ k_xy_corr_quad(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* _
   if (b_beg >= b_end) return;
   const int tr = lane & 7, qr = lane >> 3;             // row phase: lane = 8*pencil + thread
   const int c8 = lane & 7;                             // column phase: lane = 8*thread + column
-  cplx* tw = S + 2 * H * RS;                           // exp(-2 pi i k / N)
+  cplx* tw = S + 2 * SUB;                              // exp(-2 pi i k / N)
   cplx* twh = tw + N;                                  // exp(-2 pi i k / H)
   init_twiddles<N>(tw, tid, NT);
   init_twiddles<H>(twh, tid, NT);
@@ -558,15 +573,15 @@ k_xy_corr_quad(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* _
             cplx* d = S + c0 * RS + slab_swz(r0);
             d[0] = u;
             d[RS] = v;
-            d[H * RS] = c_mul(u, wy);
-            d[H * RS + RS] = c_mul(v, wy);
+            d[SUB] = c_mul(u, wy);
+            d[SUB + RS] = c_mul(v, wy);
           } else {
             if (p) { const cplx wx = tw[r0]; u = c_mul(u, wx); v = c_mul(v, wx); }
             cplx* d = S + r0 * RS;
             d[slab_swz(c0)] = u;
             d[slab_swz(c0 + 1)] = v;
-            d[H * RS + slab_swz(c0)] = c_mul(u, tw[c0]);
-            d[H * RS + slab_swz(c0 + 1)] = c_mul(v, tw[c0 + 1]);
+            d[SUB + slab_swz(c0)] = c_mul(u, tw[c0]);
+            d[SUB + slab_swz(c0 + 1)] = c_mul(v, tw[c0 + 1]);
           }
         }
       }
@@ -577,7 +592,7 @@ k_xy_corr_quad(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* _
       // ---- forward along y: all rows of both sub-slabs
 #pragma unroll 1
       for (int set = wave; set < NSET; set += W) {
-        const RowAddr<RS> ad = {(set * 8 + qr) * RS};        // sub-slab 1 starts at row H
+        const RowAddr<RS> ad = {(set / (H / 8)) * SUB + ((set % (H / 8)) * 8 + qr) * RS};
         int t = tr;
         DLPD_OPAQUE(t);
         fft_wave<H, -1, H>(S, ad, t, twh);
@@ -589,7 +604,9 @@ k_xy_corr_quad(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* _
 #pragma unroll 1
       for (int set = wave; set < NSET; set += W) {
         const int q = set / (H / 8), col = (set % (H / 8)) * 8 + c8;
-        const ColAddr<RS> ad = {q * H * RS + slab_swz(col)};
+        const ColAddr<RS> ad = {q * SUB + slab_swz(col)};
+        const ColMid<RS, P::R1 + 1> mdf = {ad.base};   // forward 10 x 8: blocks of 11 rows
+        const ColMid<RS, P::R2 + 1> mdi = {ad.base};   // inverse 8 x 10: blocks of 9 rows
         int tc = lane >> 3;
         DLPD_OPAQUE(tc);
         const cplx* rbase = rec + (size_t)b * rec_bstride + (((size_t)c * NZ + kz) * N + p) * N + (2 * col + q);
@@ -607,13 +624,13 @@ k_xy_corr_quad(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* _
           FwdP1 ps;
           ps.load(S, ad, tc, twh);
           DLPD_WAVE_SYNC();
-          ps.store(S, ad, tc);
+          ps.store_blk(S, mdf, tc);
           DLPD_WAVE_SYNC();
         }
         InvP1 qs;
         {
           FwdP2 ps;
-          ps.load(S, ad, tc, twh);
+          ps.load_blk(S, mdf, tc, twh);
 #pragma unroll
           for (int i = 0; i < FwdP2::PER; i++)
             if (ps.active(i, tc)) {
@@ -623,10 +640,10 @@ k_xy_corr_quad(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* _
             }
         }
         DLPD_WAVE_SYNC();
-        qs.store(S, ad, tc);
+        qs.store_blk(S, mdi, tc);
         DLPD_WAVE_SYNC();
         InvP2 ps;
-        ps.load(S, ad, tc, twh);
+        ps.load_blk(S, mdi, tc, twh);
         DLPD_WAVE_SYNC();
         ps.store(S, ad, tc);
       }
@@ -636,7 +653,7 @@ k_xy_corr_quad(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* _
       // ---- inverse along y -> G_p0, G_p1
 #pragma unroll 1
       for (int set = wave; set < NSET; set += W) {
-        const RowAddr<RS> ad = {(set * 8 + qr) * RS};
+        const RowAddr<RS> ad = {(set / (H / 8)) * SUB + ((set % (H / 8)) * 8 + qr) * RS};
         int t = tr;
         DLPD_OPAQUE(t);
         fft_wave<H, +1, H>(S, ad, t, twh);
@@ -652,7 +669,7 @@ k_xy_corr_quad(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* _
         if (e < H * H) {
           const cplx* g = S + u * RS;
           const cplx a0 = g[slab_swz(v)], a1 = g[slab_swz(v + 1)];
-          const cplx b0 = c_mulc(g[H * RS + slab_swz(v)], tw[v]), b1 = c_mulc(g[H * RS + slab_swz(v + 1)], tw[v + 1]);
+          const cplx b0 = c_mulc(g[SUB + slab_swz(v)], tw[v]), b1 = c_mulc(g[SUB + slab_swz(v + 1)], tw[v + 1]);
           const float4 lo = make_float4(a0.x + b0.x, a0.y + b0.y, a1.x + b1.x, a1.y + b1.y);
           const float4 hi = make_float4(a0.x - b0.x, a0.y - b0.y, a1.x - b1.x, a1.y - b1.y);
           if (p == 0) {
@@ -684,7 +701,7 @@ k_xy_corr_quad(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* _
 template <int N, int WV> static int launch_k2_quad(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, long long rbs,
                                                    hipStream_t st, int transposed = 0) {
   constexpr int NZ = N / 2 + 1, H = N / 2, RS = H + 8;
-  const size_t shmem = (size_t)(2 * H * RS + N + H) * sizeof(cplx);
+  const size_t shmem = (size_t)(2 * (H + 10) * RS + N + H) * sizeof(cplx);
   int rc = dlpd_set_max_dyn_shared((const void*)k_xy_corr_quad<N, WV>, shmem);
   if (rc) return rc;
   int nsplit = nb >= 8 ? 2 : 1;
