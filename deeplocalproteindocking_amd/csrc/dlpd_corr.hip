@@ -440,10 +440,18 @@ template <int N> static int launch_k1_cl(const float4* cl, const float* R, cplx*
 // several tiles with the next tile's first DMA behind the current tile's last group, 2.51-2.57 vs 2.40 ms --
 // the outer loop costs ~20 VGPRs of hoisted addressing next to the 96 accumulators.)
 template <int N, int MODE> struct K3Cfg { static constexpr int NT = 512, WC = 8, TY = 16; };
-template <int MODE> struct K3Cfg<80, MODE> { static constexpr int NT = 320, WC = 5, TY = 16; };
+// N = 80: five channel-owning waves, ten accumulating (the coarse grid of the real shapes: 0.78 -> 0.60 ms)
+#ifndef DLPD_K3_80_NT
+#define DLPD_K3_80_NT 640
+#endif
+// (N = 128 with 16 waves, 8 owning channels: the 128-VGPR ceiling spills the transform, 7.3 vs 2.57 ms)
+template <int MODE> struct K3Cfg<80, MODE> { static constexpr int NT = (MODE == 0 ? 320 : DLPD_K3_80_NT), WC = 5, TY = 16; };
 template <> struct K3Cfg<160, 0> { static constexpr int NT = 320, WC = 5, TY = 16; };
+// N = 160, fused: five waves own the channels' transforms, TEN accumulate (2 voxels per thread): with the two-pass
+// z transform the accumulation is the longer phase and the extra waves pay (2.90 -> 2.63 ms at the real shapes;
+// with the three-pass transform they did not: 3.96 vs 3.71 ms)
 #ifndef DLPD_K3_160_NT
-#define DLPD_K3_160_NT 320
+#define DLPD_K3_160_NT 640
 #endif
 template <> struct K3Cfg<160, 1> { static constexpr int NT = DLPD_K3_160_NT, WC = 5, TY = 8; };
 template <> struct K3Cfg<160, 2> { static constexpr int NT = DLPD_K3_160_NT, WC = 5, TY = 8; };
