@@ -395,14 +395,12 @@ template <int RS, int B> struct ColMid {
   DLPD_HD int operator()(int blk, int off) const { return (blk * B + off) * RS + base; }
 };
 
-// wave-local plans: 8 threads per pencil; passes of radix R1 (pruned), R2 and optionally R3.
-// N = 160 takes three small-radix passes: with two (10 x 16) one pass needs 2 radix-16 butterflies
-// per thread = 64 data registers + temporaries, which does not fit beside the MLP accumulators.
+// wave-local two-pass plans R1 (pruned) x R2: 8 threads per pencil.  (N = 160, used by K3 only: 20 x 8 with its own
+// pencil layout, fft_wave_pencils below; the three-pass 8 x 4 x 5 plan of round 1 cost one LDS exchange more.)
 template <int N> struct FftPlanW;
-template <> struct FftPlanW<64> { static constexpr int R1 = 8, R2 = 8, R3 = 1; };
-template <> struct FftPlanW<128> { static constexpr int R1 = 16, R2 = 8, R3 = 1; };
-template <> struct FftPlanW<80> { static constexpr int R1 = 10, R2 = 8, R3 = 1; };
-template <> struct FftPlanW<160> { static constexpr int R1 = 8, R2 = 4, R3 = 5; };
+template <> struct FftPlanW<64> { static constexpr int R1 = 8, R2 = 8; };
+template <> struct FftPlanW<128> { static constexpr int R1 = 16, R2 = 8; };
+template <> struct FftPlanW<80> { static constexpr int R1 = 10, R2 = 8; };
 
 template <int RS> struct RowAddr {
   static constexpr bool IS_ROW = true;
@@ -418,7 +416,7 @@ template <int RS> struct ColAddr {
 // all passes of a wave-local transform of one pencil set, in place (ends without a trailing sync)
 template <int N, int DIR, int NNZ, class Addr, class P = FftPlanW<N>>
 DLPD_D void fft_wave(cplx* S, const Addr& ad, int t, const cplx* tw) {
-  if constexpr (N == 80 && P::R3 == 1 && Addr::IS_ROW) {
+  if constexpr (N == 80 && Addr::IS_ROW) {
     // the 10 x 8 plan along a row: blocked intermediate (see store_blk; at N = 128 / 64 the natural order is
     // conflict-free already and measured 1 % faster)
     const RowMid<P::R1 + 1> md = {ad.base};
@@ -448,19 +446,12 @@ DLPD_D void fft_wave(cplx* S, const Addr& ad, int t, const cplx* tw) {
     DLPD_WAVE_SYNC();
     ps.store(S, ad, t);
   }
-  if (P::R3 > 1) {
-    DLPD_WAVE_SYNC();
-    FftPassW<N, (P::R3 > 1 ? P::R3 : 2), P::R1 * P::R2, DIR, 8> ps;
-    ps.load(S, ad, t, tw);
-    DLPD_WAVE_SYNC();
-    ps.store(S, ad, t);
-  }
 }
 
 // ------------------------------------------------------------------------------------------
 // Pencil layouts of the wave-local z transforms (K3).  N != 160: element e of a pencil lives at slab_swz(e) before,
 // between and after the passes.  N = 160 runs TWO passes (20 x 8, one LDS exchange; the three-pass 8 x 4 x 5 plan
-// of FftPlanW<160> needs two) and keeps its pencils in "blocks of 21": the input is stored in natural order, the
+// of rounds 1-2 needed two) and keeps its pencils in "blocks of 21": the input is stored in natural order, the
 // first pass writes its 20 outputs of butterfly t at 21 t + r and the second pass reads / writes j + 21 r -- the
 // stride 21 (42 dwords) puts the 8 threads' 8-byte stores of one r on 8 distinct bank pairs, which stride 20 does not
 // (model of the ds_write_b64 lane groups: 208 -> 80 LDS-array cycles per pencil set).  8 x 21 = 168 = the row stride.

@@ -521,7 +521,6 @@ k_xy_corr_quad(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* _
   constexpr int NP = (L * L / 2 + NT - 1) / NT;        // element pairs (float4) per thread of an L x L slab
   constexpr int NSET = 2 * (H / 8);                    // pencil sets per phase: both sub-problems
   typedef FftPlanW<H> P;
-  static_assert(P::R3 == 1, "two-pass plan");
   typedef FftPassW<H, P::R1, 1, -1, 8> FwdP1;
   typedef FftPassW<H, P::R2, P::R1, -1, 8> FwdP2;
   typedef FftPassW<H, P::R2, 1, +1, 8> InvP1;          // inverse columns run R2 x R1: pass 1 consumes FwdP2's registers
