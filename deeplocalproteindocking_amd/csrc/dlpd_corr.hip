@@ -1297,8 +1297,13 @@ int dlpd_k2_forward(const cplx* A, cplx* out, int CT, int nb, int L, float scale
 int dlpd_k2_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, int L, long long rbs, hipStream_t st,
                       int transposed = 0);
 
-static int k3_group(int CT, int maxg) {
-  int ng = (CT + maxg - 1) / maxg;
+// channels per group.  One channel per wave (16-row tiles, N <= 128): as many as there are channel-owning waves -- 49
+// channels on 8 waves are six full groups and one with the clash channel alone, 1 % faster than seven groups of seven,
+// which leave a wave idle in every transform phase.  Two channels per wave (8-row tiles, N = 160): balanced groups
+// (17 channels on 10 slots: 9 + 8 is 3 % faster than 10 + 7).
+static int k3_group(int CT, int maxg, bool balanced) {
+  if (!balanced) return CT < maxg ? CT : maxg;
+  const int ng = (CT + maxg - 1) / maxg;
   return (CT + ng - 1) / ng;
 }
 
@@ -1313,7 +1318,7 @@ template <int N, int HP, int MODE> static int launch_k3(const cplx* Bw, float* o
   const size_t shmem = (size_t)(W * 8 * RS + N) * sizeof(cplx) + (size_t)W * CPW * RAWC * 16;
   int rc = dlpd_set_max_dyn_shared((const void*)k_zifft_filter<N, HP, MODE>, shmem);
   if (rc) return rc;
-  const int G = k3_group(CT, W * CPW);         // channels per group (CPW per wave), <= W * CPW
+  const int G = k3_group(CT, W * CPW, CPW > 1);   // channels per group (CPW per wave), <= W * CPW
   dim3 grid(N / Cfg::TY, N, nb), block(Cfg::NT);
   DLPD_LAUNCH((k_zifft_filter<N, HP, MODE>), grid, block, shmem, st, Bw, out, CT, C, has_clash, G, W1t, b1, W2, b2,
               has_clip, clip, thr, aux, cd);
@@ -1331,7 +1336,7 @@ template <int N, int HP> static int launch_k3_tiles(const cplx* Bw, float* out, 
   const size_t shmem = (size_t)(W * 8 * RS + N) * sizeof(cplx) + (size_t)W * CPW * RAWC * 16;
   int rc = dlpd_set_max_dyn_shared((const void*)k_zifft_filter_tiles<N, HP, 1>, shmem);
   if (rc) return rc;
-  const int G = k3_group(CT, W * CPW);
+  const int G = k3_group(CT, W * CPW, CPW > 1);
   const int ntiles = (N / Cfg::TY) * N * nb, tpb = N / Cfg::TY;       // one x' plane per block
   DLPD_LAUNCH((k_zifft_filter_tiles<N, HP, 1>), dim3((ntiles + tpb - 1) / tpb), dim3(Cfg::NT), shmem, st, Bw, out, CT, C,
               has_clash, G, W1t, b1, W2, b2, has_clip, clip, thr, aux, ntiles, tpb, cd);
