@@ -69,6 +69,8 @@ def parse_args():
     ap.add_argument("--cpu_rotations", type=int, default=16,
                     help="rotations of the CPU baseline sample, spread over the four search groups (0: skip)")
     ap.add_argument("--no_real_shapes", action="store_true", help="skip the short N = 160 measurement")
+    ap.add_argument("--k3_form", type=int, default=0, choices=(0, 1, 2),
+                    help="kernel formulation of the fused K3 (include/dlpd.h, dlpd_zifft_filter_form): 0 = library default")
     ap.add_argument("--dry_run", action="store_true",
                     help="launch plumbing only (gloo, no GPU): every rank joins the group, rank 0 prints a JSON line")
     return ap.parse_args()
@@ -262,7 +264,7 @@ def build_workload(name, args, dev):
     thr = clash_threshold(recf, ligf)
     W = filt.parameters_tuple()
     eng = DockingEngine(L, C, *W, clip=5.0, threshold_clash=thr, has_clash=True, max_conf=args.max_conf,
-                        batch=args.batch, device=dev, coarse_channels=C1)
+                        batch=args.batch, device=dev, coarse_channels=C1, k3_form=args.k3_form)
     eng.set_receptor(rec[0], recf, rec[1] if C1 else None)
     eng.set_ligand(lig[0], ligf, lig[1] if C1 else None)
     return eng, dict(C=C, L=L, C1=C1, angle=angle, desc=desc, rec=rec, lig=lig, recf=recf, ligf=ligf, W=W, thr=thr)
@@ -377,10 +379,8 @@ def run_rank(args):
     time_steps(eng, Rd, idd, tr_of, qd_of, nb, t_first, args.steps, mark=timer.mark)
     entries = eng.top_entries()                              # waits for the side stream; D2H of this rank's list
     if world > 1:                                            # single all-gather + deterministic merge
-        from deeplocalproteindocking_amd.Docker import Docker
-        dk = Docker.__new__(Docker)
-        dk.world_size, dk.max_conf, dk.process_group, dk.device = world, K, None, dev
-        entries = dk._gather(entries)
+        from deeplocalproteindocking_amd.Docker.Docker import all_gather_top_entries
+        entries = all_gather_top_entries(entries, K, world, None, dev)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:

@@ -47,6 +47,20 @@ def fused_filter_parameters(model):
     return f(model)
 
 
+class _PivotRotation(object):
+    """ops.VolumeRotation per grid size, pivoted where the Docker's ``rotation_center`` says."""
+
+    def __init__(self, docker):
+        self.docker, self.ops = docker, {}
+
+    def __call__(self, volume, R):
+        from deeplocalproteindocking_amd.ops import VolumeRotation
+        L = volume.shape[-1]
+        if L not in self.ops:
+            self.ops[L] = VolumeRotation(center=self.docker.rotation_pivot(L), lib=self.docker._lib)
+        return self.ops[L](volume, R)
+
+
 class _FixedRotations(object):
     def __init__(self, R):
         self.R = torch.as_tensor(np.asarray(R, dtype=np.float64)).reshape(-1, 3, 3)
@@ -62,13 +76,44 @@ def random_rotation(generator=None):
     return torch.from_numpy(euler_to_matrices(phi, theta, psi)).reshape(1, 3, 3)
 
 
+def all_gather_top_entries(entries, K, world_size, process_group=None, device="cpu"):
+    """The ONE collective of the rotation-sharded search: every rank contributes its local top list
+    ``entries`` = (rot, flat index, score, pick) as a fixed-size block, one ``all_gather`` (RCCL over xGMI on the
+    ``nccl`` backend, gloo on CPU), then the same deterministic merge on every rank -- sort by (score, rotation, pick),
+    keep K -- which reproduces the single-process list exactly: the global top-K is a subset of the union of the
+    per-shard top-Ks and the key is the reference's stable insertion order (Docker.py:100-105).
+    Used by ``Docker`` and by ``bench.py``'s multi-rank leg alike."""
+    if world_size <= 1:
+        return entries
+    import torch.distributed as dist
+    pack = torch.zeros(4, K + 1, dtype=torch.float64)
+    n = len(entries[0])
+    pack[0, 0] = n
+    pack[0, 1:1 + n] = torch.from_numpy(np.asarray(entries[0], dtype=np.float64))
+    pack[1, 1:1 + n] = torch.from_numpy(np.asarray(entries[1], dtype=np.float64))
+    score_bits = np.ascontiguousarray(entries[2], dtype=np.float32).view(np.uint32)
+    pack[2, 1:1 + n] = torch.from_numpy(score_bits.astype(np.float64))   # exact score bits
+    pack[3, 1:1 + n] = torch.from_numpy(np.asarray(entries[3], dtype=np.float64))
+    backend = dist.get_backend(process_group)
+    buf = pack.to(device) if backend == "nccl" else pack
+    out = [torch.empty_like(buf) for _ in range(world_size)]
+    dist.all_gather(out, buf, group=process_group)
+    parts = []
+    for o in out:
+        o = o.cpu().numpy()
+        m = int(o[0, 0])
+        parts.append((o[0, 1:1 + m].astype(np.int64), o[1, 1:1 + m].astype(np.int64),
+                      o[2, 1:1 + m].astype(np.uint32).view(np.float32), o[3, 1:1 + m].astype(np.int64)))
+    return DeviceTopList.merge_entries(parts, K)
+
+
 LAUNCH_BATCH = 16      # rotations per launch of the fused pipeline (DESIGN.md section 3)
 
 
 class Docker:
     def __init__(self, docking_model, angle_inc=15.0, box_size=80, resolution=1.25, max_conf=1000,
                  randomize_rot=False, rotations=None, device="cuda", coords_backend=None,
-                 rank=0, world_size=1, process_group=None, lib=None, launch_batch=None):
+                 rank=0, world_size=1, process_group=None, lib=None, launch_batch=None, rotation_center=None):
         self.docking_model = docking_model
         self.log = None
 
@@ -92,6 +137,11 @@ class Docker:
         self.rank, self.world_size, self.process_group = int(rank), int(world_size), process_group
         self._lib = lib
         self.launch_batch = int(launch_batch or os.environ.get("DLPD_LAUNCH_BATCH", LAUNCH_BATCH))
+        # Pivot of the trilinear VOLUME rotation in voxel-index units (build-defined: TorchProteinLibrary's
+        # VolumeRotation has no source here).  None: index L/2 of each grid (the box centre when voxel i spans
+        # [i, i+1) * resolution, Docker.py:221-223); "grid_sample": (L-1)/2 of each grid (the centre of
+        # torch's align_corners=False sampling grid); a number: that index on the fine grid, scaled to coarser ones.
+        self.rotation_center = rotation_center
         self._top = None            # DeviceTopList behind update_top()
         self.top_list = []
         self.engine = None
@@ -163,6 +213,25 @@ class Docker:
         if rows:
             self.log.write("\n".join(rows) + "\n")
         self.log.flush()
+
+    def rotation_pivot(self, L):
+        """Pivot index of the volume rotation on a grid of L voxels per edge (see ``rotation_center``)."""
+        rc = self.rotation_center
+        if rc is None:
+            return float(L) / 2.0
+        if isinstance(rc, str):
+            if rc != "grid_sample":
+                raise Exception("Unknown rotation_center", rc)
+            return (float(L) - 1.0) / 2.0
+        return float(rc) * float(L) / float(self.box_size)
+
+    def release_engine(self):
+        """Drop the cached fused engine and its device workspaces (several GB at box 80: wsB for 16 rotations,
+        double-buffered score volumes).  The next ``dock*`` call builds a new one."""
+        if self.engine is not None:
+            self.engine.finish()
+        self.engine, self._engine_key = None, None
+        self._top = None
 
     # ------------------------------------------------------------------ the search on volumes
     def shard(self, nrot):
@@ -238,12 +307,13 @@ class Docker:
         # local_test.py docks hundreds of targets with one Docker
         C, C1, has_clash = rec[0].shape[0], (rec[1].shape[0] if two_res else 0), receptor_forbidden is not None
         key = (int(L), int(C), int(C1), has_clash, int(lib.call("dlpd_hidden_pad", int(W1.shape[0]))), int(self.max_conf),
-               int(batch_size), str(self.device))
+               int(batch_size), str(self.device), self.rotation_pivot(L))
         eng = self.engine if getattr(self, "_engine_key", None) == key else None
         if eng is None:
             eng = DockingEngine(L, C, W1.cpu(), b1.cpu(), W2.cpu(), b2.cpu(), clip=getattr(model, "clip", 5.0),
                                 threshold_clash=model.threshold_clash, has_clash=has_clash, max_conf=self.max_conf,
-                                batch=batch_size, device=self.device, lib=self._lib, coarse_channels=C1)
+                                batch=batch_size, device=self.device, lib=self._lib, coarse_channels=C1,
+                                center=self.rotation_pivot(L), coarse_center=self.rotation_pivot(L // 2))
             self.engine, self._engine_key = eng, key
         else:
             eng.finish()
@@ -276,7 +346,7 @@ class Docker:
         from deeplocalproteindocking_amd.ops import VolumeConvolution, VolumeRotation, filter_volumes
         dev = self.device
         model = self.docking_model
-        rotate, conv_noclip = VolumeRotation(lib=self._lib), VolumeConvolution(lib=self._lib)
+        rotate, conv_noclip = _PivotRotation(self), VolumeConvolution(lib=self._lib)
         convolve = getattr(model, "convolve", None) or VolumeConvolution(clip=getattr(model, "clip", 5.0), lib=self._lib)
         rec_d, lig_d, rf, lf = self._batch_inputs(rec, lig, rec_forb, lig_forb, clash_provider)
         L = rec[0].shape[-1]
@@ -311,7 +381,7 @@ class Docker:
         from deeplocalproteindocking_amd.ops import VolumeConvolution, VolumeRotation
         dev = self.device
         model = self.docking_model
-        rotate, conv_noclip = VolumeRotation(lib=self._lib), VolumeConvolution(lib=self._lib)
+        rotate, conv_noclip = _PivotRotation(self), VolumeConvolution(lib=self._lib)
         rec_d, lig_d, rf, lf = self._batch_inputs(rec, lig, rec_forb, lig_forb, clash_provider)
         L = rec[0].shape[-1]
         top = DeviceTopList(self.max_conf, batch_size, dev, self._library())
@@ -338,29 +408,7 @@ class Docker:
 
     def _gather(self, entries):
         """One all-gather of the fixed-size per-rank lists + deterministic merge (every rank)."""
-        if self.world_size <= 1:
-            return entries
-        import torch.distributed as dist
-        K = self.max_conf
-        pack = torch.zeros(4, K + 1, dtype=torch.float64)
-        n = len(entries[0])
-        pack[0, 0] = n
-        pack[0, 1:1 + n] = torch.from_numpy(np.asarray(entries[0], dtype=np.float64))
-        pack[1, 1:1 + n] = torch.from_numpy(np.asarray(entries[1], dtype=np.float64))
-        score_bits = np.ascontiguousarray(entries[2], dtype=np.float32).view(np.uint32)
-        pack[2, 1:1 + n] = torch.from_numpy(score_bits.astype(np.float64))   # exact score bits
-        pack[3, 1:1 + n] = torch.from_numpy(np.asarray(entries[3], dtype=np.float64))
-        backend = dist.get_backend(self.process_group)
-        buf = pack.to(self.device) if backend == "nccl" else pack
-        out = [torch.empty_like(buf) for _ in range(self.world_size)]
-        dist.all_gather(out, buf, group=self.process_group)
-        parts = []
-        for o in out:
-            o = o.cpu().numpy()
-            m = int(o[0, 0])
-            parts.append((o[0, 1:1 + m].astype(np.int64), o[1, 1:1 + m].astype(np.int64),
-                          o[2, 1:1 + m].astype(np.uint32).view(np.float32), o[3, 1:1 + m].astype(np.int64)))
-        return DeviceTopList.merge_entries(parts, K)
+        return all_gather_top_entries(entries, self.max_conf, self.world_size, self.process_group, self.device)
 
     # ------------------------------------------------------------------ PDB-level entries
     def _need_backend(self):

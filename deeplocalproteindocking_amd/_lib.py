@@ -39,8 +39,8 @@ SIGNATURES = {
                                            _p, _p, _p, _i, _p]),
     "dlpd_zifft_real": (_i, [_p, _p, _i, _i, _i, _i, _f, _p]),
     "dlpd_zifft_filter": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _i, _f, _f, _p]),
-    "dlpd_zifft_filter_mfma": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _i, _f, _f, _p]),
     "dlpd_zifft_filter_cand": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _i, _f, _f, _p, _i, _i, _p, _p, _p, _i, _p]),
+    "dlpd_zifft_filter_form": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _i, _f, _f, _p, _i, _i, _p, _p, _p, _i, _i, _p]),
     "dlpd_zifft_filter_aux": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _f, _i, _i, _f, _f, _p, _i, _i, _p]),
     "dlpd_score_rotations": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _f, _i, _i, _f, _f,
                                   _p, _p, _p, _p]),
@@ -48,6 +48,7 @@ SIGNATURES = {
     "dlpd_filter_preact": (_i, [_p, _i, _i, _p, _p, _i, _p, _i, _p]),
     "dlpd_filter_volumes": (_i, [_p, _i, _ll, _i, _p, _i, _i, _i, _p, _ll, _f, _i, _p, _p, _p, _f, _i, _p, _i, _p]),
     "dlpd_zifft_preact": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _f, _p]),
+    "dlpd_zifft_preact_form": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _f, _i, _p]),
     "dlpd_zifft_real_part": (_i, [_p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "dlpd_maxpool3d_5s2": (_i, [_p, _p, _i, _i, _p]),
     "dlpd_conv3d_supported": (_i, [_i, _i, _i, _i]),

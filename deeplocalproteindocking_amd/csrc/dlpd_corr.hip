@@ -18,6 +18,7 @@
 #include <dlpd_platform.h>
 #include "dlpd_fft.h"
 #include "dlpd_internal.h"
+#include "dlpd_k3.h"
 
 #define DLPD_K1_UNROLL 2                 // samples per thread whose gathers are issued together (2..16 measured equal: not latency-bound)
 template <int N> DLPD_D void init_twiddles(cplx* tw, int tid, int nthreads) {
@@ -458,36 +459,6 @@ template <> struct K3Cfg<160, 2> { static constexpr int NT = DLPD_K3_160_NT, WC 
 #ifndef DLPD_K3_LAUNDER_160
 #define DLPD_K3_LAUNDER_160 1            // N = 160: pencil / pack offsets recomputed per group instead of hoisted (no spills)
 #endif
-// Extra first-layer inputs that are already real volumes on the coarser (N/2) grid, nearest-upsampled by
-// index (DockingModels.py:74-76): either the Caux clipped correlations of that resolution (W1t rows
-// C..C+Caux-1 are applied here), or -- is_preact -- the HP first-layer pre-activations k_filter_preact
-// computed from them once per COARSE voxel (bias included; the first layer is linear): 8x fewer multiply-adds.
-struct K3Aux {
-  const float* p;   // (nb, Caux or HP, Naux^3), Naux = N/2
-  int C, N, is_preact;
-};
-// Candidate emission for the top-K stage (dlpd_topk.hip, candidate path): every score whose order-preserving key is
-// <= *tau is appended to the rotation's list; *tau == 0 means "no valid filter yet" and flags the rotation for the
-// full radix select.  tau is written by the merge kernel of earlier batches on another stream: a stale (larger) value
-// only lengthens the list.  count: [0, nb) counters, [nb, 2 nb) need-full flags.
-struct K3Cand {
-  const unsigned* tau;
-  unsigned long long* keys;   // (nb, cap)
-  unsigned* count;
-  int cap, nb;
-};
-DLPD_D unsigned k3_score_key(float v) {           // == f2key of dlpd_topk.hip
-  v = v + 0.0f;
-  const unsigned u = __float_as_uint(v);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-DLPD_D void k3_emit(const K3Cand& cd, unsigned tau, int b, unsigned flat, float score) {
-  const unsigned key = k3_score_key(score);
-  if (key <= tau) {
-    const unsigned slot = atomicAdd(&cd.count[b], 1u);
-    if (slot < (unsigned)cd.cap) cd.keys[(size_t)b * cd.cap + slot] = ((unsigned long long)key << 32) | flat;
-  }
-}
 #ifdef DLPD_STAMPS   // diagnostic build only (scripts/stamps.py): where a K3 wave spends its cycles
 __device__ unsigned long long dlpd_stamps[16];
 #endif
@@ -1281,16 +1252,17 @@ template <int N> static int launch_k1(const float* vol, const float* R, cplx* A,
   return dlpd_check_launch();
 }
 
-// K3 with the MLP on the matrix cores lives in dlpd_k3m.hip
-int dlpd_k3_mfma_supported(int L, int HP);
-int dlpd_k3_mfma(const cplx* Bw, float* V, int CT, int C, int has_clash, int nb, int L, const float* W1t, int HP,
-                 const float* b1, const float* W2, float b2, int has_clip, float clip, float thr, hipStream_t st);
-// DLPD_K3_MFMA=1 routes dlpd_zifft_filter to the matrix-core formulation where it exists (measured slower than the
-// vector-unit K3 so far: 3.0 vs 2.5 ms; off by default), read once
-static int k3_mfma_enabled() {
-  static const int v = [] { const char* e = getenv("DLPD_K3_MFMA"); return (e && e[0] == '1') ? 1 : 0; }();
-  return v;
-}
+// K3 in its role-split formulation (dedicated transform / filter waves) lives in dlpd_k3r.hip
+int dlpd_k3r_supported(int L, int HP, int mode);
+int dlpd_k3r_filter(const cplx* Bw, float* V, int CT, int C, int has_clash, int nb, int L, const float* W1t, int HP,
+                    const float* b1, const float* W2, float b2, int has_clip, float clip, float thr, K3Aux aux, K3Cand cd,
+                    hipStream_t st);
+int dlpd_k3r_preact(const cplx* Bw, float* pre, int C, int nb, int L, const float* W1rows, int HP, const float* b1,
+                    int has_clip, float clip, hipStream_t st);
+// which formulation the un-suffixed entry points take where both exist (variant builds: -DDLPD_K3_DEFAULT_FORM=1)
+#ifndef DLPD_K3_DEFAULT_FORM
+#define DLPD_K3_DEFAULT_FORM 2               // 1: channel-owning waves (this file), 2: role-split waves (dlpd_k3r.hip)
+#endif
 
 // K2 lives in dlpd_k2.hip (its own translation unit: it is built with -fno-slp-vectorize)
 int dlpd_k2_forward(const cplx* A, cplx* out, int CT, int nb, int L, float scale, hipStream_t st);
@@ -1524,11 +1496,19 @@ int dlpd_zifft_real_part(const void* wsB, float* out, int nb, int CT, int nclip,
 
 // wsB (nb, C, NZ, N, N) -> pre (nb, HP, N^3) = b1 + W1rows^T clamp(correlations): z C2R fused with the (linear) first
 // layer over these C channels, the coarse-resolution half of the filter on its own grid
+int dlpd_zifft_preact_form(const void* wsB, float* pre, int nb, int C, int L, const float* W1rows, const float* b1, int HP,
+                           int has_clip, float clip, int form, void* stream);
 int dlpd_zifft_preact(const void* wsB, float* pre, int nb, int C, int L, const float* W1rows, const float* b1, int HP,
                       int has_clip, float clip, void* stream) {
+  return dlpd_zifft_preact_form(wsB, pre, nb, C, L, W1rows, b1, HP, has_clip, clip, 0, stream);
+}
+int dlpd_zifft_preact_form(const void* wsB, float* pre, int nb, int C, int L, const float* W1rows, const float* b1, int HP,
+                           int has_clip, float clip, int form, void* stream) {
   if (!wsB || !pre || !W1rows || !b1 || nb <= 0 || C <= 0) return DLPD_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const cplx* B = (const cplx*)wsB;
+  if (form == 0) form = DLPD_K3_DEFAULT_FORM;
+  if (form == 2 && dlpd_k3r_supported(L, HP, 2)) return dlpd_k3r_preact(B, pre, C, nb, L, W1rows, HP, b1, has_clip, clip, st);
 #define DLPD_ZP(NN, H) case H: return launch_k3<NN, H, 2>(B, pre, C, C, 0, nb, W1rows, b1, b1, 0.f, has_clip, clip, 0.f, st)
 #define DLPD_ZPN(NN) switch (HP) { DLPD_ZP(NN, 2); DLPD_ZP(NN, 4); DLPD_ZP(NN, 8); DLPD_ZP(NN, 16); DLPD_ZP(NN, 24); DLPD_ZP(NN, 32); \
                                    default: return DLPD_ERR_UNSUPPORTED; }
@@ -1553,6 +1533,10 @@ int dlpd_zifft_filter_cand(const void* wsB, float* V, int nb, int C, int has_cla
                            const float* b1, const float* W2, float b2, int HP, int has_clip, float clip, float thr,
                            const float* aux, int Caux, int aux_is_preact, const void* tau, void* cand_keys,
                            void* cand_count, int cap, void* stream);
+int dlpd_zifft_filter_form(const void* wsB, float* V, int nb, int C, int has_clash, int L, const float* W1t,
+                           const float* b1, const float* W2, float b2, int HP, int has_clip, float clip, float thr,
+                           const float* aux, int Caux, int aux_is_preact, const void* tau, void* cand_keys,
+                           void* cand_count, int cap, int form, void* stream);
 
 int dlpd_zifft_filter_aux(const void* wsB, float* V, int nb, int C, int has_clash, int L, const float* W1t,
                           const float* b1, const float* W2, float b2, int HP, int has_clip, float clip, float thr,
@@ -1567,6 +1551,17 @@ int dlpd_zifft_filter_cand(const void* wsB, float* V, int nb, int C, int has_cla
                            const float* b1, const float* W2, float b2, int HP, int has_clip, float clip, float thr,
                            const float* aux, int Caux, int aux_is_preact, const void* tau, void* cand_keys,
                            void* cand_count, int cap, void* stream) {
+  return dlpd_zifft_filter_form(wsB, V, nb, C, has_clash, L, W1t, b1, W2, b2, HP, has_clip, clip, thr, aux, Caux,
+                                aux_is_preact, tau, cand_keys, cand_count, cap, 0, stream);
+}
+
+// The same with the kernel formulation named: form 0 = the library's default, 1 = channel-owning waves with
+// barrier-separated transform / filter phases (k_zifft_filter[_tiles]), 2 = role-split transform / filter waves
+// (dlpd_k3r.hip; falls back to 1 where it is not compiled).  Same arithmetic, same results bit for bit.
+int dlpd_zifft_filter_form(const void* wsB, float* V, int nb, int C, int has_clash, int L, const float* W1t,
+                           const float* b1, const float* W2, float b2, int HP, int has_clip, float clip, float thr,
+                           const float* aux, int Caux, int aux_is_preact, const void* tau, void* cand_keys,
+                           void* cand_count, int cap, int form, void* stream) {
   if (!wsB || !V || !W1t || !b1 || !W2 || nb <= 0 || C <= 0 || Caux < 0 || (Caux > 0 && !aux)) return DLPD_ERR_ARG;
   if (L % 2) return DLPD_ERR_ARG;
   if (cand_keys && (!tau || !cand_count || cap <= 0)) return DLPD_ERR_ARG;
@@ -1574,8 +1569,9 @@ int dlpd_zifft_filter_cand(const void* wsB, float* V, int nb, int C, int has_cla
   const int CT = C + (has_clash ? 1 : 0);
   const K3Aux ax = {aux, Caux, L, (Caux > 0 && aux_is_preact) ? 1 : 0};              // coarse grid N/2 = L
   const K3Cand cd = {(const unsigned*)tau, (unsigned long long*)cand_keys, (unsigned*)cand_count, cap, nb};
-  if (Caux == 0 && !cand_keys && k3_mfma_enabled() && dlpd_k3_mfma_supported(L, HP))
-    return dlpd_k3_mfma((const cplx*)wsB, V, CT, C, has_clash, nb, L, W1t, HP, b1, W2, b2, has_clip, clip, thr, st);
+  if (form == 0) form = DLPD_K3_DEFAULT_FORM;
+  if (form == 2 && dlpd_k3r_supported(L, HP, 1) && (Caux == 0 || aux_is_preact))
+    return dlpd_k3r_filter((const cplx*)wsB, V, CT, C, has_clash, nb, L, W1t, HP, b1, W2, b2, has_clip, clip, thr, ax, cd, st);
   switch (L) {
     case 32: return k3_filter_dispatch<64>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, ax, cd);
     case 40: return k3_filter_dispatch<80>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, ax, cd);
@@ -1583,15 +1579,6 @@ int dlpd_zifft_filter_cand(const void* wsB, float* V, int nb, int C, int has_cla
     case 80: return k3_filter_dispatch<160>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, ax, cd);
     default: return DLPD_ERR_UNSUPPORTED;
   }
-}
-
-// the matrix-core formulation of dlpd_zifft_filter (dlpd_k3m.hip), explicitly
-int dlpd_zifft_filter_mfma(const void* wsB, float* V, int nb, int C, int has_clash, int L, const float* W1t,
-                           const float* b1, const float* W2, float b2, int HP, int has_clip, float clip, float thr,
-                           void* stream) {
-  if (!wsB || !V || !W1t || !b1 || !W2 || nb <= 0 || C <= 0) return DLPD_ERR_ARG;
-  return dlpd_k3_mfma((const cplx*)wsB, V, C + (has_clash ? 1 : 0), C, has_clash, nb, L, W1t, HP, b1, W2, b2, has_clip,
-                      clip, thr, (hipStream_t)stream);
 }
 
 int dlpd_zifft_filter(const void* wsB, float* V, int nb, int C, int has_clash, int L, const float* W1t,

@@ -333,11 +333,11 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
 #undef K2_P1_STORE
 #undef K2_P2_LOAD
 
-// DLPD_K2_NSPLIT (diagnostic override of the batch split): read once, not on every launch
-static int k2_nsplit_override() {
-  static const int v = [] { const char* e = getenv("DLPD_K2_NSPLIT"); return (e && atoi(e) > 0) ? atoi(e) : 0; }();
-  return v;
-}
+// batch split of the persistent K2 blocks (variant builds: -DDLPD_K2_NSPLIT=n)
+#ifndef DLPD_K2_NSPLIT
+#define DLPD_K2_NSPLIT 0
+#endif
+static constexpr int k2_nsplit_override() { return DLPD_K2_NSPLIT; }
 
 template <int N, int MODE> static int launch_k2(const cplx* A, const cplx* rec, cplx* out, int CT, int nb,
                                                 long long rbs, float scale, hipStream_t st, int transposed = 0) {

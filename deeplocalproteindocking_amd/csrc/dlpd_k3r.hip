@@ -1,0 +1,407 @@
+// K3, role-split formulation: z-axis C2R + clip + SimpleFilter MLP + clash mask (gfx950 / CDNA4).
+//
+// Reference path being replaced (file:line in /root/reference):
+//   src/Models/DockingModels.py:70-83   per-channel correlation (its z-inverse), upsample + concat, SimpleFilter MLP
+//   src/Docker/Docker.py:226,232        clash threshold, mask multiply
+//
+// Same inputs, outputs and arithmetic (same products, same summation order) as k_zifft_filter /
+// k_zifft_filter_tiles of dlpd_corr.hip.  There EVERY wave alternates between the two halves of the work -- pack +
+// wave-local z transform of "its" channel (LDS-bound), then, behind a block barrier, the first-layer multiply-adds of
+// its voxels over all channels of the group (VALU-bound) -- so the LDS pipe idles while the vector units work and
+// vice versa (rocprofv3, round 2: SQ_WAIT_ANY 30 % of the wave cycles at N = 128, 53 % at N = 160, where in addition
+// half of the waves own no channel and sit out every transform phase).  Here the waves of a block have FIXED ROLES:
+//   * F transform waves: LDS-DMA of their channel's raw spectra, pack two rows per complex pencil, the two wave-local
+//     FFT passes -- nothing else, no accumulators;
+//   * M filter waves: own the tile's voxels (4 per thread at the default shapes) and fold the group's channels into
+//     their hidden units from REGISTERS: after the "pencils ready" barrier they copy their voxels' values of the
+//     group out of the pencils (G x EPT 8-byte LDS reads), a second barrier hands the pencils back, and the
+//     multiply-adds of group g then run beside pack + transform of group g + 1.
+// On one SIMD a transform wave (LDS latency, address arithmetic) and filter waves (back-to-back packed FMAs) are
+// complementary, which is the pairing MI355X_MICROARCH.md ("Two waves per SIMD", item 5) says a rendezvous pays for.
+// A block walks all y-tiles of an x' plane, so the pipeline fills once per plane, not once per tile.
+#include <dlpd_platform.h>
+#include "dlpd_fft.h"
+#include "dlpd_internal.h"
+#include "dlpd_k3.h"
+
+template <int N> DLPD_D void init_twiddles_k3r(cplx* tw, int tid, int nthreads) {
+  for (int k = tid; k < N; k += nthreads) {
+    double s, c;
+    sincospi(-2.0 * (double)k / (double)N, &s, &c);
+    tw[k] = c_make((float)c, (float)s);
+  }
+}
+
+// F transform waves, M filter waves, TY rows per tile (16: a transform wave owns one channel = 8 two-row pencils;
+// 8: two channels of 4 pencils), RAWBUF raw staging buffers per transform wave (2: the next group's DMA is issued
+// before this group is packed)
+#ifndef DLPD_K3R_F128
+#define DLPD_K3R_F128 4
+#endif
+#ifndef DLPD_K3R_M160
+#define DLPD_K3R_M160 10
+#endif
+#ifndef DLPD_K3R_RAWBUF128
+#define DLPD_K3R_RAWBUF128 2
+#endif
+#ifndef DLPD_K3R_FFT_PRIO
+#define DLPD_K3R_FFT_PRIO 0
+#endif
+template <int N> struct K3rCfg;
+template <> struct K3rCfg<64> { static constexpr int F = 4, M = 4, TY = 16, RAWBUF = 2; };
+template <> struct K3rCfg<80> { static constexpr int F = 5, M = 5, TY = 16, RAWBUF = 2; };
+template <> struct K3rCfg<128> { static constexpr int F = DLPD_K3R_F128, M = 8, TY = 16, RAWBUF = DLPD_K3R_RAWBUF128; };
+template <> struct K3rCfg<160> { static constexpr int F = 5, M = DLPD_K3R_M160, TY = 8, RAWBUF = 1; };
+
+#ifdef DLPD_STAMPS
+__device__ unsigned long long dlpd_stamps_k3r[32];
+extern "C" int dlpd_debug_read_stamps_k3r(unsigned long long* host32) {
+  if (hipMemcpyFromSymbol(host32, HIP_SYMBOL(dlpd_stamps_k3r), 32 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  unsigned long long z[32] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(dlpd_stamps_k3r), z, sizeof(z)) == hipSuccess ? 0 : 1;
+}
+#endif
+
+//   Bw   (nb, CT, NZ, N, N) complex [kz][x'][y']
+//   MODE 1: V (nb, N,N,N) = mask * (W2 . relu(W1 . clamp(corr) + b1) + b2); score channels [0,C), clash channel C
+//           if has_clash (mask = corr_C < thr); aux: HP first-layer pre-activation planes on the coarse grid (or none)
+//   MODE 2: out (nb, HP, N,N,N) = b1 + W1rows^T clamp(corr): the coarse resolution's half of the first layer
+//   W1t  (C, HP) transposed + zero padded, b1 (HP), W2 (HP);  G channels per group (<= F * CPW)
+template <int N, int HP, int MODE> __global__ void __launch_bounds__(64 * (K3rCfg<N>::F + K3rCfg<N>::M))
+k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int C, int has_clash, int G,
+                  const float* __restrict__ W1t, const float* __restrict__ b1, const float* __restrict__ W2,
+                  float b2, int has_clip, float clip, float thr, K3Aux aux, int ntiles, int tpb, K3Cand cd) {
+  typedef K3rCfg<N> Cfg;
+  constexpr int F = Cfg::F, M = Cfg::M, TY = Cfg::TY, RAWBUF = Cfg::RAWBUF;
+  constexpr int NZ = N / 2 + 1, RS = N + 8, NPAIR = TY / 2, NYT = N / TY;
+  constexpr int CPW = 8 / NPAIR;               // channels per transform wave: its 8 pencils = CPW channels x NPAIR row pairs
+  constexpr int LPK = 64 / NPAIR;              // kz rows per 64-lane DMA instruction
+  constexpr int NFULL = (N / 2) / LPK;         // full 64-lane DMA instructions per channel (bins 0..N/2-1)
+  constexpr int GMAX = F * CPW;                // channel slots per group
+  constexpr int NTM = 64 * M;                  // filter threads
+  constexpr int EPT = (NPAIR * N) / NTM;       // complex values (voxel pairs: rows 2m, 2m+1) per filter thread and channel
+  constexpr int MSTEP = NTM / N;               // pair stride between a thread's values
+  constexpr int RAWC = ((NZ * NPAIR + 63) / 64) * 64;    // float4 slots per raw channel (whole waves)
+  static_assert(NPAIR == 8 || NPAIR == 4, "one transform wave = 8 pencils x 8 threads");
+  static_assert(EPT >= 1 && EPT * NTM == NPAIR * N && NTM % N == 0, "the filter waves tile the voxels exactly");
+  static_assert(NZ * NPAIR == NFULL * 64 + NPAIR, "raw channel = NFULL full DMA instructions + one short one");
+  DLPD_DYN_SHARED(cplx, S);
+  cplx* tw = S + F * 8 * RS;
+  float4* raw = reinterpret_cast<float4*>(tw + N);        // [RAWBUF][F][CPW][RAWC]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool is_fft = wave < F;
+  const int t_beg = blockIdx.x * tpb, t_end = (t_beg + tpb < ntiles) ? t_beg + tpb : ntiles;
+  if (t_beg >= t_end) return;
+  init_twiddles_k3r<N>(tw, tid, 64 * (F + M));
+  const unsigned cand_tau = (MODE == 1 && cd.keys) ? *cd.tau : 0u;
+
+  // ---- transform role: this wave's channels of group `cb` of tile `t` -> raw staging buffer `buf`
+  //      raw[k][m] <- Bw[b][cb + wave*CPW + j][k][xo][y0+2m .. +1]   (lane = NPAIR*(k % LPK) + m: LPK runs of NPAIR*16
+  //      bytes per DMA instruction; k = N/2 is the last, short one)
+  float4* rawg = raw + wave * CPW * RAWC;
+  auto issue_channel = [&](int t, int cb, int buf) {
+    const int ty0 = (t % NYT) * TY, txo = (t / NYT) % N, tb = t / (NYT * N);
+#pragma unroll
+    for (int j = 0; j < CPW; j++) {
+      const int g = wave * CPW + j;
+      if (g < G && cb + g < CT) {
+        const cplx* src = Bw + (((size_t)tb * CT + cb + g) * NZ * N + txo) * N + ty0;
+        const cplx* lane_src = src + (size_t)(lane / NPAIR) * N * N + 2 * (lane % NPAIR);
+        float4* rj = rawg + buf * (F * CPW * RAWC) + j * RAWC;
+#pragma unroll
+        for (int it = 0; it < NFULL; it++) DLPD_GLDS16(lane_src + (size_t)it * LPK * N * N, rj + it * 64);
+        const int mt = lane % NPAIR;                        // tail lanes re-read valid elements
+        DLPD_GLDS16(src + (size_t)(N / 2) * N * N + 2 * mt, rj + NFULL * 64);
+      }
+    }
+  };
+  const int tr = lane & 7, qr = lane >> 3;     // FFT: lane = 8*pencil + thread
+  // ---- filter role: voxel ownership (rows y0 + 2m, y0 + 2m + 1, column zz)
+  const int tm = tid - 64 * F;
+  const int zz = is_fft ? 0 : tm % N, m0 = is_fft ? 0 : tm / N;
+
+  if (is_fft) {
+    if (DLPD_K3R_FFT_PRIO) DLPD_SET_PRIO(DLPD_K3R_FFT_PRIO);
+    issue_channel(t_beg, 0, 0);
+  }
+  DLPD_LDS_BARRIER();                          // twiddle table visible
+  DLPD_STAMP_DECL;
+  const int ngroups = (CT + G - 1) / G;
+  const int nsteps = (t_end - t_beg) * ngroups;
+  // The two roles are two separate loops over the same (tile, group) steps -- separate, so that the filter waves'
+  // accumulators are not live (and allocated) across the transform code -- that meet at two block barriers per step:
+  //   B1  "pencils of this group complete"   (transform waves arrive after their last store has landed)
+  //   B2  "pencils copied into registers"    (filter waves arrive after their loads have returned)
+  if (is_fft) {
+    // ================= transform waves: raw -> pencils of group (t, cbase) =================
+    int t = t_beg, cbase = 0, rb = 0;
+#pragma unroll 1
+    for (int step = 0; step < nsteps; step++) {
+      const int gn = (CT - cbase) < G ? (CT - cbase) : G;
+      const bool last_group = cbase + G >= CT;
+      const bool mine = wave * CPW < gn;
+      if (mine) {
+        DLPD_WAIT_VMEM();                      // this wave's own DMA has landed
+        DLPD_WAVE_SYNC();
+      }
+      DLPD_STAMP(0);
+      // the next group of this tile, or the first group of the next tile
+      const int nt = last_group ? t + 1 : t, ncb = last_group ? 0 : cbase + G;
+      if (RAWBUF == 2 && nt < t_end) issue_channel(nt, ncb, rb ^ 1);
+      if (mine) {
+        // pack two rows per complex pencil: Z[k] = A[k] + i B[k], Z[N-k] = conj(A[k]) + i conj(B[k]); lane ->
+        // (pencil m, kz row) dealing as in k_zifft_filter (dlpd_corr.hip: conflict-free raw reads, 5-cycle stores)
+#pragma unroll
+        for (int j = 0; j < CPW; j++) {
+          if (wave * CPW + j >= gn) break;
+          int m, kq, lq = lane;
+          DLPD_OPAQUE(lq);
+          if (NPAIR == 8) {
+            m = (lq & 3) | (((lq >> 4) & 1) << 2);
+            kq = ((lq >> 2) & 1) | (((lq >> 5) & 1) << 1) | (((lq >> 3) & 1) << 2);
+          } else {
+            m = lq % NPAIR;
+            kq = lq / NPAIR;
+          }
+          const int rot = (NPAIR == 8) ? 2 * m : 0;            // lane-dependent start of its walk over the DMA instructions
+          const int slot = NPAIR * kq + m;
+          cplx* P = S + (wave * 8 + j * NPAIR + m) * RS;
+          const float4* rj = rawg + rb * (F * CPW * RAWC) + j * RAWC;
+          constexpr int PCH = NFULL > 8 ? NFULL / 2 : NFULL;   // raw elements in flight per lane
+          const float4 qh = rj[NFULL * 64 + (lane % NPAIR)];  // k = N/2 (lanes with lane / NPAIR == 0 store it)
+#pragma unroll
+          for (int it0 = 0; it0 < NFULL; it0 += PCH) {
+            float4 q[PCH];
+#pragma unroll
+            for (int u = 0; u < PCH; u++) q[u] = rj[((it0 + u + rot) % NFULL) * 64 + slot];
+#pragma unroll
+            for (int u = 0; u < PCH; u++) {
+              const int k = ((it0 + u + rot) % NFULL) * LPK + kq;
+              // k = 0: the purely real bin of both rows (both stores then write the same value to the same place)
+              const cplx lo = (k == 0) ? c_make(q[u].x, q[u].z) : c_make(q[u].x - q[u].w, q[u].y + q[u].z);
+              const cplx hi = (k == 0) ? c_make(q[u].x, q[u].z) : c_make(q[u].x + q[u].w, q[u].z - q[u].y);
+              P[pencil_in_pos<N>(k)] = lo;
+              P[pencil_in_pos<N>((N - k) & (k == 0 ? 0 : ~0))] = hi;
+            }
+          }
+          if (lane / NPAIR == 0) S[(wave * 8 + j * NPAIR + lane % NPAIR) * RS + pencil_in_pos<N>(N / 2)] = c_make(qh.x, qh.z);
+        }
+        DLPD_WAIT_LDS();                       // raw fully read before it is refilled
+        DLPD_WAVE_SYNC();
+      }
+      DLPD_STAMP(1);
+      if (RAWBUF == 1 && nt < t_end) issue_channel(nt, ncb, 0);
+      if (mine) {
+        int tq = tr, qq = qr;
+        DLPD_OPAQUE(tq);
+        DLPD_OPAQUE(qq);
+        fft_wave_pencils<N, +1>(S, wave * 8, RS, qq, tq, tw);
+      }
+      DLPD_STAMP(2);
+      if (RAWBUF == 2) rb ^= 1;
+      DLPD_LDS_BARRIER();                      // B1
+      DLPD_STAMP(3);
+      DLPD_LDS_BARRIER();                      // B2
+      DLPD_STAMP(4);
+      if (last_group) { cbase = 0; t++; } else cbase += G;
+    }
+  } else {
+    // ================= filter waves =================
+    float nrm[EPT * 2];
+    float h[EPT * 2][HP];
+    cplx vals[GMAX][EPT];
+    int t = t_beg, cbase = 0;
+#pragma unroll 1
+    for (int step = 0; step < nsteps; step++) {
+      const int y0 = (t % NYT) * TY, xo = (t / NYT) % N, b = t / (NYT * N);
+      const int gn = (CT - cbase) < G ? (CT - cbase) : G;
+      const bool last_group = cbase + G >= CT;
+      if (cbase == 0) {
+        // first group of a tile: hidden pre-activations
+        if (MODE == 1 && cd.keys && !cand_tau && tm == 0) cd.count[cd.nb + b] = 1u;
+#pragma unroll
+        for (int e = 0; e < EPT * 2; e++) nrm[e] = 0.f;
+        if (MODE == 1 && aux.C > 0) {
+          // rows 2m, 2m+1 and columns z, z^1 of the fine grid share one coarse voxel
+          const int Na = aux.N;
+          const size_t cstride = (size_t)Na * Na * Na;
+          const float* ab = aux.p + (size_t)b * HP * cstride + ((size_t)(xo >> 1) * Na + (y0 >> 1)) * Na + (zz >> 1);
+#pragma unroll
+          for (int e = 0; e < EPT; e++)
+#pragma unroll
+            for (int j = 0; j < HP; j++) {
+              const float v = ab[(size_t)j * cstride + (size_t)(m0 + e * MSTEP) * Na];
+              h[2 * e][j] = v;
+              h[2 * e + 1][j] = v;
+            }
+        } else {
+#pragma unroll
+          for (int e = 0; e < EPT * 2; e++)
+#pragma unroll
+            for (int j = 0; j < HP; j++) h[e][j] = b1[j];
+        }
+      }
+      DLPD_STAMP(0);
+      DLPD_LDS_BARRIER();                      // B1: all pencils of the group transformed
+      DLPD_STAMP(1);
+      // score channels of this group; the clash channel (index C, always last) is peeled off
+      const int gs = (cbase + gn <= C) ? gn : (C - cbase > 0 ? C - cbase : 0);
+#pragma unroll
+      for (int g = 0; g < GMAX; g++)
+        if (g < gs) {
+#pragma unroll
+          for (int e = 0; e < EPT; e++) vals[g][e] = S[(g * NPAIR + m0 + e * MSTEP) * RS + pencil_out_pos<N>(zz)];
+        }
+      if (MODE == 1 && has_clash && cbase + gn > C) {
+        const int g = C - cbase;
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+          const cplx v = S[(g * NPAIR + m0 + e * MSTEP) * RS + pencil_out_pos<N>(zz)];
+          nrm[2 * e] = v.x;
+          nrm[2 * e + 1] = v.y;
+        }
+      }
+      DLPD_LDS_BARRIER();                      // B2: values held in registers, pencils free for the next group
+      DLPD_STAMP(2);
+      {
+        // first-layer weights are wave-uniform (scalar loads): channel g+1's row is requested before channel g's FMAs
+        float wcur[HP], wnxt[HP];
+        if (gs > 0) {
+#pragma unroll
+          for (int j = 0; j < HP; j++) wcur[j] = W1t[(size_t)cbase * HP + j];
+        }
+#pragma unroll
+        for (int g = 0; g < GMAX; g++) {
+          if (g < gs) {
+            const int gn1 = (g + 1 < gs ? g + 1 : g);
+#pragma unroll
+            for (int j = 0; j < HP; j++) wnxt[j] = W1t[(size_t)(cbase + gn1) * HP + j];
+            DLPD_SCHED_FENCE();
+#pragma unroll
+            for (int e = 0; e < EPT; e++) {
+              float v0 = vals[g][e].x, v1 = vals[g][e].y;
+              if (has_clip) { v0 = DLPD_CLAMP(v0, clip); v1 = DLPD_CLAMP(v1, clip); }
+#pragma unroll
+              for (int j = 0; j < HP; j++) {
+                h[2 * e][j] = fmaf(wcur[j], v0, h[2 * e][j]);
+                h[2 * e + 1][j] = fmaf(wcur[j], v1, h[2 * e + 1][j]);
+              }
+            }
+            DLPD_SCHED_FENCE();
+#pragma unroll
+            for (int j = 0; j < HP; j++) wcur[j] = wnxt[j];
+          }
+        }
+      }
+      DLPD_STAMP(3);
+      if (last_group) {
+        if (MODE == 2) {
+          // first-layer pre-activations of these channels as HP planes (bias included): the coarse resolution's half
+          // of SimpleFilter's first layer, which the fine grid's kernel picks up by index (DockingModels.py:74-83)
+#pragma unroll
+          for (int e = 0; e < EPT; e++) {
+            const int m = m0 + e * MSTEP;
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+              for (int j = 0; j < HP; j++)
+                out[((((size_t)b * HP + j) * N + xo) * N + y0 + 2 * m + u) * N + zz] = h[2 * e + u][j];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < EPT; e++) {
+            const int m = m0 + e * MSTEP;
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+              float acc = b2;
+#pragma unroll
+              for (int j = 0; j < HP; j++) acc = fmaf(W2[j], fmaxf(h[2 * e + u][j], 0.f), acc);
+              if (has_clash) acc = acc * ((nrm[2 * e + u] < thr) ? 1.0f : 0.0f);
+              out[(((size_t)b * N + xo) * N + y0 + 2 * m + u) * N + zz] = acc;
+              if (cd.keys && cand_tau) k3_emit(cd, cand_tau, b, (unsigned)((xo * N + y0 + 2 * m + u) * N + zz), acc);
+            }
+          }
+        }
+        DLPD_STAMP(4);
+      }
+      if (last_group) { cbase = 0; t++; } else cbase += G;
+    }
+  }
+#ifdef DLPD_STAMPS
+  if (lane == 0 && (wave == 0 || wave == F)) {
+    const int o = wave == 0 ? 0 : 16;
+    for (int i_ = 0; i_ < 8; i_++) atomicAdd(&dlpd_stamps_k3r[o + i_], st_sum[i_]);
+    atomicAdd(&dlpd_stamps_k3r[o + 15], 1ull);
+  }
+#endif
+}
+
+static int k3r_group(int CT, int maxg, bool balanced) {
+  if (!balanced) return CT < maxg ? CT : maxg;
+  const int ng = (CT + maxg - 1) / maxg;
+  return (CT + ng - 1) / ng;
+}
+
+#ifndef DLPD_K3R_TPB_DIV
+#define DLPD_K3R_TPB_DIV 1                   // tiles per block = (y-tiles of an x' plane) / DIV
+#endif
+template <int N, int HP, int MODE> static int launch_k3r(const cplx* Bw, float* out, int CT, int C, int has_clash, int nb,
+                                                         const float* W1t, const float* b1, const float* W2, float b2,
+                                                         int has_clip, float clip, float thr, hipStream_t st, K3Aux aux,
+                                                         K3Cand cd) {
+  typedef K3rCfg<N> Cfg;
+  constexpr int RS = N + 8, NZ = N / 2 + 1, NPAIR = Cfg::TY / 2, CPW = 8 / NPAIR;
+  constexpr int RAWC = ((NZ * NPAIR + 63) / 64) * 64;
+  const size_t shmem = (size_t)(Cfg::F * 8 * RS + N) * sizeof(cplx) + (size_t)Cfg::RAWBUF * Cfg::F * CPW * RAWC * 16;
+  int rc = dlpd_set_max_dyn_shared((const void*)k_zifft_filter_rs<N, HP, MODE>, shmem);
+  if (rc) return rc;
+  const int G = k3r_group(CT, Cfg::F * CPW, true);
+  const int ntiles = (N / Cfg::TY) * N * nb, tpb = (N / Cfg::TY) / DLPD_K3R_TPB_DIV;
+  DLPD_LAUNCH((k_zifft_filter_rs<N, HP, MODE>), dim3((ntiles + tpb - 1) / tpb), dim3(64 * (Cfg::F + Cfg::M)), shmem, st, Bw,
+              out, CT, C, has_clash, G, W1t, b1, W2, b2, has_clip, clip, thr, aux, ntiles, tpb, cd);
+  return dlpd_check_launch();
+}
+
+// hidden widths the role-split kernel is compiled for (the accumulators of 4 voxels per thread)
+int dlpd_k3r_supported(int L, int HP, int mode) {
+  if (HP != 2 && HP != 4 && HP != 8 && HP != 16 && HP != 24 && HP != 32) return 0;
+  if (mode == 1) return (L == 64 || L == 80) ? 1 : 0;
+  if (mode == 2) return (L == 40) ? 1 : 0;
+  return 0;
+}
+
+template <int N, int MODE> static int k3r_dispatch(int HP, const cplx* Bw, float* out, int CT, int C, int has_clash, int nb,
+                                                   const float* W1t, const float* b1, const float* W2, float b2,
+                                                   int has_clip, float clip, float thr, hipStream_t st, K3Aux aux, K3Cand cd) {
+  switch (HP) {
+    case 2: return launch_k3r<N, 2, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 4: return launch_k3r<N, 4, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 8: return launch_k3r<N, 8, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 16: return launch_k3r<N, 16, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 24: return launch_k3r<N, 24, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 32: return launch_k3r<N, 32, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    default: return DLPD_ERR_UNSUPPORTED;
+  }
+}
+
+// wsB -> V (nb, N^3); aux: HP pre-activation planes of the coarse grid (is_preact) or none
+int dlpd_k3r_filter(const cplx* Bw, float* V, int CT, int C, int has_clash, int nb, int L, const float* W1t, int HP,
+                    const float* b1, const float* W2, float b2, int has_clip, float clip, float thr, K3Aux aux, K3Cand cd,
+                    hipStream_t st) {
+  switch (L) {
+    case 64: return k3r_dispatch<128, 1>(HP, Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 80: return k3r_dispatch<160, 1>(HP, Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    default: return DLPD_ERR_UNSUPPORTED;
+  }
+}
+
+// wsB (nb, C, NZ, N, N) -> pre (nb, HP, N^3): z C2R fused with the (linear) first layer over these C channels
+int dlpd_k3r_preact(const cplx* Bw, float* pre, int C, int nb, int L, const float* W1rows, int HP, const float* b1,
+                    int has_clip, float clip, hipStream_t st) {
+  const K3Aux ax = {nullptr, 0, 0, 0};
+  const K3Cand cd = {nullptr, nullptr, nullptr, 0, 0};
+  switch (L) {
+    case 40: return k3r_dispatch<80, 2>(HP, Bw, pre, C, C, 0, nb, W1rows, b1, b1, 0.f, has_clip, clip, 0.f, st, ax, cd);
+    default: return DLPD_ERR_UNSUPPORTED;
+  }
+}

@@ -118,7 +118,7 @@ class DockingEngine:
 
     def __init__(self, L, C, W1, b1, W2, b2, clip=5.0, threshold_clash=300.0, has_clash=True,
                  max_conf=1000, batch=8, device="cuda", lib=None, center=None, coarse_channels=0,
-                 fine_unfused=None, channels_last=None):
+                 fine_unfused=None, channels_last=None, k3_form=0, coarse_center=None):
         """coarse_channels > 0: the reference's two-resolution layout -- C channels at L^3 plus
         ``coarse_channels`` at (L/2)^3 (ProteinRepresentationModels.py:72-76); W1 is (H, C+coarse)."""
         self.device = torch.device(device)
@@ -168,6 +168,7 @@ class DockingEngine:
                 raise RuntimeError("dlpd: coarse box size %d has no compiled pipeline" % L1)
             N1, NZ1, C1 = 2 * L1, L1 + 1, self.C1
             self.L1 = L1
+            self.center1 = float(L1) / 2.0 if coarse_center is None else float(coarse_center)
             self.lig1 = torch.zeros(C1, L1, L1, L1, dtype=f32, device=dev)
             self.recF1 = torch.zeros(C1, NZ1, N1, N1, 2, dtype=f32, device=dev)
             self.wsA1 = torch.empty(nb * C1 * NZ1 * L1 * L1 * 2, dtype=f32, device=dev)
@@ -188,6 +189,9 @@ class DockingEngine:
         # optional: callable(R (nb,3,3) f32 device) -> (nb,L,L,L) f32 device ligand forbidden volumes
         # re-projected from rotated ATOMS (Docker.py:221-224) instead of the rotated volume
         self.clash_provider = None
+        # kernel formulation of the fused K3 (include/dlpd.h, dlpd_zifft_filter_form): 0 = the library's default
+        # (role-split transform / filter waves where compiled), 1 = channel-owning waves; same results bit for bit
+        self.k3_form = int(k3_form)
 
     # ---- inputs ------------------------------------------------------------------------
     def set_filter(self, W1, b1, W2, b2):
@@ -286,7 +290,7 @@ class DockingEngine:
         V = self.V if out is None else out
         call, st, L = self.lib.call, _stream(self.device), self.L
         provider = self.clash_provider if self.has_clash else None
-        if not (self.C1 or provider or self.fine_unfused or mark or use_quads or self.use_cl or cset is not None):
+        if not (self.C1 or provider or self.fine_unfused or mark or use_quads or self.use_cl or cset is not None or self.k3_form):
             call("dlpd_score_rotations_oriented", _ptr(self.lig), _ptr(self.recF), _ptr(R), nb, self.C,
                  int(self.has_clash), L, self.center, _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2), self.b2,
                  self.HP, has_clip, clip, self.threshold, _ptr(self.wsA), _ptr(self.wsB), _ptr(V), tr, st)
@@ -298,13 +302,13 @@ class DockingEngine:
             L1 = self.L1
             if self.use_cl:
                 call("dlpd_zfft_channels_last", _ptr(self.ligcl1), _ptr(R), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1,
-                     float(L1) / 2.0, st)
+                     self.center1, st)
             elif use_quads:
                 call("dlpd_zfft_quads", _ptr(self.ligq1), _ptr(R), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1,
-                     float(L1) / 2.0, tr, st)
+                     self.center1, tr, st)
             else:
                 call("dlpd_zfft_oriented", _ptr(self.lig1), _ptr(R), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1, 0, 1,
-                     float(L1) / 2.0, tr, st)
+                     self.center1, tr, st)
             call("dlpd_xy_correlate_oriented", _ptr(self.wsA1), _ptr(self.recF1), _ptr(self.wsB1), nb, self.C1, L1, 0,
                  tr, st)
             self._coarse_preact(nb, has_clip, clip, st)
@@ -367,8 +371,8 @@ class DockingEngine:
     def _coarse_preact(self, nb, has_clip, clip, st):
         """Coarse grid, last stage: z-inverse + clip fused with the coarse half of the (linear) first layer
         (DockingModels.py:74-83): HP pre-activation planes on the coarse grid instead of C1 correlation volumes."""
-        self.lib.call("dlpd_zifft_preact", _ptr(self.wsB1), _ptr(self.pre), nb, self.C1, self.L1,
-                      self.W1t.data_ptr() + self.C * self.HP * 4, _ptr(self.b1), self.HP, has_clip, clip, st)
+        self.lib.call("dlpd_zifft_preact_form", _ptr(self.wsB1), _ptr(self.pre), nb, self.C1, self.L1,
+                      self.W1t.data_ptr() + self.C * self.HP * 4, _ptr(self.b1), self.HP, has_clip, clip, self.k3_form, st)
 
     def _correlate_and_filter(self, nb, V, mark, tr, cset=None):
         """K2 + K3 (+ filter) on whatever K1 left in wsA (and the coarse result in aux); tr: the slab
@@ -392,9 +396,9 @@ class DockingEngine:
             # fused K3; with a candidate set it also appends every score below the running K-th one to the batch's
             # candidate lists, which the top-K select then takes instead of a radix select over V
             tau, ck, cc, cap = (_ptr(self.top.tau), _ptr(cset["keys"]), _ptr(cset["count"]), cset["cap"]) if cset else (0, 0, 0, 0)
-            call("dlpd_zifft_filter_cand", _ptr(self.wsB), _ptr(V), nb, self.C, int(self.has_clash), L,
+            call("dlpd_zifft_filter_form", _ptr(self.wsB), _ptr(V), nb, self.C, int(self.has_clash), L,
                  _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2), self.b2, self.HP, has_clip, clip, self.threshold,
-                 aux, C1, int(C1 > 0), tau, ck, cc, cap, st)
+                 aux, C1, int(C1 > 0), tau, ck, cc, cap, self.k3_form, st)
             self._cset_used = cset
             mark("k3_zifft_filter")
         return V[:nb]
@@ -464,9 +468,8 @@ class DockingEngine:
         with torch.cuda.stream(self._side):
             self._side.wait_event(ready)
             self._side.wait_event(gate)
-            if not os.environ.get("DLPD_DIAG_NO_TOPK"):      # diagnostic: how much the side stream costs the main one
-                self.select_batch(V, nb, cset)
-                self.merge_batch(rot_ids, nb)
+            self.select_batch(V, nb, cset)
+            self.merge_batch(rot_ids, nb)
             done = torch.cuda.Event()
             done.record(self._side)
         self._consumed[k] = done

@@ -110,14 +110,6 @@ int dlpd_zifft_filter(const void* wsB, float* V, int nb, int C, int has_clash, i
                       const float* b1, const float* W2, float b2, int HP, int has_clip, float clip,
                       float thr, void* stream);
 
-/* The same stage with the MLP on the f32 matrix cores and a wave owning a row pair of all channels (no barrier
- * between transform and MLP; dlpd_k3m.hip): identical sums, compiled for L = 64 and 17 <= HP <= 32 only
- * (DLPD_ERR_UNSUPPORTED otherwise).  Measured slower than dlpd_zifft_filter so far;
- * dlpd_zifft_filter uses it only with DLPD_K3_MFMA=1 in the environment. */
-int dlpd_zifft_filter_mfma(const void* wsB, float* V, int nb, int C, int has_clash, int L, const float* W1t,
-                           const float* b1, const float* W2, float b2, int HP, int has_clip, float clip,
-                           float thr, void* stream);
-
 /* Same for the reference's two-resolution layout (ProteinRepresentationModels.py:72-76): the Caux
  * channels of the coarser resolution arrive as clipped real correlation volumes aux (nb, Caux, L^3)
  * (grid N/2 = L) and are nearest-upsampled by index (DockingModels.py:74-76); W1t has C + Caux rows.
@@ -171,6 +163,15 @@ int dlpd_zifft_filter_cand(const void* wsB, float* V, int nb, int C, int has_cla
                            const float* aux, int Caux, int aux_is_preact, const void* tau, void* cand_keys,
                            void* cand_count, int cap, void* stream);
 
+/* dlpd_zifft_filter_cand with the kernel formulation named (same arithmetic, bit-identical V): form 0 = the
+ * library's default, 1 = every wave owns a channel of the group and the transform / filter phases alternate behind
+ * block barriers, 2 = role-split blocks -- dedicated transform waves (LDS-DMA, pack, z C2R) and filter waves (the
+ * MLP of DockingModels.py:79-83 from registers) that overlap each other; falls back to 1 where 2 is not compiled. */
+int dlpd_zifft_filter_form(const void* wsB, float* V, int nb, int C, int has_clash, int L, const float* W1t,
+                           const float* b1, const float* W2, float b2, int HP, int has_clip, float clip, float thr,
+                           const float* aux, int Caux, int aux_is_preact, const void* tau, void* cand_keys,
+                           void* cand_count, int cap, int form, void* stream);
+
 /* Stage K3 for the COARSER resolution of a two-resolution model: z C2R + clip fused with that resolution's half of
  * SimpleFilter's first layer (DockingModels.py:28 after the concat of :77, linear): pre (nb, HP, N^3) = b1 +
  * W1rows^T clamp(corr), W1rows (C, HP) = the rows of W1t that belong to these channels.  The fine grid's
@@ -178,6 +179,9 @@ int dlpd_zifft_filter_cand(const void* wsB, float* V, int nb, int C, int has_cla
  * the C real correlation volumes of this resolution are never written. */
 int dlpd_zifft_preact(const void* wsB, float* pre, int nb, int C, int L, const float* W1rows, const float* b1, int HP,
                       int has_clip, float clip, void* stream);
+/* dlpd_zifft_preact with the kernel formulation named (see dlpd_zifft_filter_form). */
+int dlpd_zifft_preact_form(const void* wsB, float* pre, int nb, int C, int L, const float* W1rows, const float* b1,
+                           int HP, int has_clip, float clip, int form, void* stream);
 
 /* dlpd_zifft_real with the clamp restricted to channels [0, nclip). */
 int dlpd_zifft_real_part(const void* wsB, float* out, int nb, int CT, int nclip, int L, int has_clip, float clip,

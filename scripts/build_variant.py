@@ -17,11 +17,11 @@ def main():
     ap.add_argument("name")
     ap.add_argument("--corr", default="")
     ap.add_argument("--k2", default="")
-    ap.add_argument("--k3m", default="")
+    ap.add_argument("--k3r", default="")
     ap.add_argument("--corr-src", default=None, help="alternative source file for dlpd_corr.hip")
     args = ap.parse_args()
     entry.build()
-    extra = {"dlpd_corr.hip": args.corr.split(), "dlpd_k2.hip": args.k2.split(), "dlpd_k3m.hip": args.k3m.split()}
+    extra = {"dlpd_corr.hip": args.corr.split(), "dlpd_k2.hip": args.k2.split(), "dlpd_k3r.hip": args.k3r.split()}
     out_dir = os.path.join(ROOT, "build_variants")
     os.makedirs(out_dir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

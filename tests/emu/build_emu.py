@@ -7,12 +7,12 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.abspath(os.path.join(HERE, "..", "..", "deeplocalproteindocking_amd", "csrc"))
 OUT = os.path.join(HERE, "libdlpd_emu.so")
-SRCS = ["dlpd_corr.hip", "dlpd_k2.hip", "dlpd_k3m.hip", "dlpd_topk.hip", "dlpd_atoms.hip", "dlpd_conv.hip", "dlpd_version.hip"]
+SRCS = ["dlpd_corr.hip", "dlpd_k2.hip", "dlpd_k3r.hip", "dlpd_topk.hip", "dlpd_atoms.hip", "dlpd_conv.hip", "dlpd_version.hip"]
 
 
 def build(force=False):
     srcs = [os.path.join(CSRC, s) for s in SRCS]
-    deps = srcs + [os.path.join(CSRC, h) for h in ("dlpd_fft.h", "dlpd_internal.h")] + \
+    deps = srcs + [os.path.join(CSRC, h) for h in ("dlpd_fft.h", "dlpd_internal.h", "dlpd_k3.h")] + \
         [os.path.join(HERE, "dlpd_platform.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) > os.path.getmtime(d) for d in deps):
         return OUT

@@ -660,11 +660,15 @@ def test_two_rank_nccl_search_equals_single_process(dev, tmp_path):
     assert res["sharded"] == res["single"] and len(res["single"]) == res["K"]
 
 
-def test_matrix_core_k3_equals_the_vector_k3_at_config2_size(dev):
-    """dlpd_zifft_filter_mfma (opt-in formulation: MLP on v_mfma_f32_16x16x4_f32, waves own row pairs) against the oracle
-    and bit for bit against dlpd_zifft_filter at 48 channels x 64^3 (7 groups, the last one the clash channel alone)."""
+def test_k3_role_split_equals_the_channel_owning_k3(dev):
+    """k_zifft_filter_rs (dedicated transform / filter waves, the default) bit for bit against k_zifft_filter[_tiles]
+    (every wave owns a channel) and against the oracle: 48 channels x 64^3 (13 groups of 4, the last one the clash
+    channel alone), the reference's real shapes [16 @ 80^3, 32 @ 40^3] with the coarse pre-activation planes through
+    both forms, and 48 channels x 80^3 (five groups of ten)."""
     from test_kernels_emu import _k3_both_formulations
-    _k3_both_formulations(None, dev, 64, 48, 24, 5.0, 5)
+    _k3_both_formulations(None, dev, 64, 48, 24, 5.0, 5, nb=2)
+    _k3_both_formulations(None, dev, 80, 16, 24, 5.0, 6, C1=32, nb=2)
+    _k3_both_formulations(None, dev, 80, 48, 24, 5.0, 7)
 
 
 def test_topk_candidate_lists_from_k3_equal_the_full_select(dev, monkeypatch):

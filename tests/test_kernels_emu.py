@@ -449,42 +449,53 @@ def test_slab_orientation_is_invisible_in_the_scores(emu, L):
         assert sum(a[:4] == b[:4] for a, b in zip(got, plain)) >= len(got) - 2
 
 
-def _k3_both_formulations(lib, device, L, C, H, clip, seed):
-    """dlpd_zifft_filter (vector unit) and dlpd_zifft_filter_mfma (matrix cores, pair-owning waves) on the same K2
-    output: the first layer is the same fmaf chain in the same order; the second layer's 24-term dot product is summed
-    in another order (per-lane partial sums + a cross-lane tree), so the scores agree to round-off, and the clash mask
-    bit for bit."""
-    from deeplocalproteindocking_amd.engine import _ptr, _stream
+def _k3_both_formulations(lib, device, L, C, H, clip, seed, C1=0, nb=1):
+    """The two formulations of the fused K3 (dlpd_zifft_filter_form: 1 = channel-owning waves with barrier-separated
+    transform / filter phases, 2 = role-split transform / filter waves) on the SAME K2 output: the same fmaf chains in
+    the same order, so V must agree bit for bit; form 2 (the default) is also compared with the oracle.
+    C1 > 0: the reference's two-resolution layout (the coarse grid's pre-activation planes through both forms too)."""
     g = torch.Generator().manual_seed(seed)
     rec, lig = torch.randn(C, L, L, L, generator=g) * 0.05, torch.randn(C, L, L, L, generator=g) * 0.05
     recf, ligf = torch.rand(L, L, L, generator=g), torch.rand(L, L, L, generator=g)
-    W1, b1 = torch.randn(H, C, generator=g) * 0.4, torch.randn(H, generator=g) * 0.1
+    rec1 = lig1 = None
+    if C1:
+        rec1 = torch.randn(C1, L // 2, L // 2, L // 2, generator=g) * 0.1
+        lig1 = torch.randn(C1, L // 2, L // 2, L // 2, generator=g) * 0.1
+    W1, b1 = torch.randn(H, C + C1, generator=g) * 0.4, torch.randn(H, generator=g) * 0.1
     W2, b2 = torch.randn(1, H, generator=g), torch.randn(1, generator=g)
     thr = 0.125 * L ** 3
-    eng = DockingEngine(L, C, W1, b1, W2, b2, clip=clip, threshold_clash=thr, max_conf=10, batch=1, device=device, lib=lib)
-    eng.set_receptor(rec, recf)
-    eng.set_ligand(lig, ligf)
-    R = orc.euler_to_matrix([0.5], [1.1], [-0.4])
-    V = eng.score_batch(torch.from_numpy(R).float().to(device).contiguous())[0].cpu().clone()      # wsB stays in the engine
-    V2 = torch.empty_like(eng.V)
-    eng.lib.call("dlpd_zifft_filter_mfma", _ptr(eng.wsB), _ptr(V2), 1, C, 1, L, _ptr(eng.W1t), _ptr(eng.b1), _ptr(eng.W2),
-                 eng.b2, eng.HP, 1, float(clip), eng.threshold, _stream(eng.device))
-    V2 = V2[0].cpu()
-    Rb = torch.from_numpy(R).float()
-    S = orc.score_volumes([rec[None]], [orc.rotate_volume(lig[None], Rb)], W1, b1, W2, b2, clip=clip)[0]
-    mask, norm = orc.clash_mask(recf[None, None], orc.rotate_volume(ligf[None, None], Rb), thr)
-    sure = (norm[0] - thr).abs() > 1e-3 * thr
-    assert ((V2 - mask[0] * S).abs()[sure]).max() <= 1e-4 * S.abs().max()
-    assert float((mask[0] == 0).float().mean()) > 0.01
-    assert torch.equal(V == 0, V2 == 0)
-    assert float((V - V2).abs().max()) <= 2e-6 * float(S.abs().max())
+    eng = DockingEngine(L, C, W1, b1, W2, b2, clip=clip, threshold_clash=thr, max_conf=10, batch=nb, device=device, lib=lib,
+                        coarse_channels=C1)
+    eng.set_receptor(rec, recf, rec1)
+    eng.set_ligand(lig, ligf, lig1)
+    R = orc.euler_to_matrix([0.5, -2.1][:nb], [1.1, 0.3][:nb], [-0.4, 1.7][:nb])
+    out = {}
+    for form in (1, 2):
+        eng.k3_form = form
+        out[form] = eng.score_batch(torch.from_numpy(R).float().to(device).contiguous()).cpu().clone()
+        if C1:
+            out[(form, "pre")] = eng.pre[:nb].cpu().clone()
+    if C1:
+        assert torch.equal(out[(1, "pre")], out[(2, "pre")])
+    assert torch.equal(out[1], out[2])
+    for i in range(nb):
+        Rb = torch.from_numpy(R[i:i + 1]).float()
+        rr, ll = [rec[None]], [orc.rotate_volume(lig[None], Rb)]
+        if C1:
+            rr.append(rec1[None])
+            ll.append(orc.rotate_volume(lig1[None], Rb))
+        S = orc.score_volumes(rr, ll, W1, b1, W2, b2, clip=clip)[0]
+        mask, norm = orc.clash_mask(recf[None, None], orc.rotate_volume(ligf[None, None], Rb), thr)
+        sure = (norm[0] - thr).abs() > 1e-3 * thr
+        assert ((out[2][i] - mask[0] * S).abs()[sure]).max() <= 1e-4 * S.abs().max()
+        assert float((mask[0] == 0).float().mean()) > 0.01
 
 
-def test_k3_on_the_matrix_cores_matches_oracle_and_the_vector_k3(emu):
-    """k_zifft_mlp_mfma through the emulated matrix core: 2 score channels + clash = 3 channels (one partial group of
-    8), hidden width 20 (padded to 24, second hidden tile partly empty), clip biting, one rotation."""
+def test_k3_role_split_equals_the_channel_owning_k3_emulated(emu):
+    """k_zifft_filter_rs on the fibre emulator at N = 128: 5 score channels + clash = 6 channels (two groups of the
+    4 transform waves, the second partial), hidden width 20 (padded to 24), clip biting, one rotation."""
     assert emu.call("dlpd_hidden_pad", 20) == 24
-    _k3_both_formulations(emu, "cpu", 64, 2, 20, 0.4, 77)
+    _k3_both_formulations(emu, "cpu", 64, 5, 20, 0.4, 77)
 
 
 def _search_with_and_without_candidate_lists(lib, device, L, C, K, nrot, batch, monkeypatch, seed=3):
