@@ -39,10 +39,10 @@ template <int N> DLPD_D void init_twiddles_k3r(cplx* tw, int tid, int nthreads) 
 #define DLPD_K3R_F128 4
 #endif
 #ifndef DLPD_K3R_M160
-#define DLPD_K3R_M160 10
+#define DLPD_K3R_M160 5
 #endif
 #ifndef DLPD_K3R_RAWBUF128
-#define DLPD_K3R_RAWBUF128 2
+#define DLPD_K3R_RAWBUF128 1
 #endif
 #ifndef DLPD_K3R_FFT_PRIO
 #define DLPD_K3R_FFT_PRIO 0
@@ -61,6 +61,91 @@ extern "C" int dlpd_debug_read_stamps_k3r(unsigned long long* host32) {
   return hipMemcpyToSymbol(HIP_SYMBOL(dlpd_stamps_k3r), z, sizeof(z)) == hipSuccess ? 0 : 1;
 }
 #endif
+
+// Raw staging layout (per channel): slot NPAIR*k + msl, k = 0 .. N/2, holds {A[k].re, A[k].im, B[k].re, B[k].im} of row
+// pair m = msl ^ k3r_pair_swz(k).  The swizzle (8 pairs per bin only) makes the 16-byte reads of the first pass --
+// lane = 8*pencil + t reads bin t + 8r of its pencil -- bank-conflict free: a ds_read_b128 is served in groups of 16
+// lanes {0-3,12-15,20-27}, ..., and 8k + m alone puts lanes t, t+2 of one pencil on the same 16-byte column.
+template <int NPAIR> DLPD_HD int k3r_pair_swz(int k) { return NPAIR == 8 ? ((k & 2) << 1) : 0; }
+
+// first pass of the inverse z transform of one pencil (thread t of 8), inputs from the raw channel `rj`, outputs to the
+// pencil at S + rowoff in the layout the second pass expects (fft_wave / fft_wave_pencils of dlpd_fft.h)
+template <int N, int NPAIR> DLPD_D void k3r_first_pass(cplx* S, int rowoff, int t, int m, const float4* rj) {
+  constexpr int NH = N / 2, R1 = N / 8, RH = R1 / 2;
+  static_assert(NH % 8 == 0 && R1 % 2 == 0, "bins t + 8r: the first R1/2 direct, the others mirrored");
+  FftPassW<N, R1, 1, +1, 8> ps;
+  // lane-constant slots; k & 2 == t & 2 for the direct bins, (N/2 - t) & 2 for the mirrored ones
+  const float4* lo = rj + NPAIR * t + (m ^ k3r_pair_swz<NPAIR>(t));
+  const float4* hi = rj + NPAIR * (NH - t) + (m ^ k3r_pair_swz<NPAIR>(NH - t));
+  {
+    float4 q[RH];
+#pragma unroll
+    for (int r = 0; r < RH; r++) q[r] = lo[NPAIR * 8 * r];
+#pragma unroll
+    for (int r = 0; r < RH; r++) {
+      // k = 0: the purely real bin of both rows
+      const bool dc = (r == 0) && (t == 0);
+      ps.v[0][r] = dc ? c_make(q[r].x, q[r].z) : c_make(q[r].x - q[r].w, q[r].y + q[r].z);
+    }
+  }
+  {
+    float4 q[RH];
+#pragma unroll
+    for (int s = 0; s < RH; s++) q[s] = *(hi - NPAIR * 8 * s);
+#pragma unroll
+    for (int s = 0; s < RH; s++) {
+      // k = N/2: purely real as well
+      const bool ny = (s == 0) && (t == 0);
+      ps.v[0][RH + s] = ny ? c_make(q[s].x, q[s].z) : c_make(q[s].x + q[s].w, q[s].z - q[s].y);
+    }
+  }
+  SmallDft<R1, +1>::run(ps.v[0]);
+  cplx* P = S + rowoff;
+  if constexpr (N == 160) {
+#pragma unroll
+    for (int r = 0; r < R1; r++) lds_st(P + 21 * t + r, ps.v[0][r]);        // "blocks of 21" (dlpd_fft.h)
+  } else if constexpr (N == 80) {
+    const RowMid<R1 + 1> md = {rowoff};
+    ps.store_blk(S, md, t);
+  } else {
+    const RowAddr<0> ad = {rowoff};
+    ps.store(S, ad, t);
+  }
+}
+
+template <int N> DLPD_D void k3r_second_pass(cplx* S, int rowoff, int t, const cplx* tw) {
+  constexpr int R1 = N / 8;
+  DLPD_WAVE_SYNC();
+  if constexpr (N == 160) {
+    cplx* P = S + rowoff;
+    FftPassW<N, 8, 20, +1, 8> ps;                    // 20 butterflies of radix 8: three rounds, the last half full
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+      if (t + 8 * i < 20) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) ps.v[i][r] = lds_ld(P + t + 8 * i + 21 * r);
+        ps.twiddle_and_run(i, t + 8 * i, tw);
+      }
+    DLPD_WAVE_SYNC();
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+      if (t + 8 * i < 20) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) lds_st(P + t + 8 * i + 21 * r, ps.v[i][r]);
+      }
+  } else {
+    const RowAddr<0> ad = {rowoff};
+    FftPassW<N, 8, R1, +1, 8> ps;
+    if constexpr (N == 80) {
+      const RowMid<R1 + 1> md = {rowoff};
+      ps.load_blk(S, md, t, tw);
+    } else {
+      ps.load(S, ad, t, tw);
+    }
+    DLPD_WAVE_SYNC();
+    ps.store(S, ad, t);
+  }
+}
 
 //   Bw   (nb, CT, NZ, N, N) complex [kz][x'][y']
 //   MODE 1: V (nb, N,N,N) = mask * (W2 . relu(W1 . clamp(corr) + b1) + b2); score channels [0,C), clash channel C
@@ -106,7 +191,8 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
       const int g = wave * CPW + j;
       if (g < G && cb + g < CT) {
         const cplx* src = Bw + (((size_t)tb * CT + cb + g) * NZ * N + txo) * N + ty0;
-        const cplx* lane_src = src + (size_t)(lane / NPAIR) * N * N + 2 * (lane % NPAIR);
+        // slot NPAIR*k + msl of the raw channel holds row pair msl ^ k3r_pair_swz(k) of bin k (see k3r_first_pass)
+        const cplx* lane_src = src + (size_t)(lane / NPAIR) * N * N + 2 * ((lane % NPAIR) ^ k3r_pair_swz<NPAIR>(lane / NPAIR));
         float4* rj = rawg + buf * (F * CPW * RAWC) + j * RAWC;
 #pragma unroll
         for (int it = 0; it < NFULL; it++) DLPD_GLDS16(lane_src + (size_t)it * LPK * N * N, rj + it * 64);
@@ -148,55 +234,21 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
       // the next group of this tile, or the first group of the next tile
       const int nt = last_group ? t + 1 : t, ncb = last_group ? 0 : cbase + G;
       if (RAWBUF == 2 && nt < t_end) issue_channel(nt, ncb, rb ^ 1);
+      // FIRST PASS STRAIGHT FROM THE RAW SPECTRA.  A pencil holds two real rows as one complex sequence,
+      // Z[k] = A[k] + i B[k], Z[N-k] = conj(A[k]) + i conj(B[k]) (k <= N/2; A, B the Hermitian half-spectra of rows
+      // 2m, 2m+1).  Thread t of the first pass (radix R1 = N/8, butterfly t) needs Z[t + 8r], r < R1: the first half
+      // of them are raw bins t + 8r, the second half the mirrored bins N/2 - t - 8s -- both are 16-byte reads at
+      // lane-constant addresses plus immediates, so the separate pack phase (a ds_write_b64 per element and as many
+      // VALU as the transform itself) and the first pass' own reads disappear.
+      // (a wave whose second channel lies beyond the group transforms stale staging data into pencils nobody reads)
       if (mine) {
-        // pack two rows per complex pencil: Z[k] = A[k] + i B[k], Z[N-k] = conj(A[k]) + i conj(B[k]); lane ->
-        // (pencil m, kz row) dealing as in k_zifft_filter (dlpd_corr.hip: conflict-free raw reads, 5-cycle stores)
-#pragma unroll
-        for (int j = 0; j < CPW; j++) {
-          if (wave * CPW + j >= gn) break;
-          int m, kq, lq = lane;
-          DLPD_OPAQUE(lq);
-          if (NPAIR == 8) {
-            m = (lq & 3) | (((lq >> 4) & 1) << 2);
-            kq = ((lq >> 2) & 1) | (((lq >> 5) & 1) << 1) | (((lq >> 3) & 1) << 2);
-          } else {
-            m = lq % NPAIR;
-            kq = lq / NPAIR;
-          }
-          const int rot = (NPAIR == 8) ? 2 * m : 0;            // lane-dependent start of its walk over the DMA instructions
-          const int slot = NPAIR * kq + m;
-          cplx* P = S + (wave * 8 + j * NPAIR + m) * RS;
-          const float4* rj = rawg + rb * (F * CPW * RAWC) + j * RAWC;
-          constexpr int PCH = NFULL > 8 ? NFULL / 2 : NFULL;   // raw elements in flight per lane
-          const float4 qh = rj[NFULL * 64 + (lane % NPAIR)];  // k = N/2 (lanes with lane / NPAIR == 0 store it)
-#pragma unroll
-          for (int it0 = 0; it0 < NFULL; it0 += PCH) {
-            float4 q[PCH];
-#pragma unroll
-            for (int u = 0; u < PCH; u++) q[u] = rj[((it0 + u + rot) % NFULL) * 64 + slot];
-#pragma unroll
-            for (int u = 0; u < PCH; u++) {
-              const int k = ((it0 + u + rot) % NFULL) * LPK + kq;
-              // k = 0: the purely real bin of both rows (both stores then write the same value to the same place)
-              const cplx lo = (k == 0) ? c_make(q[u].x, q[u].z) : c_make(q[u].x - q[u].w, q[u].y + q[u].z);
-              const cplx hi = (k == 0) ? c_make(q[u].x, q[u].z) : c_make(q[u].x + q[u].w, q[u].z - q[u].y);
-              P[pencil_in_pos<N>(k)] = lo;
-              P[pencil_in_pos<N>((N - k) & (k == 0 ? 0 : ~0))] = hi;
-            }
-          }
-          if (lane / NPAIR == 0) S[(wave * 8 + j * NPAIR + lane % NPAIR) * RS + pencil_in_pos<N>(N / 2)] = c_make(qh.x, qh.z);
-        }
-        DLPD_WAIT_LDS();                       // raw fully read before it is refilled
-        DLPD_WAVE_SYNC();
+        const int m = qr % NPAIR, j = qr / NPAIR;
+        k3r_first_pass<N, NPAIR>(S, (wave * 8 + qr) * RS, tr, m, rawg + rb * (F * CPW * RAWC) + j * RAWC);
+        DLPD_WAVE_SYNC();                      // every lane's raw values are in registers: the staging buffer is free
       }
       DLPD_STAMP(1);
       if (RAWBUF == 1 && nt < t_end) issue_channel(nt, ncb, 0);
-      if (mine) {
-        int tq = tr, qq = qr;
-        DLPD_OPAQUE(tq);
-        DLPD_OPAQUE(qq);
-        fft_wave_pencils<N, +1>(S, wave * 8, RS, qq, tq, tw);
-      }
+      if (mine) k3r_second_pass<N>(S, (wave * 8 + qr) * RS, tr, tw);
       DLPD_STAMP(2);
       if (RAWBUF == 2) rb ^= 1;
       DLPD_LDS_BARRIER();                      // B1
