@@ -720,8 +720,16 @@ int dlpd_k2_forward(const cplx* A, cplx* out, int CT, int nb, int L, float scale
   }
 }
 
+// N = 160 with 4-lane pencils and affine LDS addressing: dlpd_k2q.hip (untransposed slabs)
+int dlpd_k2q_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, int L, long long rbs, int nsplit_override,
+                       hipStream_t st);
+#ifndef DLPD_K2_Q4
+#define DLPD_K2_Q4 1
+#endif
+
 int dlpd_k2_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, int L, long long rbs, hipStream_t st,
                       int transposed) {
+  if (DLPD_K2_Q4 && L == 80 && !transposed) return dlpd_k2q_correlate(A, rec, out, CT, nb, L, rbs, k2_nsplit_override(), st);
   switch (L) {
     case 32: return launch_k2<64, 1>(A, rec, out, CT, nb, rbs, 1.f, st, transposed);
     case 40: return launch_k2<80, 1>(A, rec, out, CT, nb, rbs, 1.f, st, transposed);
