@@ -19,6 +19,12 @@
 // On one SIMD a transform wave (LDS latency, address arithmetic) and filter waves (back-to-back packed FMAs) are
 // complementary, which is the pairing MI355X_MICROARCH.md ("Two waves per SIMD", item 5) says a rendezvous pays for.
 // A block walks all y-tiles of an x' plane, so the pipeline fills once per plane, not once per tile.
+// Measured and rejected (round 3): the same two roles paced by flags in LDS instead of block barriers -- every transform
+// wave a ring slot of its own (full / done words, polled with s_sleep), no channel groups, 8 + 8 waves at N = 128: 2.19 ms
+// against 1.84 ms for this kernel (2.11 with 4 + 8 waves), 2.06 against 2.09 at N = 160.  The per-channel hand-off costs
+// the filter waves more (poll + copy + atomic per channel: 11 % + 37 % waiting for "full") than the extra transform
+// waves give back, and at 16 waves the 128-register ceiling spills the radix-16 / radix-20 passes.  Wave priorities
+// (s_setprio 1..3 for the transform waves) change nothing.
 #include <dlpd_platform.h>
 #include "dlpd_fft.h"
 #include "dlpd_internal.h"
@@ -68,12 +74,13 @@ extern "C" int dlpd_debug_read_stamps_k3r(unsigned long long* host32) {
 // lanes {0-3,12-15,20-27}, ..., and 8k + m alone puts lanes t, t+2 of one pencil on the same 16-byte column.
 template <int NPAIR> DLPD_HD int k3r_pair_swz(int k) { return NPAIR == 8 ? ((k & 2) << 1) : 0; }
 
-// first pass of the inverse z transform of one pencil (thread t of 8), inputs from the raw channel `rj`, outputs to the
-// pencil at S + rowoff in the layout the second pass expects (fft_wave / fft_wave_pencils of dlpd_fft.h)
-template <int N, int NPAIR> DLPD_D void k3r_first_pass(cplx* S, int rowoff, int t, int m, const float4* rj) {
+// first pass of the inverse z transform of one pencil (thread t of 8): inputs from the raw channel `rj`, radix-R1
+// butterfly in registers (k3r_first_pass_load), outputs to the pencil at S + rowoff in the layout the second pass
+// expects (k3r_first_pass_store; fft_wave / fft_wave_pencils of dlpd_fft.h)
+template <int N> struct K3rFirst { typedef FftPassW<N, N / 8, 1, +1, 8> Pass; };
+template <int N, int NPAIR> DLPD_D void k3r_first_pass_load(typename K3rFirst<N>::Pass& ps, int t, int m, const float4* rj) {
   constexpr int NH = N / 2, R1 = N / 8, RH = R1 / 2;
   static_assert(NH % 8 == 0 && R1 % 2 == 0, "bins t + 8r: the first R1/2 direct, the others mirrored");
-  FftPassW<N, R1, 1, +1, 8> ps;
   // lane-constant slots; k & 2 == t & 2 for the direct bins, (N/2 - t) & 2 for the mirrored ones
   const float4* lo = rj + NPAIR * t + (m ^ k3r_pair_swz<NPAIR>(t));
   const float4* hi = rj + NPAIR * (NH - t) + (m ^ k3r_pair_swz<NPAIR>(NH - t));
@@ -100,6 +107,9 @@ template <int N, int NPAIR> DLPD_D void k3r_first_pass(cplx* S, int rowoff, int 
     }
   }
   SmallDft<R1, +1>::run(ps.v[0]);
+}
+template <int N> DLPD_D void k3r_first_pass_store(cplx* S, int rowoff, int t, const typename K3rFirst<N>::Pass& ps) {
+  constexpr int R1 = N / 8;
   cplx* P = S + rowoff;
   if constexpr (N == 160) {
 #pragma unroll
@@ -111,6 +121,11 @@ template <int N, int NPAIR> DLPD_D void k3r_first_pass(cplx* S, int rowoff, int 
     const RowAddr<0> ad = {rowoff};
     ps.store(S, ad, t);
   }
+}
+template <int N, int NPAIR> DLPD_D void k3r_first_pass(cplx* S, int rowoff, int t, int m, const float4* rj) {
+  typename K3rFirst<N>::Pass ps;
+  k3r_first_pass_load<N, NPAIR>(ps, t, m, rj);
+  k3r_first_pass_store<N>(S, rowoff, t, ps);
 }
 
 template <int N> DLPD_D void k3r_second_pass(cplx* S, int rowoff, int t, const cplx* tw) {
@@ -388,6 +403,9 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
 #endif
 }
 
+#ifndef DLPD_K3R_TPB_DIV
+#define DLPD_K3R_TPB_DIV 1                   // tiles per block = (y-tiles of an x' plane) / DIV
+#endif
 static int k3r_group(int CT, int maxg, bool balanced) {
   if (!balanced) return CT < maxg ? CT : maxg;
   const int ng = (CT + maxg - 1) / maxg;

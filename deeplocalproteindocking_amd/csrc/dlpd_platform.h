@@ -27,16 +27,11 @@ __device__ __forceinline__ void dlpd_glds16(const void* g, void* l) {
 // barrier that orders LDS traffic only (leaves global loads / LDS-DMA in flight)
 #define DLPD_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define DLPD_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-// all but the three youngest vector-memory operations of this wave
-// keeps three values (targets of loads that are still in flight) allocated up to this point
-#define DLPD_KEEP_ALIVE3(a, b, c) asm volatile("" ::"v"(a), "v"(b), "v"(c))
-#define DLPD_WAIT_VMEM_BUT3() asm volatile("s_waitcnt vmcnt(3)" ::: "memory")
+#define DLPD_HAS_LDS_ADDRESS_SPACE 1                 // __attribute__((address_space(3))) pointers (not in the CPU emulator)
+// wave priority for the instruction arbiter (0 lowest .. 3)
+#define DLPD_SET_PRIO(n) __builtin_amdgcn_s_setprio(n)
 // ordering point between lanes of ONE wave that exchange data through LDS: the hardware runs a
 // wave's LDS instructions in order, so only the compiler must be kept from reordering them
-#define DLPD_HAS_LDS_ADDRESS_SPACE 1                 // __attribute__((address_space(3))) pointers (not in the CPU emulator)
-// wave priority for the instruction arbiter (0 lowest .. 3): unequal priorities keep the two waves of a SIMD in
-// complementary phases (one in its butterflies while the other's LDS accesses are in flight)
-#define DLPD_SET_PRIO(n) __builtin_amdgcn_s_setprio(n)
 #define DLPD_WAVE_SYNC() asm volatile("" ::: "memory")
 #define DLPD_WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 // two consecutive floats from a 4-byte-aligned address with one global_load_dwordx2

@@ -218,8 +218,6 @@ static inline int max(int a, int b) { return a > b ? a : b; }
 #define DLPD_GLDS16(g, l) memcpy(reinterpret_cast<char*>(l) + 16 * (emu::S().cur % 64), (const void*)(g), 16)
 #define DLPD_LDS_BARRIER() emu::barrier()
 #define DLPD_WAIT_VMEM() ((void)0)
-#define DLPD_WAIT_VMEM_BUT3() ((void)0)
-#define DLPD_KEEP_ALIVE3(a, b, c) ((void)(a), (void)(b), (void)(c))
 #define DLPD_WAVE_SYNC() emu::wave_sync()
 #define DLPD_WAIT_LDS() ((void)0)
 struct dlpd_pair_t { float x, y; };
