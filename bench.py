@@ -69,6 +69,8 @@ def parse_args():
     ap.add_argument("--cpu_rotations", type=int, default=16,
                     help="rotations of the CPU baseline sample, spread over the four search groups (0: skip)")
     ap.add_argument("--no_real_shapes", action="store_true", help="skip the short N = 160 measurement")
+    ap.add_argument("--sustained_s", type=float, default=2.5,
+                    help="untimed extra: seconds of CONSECUTIVE batches from the head of the visiting sequence (0: skip)")
     ap.add_argument("--k3_form", type=int, default=0, choices=(0, 1, 2),
                     help="kernel formulation of the fused K3 (include/dlpd.h, dlpd_zifft_filter_form): 0 = library default")
     ap.add_argument("--dry_run", action="store_true",
@@ -316,7 +318,10 @@ def run_rank(args):
     from deeplocalproteindocking_amd.engine import DockingEngine
     from deeplocalproteindocking_amd.Utils.Rotations import Rotations
     K, nb = args.max_conf, args.batch
+    t_setup = time.perf_counter()
     eng, wl = build_workload(args.workload, args, dev)
+    torch.cuda.synchronize()
+    setup_s = time.perf_counter() - t_setup      # synthetic inputs + upload + receptor spectrum + channels-last copy
     C, L, C1 = wl["C"], wl["L"], wl["C1"]
     eng_unfused, eng_hp, eng_prefilter = eng.fine_unfused, eng.HP, eng.prefilter
     N = 2 * L
@@ -384,9 +389,9 @@ def run_rank(args):
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, setup_s], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, setup_s = float(t[0].item()), float(t[1].item())
     stages = timer.summary()                                 # K1/K2/K3 as measured inside the timed region
 
     # untimed extras: (i) the head of the set (the z-dominant rotations, cheapest K1 gather); (ii) the top-K
@@ -411,6 +416,10 @@ def run_rank(args):
         tk.mark("topk_merge")
     torch.cuda.synchronize()
     stages.update(tk.summary())
+
+    sustained = None
+    if rank == 0 and world == 1 and args.sustained_s > 0:
+        sustained = sustained_measurement(eng, R_all, seq_ids, seq_key, nb, N, elapsed / args.steps, args.sustained_s, dev)
 
     real_shapes = None
     if rank == 0 and world == 1 and args.workload == "config2" and not args.no_real_shapes:
@@ -478,6 +487,9 @@ def run_rank(args):
                                       "untimed extra, NOT the headline" % head_n},
             "top_entries": int(len(entries[0])),
         }
+        out["per_rank_setup_s"] = setup_s
+        if sustained is not None:
+            out["sustained"] = sustained
         if real_shapes is not None:
             out["real_shapes"] = real_shapes
         if world == 1 and args.cpu_rotations > 0 and V_first is not None:
@@ -487,6 +499,33 @@ def run_rank(args):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def sustained_measurement(eng, R_all, seq_ids, seq_key, nb, N, s_per_step, seconds, dev):
+    """Untimed extra of the default line: `seconds` worth of CONSECUTIVE batches (the search as Docker runs it, from the
+    head of the visiting sequence) -- long enough for the power-limited steady-state clock -- with the sha256 of the
+    resulting ranked list, so that two driver runs can be compared entry for entry."""
+    import hashlib
+    import numpy as np
+    import torch
+    nsteps = int(min(len(seq_ids) // nb, max(32, seconds / max(s_per_step, 1e-6))))
+    ids, key_of = seq_ids[:nsteps * nb], seq_key[:nsteps * nb]
+    tr_of, qd_of = key_of >= 2, (key_of % 2) == 1
+    Rd = R_all[ids].to(device=dev, dtype=torch.float32).contiguous()
+    idd = torch.as_tensor(ids, dtype=torch.int32).to(dev)
+    eng.reset_top()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    time_steps(eng, Rd, idd, tr_of, qd_of, nb, 0, nsteps)
+    ent = eng.top_entries()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    h = hashlib.sha256()
+    for a, ty in zip(ent, (np.int64, np.int64, np.float32, np.int64)):
+        h.update(np.ascontiguousarray(a, dtype=ty).tobytes())
+    return {"steps": nsteps, "seconds": dt, "ms_per_step": dt / nsteps * 1e3, "value": nsteps * nb * N ** 3 / dt,
+            "unit": "pose scores/s", "rotations": nsteps * nb, "list_sha256": h.hexdigest(), "list_entries": int(len(ent[0])),
+            "sample": "the first %d batches of the visiting sequence, consecutively (untimed extra, NOT the headline)" % nsteps}
 
 
 def short_measurement(name, args, dev, R_all, nb, nsteps=24):

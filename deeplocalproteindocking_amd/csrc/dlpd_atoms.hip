@@ -8,23 +8,25 @@
 // every atom adds exp(-|r - x|^2 / 2) (Angstrom^2) to the (2d+1)^3 voxels around it, d = 2, voxel
 // (i,j,k) sitting at (i,j,k) * resolution.
 //
-// DETERMINISTIC: the contributions are accumulated as 2^-24 fixed-point INTEGERS (integer atomic adds
-// commute, float ones do not), then converted to float in place.  Two runs -- and two ranks projecting the
-// same receptor -- produce bit-identical volumes, so the clash mask `corr < threshold` (Docker.py:226) and
-// with it the ranked list never depends on the order in which atoms happen to be added.  A unit-sigma
-// Gaussian per atom at protein packing density (~0.1 heavy atoms / A^3) sums to < 2 per voxel at any
-// resolution; the int32 accumulator holds +-127.
+// DETERMINISTIC: the contributions are accumulated as 2^-20 fixed-point UNSIGNED integers (integer atomic adds
+// commute, float ones do not; every contribution is positive), then converted to float in place.  Two runs -- and
+// two ranks projecting the same receptor -- produce bit-identical volumes, so the clash mask `corr < threshold`
+// (Docker.py:226) and with it the ranked list never depends on the order in which atoms happen to be added.  A
+// unit-sigma Gaussian per atom at protein packing density (~0.1 heavy atoms / A^3) sums to < 2 per voxel at any
+// resolution; the 32-bit accumulator holds 4095 -- thousands of atoms stacked on one site (duplicated records,
+// multi-model files summed into one channel) before it could wrap; the resolution 2^-20 is below the float
+// spacing of such sums.
 #include <dlpd_platform.h>
 #include "dlpd_internal.h"
 
-#define DLPD_SPLAT_SCALE 16777216.0f          // 2^24
+#define DLPD_SPLAT_SCALE 1048576.0f           // 2^20
 
 // coords (B, 3*stride_atoms) f32 [x0 y0 z0 x1 ...] ordered by atom type; ntype (B, T) counts,
 // offs (B, T) first atom of each type.  p' = R_b p + shift (R row-major, may be null).
 // out (B, T, L^3), or (B, 1, L^3) when sum_types != 0.  One thread per (b, atom).
 __global__ void __launch_bounds__(256)
 k_project_atoms(const float* __restrict__ coords, const int* __restrict__ ntype, const int* __restrict__ offs,
-                const float* __restrict__ R, float sx, float sy, float sz, int* __restrict__ out, int B,
+                const float* __restrict__ R, float sx, float sy, float sz, unsigned* __restrict__ out, int B,
                 int stride_atoms, int T, int L, float res, int sum_types) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = gid / stride_atoms, a = gid % stride_atoms;
@@ -47,7 +49,7 @@ k_project_atoms(const float* __restrict__ coords, const int* __restrict__ ntype,
   x += sx; y += sy; z += sz;
   const int ci = (int)floorf(x / res), cj = (int)floorf(y / res), ck = (int)floorf(z / res);
   const int ch = sum_types ? 0 : ty, nch = sum_types ? 1 : T;
-  int* vol = out + ((size_t)b * nch + ch) * L * L * L;
+  unsigned* vol = out + ((size_t)b * nch + ch) * L * L * L;
   for (int i = ci - 2; i <= ci + 2; i++) {
     if (i < 0 || i >= L) continue;
     const float dx = x - i * res;
@@ -58,17 +60,17 @@ k_project_atoms(const float* __restrict__ coords, const int* __restrict__ ntype,
         if (k < 0 || k >= L) continue;
         const float dz = z - k * res;
         const float w = expf(-0.5f * (dx * dx + dy * dy + dz * dz));
-        atomicAdd(&vol[((size_t)i * L + j) * L + k], (int)rintf(w * DLPD_SPLAT_SCALE));
+        atomicAdd(&vol[((size_t)i * L + j) * L + k], (unsigned)rintf(w * DLPD_SPLAT_SCALE));
       }
     }
   }
 }
 
 // fixed point -> float, in place (both are 4 bytes per voxel)
-__global__ void __launch_bounds__(256) k_splat_to_float(int* __restrict__ acc, size_t n) {
+__global__ void __launch_bounds__(256) k_splat_to_float(unsigned* __restrict__ acc, size_t n) {
   float* f = reinterpret_cast<float*>(acc);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const int v = acc[i];
+    const unsigned v = acc[i];
     f[i] = (float)v * (1.0f / DLPD_SPLAT_SCALE);
   }
 }
@@ -87,11 +89,11 @@ int dlpd_project_atoms(const float* coords, const int* num_atoms_of_type, const 
   if (hipMemsetAsync(out, 0, bytes, st) != hipSuccess) return DLPD_ERR_LAUNCH;
   const int total = B * stride_atoms;
   DLPD_LAUNCH(k_project_atoms, dim3((total + 255) / 256), dim3(256), 0, st, coords, num_atoms_of_type, offsets, R,
-              shift_x, shift_y, shift_z, reinterpret_cast<int*>(out), B, stride_atoms, ntypes, L, resolution, sum_types);
+              shift_x, shift_y, shift_z, reinterpret_cast<unsigned*>(out), B, stride_atoms, ntypes, L, resolution, sum_types);
   const size_t n = bytes / sizeof(float);
   size_t nblk = (n + 255) / 256;
   if (nblk > 16384) nblk = 16384;
-  DLPD_LAUNCH(k_splat_to_float, dim3((unsigned)nblk), dim3(256), 0, st, reinterpret_cast<int*>(out), n);
+  DLPD_LAUNCH(k_splat_to_float, dim3((unsigned)nblk), dim3(256), 0, st, reinterpret_cast<unsigned*>(out), n);
   return dlpd_check_launch();
 }
 

@@ -60,7 +60,15 @@ class DeviceTopList:
 
     def select(self, V, nb, cset=None):
         """V (nb, nvox) contiguous -> (scores, flat indices) (nb, K) in the reference's pick order.
-        cset: the candidate set the scoring kernel filled for exactly these nb rotations (or None)."""
+        cset: the candidate set the scoring kernel filled for exactly these nb rotations (or None).
+
+        Contract WITH a cset (the steady-state path of ``DockingEngine.step``): a rotation whose candidate list is
+        valid comes back with only the picks that can still enter the running list -- the scores <= tau (the K-th
+        score published by the last merge), in pick order, the rest of its row padded with +inf / index 0 -- which is
+        exactly what ``merge()`` needs and NOT the reference's full K picks (Docker.py:89-98); rotations without a valid
+        list (list not yet full, tau >= 0, overflow) get the full radix select.  A cset is SINGLE-USE: the select
+        consumes and resets its counters, so it must be refilled by the scoring kernel before the next select.  Callers
+        that want the reference's K picks per rotation pass ``cset=None``."""
         nvox = V[0].numel()
         if cset is None:
             self.lib.call("dlpd_topk_select", _ptr(V), nb, nvox, self.K, _ptr(self.cand_score), _ptr(self.cand_idx),
@@ -408,8 +416,9 @@ class DockingEngine:
         self.top.reset()
 
     def select_batch(self, V, nb, cset=None):
-        """Per-rotation picks of Docker.update_top (Docker.py:89-98) for V (nb, N^3); cset: the candidate set the
-        scoring kernel filled for this batch."""
+        """Per-rotation picks of Docker.update_top (Docker.py:89-98) for V (nb, N^3).  cset: the candidate set the
+        scoring kernel filled for this batch -- then the rows hold only the picks that can still enter the running list
+        (+inf padded) and the cset is consumed; see ``DeviceTopList.select``."""
         return self.top.select(V.reshape(nb, -1), nb, cset)
 
     def merge_batch(self, rot_ids, nb):

@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=$1; shift
 cd $ROOT
 mkdir -p gpurun_out/$TAG
-python bench.py --steps 60 --warmup 5 --cpu_rotations 0 --no_real_shapes "$@" > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err
+python bench.py --steps 60 --warmup 5 --cpu_rotations 0 --no_real_shapes --sustained_s 0 "$@" > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err
 python - <<PY
 import json
 d=json.load(open("gpurun_out/$TAG/bench.json"))

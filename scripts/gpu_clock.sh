@@ -4,7 +4,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/clock_$1; shift
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/c -- python3 $ROOT/bench.py --steps 40 --warmup 5 --cpu_rotations 0 --no_real_shapes "$@" > $OUT/log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/c -- python3 $ROOT/bench.py --steps 40 --warmup 5 --cpu_rotations 0 --no_real_shapes --sustained_s 0 "$@" > $OUT/log 2>&1
 python3 - <<PY
 import csv, glob, collections
 cc = glob.glob("$OUT/c/**/*counter_collection.csv", recursive=True)[0]

@@ -1,6 +1,6 @@
 import os as _os; _os.environ.setdefault("DLPD_ALLOW_GENERATED_ROTATIONS", "1")   # diagnostic script: SOI-sized generated set when the licensed files are absent
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import __graft_entry__ as entry
 entry.build()
@@ -14,13 +14,21 @@ model = GlobalDockingModel(repr_, SimpleFilter(repr_.get_num_outputs()), thresho
 rec, lig = repr_.make(L, "rec"), repr_.make(L, "lig")
 g = torch.Generator().manual_seed(2)
 recf, ligf = torch.rand(L, L, L, generator=g), torch.rand(L, L, L, generator=g)
-lists = []
+import hashlib, json
+lists, runs = [], []
 for nb in (16, 16, 10):
     dk = Docker(model, angle_inc=15, box_size=L, max_conf=K, device=dev)
     torch.cuda.synchronize(); t0 = time.time()
     lists.append(dk.dock_volumes(rec, lig, recf, ligf, batch_size=nb, write=False))
     torch.cuda.synchronize(); dt = time.time() - t0
     n = dk.rot.R.shape[0]
-    print("batch %d: %d rotations in %.2f s = %.0f rot/s (%.3g poses/s)" % (nb, n, dt, n / dt, n * 160 ** 3 / dt))
-assert lists[0] == lists[1] == lists[2]
-print("identical lists", len(lists[0]))
+    h = hashlib.sha256(repr(lists[-1]).encode()).hexdigest()
+    runs.append({"launch_batch": nb, "seconds": dt, "rot_per_s": n / dt, "pose_scores_per_s": n * 160 ** 3 / dt, "list_sha256": h})
+    print("batch %d: %d rotations in %.2f s = %.0f rot/s (%.3g poses/s)" % (nb, n, dt, n / dt, n * 160 ** 3 / dt), file=sys.stderr)
+same = lists[0] == lists[1] == lists[2]
+out = {"what": "complete 15-degree search at the reference's real shapes [16 @ 80^3, 32 @ 40^3] -> 160^3 through Docker.dock_volumes, K = %d" % K,
+       "rotations": int(n), "runs": runs, "identical_lists": same, "entries": len(lists[0])}
+print(json.dumps(out))
+if len(sys.argv) > 1:
+    json.dump(out, open(sys.argv[1], "w"), indent=1)
+assert same

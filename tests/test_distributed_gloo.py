@@ -114,3 +114,140 @@ def test_bench_spawns_its_own_ranks_when_started_as_plain_python():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry_run"],
                          env=dict(env, WORLD_SIZE="3"), capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# world size 8 (the node the scaling sweep runs on): uneven shards, empty shards, list sizes of the real search
+# ---------------------------------------------------------------------------------------------------------------
+class _CalledModel:
+    """A docking model with a forward of its own (not the reference's MLP): Docker calls it (path "call") between the
+    emulated rotation kernel and the emulated device top-K -- cheap enough on the emulator for dozens of rotations."""
+    threshold_clash = 1e9
+
+    def eval(self):
+        return self
+
+    def __call__(self, rec, lig):
+        r, l = rec[0], lig[0]
+        N = 2 * r.shape[-1]
+        f = torch.fft.irfftn(torch.fft.rfftn(r, s=(N, N, N)) * torch.conj(torch.fft.rfftn(l, s=(N, N, N))), s=(N, N, N))
+        return -f.abs().sum(dim=1)
+
+
+def _run8(rank, world, port, out, nrot):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(1)
+    from emu_lib import emu_lib
+    from oracle import docking_oracle as orc
+    from deeplocalproteindocking_amd.Docker import Docker
+    if world > 1:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    L, C, K = 8, 2, 25
+    g = torch.Generator().manual_seed(3)
+    rec, lig = torch.randn(1, C, L, L, L, generator=g), torch.randn(1, C, L, L, L, generator=g)
+    ang = np.random.RandomState(5).uniform(-np.pi, np.pi, size=(nrot, 3))
+    R = orc.euler_to_matrix(ang[:, 0], np.abs(ang[:, 1]), ang[:, 2])
+    dk = Docker(_CalledModel(), angle_inc=20, box_size=L, resolution=1.25, max_conf=K, rotations=R, device="cpu",
+                rank=rank, world_size=world, lib=emu_lib())
+    top = dk.dock_volumes([rec], [lig], None, None, batch_size=4, write=False)
+    assert dk.path == "call"
+    out[rank] = (top, len(dk.shard(nrot)))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _spawn(target, world, port, *args):
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    procs = [ctx.Process(target=target, args=(r, world, port, out) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    return out, procs
+
+
+def _join(procs):
+    for p in procs:
+        p.join(900)
+        assert p.exitcode == 0
+
+
+def test_eight_rank_uneven_shards_equal_single_process():
+    """54 rotations over 8 ranks: six ranks score 7, two score 6 (the remainder pattern of 1,854 % 8 = 6: six ranks get
+    one more); every rank must end with the single-process list."""
+    out, procs = _spawn(_run8, 8, 33100 + (os.getpid() % 2000), 54)
+    single = {}
+    _run8(0, 1, 0, single, 54)
+    _join(procs)
+    assert sorted(out[r][1] for r in range(8)) == [6, 6, 7, 7, 7, 7, 7, 7]
+    for r in range(8):
+        assert list(out[r][0]) == single[0][0]
+    assert len({t[0] % 8 for t in single[0][0]}) > 2            # entries from several shards
+
+
+def test_eight_ranks_with_three_empty_shards():
+    """5 rotations over 8 ranks: ranks 5, 6, 7 score nothing and still join the one all-gather."""
+    out, procs = _spawn(_run8, 8, 35200 + (os.getpid() % 2000), 5)
+    single = {}
+    _run8(0, 1, 0, single, 5)
+    _join(procs)
+    assert [out[r][1] for r in range(8)] == [1, 1, 1, 1, 1, 0, 0, 0]
+    for r in range(8):
+        assert list(out[r][0]) == single[0][0]
+
+
+def _gather_only(rank, world, port, out, nrot, K):
+    """The collective + merge alone at the real search's sizes: every rank keeps the top K of its interleaved shard of a
+    synthetic table of picks (heavy ties, signed zeros), one all-gather, the merged list must be the global sort."""
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from deeplocalproteindocking_amd.Docker.Docker import all_gather_top_entries
+    from deeplocalproteindocking_amd.engine import DeviceTopList
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    rot, idx, score, pick = _synthetic_picks(nrot)
+    mine = (rot % world) == rank
+    local = DeviceTopList.merge_entries([(rot[mine], idx[mine], score[mine], pick[mine])], K)
+    merged = all_gather_top_entries(local, K, world, None, "cpu")
+    out[rank] = tuple(np.asarray(a).tolist() for a in merged)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _synthetic_picks(nrot, per_rot=40):
+    rs = np.random.RandomState(11)
+    rot = np.repeat(np.arange(nrot), per_rot)
+    pick = np.tile(np.arange(per_rot), nrot)
+    idx = rs.randint(0, 128 ** 3, size=rot.size)
+    score = -np.round(rs.rand(rot.size) * 50).astype(np.float32) / 8      # 400 distinct values: ties everywhere
+    score[rs.rand(rot.size) < 0.01] = np.float32(-0.0)
+    return rot, idx, score, pick
+
+
+def test_eight_rank_gather_of_full_size_lists_equals_the_global_sort():
+    """1,854 rotations (the 20-degree set: 1,854 % 8 = 6), K = 2000, 40 picks per rotation with heavily tied scores: the
+    list every rank holds after the single all-gather equals the sort of ALL picks by (score, rotation, pick) -- the
+    reference's stable insertion order (Docker.py:100-105) -- entry for entry."""
+    nrot, K = 1854, 2000
+    out, procs = _spawn(_gather_only, 8, 37300 + (os.getpid() % 2000), nrot, K)
+    _join(procs)
+    rot, idx, score, pick = _synthetic_picks(nrot)
+    order = np.lexsort((pick, rot, score + np.float32(0.0)))[:K]
+    want = (rot[order].tolist(), idx[order].tolist(), score[order].tolist(), pick[order].tolist())
+    for r in range(8):
+        assert out[r][0] == want[0] and out[r][1] == want[1] and out[r][3] == want[3]
+        assert np.array_equal(np.asarray(out[r][2], dtype=np.float32), np.asarray(want[2], dtype=np.float32))
+
+
+def test_bench_eight_rank_launch_plumbing():
+    """`python bench.py --gpus 8 --dry_run`: the launcher the driver's scaling sweep uses, at the node's width."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1",
+                        "--dry_run"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"dry_run": True, "n_gpus": 8, "steps": 4, "warmup": 1}
