@@ -147,6 +147,43 @@ class Docker:
         self.engine = None
         atexit.register(self.cleanup)
 
+    # ------------------------------------------------------------------ the reference's operator objects
+    # Docker.py:29-40 creates TorchProteinLibrary operators as attributes; nothing outside the class reads them, but
+    # a subclass may.  They are thin views of the coords backend / the volume ops with TPL's call signatures,
+    # created on first use (the constructor must not need a GPU or a backend).
+    @property
+    def rotate(self):                       # CoordsRotate()(coords, R, num_atoms)
+        return self._need_backend().rotate
+
+    @property
+    def translate(self):                    # CoordsTranslate()(coords, T, num_atoms)
+        return self._need_backend().translate
+
+    translation = translate
+
+    @property
+    def pdb2coords(self):                   # PDB2CoordsUnordered()(filenames)
+        return self._need_backend().pdb2coords
+
+    @property
+    def assignTypes(self):                  # Coords2TypedCoords()(coords, resnames, atomnames, num_atoms)
+        return self._need_backend().assign_types
+
+    @property
+    def project(self):                      # TypedCoords2Volume(box_size, resolution)(coords, num_atoms_of_type, offsets)
+        be = self._need_backend()
+        return lambda coords, num_atoms_of_type, offsets: be.project(coords, num_atoms_of_type, offsets, self.box_size,
+                                                                     self.resolution, self.device)
+
+    @property
+    def convolve(self):                     # VolumeConvolution()(volume1, volume2): no clip (Docker.py:32)
+        from deeplocalproteindocking_amd.ops import VolumeConvolution
+        return VolumeConvolution(lib=self._lib)
+
+    @property
+    def vol_rotate(self):                   # VolumeRotation()(volume, R), pivoted as ``rotation_center`` says
+        return _PivotRotation(self)
+
     # ------------------------------------------------------------------ logging (Docker.py:63-84)
     def new_log(self, log_file_name, rewrite=True):
         """Open the .dat of the next target.  Resume rule of Docker.py:63-79: with ``rewrite=False`` a file
@@ -300,13 +337,14 @@ class Docker:
         if not (len(rec) == 1 or two_res):
             return None
         W1, b1, W2, b2 = params
-        if lib.call("dlpd_hidden_pad", int(W1.shape[0])) < 0 or W1.shape[1] != sum(v.shape[0] for v in rec):
+        HP = int(lib.call("dlpd_fused_hidden_pad", int(W1.shape[0]), int(L), int(two_res)))
+        if HP < 0 or W1.shape[1] != sum(v.shape[0] for v in rec):
             return None
         model = self.docking_model
         # one engine (multi-GB workspaces, side stream, top-list buffers) serves every pair of the same shape:
         # local_test.py docks hundreds of targets with one Docker
         C, C1, has_clash = rec[0].shape[0], (rec[1].shape[0] if two_res else 0), receptor_forbidden is not None
-        key = (int(L), int(C), int(C1), has_clash, int(lib.call("dlpd_hidden_pad", int(W1.shape[0]))), int(self.max_conf),
+        key = (int(L), int(C), int(C1), has_clash, HP, int(self.max_conf),
                int(batch_size), str(self.device), self.rotation_pivot(L))
         eng = self.engine if getattr(self, "_engine_key", None) == key else None
         if eng is None:

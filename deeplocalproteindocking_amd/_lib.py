@@ -21,6 +21,10 @@ SIGNATURES = {
     "dlpd_source_hash": (ctypes.c_char_p, []),
     "dlpd_grid_supported": (_i, [_i]),
     "dlpd_hidden_pad": (_i, [_i]),
+    "dlpd_fused_hidden_pad": (_i, [_i, _i, _i]),
+    "dlpd_generic_box_supported": (_i, [_i]),
+    "dlpd_correlate_generic_ws_bytes": (_sz, [_i, _i]),
+    "dlpd_correlate_generic": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p]),
     "dlpd_rotate_trilinear": (_i, [_p, _p, _p, _i, _i, _i, _ll, _f, _p]),
     "dlpd_zfft": (_i, [_p, _p, _p, _i, _i, _i, _ll, _i, _f, _p]),
     "dlpd_zfft_into": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _ll, _i, _f, _p]),
@@ -95,7 +99,7 @@ class DlpdLib:
     def call(self, name, *args):
         rc = getattr(self, "_" + name)(*args)
         if SIGNATURES[name][0] is _i and name not in ("dlpd_version", "dlpd_grid_supported", "dlpd_conv3d_supported",
-                                                      "dlpd_hidden_pad") and rc != 0:
+                                                      "dlpd_hidden_pad", "dlpd_fused_hidden_pad", "dlpd_generic_box_supported") and rc != 0:
             raise RuntimeError("dlpd: %s failed: %s" % (name, ERRORS.get(rc, rc)))
         return rc
 

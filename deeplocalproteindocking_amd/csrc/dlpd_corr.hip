@@ -1361,6 +1361,16 @@ int dlpd_hidden_pad(int H) {
 
 int dlpd_grid_supported(int L) { return (L == 32 || L == 40 || L == 64 || L == 80) ? 1 : 0; }
 
+// hidden width the FUSED pipeline pads H to on a fine grid of L^3 voxels per volume (two_res: plus a coarse grid of
+// (L/2)^3, the reference's layout): dlpd_hidden_pad's widths, and 48 -- the reference class default's hidden width,
+// two voxels per thread in the role-split K3 -- where that kernel exists; -1: no fused kernel (the ops path takes over)
+int dlpd_fused_hidden_pad(int H, int L, int two_res) {
+  const int hp = dlpd_hidden_pad(H);
+  if (hp > 0) return hp;
+  if (H <= 48 && dlpd_k3r_supported(L, 48, 1) && (!two_res || dlpd_k3r_supported(L / 2, 48, 2))) return 48;
+  return -1;
+}
+
 int dlpd_rotate_trilinear(const float* vol, const float* R, float* out, int B, int C, int L, long long vol_bstride,
                           float center, void* stream) {
   if (!vol || !R || !out || B <= 0 || C <= 0 || L <= 0) return DLPD_ERR_ARG;

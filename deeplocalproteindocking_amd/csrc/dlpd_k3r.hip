@@ -53,11 +53,17 @@ template <int N> DLPD_D void init_twiddles_k3r(cplx* tw, int tid, int nthreads) 
 #ifndef DLPD_K3R_FFT_PRIO
 #define DLPD_K3R_FFT_PRIO 0
 #endif
-template <int N> struct K3rCfg;
-template <> struct K3rCfg<64> { static constexpr int F = 4, M = 4, TY = 16, RAWBUF = 2; };
-template <> struct K3rCfg<80> { static constexpr int F = 5, M = 5, TY = 16, RAWBUF = 2; };
-template <> struct K3rCfg<128> { static constexpr int F = DLPD_K3R_F128, M = 8, TY = 16, RAWBUF = DLPD_K3R_RAWBUF128; };
-template <> struct K3rCfg<160> { static constexpr int F = 5, M = DLPD_K3R_M160, TY = 8, RAWBUF = 1; };
+// WIDE: hidden widths 33..48 (the reference class default: multiplier 16 -> [32, 64] channels -> hidden 48,
+// ProteinRepresentationModels.py:24,35-36): 96 accumulators are two voxels x 48 hidden units, so the filter waves
+// take two voxels per thread and the tile shrinks to 8 rows where 16 rows would need 16 filter waves.
+template <int N, bool WIDE> struct K3rCfg;
+template <> struct K3rCfg<64, false> { static constexpr int F = 4, M = 4, TY = 16, RAWBUF = 2; };
+template <> struct K3rCfg<80, false> { static constexpr int F = 5, M = 5, TY = 16, RAWBUF = 2; };
+template <> struct K3rCfg<128, false> { static constexpr int F = DLPD_K3R_F128, M = 8, TY = 16, RAWBUF = DLPD_K3R_RAWBUF128; };
+template <> struct K3rCfg<160, false> { static constexpr int F = 5, M = DLPD_K3R_M160, TY = 8, RAWBUF = 1; };
+template <> struct K3rCfg<80, true> { static constexpr int F = 5, M = 10, TY = 16, RAWBUF = 1; };
+template <> struct K3rCfg<128, true> { static constexpr int F = 4, M = 8, TY = 8, RAWBUF = 1; };
+template <> struct K3rCfg<160, true> { static constexpr int F = 5, M = 10, TY = 8, RAWBUF = 1; };
 
 #ifdef DLPD_STAMPS
 __device__ unsigned long long dlpd_stamps_k3r[32];
@@ -167,11 +173,11 @@ template <int N> DLPD_D void k3r_second_pass(cplx* S, int rowoff, int t, const c
 //           if has_clash (mask = corr_C < thr); aux: HP first-layer pre-activation planes on the coarse grid (or none)
 //   MODE 2: out (nb, HP, N,N,N) = b1 + W1rows^T clamp(corr): the coarse resolution's half of the first layer
 //   W1t  (C, HP) transposed + zero padded, b1 (HP), W2 (HP);  G channels per group (<= F * CPW)
-template <int N, int HP, int MODE> __global__ void __launch_bounds__(64 * (K3rCfg<N>::F + K3rCfg<N>::M))
+template <int N, int HP, int MODE> __global__ void __launch_bounds__(64 * (K3rCfg<N, (HP > 32)>::F + K3rCfg<N, (HP > 32)>::M))
 k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int C, int has_clash, int G,
                   const float* __restrict__ W1t, const float* __restrict__ b1, const float* __restrict__ W2,
                   float b2, int has_clip, float clip, float thr, K3Aux aux, int ntiles, int tpb, K3Cand cd) {
-  typedef K3rCfg<N> Cfg;
+  typedef K3rCfg<N, (HP > 32)> Cfg;
   constexpr int F = Cfg::F, M = Cfg::M, TY = Cfg::TY, RAWBUF = Cfg::RAWBUF;
   constexpr int NZ = N / 2 + 1, RS = N + 8, NPAIR = TY / 2, NYT = N / TY;
   constexpr int CPW = 8 / NPAIR;               // channels per transform wave: its 8 pencils = CPW channels x NPAIR row pairs
@@ -419,7 +425,7 @@ template <int N, int HP, int MODE> static int launch_k3r(const cplx* Bw, float* 
                                                          const float* W1t, const float* b1, const float* W2, float b2,
                                                          int has_clip, float clip, float thr, hipStream_t st, K3Aux aux,
                                                          K3Cand cd) {
-  typedef K3rCfg<N> Cfg;
+  typedef K3rCfg<N, (HP > 32)> Cfg;
   constexpr int RS = N + 8, NZ = N / 2 + 1, NPAIR = Cfg::TY / 2, CPW = 8 / NPAIR;
   constexpr int RAWC = ((NZ * NPAIR + 63) / 64) * 64;
   const size_t shmem = (size_t)(Cfg::F * 8 * RS + N) * sizeof(cplx) + (size_t)Cfg::RAWBUF * Cfg::F * CPW * RAWC * 16;
@@ -432,9 +438,9 @@ template <int N, int HP, int MODE> static int launch_k3r(const cplx* Bw, float* 
   return dlpd_check_launch();
 }
 
-// hidden widths the role-split kernel is compiled for (the accumulators of 4 voxels per thread)
+// hidden widths the role-split kernel is compiled for (96 accumulators: 4 voxels x <= 24..32, or 2 voxels x 48)
 int dlpd_k3r_supported(int L, int HP, int mode) {
-  if (HP != 2 && HP != 4 && HP != 8 && HP != 16 && HP != 24 && HP != 32) return 0;
+  if (HP != 2 && HP != 4 && HP != 8 && HP != 16 && HP != 24 && HP != 32 && HP != 48) return 0;
   if (mode == 1) return (L == 64 || L == 80) ? 1 : 0;
   if (mode == 2) return (L == 40) ? 1 : 0;
   return 0;
@@ -450,6 +456,7 @@ template <int N, int MODE> static int k3r_dispatch(int HP, const cplx* Bw, float
     case 16: return launch_k3r<N, 16, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
     case 24: return launch_k3r<N, 24, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
     case 32: return launch_k3r<N, 32, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 48: return launch_k3r<N, 48, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
     default: return DLPD_ERR_UNSUPPORTED;
   }
 }

@@ -12,7 +12,7 @@
 //   * the global list is the K smallest entries ordered by (score, rotation, pick order).
 //
 // Selection = exact radix select on unique 64-bit keys (order-preserving float key << 32 | idx):
-// 3 value digits + 2 index digits with early exit, multi-block histograms, then a compaction
+// 3 value digits + 3 index digits with early exit, multi-block histograms, then a compaction
 // and a one-block bitonic sort of the K survivors.  No host synchronisation anywhere.
 #include <dlpd_platform.h>
 #include "dlpd_internal.h"
@@ -43,8 +43,11 @@ DLPD_HD float key2f(unsigned k) {
   return __uint_as_float(u);
 }
 
-__device__ const int kShift[5] = {53, 42, 32, 11, 0};
-__device__ const int kBits[5] = {11, 11, 10, 11, 11};
+// digits of the 64-bit key, most significant first: three of the score (32 bits), three of the flat index (32 bits:
+// grids up to 2^31 voxels -- any box size the generic correlation path accepts)
+#define TOPK_NPASS 6
+__device__ const int kShift[TOPK_NPASS] = {53, 42, 32, 22, 11, 0};
+__device__ const int kBits[TOPK_NPASS] = {11, 11, 10, 10, 11, 11};
 
 __global__ void __launch_bounds__(256) k_topk_init(TopkState* st, int nb, unsigned K) {
   const int b = blockIdx.x;
@@ -106,9 +109,9 @@ __global__ void __launch_bounds__(256) k_topk_scan(TopkState* st, int pass) {
     if (bin == chunk * PER + PER) bin--;
     const int shift = kShift[pass];
     u64 kth = st[b].kth | ((u64)bin << shift);
-    if (cum + cnt == krem || pass == 4) {
+    if (cum + cnt == krem || pass == TOPK_NPASS - 1) {
       // everything in this bin (and below) is selected: close the key with all-ones below
-      if (pass != 4) kth |= ((u64)1 << shift) - 1;
+      if (pass != TOPK_NPASS - 1) kth |= ((u64)1 << shift) - 1;
       st[b].done = 1;
     } else {
       st[b].krem = krem - cum;
@@ -373,7 +376,7 @@ int dlpd_topk_select(const float* V, int nb, long long nvox, int K, float* out_s
 int dlpd_topk_select_cand(const float* V, int nb, long long nvox, int K, float* out_score, int* out_idx, void* ws,
                           const void* cand_keys, void* cand_count, int cap, void* stream) {
   if (!V || !out_score || !out_idx || !ws || nb <= 0 || nvox <= 0 || K <= 0) return DLPD_ERR_ARG;
-  if (K > TOPK_MAXK || (long long)K > nvox || nvox > (1ll << 22)) return DLPD_ERR_UNSUPPORTED;
+  if (K > TOPK_MAXK || (long long)K > nvox || nvox >= (1ll << 31)) return DLPD_ERR_UNSUPPORTED;
   if ((cand_keys != nullptr) != (cand_count != nullptr) || (cand_keys && (cap < 64 || cap > 8192))) return DLPD_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   TopkState* state = (TopkState*)ws;
@@ -388,7 +391,7 @@ int dlpd_topk_select_cand(const float* V, int nb, long long nvox, int K, float* 
     DLPD_LAUNCH(k_topk_from_cand, dim3(nb), dim3(256), shmem, st, state, (const u64*)cand_keys, (unsigned*)cand_count, nb,
                 cap, K, out_score, out_idx);
   }
-  for (int pass = 0; pass < 5; pass++) {
+  for (int pass = 0; pass < TOPK_NPASS; pass++) {
     DLPD_LAUNCH(k_topk_hist, dim3(TOPK_HIST_BLOCKS, nb), dim3(TOPK_HIST_THREADS), 0, st, V, nvox, state, pass);
     DLPD_LAUNCH(k_topk_scan, dim3(nb), dim3(256), 0, st, state, pass);
   }

@@ -150,6 +150,8 @@ class DockingEngine:
         dev = self.device
         f32 = torch.float32
         self.C1 = int(coarse_channels)
+        self.k3_form = int(k3_form)
+        self.fine_unfused = bool(fine_unfused)
         self.set_filter(W1, b1, W2, b2)
         nb, CT, NZ, N = self.batch, self.CT, self.NZ, self.N
         self.lig = torch.zeros(CT, L, L, L, dtype=f32, device=dev)
@@ -208,9 +210,11 @@ class DockingEngine:
         f32, dev, lib = torch.float32, self.device, self.lib
         W1 = torch.as_tensor(W1, dtype=f32).reshape(-1, self.C + self.C1)
         H = W1.shape[0]
-        HP = lib.call("dlpd_hidden_pad", int(H))
+        HP = lib.call("dlpd_fused_hidden_pad", int(H), self.L, int(self.C1 > 0))
         if HP < 0:
-            raise RuntimeError("dlpd: hidden width %d > 32 unsupported by the fused filter" % H)
+            raise RuntimeError("dlpd: hidden width %d has no fused filter kernel at box %d" % (H, self.L))
+        if HP > 32 and (getattr(self, "fine_unfused", False) or self.k3_form == 1):
+            raise RuntimeError("dlpd: hidden width %d runs on the role-split K3 only" % H)
         if getattr(self, "HP", HP) != HP:
             raise RuntimeError("dlpd: a live engine keeps its hidden width (%d), got %d" % (self.HP, HP))
         self.H, self.HP = H, HP

@@ -7,6 +7,7 @@ TorchProteinLibrary's volume ops, backed by libdlpd.so.
         reference calls: src/Docker/Docker.py:32,225 ; src/Models/DockingModels.py:48,71
 
 Inference only (the docking search runs under torch.no_grad(), local_test.py:67).
+Box sizes 32 / 40 / 64 / 80 run the compiled FFT pipeline, any other box (<= 128) a plan-free slow path.
 Build-defined conventions (TPL source absent, parity unpinned): rotation about index L/2 with
 trilinear interpolation and zeros outside; ``clip`` clamps the correlation OUTPUT to +-clip.
 """
@@ -59,7 +60,7 @@ class VolumeConvolution(nn.Module):
         B, C, L = v1.shape[0], v1.shape[1], v1.shape[2]
         lib = self.lib or get_lib()
         if not lib.call("dlpd_grid_supported", L):
-            raise RuntimeError("dlpd: VolumeConvolution box size %d not compiled (supported: 32, 40, 64, 80)" % L)
+            return self._forward_generic(v1, v2, lib)
         N, NZ, nvol = 2 * L, L + 1, B * C
         dev, st = v1.device, _stream(v1.device)
         wsA = torch.empty(nvol * NZ * L * L * 2, dtype=torch.float32, device=dev)
@@ -72,6 +73,29 @@ class VolumeConvolution(nn.Module):
         lib.call("dlpd_zifft_real", _ptr(wsB), _ptr(out), 1, nvol, L, 0 if self.clip is None else 1,
                  float(self.clip or 0.0), st)
         return out
+
+
+def _vc_generic(self, v1, v2, lib):
+    """Any other box size (the reference's ``box_size`` is free, Docker.py:18): the plan-free correlation of
+    dlpd_correlate_generic, in chunks of volumes that keep the scratch below ~4 GB."""
+    B, C, L = v1.shape[0], v1.shape[1], v1.shape[2]
+    if not lib.call("dlpd_generic_box_supported", L):
+        raise RuntimeError("dlpd: VolumeConvolution box size %d exceeds the generic path (box <= 128)" % L)
+    N, nvol = 2 * L, B * C
+    dev, st = v1.device, _stream(v1.device)
+    out = torch.empty(B, C, N, N, N, dtype=torch.float32, device=dev)
+    per = lib.call("dlpd_correlate_generic_ws_bytes", 1, L)
+    chunk = max(1, min(nvol, (4 << 30) // per, 65535 // N))
+    ws = torch.empty(per * chunk, dtype=torch.uint8, device=dev)
+    a, b, o = v1.reshape(nvol, -1), v2.reshape(nvol, -1), out.reshape(nvol, -1)
+    for beg in range(0, nvol, chunk):
+        n = min(chunk, nvol - beg)
+        lib.call("dlpd_correlate_generic", _ptr(a[beg]), _ptr(b[beg]), _ptr(o[beg]), n, L, 0 if self.clip is None else 1,
+                 float(self.clip or 0.0), _ptr(ws), st)
+    return out
+
+
+VolumeConvolution._forward_generic = _vc_generic
 
 
 def filter_volumes(conv_list, W1, b1, W2, b2, mask_norm=None, threshold=0.0, lib=None):

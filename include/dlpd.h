@@ -31,6 +31,11 @@ const char* dlpd_source_hash(void);
 int dlpd_grid_supported(int L);
 /* hidden width the filter kernel pads H to (2,4,8,16,24,32), -1 if H > 32 */
 int dlpd_hidden_pad(int H);
+/* Hidden width the FUSED pipeline (dlpd_zifft_filter*, dlpd_zifft_preact) pads H to on a fine grid of L^3 voxels
+ * (two_res: with a coarse (L/2)^3 grid, ProteinRepresentationModels.py:72-76): dlpd_hidden_pad's widths plus 48 -- the
+ * reference class default SimpleFilter([32, 64]) has hidden width 48 (DockingModels.py:25-27) -- where the role-split
+ * K3 is compiled (L = 64, 80; coarse 40); -1: no fused kernel for this width, use dlpd_filter_mask. */
+int dlpd_fused_hidden_pad(int H, int L, int two_res);
 
 /* TPL VolumeRotation call, src/Docker/Docker.py:218 (ctor :40; DockingModels.py:49).
  * out[b,c](i) = trilinear vol[b,c]( center + R_b^T (i - center) ), zeros outside.
@@ -97,6 +102,15 @@ int dlpd_rfft3d_padded(const float* vol, void* spec, void* wsA, int nvol, int L,
  * rec (CT spectra, or nb*CT with rec_bstride = CT*NZ*N*N); wsB: nb*CT*NZ*N*N complex64. */
 int dlpd_xy_correlate(const void* wsA, const void* rec, void* wsB, int nb, int CT, int L,
                       long long rec_bstride, void* stream);
+
+/* VolumeConvolution (Docker.py:32,225; DockingModels.py:48,71) for ANY box size -- `box_size` is a free constructor
+ * argument of the reference's Docker (Docker.py:18,22-24,31): out (nvol, N^3)[t mod N] = sum_r v1[r + t] v2[r], N = 2L,
+ * optional clamp to +-clip.  Direct O(n N) transforms, no radix plan: the slow path for boxes without a compiled
+ * pipeline (dlpd_grid_supported(L) == 0), L <= 128.  ws: dlpd_correlate_generic_ws_bytes(nvol, L) bytes of scratch. */
+int dlpd_generic_box_supported(int L);
+size_t dlpd_correlate_generic_ws_bytes(int nvol, int L);
+int dlpd_correlate_generic(const float* v1, const float* v2, float* out, int nvol, int L, int has_clip, float clip,
+                           void* ws, void* stream);
 
 /* Stage K3, plain: real correlation volumes out (nb, CT, N^3) [+ clamp to +-clip]
  * (output of VolumeConvolution(clip), DockingModels.py:48,71). */

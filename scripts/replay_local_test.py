@@ -19,7 +19,7 @@ rotation files from DLPD_ROTATIONS_DIR (or DLPD_ALLOW_GENERATED_ROTATIONS=1).
 
 Extras that the reference driver does not have (all optional): ``-seed`` fixes the random receptor
 rotation, ``-init_weights 1`` writes a randomly initialised checkpoint first when none exists (there
-are no trained weights in the reference tree), ``-report`` prints one JSON line with rotations/s.
+are no trained weights in the reference tree), ``-report`` prints one JSON line with rotations/s, the random receptor rotation and the two file names.
 """
 import argparse
 import json
@@ -110,7 +110,8 @@ def main():
             dt = time.perf_counter() - t0
             report.append({"target": pdb_name, "seconds": dt, "rotations": int(docker.rot.R.shape[0]),
                            "rot_per_s": docker.rot.R.shape[0] / dt, "launch_batch": docker.launch_batch,
-                           "path": getattr(docker, "path", None), "poses": len(docker.top_list)})
+                           "path": getattr(docker, "path", None), "poses": len(docker.top_list),
+                           "randR": docker.randR.reshape(3, 3).tolist(), "receptor": rec_path, "ligand": lig_path})
         else:
             print("Skipping", pdb_name)
     docker.cleanup()

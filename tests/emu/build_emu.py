@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.abspath(os.path.join(HERE, "..", "..", "deeplocalproteindocking_amd", "csrc"))
 OUT = os.path.join(HERE, "libdlpd_emu.so")
-SRCS = ["dlpd_corr.hip", "dlpd_k2.hip", "dlpd_k2q.hip", "dlpd_k3r.hip", "dlpd_topk.hip", "dlpd_atoms.hip", "dlpd_conv.hip", "dlpd_version.hip"]
+SRCS = ["dlpd_corr.hip", "dlpd_k2.hip", "dlpd_k2q.hip", "dlpd_k3r.hip", "dlpd_topk.hip", "dlpd_generic.hip", "dlpd_atoms.hip", "dlpd_conv.hip", "dlpd_version.hip"]
 
 
 def build(force=False):

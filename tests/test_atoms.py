@@ -221,8 +221,9 @@ class _Model(torch.nn.Module):
         self.representation, self.filter, self.threshold_clash, self.clip = repr_, filt, thr, 5.0
 
 
-def _dock_reference_shape(be, model, frec, flig, R, L, res, K):
-    """The reference loop of Docker.dockSE3 restated with the oracle pieces."""
+def _dock_reference_shape(be, model, frec, flig, R, L, res, K, randR=None):
+    """The reference loop of Docker.dockSE3 restated with the oracle pieces (randR: the random rotation the
+    reference applies to the receptor's atoms, Docker.py:193-194)."""
     centre = torch.full((1, 3), L * res / 2.0, dtype=torch.double)
 
     def load(f):
@@ -233,6 +234,7 @@ def _dock_reference_shape(be, model, frec, flig, R, L, res, K):
     rc, rn_, ro = load(frec)
     lc, ln_, lo = load(flig)
     rec = torch.from_numpy(orc.project_atoms(rc[0].numpy(), rn_[0].numpy(), ro[0].numpy(), L, res,
+                                             R=None if randR is None else np.asarray(randR, dtype=np.float64),
                                              shift=centre[0].numpy())).float()[None]
     lig = torch.from_numpy(orc.project_atoms(lc[0].numpy(), ln_[0].numpy(), lo[0].numpy(), L, res,
                                              shift=centre[0].numpy())).float()[None]
@@ -445,8 +447,8 @@ def test_user_defined_filter_and_model_are_called_on_gpu():
 
 
 def _run_wide_hidden(lib, device):
-    """Hidden width 40 > 32 (the fused K3 pads to at most 32; the class default multiplier=16 gives
-    48): the search must take the stand-alone ops + HIP filter kernel instead of raising."""
+    """Hidden width 40 > 32 at box 32, where the fused pipeline has no wide-hidden kernel (it has at box 64 / 80:
+    dlpd_fused_hidden_pad): the search must take the stand-alone ops + HIP filter kernel instead of raising."""
     from deeplocalproteindocking_amd.Docker import Docker
     from deeplocalproteindocking_amd.Models import GlobalDockingModel, SimpleFilter, SyntheticRepr
     L, C, K, thr = 32, 4, 25, 4000.0
@@ -462,6 +464,88 @@ def _run_wide_hidden(lib, device):
     got = dk.dock_volumes([rec], [lig], recf, ligf, write=False)
     assert dk.path == "ops"
     _check_lists(got, want[0], scale, K)
+
+
+def _oracle_list_with_pivot(rec, lig, recf, ligf, R, W, thr, K, pivot):
+    top, scale, N = [], 0.0, 2 * rec.shape[-1]
+    for ri in range(R.shape[0]):
+        Rb = torch.from_numpy(R[ri:ri + 1]).float()
+        lrot = [orc.rotate_volume(lig, Rb, center=pivot)]
+        lf = orc.rotate_volume(ligf[None, None], Rb, center=pivot)
+        mask, _ = orc.clash_mask(recf[None, None], lf, thr)
+        V = (mask * orc.score_volumes([rec], lrot, *W, clip=5.0))[0].contiguous()
+        scale = max(scale, float(V.abs().max()))
+        idx, sc = orc.rotation_picks_fast(V.numpy(), K)
+        x, y, z = orc.flat_to_xyz(idx, N)
+        top += [(ri, int(x[i]), int(y[i]), int(z[i]), float(sc[i])) for i in range(K)]
+        top.sort(key=lambda t: t[4])
+        top = top[:K]
+    return top, scale
+
+
+def _run_rotation_pivot(lib, device, L):
+    """``Docker(rotation_center=...)`` moves the pivot of the trilinear volume rotation (the one TorchProteinLibrary
+    convention most likely to differ from this build's, unpinnable here): "grid_sample" = index (L-1)/2.  The fused
+    engine (compiled box) and the stand-alone ops (any other box) must both follow it -- oracle with the same pivot --
+    and the default (L/2) must give a different list."""
+    from deeplocalproteindocking_amd.Docker import Docker
+    from deeplocalproteindocking_amd.Models import GlobalDockingModel, SimpleFilter, SyntheticRepr
+    C, K = 4, 20
+    thr = 0.12 * L ** 3
+    rec, lig, recf, ligf, R = _volume_case(35, C, L)
+    torch.manual_seed(6)
+    filt = SimpleFilter([C])
+    model = GlobalDockingModel(SyntheticRepr((C,)), filt, threshold_clash=thr, lib=lib).to(device)
+    W = [w.cpu() for w in filt.parameters_tuple()]
+    want, scale = _oracle_list_with_pivot(rec, lig, recf, ligf, R, W, thr, K, (L - 1) / 2.0)
+    dk = Docker(model, box_size=L, max_conf=K, rotations=R, device=device, lib=lib, rotation_center="grid_sample")
+    got = dk.dock_volumes([rec], [lig], recf, ligf, write=False)
+    _check_lists(got, want, scale, K)
+    default = Docker(model, box_size=L, max_conf=K, rotations=R, device=device, lib=lib).dock_volumes([rec], [lig], recf, ligf,
+                                                                                               write=False)
+    assert [t[:4] for t in default] != [t[:4] for t in got]
+    return dk.path
+
+
+def test_rotation_pivot_is_switchable_from_docker_emulated(emu):
+    assert _run_rotation_pivot(emu, "cpu", 32) == "fused"
+    assert _run_rotation_pivot(emu, "cpu", 12) == "ops"
+
+
+def _run_uncompiled_box(lib, device, L, K):
+    """A box size without a compiled FFT plan (the reference's box_size is a free argument, Docker.py:18,22-24,31):
+    Docker must run the search through the stand-alone ops -- generic plan-free correlation, HIP filter kernel, device
+    top-K -- instead of raising; ranked list against the oracle."""
+    from deeplocalproteindocking_amd.Docker import Docker
+    from deeplocalproteindocking_amd.Models import GlobalDockingModel, SimpleFilter, SyntheticRepr
+    C = 4
+    thr = 0.12 * L ** 3
+    rec, lig, recf, ligf, R = _volume_case(33, C, L)
+    torch.manual_seed(6)
+    filt = SimpleFilter([C])
+    model = GlobalDockingModel(SyntheticRepr((C,)), filt, threshold_clash=thr, lib=lib)
+    W = [w.cpu() for w in filt.parameters_tuple()]
+    want = orc.dock_volumes([rec], [lig], recf[None, None], ligf[None, None], R, *W, thr, K, clip=5.0, return_V=True)
+    scale = max(float(v.abs().max()) for v in want[1])
+    dk = Docker(model.to(device), box_size=L, max_conf=K, rotations=R, device=device, lib=lib)
+    got = dk.dock_volumes([rec], [lig], recf, ligf, write=False)
+    assert dk.path == "ops" and dk.engine is None
+    _check_lists(got, want[0], scale, K)
+
+
+def test_uncompiled_box_size_takes_the_generic_path_emulated(emu):
+    assert not emu.call("dlpd_grid_supported", 12) and emu.call("dlpd_generic_box_supported", 12)
+    assert not emu.call("dlpd_generic_box_supported", 129)
+    _run_uncompiled_box(emu, "cpu", 12, 20)
+
+
+@pytest.mark.gpu
+def test_uncompiled_box_sizes_take_the_generic_path_on_gpu():
+    """box_size 48 (grid 96^3) and 50 (grid 100^3: not a multiple of 8, radix 5) on the device."""
+    import __graft_entry__ as entry
+    entry.build()
+    _run_uncompiled_box(None, torch.device("cuda:0"), 48, 200)
+    _run_uncompiled_box(None, torch.device("cuda:0"), 50, 200)
 
 
 def test_hidden_width_above_32_takes_the_ops_path_emulated(emu):
@@ -514,6 +598,12 @@ def test_dockSE3_and_dockE3_on_gpu(tmp_path):
     s = max(abs(t[4]) for t in d1.top_list) + 1e-6
     assert max(abs(a[4] - b[4]) for a, b in zip(d1.top_list, d2.top_list)) <= 1e-4 * s
     assert sum(a[:4] == b[:4] for a, b in zip(d1.top_list, d2.top_list)) >= K - 2
+    # ... and both equal the oracle restatement of the loop (not only each other)
+    import copy
+    want2, scale2 = _dock_reference_shape(be, copy.deepcopy(gm).cpu(), frec, flig, I, L2, res, K)
+    for got2 in (d1.top_list, d2.top_list):
+        assert max(abs(a[4] - b[4]) for a, b in zip(got2, want2)) <= 1e-4 * scale2
+        assert sum(a[:4] == b[:4] for a, b in zip(got2, want2)) >= K - 2
 
 
 @pytest.mark.gpu

@@ -671,6 +671,16 @@ def test_k3_role_split_equals_the_channel_owning_k3(dev):
     _k3_both_formulations(None, dev, 80, 48, 24, 5.0, 7)
 
 
+def test_reference_class_default_hidden_width_48_is_fused(dev):
+    """The reference CLASS default (multiplier = 16: [32 @ 80^3, 64 @ 40^3] channels, SimpleFilter hidden width 48,
+    ProteinRepresentationModels.py:24,35-36 / DockingModels.py:25-27) on the fused pipeline -- fine K3 and the coarse
+    grid's pre-activation kernel with two voxels per filter thread -- against the oracle; and 48 ch x 64^3 at hidden
+    width 40 (8-row tiles at N = 128)."""
+    from test_kernels_emu import _fused_wide_hidden
+    _fused_wide_hidden(None, dev, 80, 32, 64, 48, 2, 93)
+    _fused_wide_hidden(None, dev, 64, 48, 0, 40, 2, 94)
+
+
 def test_topk_candidate_lists_from_k3_equal_the_full_select(dev, monkeypatch):
     """The candidate path of the top-K stage at BASELINE config 2 size (48 ch, 64^3, K = 2000, 60 rotations in batches
     of 16) and on the N = 160 tile-walking K3 (16 ch at 80^3): identical ranked lists with and without it."""

@@ -165,6 +165,17 @@ def test_docker_interface_surface():
     assert dk.box_length == 5.0 and dk.shard(10).tolist() == list(range(10))
     dk.rank, dk.world_size = 1, 4
     assert dk.shard(10).tolist() == [1, 5, 9]
+    # the reference's operator attributes (Docker.py:29-40) exist for subclasses that touch them
+    for name in ("rotate", "translate", "translation", "project", "convolve", "vol_rotate", "pdb2coords", "assignTypes"):
+        assert callable(getattr(dk, name)), name
+    moved = dk.translate(torch.zeros(1, 6, dtype=torch.double), torch.ones(1, 3, dtype=torch.double), torch.tensor([2], dtype=torch.int32))
+    assert moved.tolist() == [[1.0] * 6]
+    # pivot of the volume rotation: index L/2 by default, (L-1)/2 for torch's sampling-grid centre, scaled to coarse grids
+    assert dk.rotation_pivot(4) == 2.0 and dk.rotation_pivot(2) == 1.0
+    dk.rotation_center = "grid_sample"
+    assert dk.rotation_pivot(4) == 1.5 and dk.rotation_pivot(2) == 0.5
+    dk.rotation_center = 1.75
+    assert dk.rotation_pivot(4) == 1.75 and dk.rotation_pivot(2) == 0.875
 
 
 def test_simple_filter_matches_reference_structure(golden):

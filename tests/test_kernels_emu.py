@@ -498,6 +498,46 @@ def test_k3_role_split_equals_the_channel_owning_k3_emulated(emu):
     _k3_both_formulations(emu, "cpu", 64, 5, 20, 0.4, 77)
 
 
+def _fused_wide_hidden(lib, device, L, C, C1, H, nb, seed):
+    """Hidden widths 33..48 on the fused pipeline (role-split K3, two voxels per thread): V against the oracle."""
+    g = torch.Generator().manual_seed(seed)
+    rec, lig = torch.randn(C, L, L, L, generator=g) * 0.05, torch.randn(C, L, L, L, generator=g) * 0.05
+    recf, ligf = torch.rand(L, L, L, generator=g), torch.rand(L, L, L, generator=g)
+    rec1 = lig1 = None
+    if C1:
+        rec1 = torch.randn(C1, L // 2, L // 2, L // 2, generator=g) * 0.1
+        lig1 = torch.randn(C1, L // 2, L // 2, L // 2, generator=g) * 0.1
+    W1, b1 = torch.randn(H, C + C1, generator=g) * 0.4, torch.randn(H, generator=g) * 0.1
+    W2, b2 = torch.randn(1, H, generator=g), torch.randn(1, generator=g)
+    thr = 0.125 * L ** 3
+    eng = DockingEngine(L, C, W1, b1, W2, b2, clip=0.6, threshold_clash=thr, max_conf=10, batch=nb, device=device, lib=lib,
+                        coarse_channels=C1)
+    assert eng.HP == 48
+    eng.set_receptor(rec, recf, rec1)
+    eng.set_ligand(lig, ligf, lig1)
+    R = orc.euler_to_matrix([0.5, -2.1][:nb], [1.1, 0.3][:nb], [-0.4, 1.7][:nb])
+    V = eng.score_batch(torch.from_numpy(R).float().to(device).contiguous()).cpu().clone()
+    for i in range(nb):
+        Rb = torch.from_numpy(R[i:i + 1]).float()
+        rr, ll = [rec[None]], [orc.rotate_volume(lig[None], Rb)]
+        if C1:
+            rr.append(rec1[None])
+            ll.append(orc.rotate_volume(lig1[None], Rb))
+        S = orc.score_volumes(rr, ll, W1, b1, W2, b2, clip=0.6)[0]
+        mask, norm = orc.clash_mask(recf[None, None], orc.rotate_volume(ligf[None, None], Rb), thr)
+        sure = (norm[0] - thr).abs() > 1e-3 * thr
+        assert ((V[i] - mask[0] * S).abs()[sure]).max() <= 1e-4 * S.abs().max()
+        assert float((mask[0] == 0).float().mean()) > 0.01
+
+
+def test_hidden_width_48_is_fused_emulated(emu):
+    """Hidden width 40 (padded to 48) at N = 128: 8-row tiles, two voxels per filter thread, 3 + 1 channels (one group of
+    the four two-channel transform waves)."""
+    assert emu.call("dlpd_fused_hidden_pad", 40, 64, 0) == 48 and emu.call("dlpd_fused_hidden_pad", 40, 32, 0) == -1
+    assert emu.call("dlpd_fused_hidden_pad", 49, 64, 0) == -1 and emu.call("dlpd_fused_hidden_pad", 24, 32, 0) == 24
+    _fused_wide_hidden(emu, "cpu", 64, 3, 0, 40, 1, 91)
+
+
 def _search_with_and_without_candidate_lists(lib, device, L, C, K, nrot, batch, monkeypatch, seed=3):
     """The top-K candidate path (K3 appends every score below the running K-th score, the select takes that list
     instead of a radix select over V) must give exactly the list of the full select path."""

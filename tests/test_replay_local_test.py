@@ -84,6 +84,56 @@ def test_reference_driver_replay_dockSE3_and_dockE3(tmp_path):
     assert len(open(os.path.join(rep4["test_dir"], "1SYN.dat")).read().strip().split("\n")) == 2000
 
 
+@pytest.mark.gpu
+def test_reference_driver_replay_scores_equal_the_oracle(tmp_path):
+    """The poses the unchanged call sequence writes -- not only their count and order: a 10-row ``oim20.eul`` in
+    DLPD_ROTATIONS_DIR makes local_test.py's own calls (``Docker(..., angle_inc=20, randomize_rot=True)``,
+    ``dockSE3(rec, lig, batch_size=2)``) search ten rotations; the .dat is compared line by line with the oracle
+    restatement of Docker.py:184-238 on the same files, checkpoint and random receptor rotation: scores within
+    1e-4 of max|V|, pose columns identical except for swaps inside that band."""
+    import numpy as np
+    import torch
+    import __graft_entry__ as entry
+    entry.build()
+    from test_atoms import _dock_reference_shape
+    from deeplocalproteindocking_amd.Docker import Docker
+    from deeplocalproteindocking_amd.Models import GlobalDockingModel, SE3MultiResReprScalar, SimpleFilter
+    from deeplocalproteindocking_amd.Utils.FullAtom import CoordsBackend
+    from deeplocalproteindocking_amd.Utils.Rotations import euler_to_matrices
+    root = str(tmp_path)
+    make_benchmark(root, targets=(("1SYN", 60, 40, 21),))
+    rotdir = os.path.join(root, "rotations")
+    os.makedirs(rotdir)
+    ang = np.random.RandomState(17).uniform(-np.pi, np.pi, size=(10, 3))
+    ang[:, 1] = np.abs(ang[:, 1])
+    np.savetxt(os.path.join(rotdir, "oim20.eul"), ang, fmt="%.9f")
+    ang = np.loadtxt(os.path.join(rotdir, "oim20.eul")).reshape(-1, 3)     # what the loader parses
+    rep, _ = _replay(root, "logC", extra_env={"DLPD_ROTATIONS_DIR": rotdir, "DLPD_ALLOW_GENERATED_ROTATIONS": ""},
+                     extra_args=["-rewrite", "1", "-threshold_clash", "3.0"])
+    t = rep["targets"][0]
+    assert t["rotations"] == 10 and t["path"] == "fused" and t["poses"] == 2000
+    got = [[float(v) for v in l.split("\t")] for l in open(os.path.join(rep["test_dir"], "1SYN.dat")).read().strip().split("\n")]
+    # the same model from the checkpoint the replay wrote, on the CPU
+    repr_ = SE3MultiResReprScalar(multiplier=8)
+    model = GlobalDockingModel(repr_, SimpleFilter(repr_.get_num_outputs()), threshold_clash=3.0)
+    model.load(os.path.join(root, "models", "LocalDebugSE3"), epoch=299)
+    R = euler_to_matrices(ang[:, 0], ang[:, 1], ang[:, 2])
+    randR = np.asarray(t["randR"], dtype=np.float64)
+    want, scale = _dock_reference_shape(CoordsBackend(), model, t["receptor"], t["ligand"], R, 80, 1.25, 2000, randR=randR)
+    # the oracle's list in the .dat's own format (Docker.write_conformations: index wrap, resolution, randR undone)
+    ref = Docker(model, angle_inc=20, box_size=80, resolution=1.25, max_conf=2000, rotations=R, device="cpu")
+    ref.randomize_rot, ref.randR = True, torch.from_numpy(randR).reshape(1, 3, 3)
+    ref.top_list = want
+    assert ref.new_log(os.path.join(root, "oracle.dat"))
+    ref.write_conformations()
+    ref.cleanup()
+    exp = [[float(v) for v in l.split("\t")] for l in open(os.path.join(root, "oracle.dat")).read().strip().split("\n")]
+    assert len(got) == len(exp) == 2000
+    assert max(abs(a[12] - b[12]) for a, b in zip(got, exp)) <= 1e-4 * scale
+    same = sum(1 for a, b in zip(got, exp) if max(abs(x - y) for x, y in zip(a[:12], b[:12])) < 1e-5)
+    assert same >= 2000 - 40, same                                 # swaps only between scores closer than the band
+
+
 def test_synthetic_benchmark_directory_is_what_the_loader_reads(tmp_path):
     from deeplocalproteindocking_amd.Dataset import get_benchmark_stream
     bench = make_benchmark(str(tmp_path), targets=(("1SYN", 30, 20, 3), ("2SYN", 25, 15, 9)))
