@@ -129,9 +129,19 @@ def test_reference_driver_replay_scores_equal_the_oracle(tmp_path):
     ref.cleanup()
     exp = [[float(v) for v in l.split("\t")] for l in open(os.path.join(root, "oracle.dat")).read().strip().split("\n")]
     assert len(got) == len(exp) == 2000
-    assert max(abs(a[12] - b[12]) for a, b in zip(got, exp)) <= 1e-4 * scale
-    same = sum(1 for a, b in zip(got, exp) if max(abs(x - y) for x, y in zip(a[:12], b[:12])) < 1e-5)
-    assert same >= 2000 - 40, same                                 # swaps only between scores closer than the band
+    tol = 1e-4 * scale
+    assert max(abs(a[12] - b[12]) for a, b in zip(got, exp)) <= tol          # rank by rank
+    # pose by pose: every written pose is a pose of the oracle's list with the same score (to the tolerance) -- rows
+    # may be swapped only among scores closer than the band, and only poses within the band of the K-th score may
+    # differ between the two lists (they are cut off at different sides of the boundary)
+    key = lambda row: tuple(int(round(v * 1e4)) for v in row[:12])
+    exp_score = {key(r): r[12] for r in exp}
+    missing = [r for r in got if key(r) not in exp_score]
+    assert all(abs(r[12] - exp[-1][12]) <= tol for r in missing), len(missing)
+    assert len(missing) <= 20
+    assert max(abs(r[12] - exp_score[key(r)]) for r in got if key(r) in exp_score) <= tol
+    same_row = sum(1 for a, b in zip(got, exp) if key(a) == key(b))
+    assert same_row >= 1800, same_row                                        # most rows are not even swapped
 
 
 def test_synthetic_benchmark_directory_is_what_the_loader_reads(tmp_path):
