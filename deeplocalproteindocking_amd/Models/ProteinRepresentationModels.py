@@ -18,8 +18,10 @@ tests compare against; training is outside this build).
 Loading reference checkpoints: ``E3MultiResRepr4x4`` loads ``*_repr_epochN.th`` of the reference
 as they are (identical module tree: ``conv1.{0,2,4,6,8}.weight``, ``conv2.{1,3,5,7}.weight``).
 ``SE3MultiResReprScalar`` cannot: se3cnn stores, per layer, coefficients on ITS radial basis, and
-neither that basis nor its version is in the reference tree.  ``IsotropicConv3d.load_radial_profile``
-documents what a user who has se3cnn supplies instead: the dense kernels it produces.
+neither that basis nor its version is in the reference tree.  ``SE3MultiResReprScalar.load_dense_kernels`` is the
+hand-over for a user who has se3cnn: the eight dense (cout, cin, 5, 5, 5) kernels it evaluates, by the reference's own
+module names (``dense_kernel_contract``), used as they are -- the scalar-field SE3Convolution is a plain conv3d with that
+kernel, so the representation then IS the reference's.
 """
 import os
 import warnings
@@ -153,6 +155,7 @@ class IsotropicConv3d(Module):
         shells = torch.stack([torch.exp(-0.5 * ((r - k) / sigma) ** 2) for k in range(nr)])
         shells = shells * (r <= size // 2 + 0.5)                      # spherical support
         self.register_buffer("shells", shells / shells.flatten(1).norm(dim=1)[:, None, None, None])
+        self.register_buffer("dense", None)        # se3cnn's dense kernel once load_dense_kernel(exact=True) has run
         self.weight = nn.Parameter(torch.empty(cout, cin, nr))
         # He-style scale for inputs that vary slowly across the 5^3 window (atom densities are smooth
         # and non-negative): the gain that matters is the kernel SUM, not its norm; without this the
@@ -161,7 +164,22 @@ class IsotropicConv3d(Module):
         nn.init.normal_(self.weight, std=(2.0 / (cin * dc2)) ** 0.5)
 
     def kernel(self):
+        if self.dense is not None:                 # se3cnn's own kernel, handed over as it is (load_dense_kernel)
+            return self.dense
         return torch.einsum("oik,kxyz->oixyz", self.weight, self.shells)
+
+    def load_dense_kernel(self, dense_kernel, exact=True):
+        """The dense (cout, cin, size, size, size) kernel se3cnn evaluates for this layer.  exact: it is used AS IS from now
+        on (the layer stops being parametrised by its own shells -- inference with reference weights); otherwise it is
+        projected onto the shells (load_radial_profile).  Returns the relative residual of that projection either way."""
+        K = torch.as_tensor(dense_kernel, dtype=torch.float32)
+        want = (self.weight.shape[0], self.weight.shape[1]) + tuple(self.shells.shape[1:])
+        if tuple(K.shape) != want:
+            raise Exception("Dense kernel shape mismatch", tuple(K.shape), want)
+        res = self.load_radial_profile(K)
+        if exact:
+            self.dense = K.to(self.weight.device).contiguous()
+        return res
 
     hip_lib = None                     # tests: the emulated library
 
@@ -210,6 +228,37 @@ class SE3MultiResReprScalar(Module):
 
     def get_num_outputs(self):
         return [self.num_outputs_res0, self.num_outputs_res1]
+
+    # ---- hand-over of a reference checkpoint by users who have se3cnn --------------------------------------------
+    def dense_kernel_contract(self):
+        """{tensor name: shape} of the dense kernels ``load_dense_kernels`` expects: one per SE3Convolution of the
+        reference module tree (ProteinRepresentationModels.py:38-61: ``sequence_res0.{0,2,4,6}``,
+        ``sequence_res1.{0,2,4,6}``; the odd indices are the ScalarActivations, which have no parameters with
+        ``bias=False``), each (cout, cin, 5, 5, 5) -- what ``SE3Convolution.kernel()`` returns there for scalar
+        (l = 0) fields, where it is the convolution weight passed to ``conv3d`` (stride 2 on ``sequence_res1.0``)."""
+        out = {}
+        for seq_name in ("sequence_res0", "sequence_res1"):
+            for i, m in enumerate(getattr(self, seq_name)):
+                if isinstance(m, IsotropicConv3d):
+                    out["%s.%d" % (seq_name, i)] = (m.weight.shape[0], m.weight.shape[1]) + tuple(m.shells.shape[1:])
+        return out
+
+    def load_dense_kernels(self, kernels, exact=True):
+        """kernels: {name: tensor} exactly as ``dense_kernel_contract()`` lists them (missing / unknown names and wrong
+        shapes raise).  With se3cnn installed next to the reference:
+            ref = SE3MultiResReprScalar(multiplier=8); ref.load_state_dict(torch.load('DPD_Model_repr_epoch299.th'))
+            kernels = {'%s.%d' % (s, i): getattr(ref, s)[i].kernel().detach() for s in ('sequence_res0', 'sequence_res1')
+                       for i in (0, 2, 4, 6)}
+        Returns {name: relative residual of the projection onto this build's radial shells} (exact=True keeps the dense
+        kernels themselves, so the residual is only a diagnostic then)."""
+        want = self.dense_kernel_contract()
+        if set(kernels) != set(want):
+            raise Exception("Dense kernel names do not match the contract", sorted(set(kernels) ^ set(want)))
+        res = {}
+        for name, shape in want.items():
+            seq_name, idx = name.split(".")
+            res[name] = getattr(self, seq_name)[int(idx)].load_dense_kernel(kernels[name], exact=exact)
+        return res
 
     def forward(self, volume):
         vol1 = self.sequence_res0(volume)

@@ -1,1 +1,2 @@
 from .DockerParser import DockerParser, kabsch_rmsd
+from . import InterfaceSelection

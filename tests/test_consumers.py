@@ -70,3 +70,83 @@ def test_kabsch_rmsd_and_pose_reconstruction(tmp_path):
     rec = X[15:]
     native = torch.cat([rec, want]) @ R.t() + 4.0                # the same complex in another frame
     assert dp.interface_rmsd([(rec, lig)], [native], 0) < 1e-9
+
+
+def _write_chain_pdb(path, chain, residues, Q=None, shift=None, skip=()):
+    """residues: [(resnum, resname, {atomname: xyz})]; optional rigid motion x -> Q x + shift; ``skip``: residue numbers
+    left out (an unbound structure with missing residues)."""
+    from synth_pdb import _atom_line
+    lines, serial = [], 1
+    for resnum, resname, atoms in residues:
+        if resnum in skip:
+            continue
+        for an, xyz in atoms.items():
+            p = np.asarray(xyz, dtype=np.float64)
+            if Q is not None:
+                p = Q @ p + shift
+            lines.append(_atom_line("ATOM", serial, an, " ", resname, chain, resnum, " ", p, an[0]))
+            serial += 1
+    lines.append("END")
+    open(path, "w").write("\n".join(lines) + "\n")
+
+
+def test_interface_selection_and_irmsd_from_four_pdb_files(tmp_path):
+    """EvaluateBenchmark.get_irmsd's data flow (EvaluateBenchmark.py:44-113) on a synthetic target: contact residues of the
+    bound complex (5 A, any atom), transferred to unbound structures that miss residues and sit in other frames,
+    C-alpha selections, and the superposed interface RMSD of every pose of a .dat -- against a brute-force computation."""
+    from synth_pdb import RES
+    from deeplocalproteindocking_amd.Results import InterfaceSelection as isel
+    rs = np.random.RandomState(4)
+    names = [n for n in RES if n not in ("GLY",)]
+
+    def chain(n, origin, first):
+        out, pos = [], np.asarray(origin, dtype=np.float64)
+        for k in range(n):
+            step = rs.normal(size=3)
+            pos = pos + step * (3.8 / np.linalg.norm(step)) * np.array([1.0, 0.35, 0.35])      # an elongated coil along x
+            rn = names[rs.randint(len(names))]
+            atoms = {"N": pos + [0, 1.3, 0], "CA": pos, "C": pos + [1.2, -0.6, 0], "O": pos + [1.4, -1.8, 0.3],
+                     "CB": pos + [-0.6, -0.8, 1.2]}
+            out.append((first + k, rn, atoms))
+        return out
+    rec = chain(40, (0.0, 0.0, 0.0), 5)
+    lig = chain(30, (20.0, 6.0, 0.0), 101)              # runs alongside part of the receptor, ~6 A away
+    Qr, Ql = orc.euler_to_matrix(0.3, 0.8, -1.0), orc.euler_to_matrix(-2.0, 0.4, 0.9)
+    sr, sl = np.array([12.0, -7.0, 3.0]), np.array([-40.0, 15.0, 22.0])
+    f = {k: str(tmp_path / (k + ".pdb")) for k in ("rb", "lb", "ru", "lu")}
+    _write_chain_pdb(f["rb"], "A", rec)
+    _write_chain_pdb(f["lb"], "B", lig)
+    _write_chain_pdb(f["ru"], "A", rec, Qr, sr, skip=(9, 30))          # unbound structures: other frames, missing residues
+    _write_chain_pdb(f["lu"], "B", lig, Ql, sl, skip=(110,))
+    br, bl, ur, ul = (isel.read_structure(f[k]) for k in ("rb", "lb", "ru", "lu"))
+    # contacts against a brute-force search over the bound files as written
+    rec_sel, lig_sel = isel.get_contacts(br, bl, 5.0)
+    d = np.linalg.norm(br["xyz"][:, None, :] - bl["xyz"][None, :, :], axis=2) < 5.0
+    assert sorted({int(n) for n in br["resnum"][d.any(axis=1)]}) == [r[1] for r in rec_sel]
+    assert sorted({int(n) for n in bl["resnum"][d.any(axis=0)]}) == [r[1] for r in lig_sel]
+    assert 4 <= len(rec_sel) <= 30 and 4 <= len(lig_sel) <= 25
+    # alignment maps residue numbers across the gaps; missing residues are dropped from both sides
+    pairs, ident = isel.align_global("ACDEFGH", "ACEFGH")
+    assert pairs == [(0, 0), (1, 1), (3, 2), (4, 3), (5, 4), (6, 5)] and abs(ident - 6.0 / 7.0) < 1e-12
+    (urec, ulig, brec, blig), = isel.unbound_interfaces(br, bl, ur, ul)
+    assert [r[1] for r in urec] == [r[1] for r in brec] == [r[1] for r in rec_sel if r[1] not in (9, 30)]
+    assert [r[1] for r in ulig] == [r[1] for r in blig] == [r[1] for r in lig_sel if r[1] != 110]
+    # the pose that re-assembles the complex in the docking frame (each unbound structure centred on its bounding box)
+    R = Qr @ Ql.T
+    t = -(isel.bbox_centre(ur) - sr) + R @ (isel.bbox_centre(ul) - sl)
+    rows = ["\t".join("%f" % v for v in list(R.reshape(-1)) + list(t) + [-3.0]),
+            "\t".join("%f" % v for v in list(orc.euler_to_matrix(1.0, 2.0, 0.5).reshape(-1)) + [4.0, -9.0, 1.0, -2.0])]
+    (tmp_path / "T.dat").write_text("\n".join(rows) + "\n")
+    dp = DockerParser(str(tmp_path))
+    got = isel.evaluate_target(dp, "T", f["rb"], f["lb"], f["ru"], f["lu"])
+    assert isel.evaluate_target(dp, "missing", f["rb"], f["lb"], f["ru"], f["lu"]) is None
+    # brute force: the same selections by residue number, poses as parse_output keeps them (truncated translation)
+    ca = lambda s, sel: torch.from_numpy(np.stack([s["xyz"][(s["resnum"] == r[1]) & (s["atomname"] == "CA")][0] for r in sel]))
+    static = torch.cat([ca(br, brec), ca(bl, blig)])
+    want = []
+    for Rp, tp, _ in dp.target_dict["conformations"]:
+        mob = torch.cat([ca(ur, urec) - torch.from_numpy(isel.bbox_centre(ur)),
+                         (ca(ul, ulig) - torch.from_numpy(isel.bbox_centre(ul))) @ Rp[0].t() + tp[0]])
+        want.append(float(kabsch_rmsd(mob, static)))
+    assert len(got) == 2 and np.allclose(got, want, atol=1e-9)
+    assert got[0] < 1.0 < got[1]                        # the exact pose is off by the truncated fraction of t only

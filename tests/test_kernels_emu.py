@@ -322,6 +322,51 @@ def test_isotropic_layer_takes_dense_radial_kernels():
     assert dst.load_radial_profile(K + 0.05 * torch.randn_like(K)) > 1e-3
 
 
+def test_se3_representation_takes_the_reference_checkpoint_as_dense_kernels():
+    """The tensor contract for loading a reference SE3 checkpoint through se3cnn-evaluated kernels
+    (ProteinRepresentationModels.py:38-61): eight tensors named after the reference's module tree, (cout, cin, 5, 5, 5);
+    used as they are, the plugin computes exactly conv3d / ReLU with those kernels (stride 2 on sequence_res1.0)."""
+    import pytest
+    from deeplocalproteindocking_amd.Models import SE3MultiResReprScalar
+    for mult in (8, 16):
+        m = SE3MultiResReprScalar(multiplier=mult)
+        c0, c1 = 2 * mult, 4 * mult
+        want = {"sequence_res0.0": (c0, 11, 5, 5, 5), "sequence_res0.2": (c0, c0, 5, 5, 5), "sequence_res0.4": (c0, c0, 5, 5, 5),
+                "sequence_res0.6": (c0, c0, 5, 5, 5), "sequence_res1.0": (c1, c0, 5, 5, 5), "sequence_res1.2": (c1, c1, 5, 5, 5),
+                "sequence_res1.4": (c1, c1, 5, 5, 5), "sequence_res1.6": (c1, c1, 5, 5, 5)}
+        assert m.dense_kernel_contract() == want
+    torch.manual_seed(9)
+    m = SE3MultiResReprScalar(multiplier=1)                     # [2 @ L^3, 4 @ (L/2)^3]: small enough for torch on the CPU
+    kernels = {k: torch.randn(*shape) * 0.05 for k, shape in m.dense_kernel_contract().items()}   # NOT radial
+    res = m.load_dense_kernels(kernels)
+    assert set(res) == set(kernels) and min(res.values()) > 0.1           # far from the shells: kept exactly anyway
+    x = torch.rand(1, 11, 12, 12, 12)
+    with torch.no_grad():
+        got = m(x)
+        y = x
+        for i in (0, 2, 4, 6):
+            y = torch.nn.functional.conv3d(y, kernels["sequence_res0.%d" % i], padding=2)
+            y = torch.relu(y) if i < 6 else y
+        z = y
+        for i in (0, 2, 4, 6):
+            z = torch.nn.functional.conv3d(z, kernels["sequence_res1.%d" % i], padding=2, stride=2 if i == 0 else 1)
+            z = torch.relu(z) if i < 6 else z
+    assert torch.allclose(got[0], y, atol=1e-6) and torch.allclose(got[1], z, atol=1e-6)
+    assert got[0].shape == (1, 2, 12, 12, 12) and got[1].shape == (1, 4, 6, 6, 6)
+    with pytest.raises(Exception, match="names do not match"):
+        m.load_dense_kernels({k: v for k, v in kernels.items() if k != "sequence_res1.6"})
+    with pytest.raises(Exception, match="shape mismatch"):
+        m.load_dense_kernels(dict(kernels, **{"sequence_res0.0": torch.zeros(2, 11, 3, 3, 3)}))
+    # radial kernels survive the projection mode too (exact=False re-parametrises on the shells)
+    src = SE3MultiResReprScalar(multiplier=1)
+    radial = {k: getattr(src, k.split(".")[0])[int(k.split(".")[1])].kernel().detach() for k in src.dense_kernel_contract()}
+    m2 = SE3MultiResReprScalar(multiplier=1)
+    assert max(m2.load_dense_kernels(radial, exact=False).values()) < 1e-5
+    with torch.no_grad():
+        a, b = src(x), m2(x)
+    assert torch.allclose(a[1], b[1], atol=1e-5)
+
+
 def test_topk_kernels_fuzz_against_faithful_update_top(emu):
     """Randomised small volumes built to provoke every corner of Docker.update_top (Docker.py:86-105): many
     exact ties, zeros of both signs, fewer negatives than K, no zero at all, K up to the voxel count, batches
