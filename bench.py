@@ -574,13 +574,16 @@ def pmc_traffic(workload, C, L, nb, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
     (profiles/*_pmc_traffic.json; FETCH_SIZE doubled per the gfx950 note), newest round first."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
         try:
             pmc = json.load(open(path))
-            if pmc["config"] == {"channels": C, "box": L, "batch": nb} and kernel in pmc["bytes_per_launch"]:
+            cfg = pmc["config"]
+            if (cfg.get("channels"), cfg.get("box"), cfg.get("batch")) == (C, L, nb) and kernel in pmc["bytes_per_launch"]:
                 t = pmc["bytes_per_launch"][kernel]
-                return (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0, \
-                    "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per gfx950 note)" % os.path.basename(path)
+                scale = float(t.get("fetch_scale", 2.0))
+                return (scale * t["fetch_kb"] + t["write_kb"]) * 1024.0, \
+                    "profiles/%s (rocprofv3 --pmc FETCH_SIZE x %.0f / WRITE_SIZE; gfx950 tallies 128-byte read requests at 64 bytes)" % (
+                        os.path.basename(path), scale)
         except Exception:
             continue
     return None, None
