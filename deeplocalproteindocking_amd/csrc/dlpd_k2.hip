@@ -726,10 +726,14 @@ int dlpd_k2q_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb
 #ifndef DLPD_K2_Q4
 #define DLPD_K2_Q4 1
 #endif
+#ifndef DLPD_K2_S4
+#define DLPD_K2_S4 1
+#endif
 
 int dlpd_k2_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, int L, long long rbs, hipStream_t st,
                       int transposed) {
-  if (DLPD_K2_Q4 && L == 80 && !transposed) return dlpd_k2q_correlate(A, rec, out, CT, nb, L, rbs, k2_nsplit_override(), st);
+  if (((DLPD_K2_Q4 && L == 80) || (DLPD_K2_S4 && L == 40)) && !transposed)
+    return dlpd_k2q_correlate(A, rec, out, CT, nb, L, rbs, k2_nsplit_override(), st);
   switch (L) {
     case 32: return launch_k2<64, 1>(A, rec, out, CT, nb, rbs, 1.f, st, transposed);
     case 40: return launch_k2<80, 1>(A, rec, out, CT, nb, rbs, 1.f, st, transposed);

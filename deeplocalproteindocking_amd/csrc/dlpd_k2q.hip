@@ -76,6 +76,20 @@ template <int ES> struct Q4 {
 #pragma unroll
     for (int r = 0; r < 20; r++) lds_st(p1 + r * ES, v[r]);
   }
+  // the same for a zero-padded pencil: only inputs 0 .. 39 are non-zero (r < 10), the others are not even read
+  DLPD_D static void fwd_a_pruned(cplx* S, int base, int t) {
+    cplx v[20];
+    const cplx* p0 = S + base + t * ES;
+#pragma unroll
+    for (int r = 0; r < 10; r++) v[r] = lds_ld(p0 + 4 * r * ES);
+#pragma unroll
+    for (int r = 10; r < 20; r++) v[r] = c_make(0.f, 0.f);
+    SmallDft<20, -1>::run(v);
+    DLPD_WAVE_SYNC();
+    cplx* p1 = S + base + 21 * t * ES;
+#pragma unroll
+    for (int r = 0; r < 20; r++) lds_st(p1 + r * ES, v[r]);
+  }
   // forward pass B: five radix-4 butterflies j = t + 4 i over the blocks' offset j, twiddle tw80[j r]; results
   // u[i][r] = X[j + 20 r] stay in registers
   DLPD_D static void fwd_b_load(const cplx* S, int base, int t, const cplx* tw80, cplx (&u)[5][4]) {
@@ -341,15 +355,158 @@ k_xy_corr_q4(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __r
   DLPD_STAMP_FLUSH(dlpd_stamps_k2q, DLPD_STAMPS);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// N = 80 (box 40: the coarse grid of the reference's real shapes): the 80 x 80 slab FITS (56 KB: two blocks per CU), so
+// no decimation -- the zero-padded forward transforms (40 non-zero rows / columns: pruned first passes), the receptor
+// product and the inverse -- on the same 4-lane pencils and affine addressing.  Five waves: wave w stages and
+// y-transforms input rows 8w..8w+7 (its upper 32 lanes run the same code on rows 40 + 8w.., which nobody reads before the
+// column passes overwrite them), owns 16 columns of the column phase, and rows 16w..16w+15 of the inverse y transform,
+// which it also copies out; two block barriers per slab.
+// ------------------------------------------------------------------------------------------------------------------
+template <int N> __global__ void __launch_bounds__(320)
+k_xy_corr_s4(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __restrict__ out,
+             int CT, int nb, int nsplit, long long rec_bstride) {
+  constexpr int L = N / 2, NZ = N / 2 + 1, RS = N + 4, HR = N + 4;
+  constexpr int NT = 320, W = NT / 64;
+  static_assert(N == 80 && 16 * W == N && 8 * W == L, "five waves: 8 input rows, 16 columns and 16 output rows each");
+  static_assert(RS % 32 == 20 && RS % 2 == 0, "bank spreading of the row / column sets");
+  constexpr int NIN = 8 * L / 2;                       // float4 in a wave's 8 input rows (160)
+  constexpr int NPI = (NIN + 63) / 64;
+  constexpr int NOUT = 16 * N / 2 / 64;                // float4 per lane of a wave's 16 output rows (10)
+  DLPD_DYN_SHARED(cplx, S);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bid = blockIdx.x;
+  const int part = (bid >> 3) % nsplit;
+  const int slab = (bid / (8 * nsplit)) * 8 + (bid & 7);
+  if (slab >= NZ * CT) return;
+  const int kz = slab % NZ, c = slab / NZ;
+  const int b_beg = (int)(((long long)nb * part) / nsplit), b_end = (int)(((long long)nb * (part + 1)) / nsplit);
+  if (b_beg >= b_end) return;
+  cplx* twh = S + HR * RS;                             // exp(-2 pi i k / N)
+  init_twiddles_k2q<N>(twh, tid, NT);
+  const int t = lane & 3, pidx = lane >> 2;
+  // forward rows: lanes 0-31 the wave's 8 input rows, lanes 32-63 dummy rows 40 + 8w..
+  const int fbase = ((pidx >> 3) * L + 8 * wave + (pidx & 7)) * RS;
+  // inverse rows: 16w .. 16w + 15
+  const int ibase = (16 * wave + pidx) * RS;
+  // columns: pairs of 4-column blocks 16 eight-byte columns apart (mod 32) share a 32-lane read group; the last wave's
+  // blocks 16..19 have no such partner (a 2-way conflict on an eighth of its loads)
+  const int pr = 2 * wave + (pidx >> 3);
+  const int blk = (pr < 8) ? ((pr & 3) + 8 * (pr >> 2) + 4 * ((pidx >> 2) & 1)) : (16 + 2 * (pr - 8) + ((pidx >> 2) & 1));
+  const int ccol = 4 * blk + (pidx & 3);
+  const int cbase = ccol;
+  const typename Q4<1>::Rot rot_r = Q4<1>::rot_of(t);
+  const typename Q4<RS>::Rot rot_c = Q4<RS>::rot_of(t);
+
+  float4 apref[NPI];
+  auto fetch_A = [&](int b) {
+    const float4* a4 = reinterpret_cast<const float4*>(A + (((size_t)b * CT + c) * NZ + kz) * L * L + (size_t)wave * 8 * L);
+#pragma unroll
+    for (int k = 0; k < NPI; k++)
+      if (lane + 64 * k < NIN) apref[k] = DLPD_LOAD_STREAM(a4 + lane + 64 * k);
+  };
+  fetch_A(b_beg);
+  DLPD_LDS_BARRIER();                                  // twiddle table visible
+  for (int b = b_beg; b < b_end; b++) {
+    // ---- own input rows -> slab rows 8w..8w+7, columns 0..L-1
+#pragma unroll
+    for (int k = 0; k < NPI; k++) {
+      const int f = lane + 64 * k, r = f / (L / 2), y = 2 * (f % (L / 2));
+      if (f < NIN) *reinterpret_cast<float4*>(S + (8 * wave + r) * RS + y) = apref[k];
+    }
+    DLPD_WAVE_SYNC();
+    // ---- forward along y (zero-padded: pruned first pass)
+    Q4<1>::fwd_a_pruned(S, fbase, t);
+    DLPD_WAVE_SYNC();
+    {
+      cplx u[5][4];
+      Q4<1>::fwd_b_load(S, fbase, t, twh, u);
+      DLPD_WAVE_SYNC();
+      Q4<1>::store_nat(S, fbase, t, u);
+    }
+    cplx rv[5][4];
+    {
+      const cplx* rb = rec + (size_t)b * rec_bstride + ((size_t)c * NZ + kz) * N * N + ccol + (size_t)N * t;
+#pragma unroll
+      for (int i = 0; i < 5; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) rv[i][r] = rb[(unsigned)(N * (4 * i + 20 * r))];
+    }
+    if (b + 1 < b_end) fetch_A(b + 1);
+    DLPD_LDS_BARRIER();                                // all rows y-transformed
+    // ---- columns: forward x (pruned), receptor product, inverse x
+    {
+      Q4<RS>::fwd_a_pruned(S, cbase, t);
+      DLPD_WAVE_SYNC();
+      cplx u[5][4];
+      {
+        const cplx* p0 = S + cbase + t * RS;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) u[i][r] = lds_ld(p0 + (21 * r + 4 * i) * RS);
+#pragma unroll
+          for (int r = 1; r < 4; r++) u[i][r] = c_mul(u[i][r], twh[t * r + 4 * i * r]);
+          dft4<-1>(u[i][0], u[i][1], u[i][2], u[i][3]);
+#pragma unroll
+          for (int r = 0; r < 4; r++) u[i][r] = c_mulc(rv[i][r], u[i][r]);
+          dft4<+1>(u[i][0], u[i][1], u[i][2], u[i][3]);
+          DLPD_SCHED_FENCE();
+        }
+      }
+      DLPD_WAVE_SYNC();
+      cplx* p4 = S + cbase + 4 * t * RS;
+#pragma unroll
+      for (int i = 0; i < 5; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) lds_st(p4 + rot_c.o[r] + 16 * i * RS, u[i][r]);
+    }
+    DLPD_WAVE_SYNC();
+    {
+      cplx v[20];
+      Q4<RS>::inv_b_load(S, cbase, t, rot_c, twh, v);
+      DLPD_WAVE_SYNC();
+      Q4<RS>::store_a(S, cbase, t, v);
+    }
+    DLPD_LDS_BARRIER();                                // all columns done
+    // ---- inverse along y of the wave's 16 rows, then those rows to global memory (contiguous 10 KB)
+    Q4<1>::inverse(S, ibase, t, rot_r, twh);
+    DLPD_WAVE_SYNC();
+    {
+      float4* o = reinterpret_cast<float4*>(out + (((size_t)b * CT + c) * NZ + kz) * N * N + (size_t)wave * 16 * N);
+#pragma unroll
+      for (int k = 0; k < NOUT; k++) {
+        const int f = lane + 64 * k, r = f / (N / 2), y = 2 * (f % (N / 2));
+        DLPD_STORE_STREAM(o + f, *reinterpret_cast<const float4*>(S + (16 * wave + r) * RS + y));
+      }
+    }
+    DLPD_WAVE_SYNC();                                  // own rows read before the next rotation's staging refills rows 8w..
+    // (rows 8w..8w+7 and 40+8w.. of the next staging / dummy transform belong to OTHER waves' output rows when
+    //  w > 0: the block barrier below keeps them from being refilled while still being copied out)
+    DLPD_LDS_BARRIER();
+  }
+}
+
+int dlpd_k2q_supported(int L) { return (L == 80 || L == 40) ? 1 : 0; }
+
 int dlpd_k2q_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, int L, long long rbs, int nsplit_override,
                        hipStream_t st) {
+  int nsplit = nb >= 8 ? 2 : 1;
+  if (nsplit_override > 0) nsplit = nsplit_override;
+  if (L == 40) {
+    constexpr int N = 80, NZ = N / 2 + 1, RS = N + 4;
+    const size_t shmem = (size_t)(RS * RS + N) * sizeof(cplx);
+    int rc = dlpd_set_max_dyn_shared((const void*)k_xy_corr_s4<N>, shmem);
+    if (rc) return rc;
+    const int slabs8 = ((NZ * CT + 7) / 8) * 8;
+    DLPD_LAUNCH((k_xy_corr_s4<N>), dim3(slabs8 * nsplit), dim3(320), shmem, st, A, rec, out, CT, nb, nsplit, rbs);
+    return dlpd_check_launch();
+  }
   if (L != 80) return DLPD_ERR_UNSUPPORTED;
   constexpr int N = 160, NZ = N / 2 + 1, H = N / 2, RS = H + 4;
   const size_t shmem = (size_t)(2 * RS * RS + N + H) * sizeof(cplx) + (size_t)(5 - DLPD_K2Q_H0_REGS) * 2 * 640 * sizeof(float4);
   int rc = dlpd_set_max_dyn_shared((const void*)k_xy_corr_q4<N>, shmem);
   if (rc) return rc;
-  int nsplit = nb >= 8 ? 2 : 1;
-  if (nsplit_override > 0) nsplit = nsplit_override;
   const int slabs8 = ((NZ * CT + 7) / 8) * 8;
   DLPD_LAUNCH((k_xy_corr_q4<N>), dim3(slabs8 * nsplit), dim3(640), shmem, st, A, rec, out, CT, nb, nsplit, rbs);
   return dlpd_check_launch();
