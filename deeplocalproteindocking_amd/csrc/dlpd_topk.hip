@@ -22,7 +22,7 @@ typedef unsigned long long u64;
 #define TOPK_BINS 2048
 #define TOPK_HIST_BLOCKS 64
 #define TOPK_HIST_THREADS 256
-#define TOPK_MAXK 2048
+#define TOPK_MAXK 4096
 
 struct TopkState {           // one per rotation in the batch
   u64 kth;                   // decided high bits of the K-th key, finally the K-th key itself

@@ -153,6 +153,35 @@ def test_topk_full_size_exact(dev):
         assert np.array_equal(ci[j], idx) and np.array_equal(cs[j].view(np.uint32), sc.view(np.uint32))
 
 
+def test_topk_and_merge_with_4096_conformations(dev):
+    """max_conf = 4096 (the device limit; the reference uses 2000): per-rotation picks exact against the vectorised oracle
+    at 128^3 and the merged running list of three rotations against the faithful sequence of update_top calls' closed
+    form (sort of all picks by (score, rotation, pick))."""
+    from deeplocalproteindocking_amd.engine import DeviceTopList
+    from deeplocalproteindocking_amd._lib import get_lib
+    N, K, nb = 128, 4096, 3
+    g = torch.Generator().manual_seed(14)
+    V = torch.randn(nb, N, N, N, generator=g)
+    V[1] = torch.round(V[1] * 8) / 8                                         # ties
+    top = DeviceTopList(K, nb, dev, get_lib())
+    top.reset()
+    cs, ci = top.select(V.to(dev).reshape(nb, -1), nb)
+    cs, ci = cs.cpu().numpy().copy(), ci.cpu().numpy().copy()
+    picks = []
+    for j in range(nb):
+        idx, sc = orc.rotation_picks_fast(V[j].numpy(), K)
+        assert np.array_equal(ci[j], idx) and np.array_equal(cs[j].view(np.uint32), sc.view(np.uint32))
+        picks += [(float(sc[i]), j, i, int(idx[i])) for i in range(K)]
+    top.merge(torch.arange(nb, dtype=torch.int32, device=dev), nb)
+    rot, idx, score, pick = top.entries()
+    picks.sort(key=lambda p: (p[0], p[1], p[2]))
+    want = picks[:K]
+    assert rot.tolist() == [p[1] for p in want] and idx.tolist() == [p[3] for p in want]
+    assert np.array_equal(np.asarray(score, dtype=np.float32), np.asarray([p[0] for p in want], dtype=np.float32))
+    with pytest.raises(RuntimeError):
+        DeviceTopList(4097, 1, dev, get_lib()).select(V.to(dev).reshape(nb, -1)[:1], 1)
+
+
 @pytest.mark.parametrize("tag,nres", [("multires", 2), ("single", 1)])
 def test_filter_kernel_reproduces_reference_forward(dev, golden, tag, nres):
     from deeplocalproteindocking_amd.ops import filter_volumes
