@@ -27,6 +27,10 @@
 // (s_setprio 1..3 for the transform waves) change nothing.  THREE roles at N = 128 -- first-pass waves, second-pass waves and
 // filter waves pipelined over three pencil buffers with one barrier per group (4 + 4 + 8 waves, 128 registers, the filter
 // waves reading their values from LDS as in the channel-owning kernel): bit-identical, 2.13 ms against 1.82.
+// At N = 160, where the filter waves are the longer role (prologue = 48 global loads of coarse pre-activations per thread, 15 %
+// of their time): those planes staged in LDS one tile ahead by the transform waves' LDS-DMA (30 KB, waited for before the
+// tile's last hand-back barrier): bit-identical, 2.21 ms against 2.08 -- the extra wait in front of the barrier costs the
+// filter waves more than the shorter prologue saves.
 #include <dlpd_platform.h>
 #include "dlpd_fft.h"
 #include "dlpd_internal.h"
