@@ -212,12 +212,16 @@ k_xy_corr_q4(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __r
   const typename Q4<1>::Rot rot_r = Q4<1>::rot_of(t);
   const typename Q4<RS>::Rot rot_c = Q4<RS>::rot_of(t);
 
-  // this wave's 8 rows of a rotation's A slab: 8 L contiguous complex, lane reads float4 number lane + 64 k
+  // this wave's 8 rows of a rotation's A slab (8 L contiguous complex): lane = 8 * row + piece reads float4 number
+  // piece + 8 k of its row -- eight 128-byte lines per instruction and no division anywhere (staging and combination
+  // use the same dealing: their (row, column) are a shift, a mask and an immediate)
+  static_assert(L / 2 == 8 * NP, "row = 8 lanes x NP float4");
   float4 apref[NP];
   auto fetch_A = [&](int b) {
-    const float4* a4 = reinterpret_cast<const float4*>(A + (((size_t)b * CT + c) * NZ + kz) * L * L + (size_t)wave * 8 * L);
+    const int srow = 8 * wave + (lane >> 3);
+    const float4* a4 = reinterpret_cast<const float4*>(A + (((size_t)b * CT + c) * NZ + kz) * L * L + (size_t)srow * L) + (lane & 7);
 #pragma unroll
-    for (int k = 0; k < NP; k++) apref[k] = DLPD_LOAD_STREAM(a4 + lane + 64 * k);
+    for (int k = 0; k < NP; k++) apref[k] = DLPD_LOAD_STREAM(a4 + 8 * k);
   };
   // H_0[u][v..v+1], H_0[u][v+H..] wait for H_1: NPR of the NP pairs in registers, the others parked in the LDS the
   // sub-slabs leave free (with all 40 registers held the column phase of p = 1 spills)
@@ -234,12 +238,15 @@ k_xy_corr_q4(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __r
       // ---- own rows of the A slab (registers) times w^(p x) -> sub-slab q = 0, times w^y -> sub-slab q = 1
       {
         int lq = lane;
-        DLPD_OPAQUE(lq);                               // (the five (row, column) pairs are recomputed, not kept in VGPRs)
+        DLPD_OPAQUE(lq);                               // (row and column are recomputed, not kept in VGPRs)
+        const int x = 8 * wave + (lq >> 3), scol = 2 * (lq & 7);
+        cplx wx = c_make(1.f, 0.f);
+        if (p) wx = tw[x];
 #pragma unroll
         for (int k = 0; k < NP; k++) {
-          const int f = lq + 64 * k, r = f / (L / 2), y = 2 * (f % (L / 2)), x = 8 * wave + r;
+          const int y = scol + 16 * k;
           cplx u = c_make(apref[k].x, apref[k].y), v = c_make(apref[k].z, apref[k].w);
-          if (p) { const cplx wx = tw[x]; u = c_mul(u, wx); v = c_mul(v, wx); }
+          if (p) { u = c_mul(u, wx); v = c_mul(v, wx); }
           cplx* d = S + x * RS + y;
           const float4 wy = *reinterpret_cast<const float4*>(tw + y);
           const cplx u1 = c_mul(u, c_make(wy.x, wy.y)), v1 = c_mul(v, c_make(wy.z, wy.w));
@@ -318,16 +325,20 @@ k_xy_corr_q4(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __r
       {
         int lq = lane;
         DLPD_OPAQUE(lq);
+        const int u = 8 * wave + (lq >> 3), scol = 2 * (lq & 7);
+        cplx wu = c_make(1.f, 0.f);
+        if (p) wu = tw[u];
 #pragma unroll
         for (int k = 0; k < NP; k++) {
-          const int f = lq + 64 * k, r = f / (H / 2), v = 2 * (f % (H / 2)), u = 8 * wave + r;
+          const int v = scol + 16 * k;
           const cplx* g = S + u * RS + v;
           const float4 ga = *reinterpret_cast<const float4*>(g), gb = *reinterpret_cast<const float4*>(g + SUB);
           const float4 wv = *reinterpret_cast<const float4*>(tw + v);
+          const cplx a0 = c_make(ga.x, ga.y), a1 = c_make(ga.z, ga.w);
           const cplx b0 = c_mulc(c_make(gb.x, gb.y), c_make(wv.x, wv.y)), b1 = c_mulc(c_make(gb.z, gb.w), c_make(wv.z, wv.w));
-          const float4 lo = make_float4(ga.x + b0.x, ga.y + b0.y, ga.z + b1.x, ga.w + b1.y);
-          const float4 hi = make_float4(ga.x - b0.x, ga.y - b0.y, ga.z - b1.x, ga.w - b1.y);
+          const cplx lo0 = c_add(a0, b0), lo1 = c_add(a1, b1), hi0 = c_sub(a0, b0), hi1 = c_sub(a1, b1);
           if (p == 0) {
+            const float4 lo = make_float4(lo0.x, lo0.y, lo1.x, lo1.y), hi = make_float4(hi0.x, hi0.y, hi1.x, hi1.y);
             if (k < NPR) {
               h0[k][0] = lo;
               h0[k][1] = hi;
@@ -336,15 +347,16 @@ k_xy_corr_q4(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __r
               park[((k - NPR) * 2 + 1) * NT] = hi;
             }
           } else {
-            const cplx wu = tw[u];
-            const cplx l0 = c_mulc(c_make(lo.x, lo.y), wu), l1 = c_mulc(c_make(lo.z, lo.w), wu);
-            const cplx k0 = c_mulc(c_make(hi.x, hi.y), wu), k1 = c_mulc(c_make(hi.z, hi.w), wu);
+            const cplx l0 = c_mulc(lo0, wu), l1 = c_mulc(lo1, wu), k0 = c_mulc(hi0, wu), k1 = c_mulc(hi1, wu);
             const float4 fa = k < NPR ? h0[k < NPR ? k : 0][0] : park[((k - NPR) * 2) * NT];
             const float4 fb = k < NPR ? h0[k < NPR ? k : 0][1] : park[((k - NPR) * 2 + 1) * NT];
-            DLPD_STORE_STREAM(o + (u * N + v) / 2, make_float4(fa.x + l0.x, fa.y + l0.y, fa.z + l1.x, fa.w + l1.y));
-            DLPD_STORE_STREAM(o + (u * N + v + H) / 2, make_float4(fb.x + k0.x, fb.y + k0.y, fb.z + k1.x, fb.w + k1.y));
-            DLPD_STORE_STREAM(o + ((u + H) * N + v) / 2, make_float4(fa.x - l0.x, fa.y - l0.y, fa.z - l1.x, fa.w - l1.y));
-            DLPD_STORE_STREAM(o + ((u + H) * N + v + H) / 2, make_float4(fb.x - k0.x, fb.y - k0.y, fb.z - k1.x, fb.w - k1.y));
+            const cplx fa0 = c_make(fa.x, fa.y), fa1 = c_make(fa.z, fa.w), fb0 = c_make(fb.x, fb.y), fb1 = c_make(fb.z, fb.w);
+            const cplx o00 = c_add(fa0, l0), o01 = c_add(fa1, l1), o10 = c_add(fb0, k0), o11 = c_add(fb1, k1);
+            const cplx o20 = c_sub(fa0, l0), o21 = c_sub(fa1, l1), o30 = c_sub(fb0, k0), o31 = c_sub(fb1, k1);
+            DLPD_STORE_STREAM(o + (u * N + v) / 2, make_float4(o00.x, o00.y, o01.x, o01.y));
+            DLPD_STORE_STREAM(o + (u * N + v + H) / 2, make_float4(o10.x, o10.y, o11.x, o11.y));
+            DLPD_STORE_STREAM(o + ((u + H) * N + v) / 2, make_float4(o20.x, o20.y, o21.x, o21.y));
+            DLPD_STORE_STREAM(o + ((u + H) * N + v + H) / 2, make_float4(o30.x, o30.y, o31.x, o31.y));
           }
         }
       }
