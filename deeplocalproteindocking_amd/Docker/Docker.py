@@ -76,14 +76,15 @@ def random_rotation(generator=None):
     return torch.from_numpy(euler_to_matrices(phi, theta, psi)).reshape(1, 3, 3)
 
 
-def all_gather_top_entries(entries, K, world_size, process_group=None, device="cpu"):
+def all_gather_top_entries(entries, K, world_size, process_group=None, device="cpu", always=False):
     """The ONE collective of the rotation-sharded search: every rank contributes its local top list
     ``entries`` = (rot, flat index, score, pick) as a fixed-size block, one ``all_gather`` (RCCL over xGMI on the
     ``nccl`` backend, gloo on CPU), then the same deterministic merge on every rank -- sort by (score, rotation, pick),
     keep K -- which reproduces the single-process list exactly: the global top-K is a subset of the union of the
     per-shard top-Ks and the key is the reference's stable insertion order (Docker.py:100-105).
-    Used by ``Docker`` and by ``bench.py``'s multi-rank leg alike."""
-    if world_size <= 1:
+    Used by ``Docker`` and by ``bench.py``'s multi-rank leg alike.  ``always`` runs the collective for a group of one
+    too (the one-GPU boxes' RCCL check, scripts/rccl_one_rank_check.py)."""
+    if world_size <= 1 and not always:
         return entries
     import torch.distributed as dist
     pack = torch.zeros(4, K + 1, dtype=torch.float64)

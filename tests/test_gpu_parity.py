@@ -667,6 +667,25 @@ def test_two_rank_sharded_search_on_one_gpu_equals_single_process(dev, tmp_path)
     assert res["sharded"] == res["single"] and len(res["single"]) == res["K"]
 
 
+def test_rccl_all_gather_of_the_top_list_runs_on_this_gpu(dev, tmp_path):
+    """The collective of SURVEY 8(e) on the ``nccl`` (= RCCL) backend on the one GPU a box has: a process group of one
+    rank, the same ``all_gather_top_entries`` Docker and bench.py call, with the early return for a single rank switched
+    off -- RCCL initialises, gathers the device-side pack and the merge returns the rank's own list bit for bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    out = str(tmp_path / "rccl.json")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29645", os.path.join(root, "scripts", "rccl_one_rank_check.py"), "--out", out]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.load(open(out))
+    assert res == {"world": 1, "backend": "nccl", "entries": 2000, "identical": True}
+
+
 def test_two_rank_nccl_search_equals_single_process(dev, tmp_path):
     """SURVEY 8(e) on hardware: two ranks (one per GPU, RCCL) search interleaved shards of the rotation set
     and all-gather their lists once; the merged list must equal the single-process list.  Needs two GPUs
