@@ -1,14 +1,13 @@
 #!/bin/bash
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT
-OUT=gpurun_out/r03_s
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "scores_match_oracle or all_four_search_paths" 2>&1 | tail -2
+OUT=gpurun_out/r03_t
 mkdir -p $OUT
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "scores_match_oracle or all_four_search_paths" > $OUT/pytest.log 2>&1
-tail -3 $OUT/pytest.log
 run() { # tag, env lib, bench args
   local tag=$1 lib=$2; shift 2
   if [ "$lib" = "default" ]; then unset DLPD_LIB_PATH; else export DLPD_LIB_PATH=$ROOT/build_variants/libdlpd_$lib.so; fi
-  timeout 300 python bench.py --steps 60 --warmup 5 --cpu_rotations 0 --no_real_shapes --sustained_s 0 "$@" > $OUT/$tag.json 2> $OUT/$tag.err
+  timeout 300 python bench.py --steps 200 --warmup 5 --cpu_rotations 0 --no_real_shapes --sustained_s 0 "$@" > $OUT/$tag.json 2> $OUT/$tag.err
   python - <<PY
 import json
 try:
@@ -20,6 +19,10 @@ PY
 }
 run warm default
 run w16 default
-run w8 k2_w8
+run w8new k2_w8new
+run head k2_head
 run w16_b default
-run w8_b k2_w8
+run w8new_b k2_w8new
+run head_b k2_head
+run w16_c default
+run head_c k2_head
