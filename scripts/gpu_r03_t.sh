@@ -18,11 +18,9 @@ except Exception as e:
 PY
 }
 run warm default
-run w16 default
-run w8new k2_w8new
-run head k2_head
-run w16_b default
-run w8new_b k2_w8new
-run head_b k2_head
-run w16_c default
-run head_c k2_head
+run twreg default
+run notw k2_notw
+run twreg_b default
+run notw_b k2_notw
+run twreg_c default
+run notw_c k2_notw
