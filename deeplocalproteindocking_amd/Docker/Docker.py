@@ -143,6 +143,9 @@ class Docker:
         # [i, i+1) * resolution, Docker.py:221-223); "grid_sample": (L-1)/2 of each grid (the centre of
         # torch's align_corners=False sampling grid); a number: that index on the fine grid, scaled to coarser ones.
         self.rotation_center = rotation_center
+        # box sizes without a compiled plan: on the fused kernels inside the next compiled box (_dock_volumes_embedded);
+        # False: the plan-free stand-alone ops (ops.VolumeConvolution._forward_generic), any box up to 128
+        self.embed_uncompiled_boxes = True
         self._top = None            # DeviceTopList behind update_top()
         self.top_list = []
         self.engine = None
@@ -301,8 +304,17 @@ class Docker:
         ids = self.shard(R_all.shape[0]) if rot_indices is None else np.asarray(rot_indices, dtype=np.int64)
         params = fused_filter_parameters(model)
         eng = self._make_engine(rec, receptor_forbidden, nb, params)
-        self.path = "fused" if eng is not None else ("ops" if self._ops_path_ok(rec, params) else "call")
-        if eng is not None:
+        entries = None
+        if eng is None and self.embed_uncompiled_boxes and not self._library().call("dlpd_grid_supported", int(L)):
+            entries = self._dock_volumes_embedded(rec, lig, receptor_forbidden, ligand_forbidden, nb, ids,
+                                                  clash_provider, params)
+        if entries is not None:
+            self.path = "embedded"
+        else:
+            self.path = "fused" if eng is not None else ("ops" if self._ops_path_ok(rec, params) else "call")
+        if entries is not None:
+            pass
+        elif eng is not None:
             two_res = eng.C1 > 0
             eng.set_ligand(lig[0], ligand_forbidden if ligand_forbidden is not None else torch.zeros(L, L, L),
                            lig[1] if two_res else None)
@@ -360,6 +372,78 @@ class Docker:
             eng.clip, eng.threshold = getattr(model, "clip", 5.0), float(model.threshold_clash)
         eng.set_receptor(rec[0], receptor_forbidden, rec[1] if two_res else None)
         return eng
+
+    def _embedding_box(self, L, two_res):
+        """The smallest box WITH a compiled plan that holds an L^3 volume (and, for the reference's two
+        resolutions, whose half holds the L/2 grid); None if there is none."""
+        lib = self._library()
+        for Lc in (32, 40, 64, 80):
+            if Lc > L and lib.call("dlpd_grid_supported", Lc):
+                if not two_res or (L % 2 == 0 and lib.call("dlpd_grid_supported", Lc // 2)):
+                    return Lc
+        return None
+
+    def _dock_volumes_embedded(self, rec, lig, rec_forb, lig_forb, batch_size, ids, clash_provider, params):
+        """A box size without a compiled plan on the FUSED kernels (box_size is a free argument of the reference,
+        Docker.py:18,22-24,31): the L^3 volumes sit in the corner of the next compiled box Lc^3, zeros around them.
+        The correlation of two L-sized volumes is linear for every translation |t| < L on any grid of at least 2L
+        points, so the 2Lc grid holds the reference's (2L)^3 grid exactly: index t for 0 <= t <= L (t = L: no overlap,
+        zero -- the reference's wrap plane) and 2Lc + t for -L < t < 0.  Per batch: the ligand is rotated at its own size
+        about its own pivot (stand-alone rotation op), copied into the corner of the Lc^3 buffers, scored by the
+        engine as volumes given per rotation (the dockE3 entry: z-FFT without rotation, K2, fused K3), and the scores of
+        the reference's grid are gathered out of the larger one -- monotonic in every index, so ties keep the reference's
+        order -- for the device top-K.  None when no compiled box fits or the model's scoring is not the fused MLP."""
+        if params is None:
+            return None
+        L = rec[0].shape[-1]
+        two_res = len(rec) == 2 and rec[1].shape[-1] * 2 == L
+        if not (len(rec) == 1 or two_res):
+            return None
+        Lc = self._embedding_box(L, two_res)
+        if Lc is None:
+            return None
+        dev = self.device
+
+        def embed(v, Le):
+            out = torch.zeros(tuple(v.shape[:-3]) + (Le, Le, Le), dtype=torch.float32, device=v.device)
+            l = v.shape[-1]
+            out[..., :l, :l, :l] = v
+            return out
+
+        has_clash = rec_forb is not None
+        rec_e = [embed(rec[0], Lc)] + ([embed(rec[1], Lc // 2)] if two_res else [])
+        rf_e = embed(torch.as_tensor(rec_forb, dtype=torch.float32).reshape(L, L, L), Lc) if has_clash else None
+        eng = self._make_engine(rec_e, rf_e, batch_size, params)
+        if eng is None:
+            return None
+        self.engine_box = Lc
+        rotate = _PivotRotation(self)
+        rec_d, lig_d, rf, lf = self._batch_inputs(rec, lig, rec_forb, lig_forb, clash_provider)
+        C, C1, L1, Lc1 = lig[0].shape[0], (lig[1].shape[0] if two_res else 0), L // 2, Lc // 2
+        lig_e = torch.zeros(batch_size, C, Lc, Lc, Lc, dtype=torch.float32, device=dev)
+        forb_e = torch.zeros(batch_size, Lc, Lc, Lc, dtype=torch.float32, device=dev) if has_clash else None
+        crs_e = torch.zeros(batch_size, C1, Lc1, Lc1, Lc1, dtype=torch.float32, device=dev) if two_res else None
+        Nc = 2 * Lc
+        idx = torch.tensor(list(range(0, L + 1)) + list(range(Nc - (L - 1), Nc)), dtype=torch.long, device=dev)
+        top = DeviceTopList(self.max_conf, batch_size, dev, self._library())
+        top.reset()
+        R_all = self.rot.R
+        for beg in range(0, len(ids), batch_size):
+            bid = ids[beg:beg + batch_size]
+            nb = len(bid)
+            Rb = R_all[bid].to(device=dev, dtype=torch.float32).contiguous()
+            lig_e[:nb, :, :L, :L, :L] = rotate(lig_d[0].unsqueeze(0).expand(nb, -1, -1, -1, -1).contiguous(), Rb)
+            if two_res:
+                crs_e[:nb, :, :L1, :L1, :L1] = rotate(lig_d[1].unsqueeze(0).expand(nb, -1, -1, -1, -1).contiguous(), Rb)
+            if has_clash:
+                lfr = (clash_provider(Rb).reshape(nb, L, L, L) if clash_provider is not None
+                       else rotate(lf.expand(nb, -1, -1, -1, -1).contiguous(), Rb).reshape(nb, L, L, L))
+                forb_e[:nb, :L, :L, :L] = lfr
+            V = eng.score_batch(None, volumes=(lig_e[:nb], forb_e[:nb] if has_clash else None, crs_e[:nb] if two_res else None))
+            V = V.reshape(nb, Nc, Nc, Nc).index_select(1, idx).index_select(2, idx).index_select(3, idx).contiguous()
+            top.select(V.reshape(nb, -1), nb)
+            top.merge(torch.as_tensor(bid, dtype=torch.int32).to(dev), nb)
+        return top.entries()
 
     @staticmethod
     def _ops_path_ok(rec, params):

@@ -403,6 +403,25 @@ def _check_lists(got, want, scale, K):
     assert sum(a[:4] == b[:4] for a, b in zip(got, want)) >= K - 2
 
 
+def _check_lists_band(got, want, scale, K, tol=1e-4):
+    """Same ranked list up to the rounding band: scores rank by rank within tol * scale, every pose of the list is a pose
+    of the oracle's list unless it sits within the band of the K-th score, and a pose may stand at another rank only if
+    the oracle's scores at the two ranks are closer than the band."""
+    assert len(got) == len(want) == K
+    band = tol * scale
+    assert max(abs(a[4] - b[4]) for a, b in zip(got, want)) <= band
+    where = {tuple(b[:4]): i for i, b in enumerate(want)}
+    moved = 0
+    for i, a in enumerate(got):
+        j = where.get(tuple(a[:4]))
+        if j is None:
+            assert abs(a[4] - want[-1][4]) <= band
+        else:
+            assert abs(want[i][4] - want[j][4]) <= band and abs(a[4] - want[j][4]) <= band
+            moved += int(i != j)
+    return moved
+
+
 def _run_user_filter(lib, device):
     """Docker.py:229: ``V = self.docking_model(rec, lig_rot)`` really calls the user's module."""
     from deeplocalproteindocking_amd.Docker import Docker
@@ -509,7 +528,7 @@ def _run_rotation_pivot(lib, device, L):
 
 def test_rotation_pivot_is_switchable_from_docker_emulated(emu):
     assert _run_rotation_pivot(emu, "cpu", 32) == "fused"
-    assert _run_rotation_pivot(emu, "cpu", 12) == "ops"
+    assert _run_rotation_pivot(emu, "cpu", 12) == "embedded"      # (rotated at its own size about its own pivot)
 
 
 def _run_uncompiled_box(lib, device, L, K):
@@ -528,9 +547,15 @@ def _run_uncompiled_box(lib, device, L, K):
     want = orc.dock_volumes([rec], [lig], recf[None, None], ligf[None, None], R, *W, thr, K, clip=5.0, return_V=True)
     scale = max(float(v.abs().max()) for v in want[1])
     dk = Docker(model.to(device), box_size=L, max_conf=K, rotations=R, device=device, lib=lib)
+    dk.embed_uncompiled_boxes = False
     got = dk.dock_volumes([rec], [lig], recf, ligf, write=False)
     assert dk.path == "ops" and dk.engine is None
     _check_lists(got, want[0], scale, K)
+    # the default for such a box: the fused kernels on the next compiled box, the reference's grid gathered out of it
+    dk2 = Docker(model.to(device), box_size=L, max_conf=K, rotations=R, device=device, lib=lib)
+    got2 = dk2.dock_volumes([rec], [lig], recf, ligf, write=False)
+    assert dk2.path == "embedded" and dk2.engine is not None and dk2.engine.L == dk2.engine_box > L
+    _check_lists(got2, want[0], scale, K)
 
 
 def test_uncompiled_box_size_takes_the_generic_path_emulated(emu):
@@ -546,6 +571,39 @@ def test_uncompiled_box_sizes_take_the_generic_path_on_gpu():
     entry.build()
     _run_uncompiled_box(None, torch.device("cuda:0"), 48, 200)
     _run_uncompiled_box(None, torch.device("cuda:0"), 50, 200)
+
+
+def _run_embedded_two_resolutions(lib, device, L, C0, C1, K):
+    """The reference's two-resolution layout [C0 @ L^3, C1 @ (L/2)^3] at a box size without a compiled plan: fused kernels
+    on the next compiled pair (L -> 80 / 40 or 64 / 32), ranked list against the oracle at the box's own size."""
+    from deeplocalproteindocking_amd.Docker import Docker
+    from deeplocalproteindocking_amd.Models import GlobalDockingModel, SimpleFilter, SyntheticRepr
+    thr = 0.12 * L ** 3
+    rec, lig, recf, ligf, R = _volume_case(41, C0, L)
+    g = torch.Generator().manual_seed(42)
+    rec1, lig1 = torch.randn(1, C1, L // 2, L // 2, L // 2, generator=g) * 0.1, torch.randn(1, C1, L // 2, L // 2, L // 2, generator=g) * 0.1
+    R = R[:2]
+    torch.manual_seed(8)
+    filt = SimpleFilter([C0, C1])
+    model = GlobalDockingModel(SyntheticRepr((C0, C1)), filt, threshold_clash=thr, lib=lib)
+    W = [w.cpu() for w in filt.parameters_tuple()]
+    want = orc.dock_volumes([rec, rec1], [lig, lig1], recf[None, None], ligf[None, None], R, *W, thr, K, clip=5.0, return_V=True)
+    scale = max(float(v.abs().max()) for v in want[1])
+    dk = Docker(model.to(device), box_size=L, max_conf=K, rotations=R, device=device, lib=lib)
+    got = dk.dock_volumes([rec, rec1], [lig, lig1], recf, ligf, write=False)
+    assert dk.path == "embedded" and dk.engine.C1 == C1 and dk.engine.L > L
+    # (a transform of another length rounds differently: poses whose oracle scores are ~1e-6 apart may swap)
+    assert _check_lists_band(got, want[0], scale, K) <= K // 20
+    return dk.engine_box
+
+
+@pytest.mark.gpu
+def test_uncompiled_two_resolution_boxes_run_on_the_fused_kernels():
+    """box 72 -> [4 @ 72^3, 6 @ 36^3] inside the 80 / 40 plans; box 56 -> inside 64 / 32."""
+    import __graft_entry__ as entry
+    entry.build()
+    assert _run_embedded_two_resolutions(None, torch.device("cuda:0"), 72, 4, 6, 200) == 80
+    assert _run_embedded_two_resolutions(None, torch.device("cuda:0"), 56, 4, 6, 200) == 64
 
 
 def test_hidden_width_above_32_takes_the_ops_path_emulated(emu):
