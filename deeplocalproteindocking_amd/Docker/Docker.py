@@ -469,8 +469,11 @@ class Docker:
         from deeplocalproteindocking_amd.ops import VolumeConvolution, VolumeRotation, filter_volumes
         dev = self.device
         model = self.docking_model
-        rotate, conv_noclip = _PivotRotation(self), VolumeConvolution(lib=self._lib)
+        emb = self.embed_uncompiled_boxes
+        rotate, conv_noclip = _PivotRotation(self), VolumeConvolution(lib=self._lib, embed=emb)
         convolve = getattr(model, "convolve", None) or VolumeConvolution(clip=getattr(model, "clip", 5.0), lib=self._lib)
+        if isinstance(convolve, VolumeConvolution):        # the reference's op: same clip, this Docker's box policy
+            convolve = VolumeConvolution(clip=convolve.clip, lib=self._lib, embed=emb)
         rec_d, lig_d, rf, lf = self._batch_inputs(rec, lig, rec_forb, lig_forb, clash_provider)
         L = rec[0].shape[-1]
         top = DeviceTopList(self.max_conf, batch_size, dev, self._library())
@@ -504,7 +507,7 @@ class Docker:
         from deeplocalproteindocking_amd.ops import VolumeConvolution, VolumeRotation
         dev = self.device
         model = self.docking_model
-        rotate, conv_noclip = _PivotRotation(self), VolumeConvolution(lib=self._lib)
+        rotate, conv_noclip = _PivotRotation(self), VolumeConvolution(lib=self._lib, embed=self.embed_uncompiled_boxes)
         rec_d, lig_d, rf, lf = self._batch_inputs(rec, lig, rec_forb, lig_forb, clash_provider)
         L = rec[0].shape[-1]
         top = DeviceTopList(self.max_conf, batch_size, dev, self._library())

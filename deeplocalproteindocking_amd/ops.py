@@ -48,10 +48,11 @@ class VolumeConvolution(nn.Module):
     """Per-channel circular cross-correlation on the 2L zero-padded grid:
     out[b,c,t mod 2L] = sum_r v1[b,c,r+t] * v2[b,c,r]  (semantics: MultiplyVolumes.py:13-47)."""
 
-    def __init__(self, clip=None, lib=None):
+    def __init__(self, clip=None, lib=None, embed=True):
         super().__init__()
         self.clip = clip
         self.lib = lib
+        self.embed = embed          # boxes without a compiled plan: inside the next compiled box (False: plan-free transforms)
 
     def forward(self, input_volume1, input_volume2):
         v1, v2 = _check(input_volume1, "volume1", self.lib), _check(input_volume2, "volume2", self.lib)
@@ -60,7 +61,17 @@ class VolumeConvolution(nn.Module):
         B, C, L = v1.shape[0], v1.shape[1], v1.shape[2]
         lib = self.lib or get_lib()
         if not lib.call("dlpd_grid_supported", L):
-            return self._forward_generic(v1, v2, lib)
+            Lc = next((c for c in (32, 40, 64, 80) if c > L and lib.call("dlpd_grid_supported", c)), None) if self.embed else None
+            if Lc is None:
+                return self._forward_generic(v1, v2, lib)
+            # the L^3 volumes in the corner of the next compiled box: the correlation of two L-sized volumes is linear
+            # for every |t| < L on any grid of >= 2L points, so the (2L)^3 result sits inside the (2Lc)^3 one at index t
+            # (0 <= t <= L; t = L: no overlap, zero) and 2Lc + t (-L < t < 0)
+            e1, e2 = (torch.zeros(B, C, Lc, Lc, Lc, dtype=torch.float32, device=v1.device) for _ in range(2))
+            e1[:, :, :L, :L, :L], e2[:, :, :L, :L, :L] = v1, v2
+            big = self.forward(e1, e2)
+            idx = torch.tensor(list(range(0, L + 1)) + list(range(2 * Lc - (L - 1), 2 * Lc)), dtype=torch.long, device=v1.device)
+            return big.index_select(2, idx).index_select(3, idx).index_select(4, idx).contiguous()
         N, NZ, nvol = 2 * L, L + 1, B * C
         dev, st = v1.device, _stream(v1.device)
         wsA = torch.empty(nvol * NZ * L * L * 2, dtype=torch.float32, device=dev)

@@ -646,6 +646,13 @@ def test_baseline_config5_shape_48ch_80cube_matches_oracle(dev):
     assert float((c.abs() > 5.0).float().mean()) > 1e-3
 
 
+def test_volume_convolution_at_uncompiled_boxes(dev):
+    """The stand-alone correlation op at box 50 (inside the 64 plan) and 72 (inside 80), and the plan-free route."""
+    from test_kernels_emu import _volume_convolution_uncompiled_box
+    _volume_convolution_uncompiled_box(None, dev, 50)
+    _volume_convolution_uncompiled_box(None, dev, 72, B=1, C=2)
+
+
 def test_two_rank_sharded_search_on_one_gpu_equals_single_process(dev, tmp_path):
     """SURVEY 8(e) end to end in two PROCESSES on the one GPU of this box: interleaved rotation shards searched by the
     HIP pipeline in each rank, one all-gather of the per-rank lists (gloo transport here -- RCCL needs one device per

@@ -211,6 +211,34 @@ def test_volume_convolution_stages_match_oracle_and_definition(emu, L, nvol):
     assert (out.double() - ref.clamp(-2.0, 2.0)).abs().max() < 1e-4 + 1e-6 * ref.abs().max() and out.abs().max() <= 2.0
 
 
+def _volume_convolution_uncompiled_box(lib, device, L, B=2, C=3):
+    """ops.VolumeConvolution at a box size without a compiled plan, both routes -- inside the next compiled box (default)
+    and the plan-free transforms -- against the oracle and the MultiplyVolumes definition at a few translations."""
+    from deeplocalproteindocking_amd.ops import VolumeConvolution
+    torch.manual_seed(14)
+    N = 2 * L
+    v1, v2 = torch.randn(B, C, L, L, L), torch.randn(B, C, L, L, L)
+    ref = orc.correlate_fft(v1, v2, dtype=torch.float64)
+    outs = {}
+    for name, embed in (("embedded", True), ("plan-free", False)):
+        out = VolumeConvolution(clip=None, lib=lib, embed=embed)(v1.to(device), v2.to(device)).cpu()
+        assert out.shape == (B, C, N, N, N)
+        assert (out.double() - ref).abs().max() < 1e-5 * ref.abs().max(), name
+        assert out[:, :, L].abs().max() < 1e-3 and out[:, :, :, :, L].abs().max() < 1e-3      # |t| = L: no overlap
+        outs[name] = out
+    for t in [(0, 0, 0), (3, -2, 5), (1 - L, L - 1, 0), (-1, -1, -1)]:
+        sl1 = tuple(slice(max(d, 0), L + min(d, 0)) for d in t)
+        sl2 = tuple(slice(max(-d, 0), L + min(-d, 0)) for d in t)
+        direct = (v1[(slice(None), slice(None)) + sl1].double() * v2[(slice(None), slice(None)) + sl2].double()).sum(dim=(2, 3, 4))
+        assert (outs["embedded"][:, :, t[0] % N, t[1] % N, t[2] % N].double() - direct).abs().max() < 1e-3
+    clipped = VolumeConvolution(clip=2.0, lib=lib)(v1.to(device), v2.to(device)).cpu()
+    assert (clipped.double() - ref.clamp(-2.0, 2.0)).abs().max() < 1e-4 + 1e-6 * ref.abs().max() and clipped.abs().max() <= 2.0
+
+
+def test_volume_convolution_at_an_uncompiled_box_emulated(emu):
+    _volume_convolution_uncompiled_box(emu, "cpu", 10, B=1, C=2)
+
+
 @pytest.mark.parametrize("tag,nres", [("multires", 2), ("single", 1)])
 def test_generic_filter_kernel_reproduces_reference_forward(emu, golden, tag, nres):
     """dlpd_filter_mask on oracle correlations == reference GlobalDockingModel.forward output (G5):
