@@ -620,9 +620,12 @@ class Docker:
             if eng is not None:
                 eng.reset_top()
             else:
-                conv_noclip = VolumeConvolution(lib=self._lib)
+                emb = self.embed_uncompiled_boxes
+                conv_noclip = VolumeConvolution(lib=self._lib, embed=emb)
                 convolve = getattr(model, "convolve", None) or VolumeConvolution(clip=getattr(model, "clip", 5.0),
                                                                                  lib=self._lib)
+                if isinstance(convolve, VolumeConvolution):
+                    convolve = VolumeConvolution(clip=convolve.clip, lib=self._lib, embed=emb)
                 top = DeviceTopList(self.max_conf, nbatch, dev, self._library())
                 top.reset()
                 receptor_forbidden = receptor.sum(dim=1).unsqueeze(dim=1).contiguous()
