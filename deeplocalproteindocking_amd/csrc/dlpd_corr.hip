@@ -277,7 +277,7 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
 #define DLPD_K1CL_CC 16                   // channel padding of the channels-last copy
 // rows x channels per block (64 two-row pencils either way).  8 x 16: 64-byte gathers, 64-byte output pieces;
 // 16 x 8: 32-byte gathers, full 128-byte output lines.  Measured: N = 128 (48 channels) 0.83 / 0.75 ms,
-// N = 160 (16 channels) 0.61 / 0.66 ms.
+// N = 160 (16 channels) 0.61 / 0.66 ms.  32 x 4 (16-byte gathers, 256-byte pieces), round 3: 1.24 ms at N = 128.
 template <int N> struct K1ClCfg { static constexpr int YG = (N == 128) ? 16 : 8, CC = 128 / YG; };
 template <int N> __global__ void __launch_bounds__(64 * FftPlan<N>::T)
 k_rotate_zfft_cl(const float4* __restrict__ cl, const float* __restrict__ R, cplx* __restrict__ A,

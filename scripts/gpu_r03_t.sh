@@ -18,9 +18,7 @@ except Exception as e:
 PY
 }
 run warm default
-run twreg default
-run notw k2_notw
-run twreg_b default
-run notw_b k2_notw
-run twreg_c default
-run notw_c k2_notw
+run yg16 default
+run yg32 k1_yg32
+run yg16_b default
+run yg32_b k1_yg32
