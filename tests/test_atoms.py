@@ -694,6 +694,35 @@ def test_dockSE3_reference_configuration_on_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_dockSE3_at_a_box_without_a_compiled_plan(tmp_path):
+    """The same call sequence with ``box_size=72`` (a free argument of the reference, Docker.py:18): PDB files ->
+    densities at 72^3 -> [16 @ 72^3, 32 @ 36^3], clash volume re-projected from the rotated atoms per batch, the search
+    on the fused kernels inside the 80 / 40 plans; ranked list against the oracle at box 72."""
+    import __graft_entry__ as entry
+    entry.build()
+    from deeplocalproteindocking_amd.Docker import Docker
+    from deeplocalproteindocking_amd.Models import GlobalDockingModel, SE3MultiResReprScalar, SimpleFilter
+    dev = torch.device("cuda:0")
+    L, res, K = 72, 1.25, 40
+    frec, _, _, _ = _typed(tmp_path, 40, seed=15)
+    flig, _, _, _ = _typed(tmp_path, 25, seed=16)
+    torch.manual_seed(80)
+    repr_ = SE3MultiResReprScalar(multiplier=8)
+    model = GlobalDockingModel(repr_, SimpleFilter(repr_.get_num_outputs()), threshold_clash=3.0)
+    R = orc.euler_to_matrix([0.3, -1.0], [1.1, 0.4], [-2.0, 2.5])
+    be = CoordsBackend()
+    want, scale = _dock_reference_shape(be, model, frec, flig, R, L, res, K)
+    dk = Docker(model.to(dev), box_size=L, resolution=res, max_conf=K, rotations=R, device=dev, coords_backend=be)
+    assert dk.new_log(str(tmp_path / "pair72.dat"))
+    with torch.no_grad():
+        dk.dockSE3(frec, flig, batch_size=2)
+    assert dk.path == "embedded" and dk.engine_box == 80
+    assert _check_lists_band(dk.top_list, want, scale, K) <= 2
+    dk.cleanup()
+    assert len(open(tmp_path / "pair72.dat").read().strip().splitlines()) == K
+
+
+@pytest.mark.gpu
 def test_dockE3_reference_configuration_on_gpu(tmp_path):
     """BASELINE config 5 geometry: E3MultiResRepr4x4(multiplier=8) = [16 @ 80^3, 32 @ 40^3], the ligand
     re-projected and re-represented for every rotation (local_test.py:67, Docker.py:135-182), scored by the
