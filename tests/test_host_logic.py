@@ -214,3 +214,33 @@ def test_se3_scalar_representation_is_equivariant_and_shaped_like_the_reference(
     assert torch.allclose(k, k.flip(2)) and torch.allclose(k, k.transpose(2, 3))      # radial kernels
     # even box + stride 2 samples a rotated lattice, so only the full-resolution branch is exactly equivariant
     assert r1.shape == v1.shape
+
+
+def test_bench_reads_the_dominant_kernels_traffic_from_a_counter_pass(tmp_path, monkeypatch):
+    """bench.py's ``roofline.traffic``: the parser of the two rocprofv3 --pmc child passes (FETCH_SIZE x 2 + WRITE_SIZE,
+    KB per dispatch summed over a launch's rows, averaged over the launches of the stage's main kernel); the profiler and
+    the child are replaced by a canned counter_collection.csv."""
+    import subprocess
+    import bench
+
+    def fake_run(cmd, **kw):
+        out = cmd[cmd.index("-d") + 1]
+        counter = cmd[cmd.index("--pmc") + 1]
+        os.makedirs(os.path.join(out, "host"), exist_ok=True)
+        rows = ["Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value"]
+        val = {"FETCH_SIZE": 1000.0, "WRITE_SIZE": 3000.0}[counter]
+        for d in (1, 2):                                  # two launches, the counter split over two rows each
+            rows += ['%d,"void k_xy_corr<128, 1>(float2 const*, int)",%s,%f' % (d, counter, val / 2)] * 2
+        rows.append('3,"void k_xy_corr<128, 0>(float2 const*, int)",%s,77777' % counter)     # receptor prep: not the stage
+        rows.append('4,"void k_zifft_filter_rs<128, 24, 1>(void const*)",%s,55555' % counter)
+        open(os.path.join(out, "host", "1_counter_collection.csv"), "w").write("\n".join(rows) + "\n")
+        return subprocess.CompletedProcess(cmd, 0, "", "")
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(os.path, "exists", lambda p: True)
+    import sys
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    args = bench.parse_args()
+    traffic, src = bench.live_pmc_traffic(args, "k2_xy_corr", 128)
+    assert traffic == (2.0 * 1000.0 + 3000.0) * 1024.0 and "measured in this run" in src
+    assert bench.live_pmc_traffic(args, "topk_select", 128) == (None, None)
