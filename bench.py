@@ -612,6 +612,9 @@ def live_pmc_traffic(args, stage, N):
     pats = STAGE_KERNELS.get(stage)
     if not os.path.exists(exe) or pats is None:
         return None, None
+    # never start a profiler from inside a profiled process (this run itself under rocprofv3 / rocprof)
+    if any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, None
     pats = tuple(p % N for p in pats)
     child = [sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--cpu_rotations", "0", "--no_real_shapes",
              "--sustained_s", "0", "--workload", args.workload, "--batch", str(args.batch), "--max_conf", str(args.max_conf),
