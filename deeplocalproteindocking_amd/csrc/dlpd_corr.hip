@@ -278,6 +278,14 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
 // rows x channels per block (64 two-row pencils either way).  8 x 16: 64-byte gathers, 64-byte output pieces;
 // 16 x 8: 32-byte gathers, full 128-byte output lines.  Measured: N = 128 (48 channels) 0.83 / 0.75 ms,
 // N = 160 (16 channels) 0.61 / 0.66 ms.  32 x 4 (16-byte gathers, 256-byte pieces), round 3: 1.24 ms at N = 128.
+// Also measured in round 3 (all bit-identical or equal to rounding, none kept):
+//  * a lane fetching TWO adjacent channel quads of a corner itself (position, weights and offsets computed once per voxel
+//    instead of once per lane: a third fewer vector instructions): 1.56 ms at N = 128, 0.66 against 0.60 at N = 160 (four
+//    quads per lane 0.90) -- what the gather costs is the number of (lane, instruction) line requests, and two lanes
+//    reading 32 adjacent bytes in ONE instruction are one request where one lane reading them in two instructions is two;
+//  * the z transform as two half-length transforms (Z[2j] = FFT_L(z), Z[2j+1] = FFT_L(z w_N^n); samples kept in registers,
+//    34 KB of LDS and 63 registers: four blocks per CU instead of two): 0.90-0.93 ms against 0.77 with 2, 3 or 4 resident
+//    blocks alike -- the kernel is not waiting for a free block slot, and the second set of passes and barriers costs.
 template <int N> struct K1ClCfg { static constexpr int YG = (N == 128) ? 16 : 8, CC = 128 / YG; };
 template <int N> __global__ void __launch_bounds__(64 * FftPlan<N>::T)
 k_rotate_zfft_cl(const float4* __restrict__ cl, const float* __restrict__ R, cplx* __restrict__ A,
