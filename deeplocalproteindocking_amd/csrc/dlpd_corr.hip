@@ -286,6 +286,8 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
 //  * the z transform as two half-length transforms (Z[2j] = FFT_L(z), Z[2j+1] = FFT_L(z w_N^n); samples kept in registers,
 //    34 KB of LDS and 63 registers: four blocks per CU instead of two): 0.90-0.93 ms against 0.77 with 2, 3 or 4 resident
 //    blocks alike -- the kernel is not waiting for a free block slot, and the second set of passes and barriers costs.
+//  * 16 rows x 16 channels = 128 pencils per block (64-byte gathers AND 128-byte pieces; 145 KB, one block per CU, 1024
+//    threads): 0.77-0.80 ms against 0.76-0.77.
 template <int N> struct K1ClCfg { static constexpr int YG = (N == 128) ? 16 : 8, CC = 128 / YG; };
 template <int N> __global__ void __launch_bounds__(64 * FftPlan<N>::T)
 k_rotate_zfft_cl(const float4* __restrict__ cl, const float* __restrict__ R, cplx* __restrict__ A,
