@@ -335,7 +335,7 @@ class Docker:
             self.write_conformations()
         return self.top_list
 
-    def _make_engine(self, rec, receptor_forbidden, batch_size, params):
+    def _make_engine(self, rec, receptor_forbidden, batch_size, params, inner_box=None):
         """DockingEngine for one receptor (one resolution, or the reference's [C0 @ L, C1 @ L/2] pair);
         None when the fused pipeline has no kernel for the shape (other grids or resolution layouts,
         hidden width above 32) or the model's scoring is not the MLP it fuses: the stand-alone-op paths
@@ -357,14 +357,18 @@ class Docker:
         # one engine (multi-GB workspaces, side stream, top-list buffers) serves every pair of the same shape:
         # local_test.py docks hundreds of targets with one Docker
         C, C1, has_clash = rec[0].shape[0], (rec[1].shape[0] if two_res else 0), receptor_forbidden is not None
+        # inner_box: the volumes are inner_box^3 boxes in the corner of the L^3 ones (_dock_volumes_embedded): pivots and
+        # crop of the rotation are the small box's
+        Lp = int(inner_box or L)
         key = (int(L), int(C), int(C1), has_clash, HP, int(self.max_conf),
-               int(batch_size), str(self.device), self.rotation_pivot(L))
+               int(batch_size), str(self.device), self.rotation_pivot(Lp), Lp)
         eng = self.engine if getattr(self, "_engine_key", None) == key else None
         if eng is None:
             eng = DockingEngine(L, C, W1.cpu(), b1.cpu(), W2.cpu(), b2.cpu(), clip=getattr(model, "clip", 5.0),
                                 threshold_clash=model.threshold_clash, has_clash=has_clash, max_conf=self.max_conf,
                                 batch=batch_size, device=self.device, lib=self._lib, coarse_channels=C1,
-                                center=self.rotation_pivot(L), coarse_center=self.rotation_pivot(L // 2))
+                                center=self.rotation_pivot(Lp), coarse_center=self.rotation_pivot(Lp // 2),
+                                extent=(Lp if Lp < L else None))
             self.engine, self._engine_key = eng, key
         else:
             eng.finish()
@@ -388,11 +392,11 @@ class Docker:
         Docker.py:18,22-24,31): the L^3 volumes sit in the corner of the next compiled box Lc^3, zeros around them.
         The correlation of two L-sized volumes is linear for every translation |t| < L on any grid of at least 2L
         points, so the 2Lc grid holds the reference's (2L)^3 grid exactly: index t for 0 <= t <= L (t = L: no overlap,
-        zero -- the reference's wrap plane) and 2Lc + t for -L < t < 0.  Per batch: the ligand is rotated at its own size
-        about its own pivot (stand-alone rotation op), copied into the corner of the Lc^3 buffers, scored by the
-        engine as volumes given per rotation (the dockE3 entry: z-FFT without rotation, K2, fused K3), and the scores of
-        the reference's grid are gathered out of the larger one -- monotonic in every index, so ties keep the reference's
-        order -- for the device top-K.  None when no compiled box fits or the model's scoring is not the fused MLP."""
+        zero -- the reference's wrap plane) and 2Lc + t for -L < t < 0.  The engine rotates the embedded ligand about the
+        SMALL box's pivot and crops the result to the small box (K1's ``extent``, include/dlpd.h), so a batch costs what
+        it costs at box Lc; the scores of the reference's grid are gathered out of the larger one -- monotonic in every
+        index, so ties keep the reference's order -- for the device top-K.  None when no compiled box fits or the model's
+        scoring is not the fused MLP."""
         if params is None:
             return None
         L = rec[0].shape[-1]
@@ -413,37 +417,29 @@ class Docker:
         has_clash = rec_forb is not None
         rec_e = [embed(rec[0], Lc)] + ([embed(rec[1], Lc // 2)] if two_res else [])
         rf_e = embed(torch.as_tensor(rec_forb, dtype=torch.float32).reshape(L, L, L), Lc) if has_clash else None
-        eng = self._make_engine(rec_e, rf_e, batch_size, params)
+        eng = self._make_engine(rec_e, rf_e, batch_size, params, inner_box=L)
         if eng is None:
             return None
         self.engine_box = Lc
-        rotate = _PivotRotation(self)
-        rec_d, lig_d, rf, lf = self._batch_inputs(rec, lig, rec_forb, lig_forb, clash_provider)
-        C, C1, L1, Lc1 = lig[0].shape[0], (lig[1].shape[0] if two_res else 0), L // 2, Lc // 2
-        lig_e = torch.zeros(batch_size, C, Lc, Lc, Lc, dtype=torch.float32, device=dev)
-        forb_e = torch.zeros(batch_size, Lc, Lc, Lc, dtype=torch.float32, device=dev) if has_clash else None
-        crs_e = torch.zeros(batch_size, C1, Lc1, Lc1, Lc1, dtype=torch.float32, device=dev) if two_res else None
-        Nc = 2 * Lc
-        idx = torch.tensor(list(range(0, L + 1)) + list(range(Nc - (L - 1), Nc)), dtype=torch.long, device=dev)
-        top = DeviceTopList(self.max_conf, batch_size, dev, self._library())
-        top.reset()
-        R_all = self.rot.R
-        for beg in range(0, len(ids), batch_size):
-            bid = ids[beg:beg + batch_size]
-            nb = len(bid)
-            Rb = R_all[bid].to(device=dev, dtype=torch.float32).contiguous()
-            lig_e[:nb, :, :L, :L, :L] = rotate(lig_d[0].unsqueeze(0).expand(nb, -1, -1, -1, -1).contiguous(), Rb)
-            if two_res:
-                crs_e[:nb, :, :L1, :L1, :L1] = rotate(lig_d[1].unsqueeze(0).expand(nb, -1, -1, -1, -1).contiguous(), Rb)
-            if has_clash:
-                lfr = (clash_provider(Rb).reshape(nb, L, L, L) if clash_provider is not None
-                       else rotate(lf.expand(nb, -1, -1, -1, -1).contiguous(), Rb).reshape(nb, L, L, L))
-                forb_e[:nb, :L, :L, :L] = lfr
-            V = eng.score_batch(None, volumes=(lig_e[:nb], forb_e[:nb] if has_clash else None, crs_e[:nb] if two_res else None))
-            V = V.reshape(nb, Nc, Nc, Nc).index_select(1, idx).index_select(2, idx).index_select(3, idx).contiguous()
-            top.select(V.reshape(nb, -1), nb)
-            top.merge(torch.as_tensor(bid, dtype=torch.int32).to(dev), nb)
-        return top.entries()
+        lf_e = None
+        if has_clash:
+            lf_e = embed(torch.as_tensor(lig_forb, dtype=torch.float32).reshape(L, L, L), Lc) if clash_provider is None \
+                else torch.zeros(Lc, Lc, Lc)
+        eng.set_ligand(embed(lig[0], Lc), lf_e, embed(lig[1], Lc // 2) if two_res else None)
+        forb_e = torch.zeros(batch_size, Lc, Lc, Lc, dtype=torch.float32, device=dev) if clash_provider is not None else None
+
+        def provider(Rb):          # the re-projected clash volumes of the batch (Docker.py:221-224), into the corner of Lc^3
+            n = Rb.shape[0]
+            forb_e[:n, :L, :L, :L] = clash_provider(Rb).reshape(n, L, L, L)
+            return forb_e[:n]
+
+        eng.clash_provider = provider if clash_provider is not None else None
+        eng.reset_top()
+        eng.search(self.rot.R[ids], rot_ids=ids)          # the engine's top-K works on the gathered (2L)^3 grid (engine.window)
+        self.engine = eng
+        entries = eng.top_entries()
+        eng.clash_provider = None
+        return entries
 
     @staticmethod
     def _ops_path_ok(rec, params):

@@ -160,7 +160,7 @@ extern "C" int dlpd_debug_read_stamps_k1(unsigned long long* host16) {
 template <int N> __global__ void __launch_bounds__((N / 4) * FftPlan<N>::T)
 k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* __restrict__ A,
               int CT, int nb, long long vol_bstride, int do_rotate, float c0, int CT_out, int c_base,
-              int transposed, const float4* __restrict__ quads) {
+              int transposed, const float4* __restrict__ quads, int ext) {
   constexpr int L = N / 2, NZ = N / 2 + 1, RS = N + 1, NP = L / 2;
   constexpr int T = FftPlan<N>::T, R1 = FftPlan<N>::R1, R2 = FftPlan<N>::R2;
   constexpr int NT = NP * T;
@@ -211,9 +211,12 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
       const float px = c0 + (r0 * dx + r3 * dy + r6 * dz);
       const float py = c0 + (r1 * dx + r4 * dy + r7 * dz);
       const float pz = c0 + (r2 * dx + r5 * dy + r8 * dz);
+      // ext < L: the volume is an ext^3 box in the corner of the L^3 one (Docker._dock_volumes_embedded): the rotated
+      // volume is cropped to that box, as the reference crops it to its own
       Sf[((y >> 1) * RS + z) * 2 + (y & 1)] =
-          quads ? trilinear_fetch_quads(quads + (size_t)c * L * (L - 1) * (L - 1), L, px, py, pz)
-                : trilinear_fetch(v, L, px, py, pz);
+          (max(x, max(y, z)) >= ext) ? 0.f
+          : quads ? trilinear_fetch_quads(quads + (size_t)c * L * (L - 1) * (L - 1), L, px, py, pz)
+                  : trilinear_fetch(v, L, px, py, pz);
     }
   } else {
     for (int s = tid; s < L * L; s += NT) {
@@ -291,7 +294,7 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
 template <int N> struct K1ClCfg { static constexpr int YG = (N == 128) ? 16 : 8, CC = 128 / YG; };
 template <int N> __global__ void __launch_bounds__(64 * FftPlan<N>::T)
 k_rotate_zfft_cl(const float4* __restrict__ cl, const float* __restrict__ R, cplx* __restrict__ A,
-                 int C, int Cq, int nb, float c0, int CT_out, int c_base) {
+                 int C, int Cq, int nb, float c0, int CT_out, int c_base, int ext) {
   constexpr int L = N / 2, NZ = N / 2 + 1, NP = 64, CC = K1ClCfg<N>::CC, YG = K1ClCfg<N>::YG, NPR = YG / 2;
   constexpr int LPV = CC / 4, SKEW = 16 / LPV;         // lanes per voxel; bank skew (complex) between channel quads
   static_assert(CC * NPR == NP && L % YG == 0, "64 pencils per block");
@@ -321,6 +324,10 @@ k_rotate_zfft_cl(const float4* __restrict__ cl, const float* __restrict__ R, cpl
       float4 acc[2];
 #pragma unroll
       for (int u = 0; u < 2; u++) {
+        if (max(x, max(yg * YG + 2 * m + u, z)) >= ext) {      // outside the embedded box (ext < L): cropped
+          acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          continue;
+        }
         const float dy = (yg * YG + 2 * m + u) - c0;
         const float px = c0 + (r0 * dx + r3 * dy + r6 * dz);
         const float py = c0 + (r1 * dx + r4 * dy + r7 * dz);
@@ -416,7 +423,7 @@ __global__ void __launch_bounds__(256) k_make_channels_last(const float* __restr
 }
 
 template <int N> static int launch_k1_cl(const float4* cl, const float* R, cplx* A, int C, int nb, float c0, hipStream_t st,
-                                         int CT_out, int c_base) {
+                                         int CT_out, int c_base, int ext = 0) {
   constexpr int L = N / 2, RS = N + 13;
   const int Cq = ((C + DLPD_K1CL_CC - 1) / DLPD_K1CL_CC) * (DLPD_K1CL_CC / 4);
   const size_t shmem = (size_t)(64 * RS + N) * sizeof(cplx);
@@ -425,7 +432,7 @@ template <int N> static int launch_k1_cl(const float4* cl, const float* R, cplx*
   const int per = (L / K1ClCfg<N>::YG) * (Cq / (K1ClCfg<N>::CC / 4));
   const int gper = (nb * L + 7) / 8;
   dim3 grid((unsigned)(8 * gper * per)), block(64 * FftPlan<N>::T);
-  DLPD_LAUNCH((k_rotate_zfft_cl<N>), grid, block, shmem, st, cl, R, A, C, Cq, nb, c0, CT_out, c_base);
+  DLPD_LAUNCH((k_rotate_zfft_cl<N>), grid, block, shmem, st, cl, R, A, C, Cq, nb, c0, CT_out, c_base, (ext > 0 && ext < L) ? ext : L);
   return dlpd_check_launch();
 }
 
@@ -1253,12 +1260,12 @@ template <int HP> static int launch_filter_vec(const float* conv0, int C0, long 
 // ------------------------------------------------------------------------------------------
 template <int N> static int launch_k1(const float* vol, const float* R, cplx* A, int CT, int nb, long long vbs,
                                       int do_rotate, float c0, hipStream_t st, int CT_out = 0, int c_base = 0,
-                                      int transposed = 0, const float4* quads = nullptr) {
+                                      int transposed = 0, const float4* quads = nullptr, int ext = 0) {
   constexpr int L = N / 2;
   const int groups = ((CT * nb + 7) / 8) * 8;
   dim3 grid(groups * L), block((N / 4) * FftPlan<N>::T);
   DLPD_LAUNCH((k_rotate_zfft<N>), grid, block, 0, st, vol, R, A, CT, nb, vbs, do_rotate, c0,
-              CT_out > 0 ? CT_out : CT, c_base, transposed ? 1 : 0, quads);
+              CT_out > 0 ? CT_out : CT, c_base, transposed ? 1 : 0, quads, (ext > 0 && ext < L) ? ext : L);
   return dlpd_check_launch();
 }
 
@@ -1394,19 +1401,24 @@ int dlpd_rotate_trilinear(const float* vol, const float* R, float* out, int B, i
 
 // vol (nb*CT volumes as (nb, CT, L^3), or one (CT, L^3) set with vol_bstride = 0) -> channels
 // [c_base, c_base + CT) of wsA (nb, CT_out, NZ, L, L)
-int dlpd_zfft_oriented(const float* vol, const float* R, void* wsA, int nb, int CT, int CT_out, int c_base, int L,
-                       long long vol_bstride, int do_rotate, float center, int transposed, void* stream) {
-  if (!vol || !wsA || nb <= 0 || CT <= 0 || c_base < 0 || c_base + CT > CT_out) return DLPD_ERR_ARG;
+int dlpd_zfft_oriented_ext(const float* vol, const float* R, void* wsA, int nb, int CT, int CT_out, int c_base, int L,
+                           long long vol_bstride, int do_rotate, float center, int transposed, int extent, void* stream) {
+  if (!vol || !wsA || nb <= 0 || CT <= 0 || c_base < 0 || c_base + CT > CT_out || extent < 0 || extent > L) return DLPD_ERR_ARG;
   if (do_rotate && !R) return DLPD_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   cplx* A = (cplx*)wsA;
   switch (L) {
-    case 32: return launch_k1<64>(vol, R, A, CT, nb, vol_bstride, do_rotate, center, st, CT_out, c_base, transposed);
-    case 40: return launch_k1<80>(vol, R, A, CT, nb, vol_bstride, do_rotate, center, st, CT_out, c_base, transposed);
-    case 64: return launch_k1<128>(vol, R, A, CT, nb, vol_bstride, do_rotate, center, st, CT_out, c_base, transposed);
-    case 80: return launch_k1<160>(vol, R, A, CT, nb, vol_bstride, do_rotate, center, st, CT_out, c_base, transposed);
+    case 32: return launch_k1<64>(vol, R, A, CT, nb, vol_bstride, do_rotate, center, st, CT_out, c_base, transposed, nullptr, extent);
+    case 40: return launch_k1<80>(vol, R, A, CT, nb, vol_bstride, do_rotate, center, st, CT_out, c_base, transposed, nullptr, extent);
+    case 64: return launch_k1<128>(vol, R, A, CT, nb, vol_bstride, do_rotate, center, st, CT_out, c_base, transposed, nullptr, extent);
+    case 80: return launch_k1<160>(vol, R, A, CT, nb, vol_bstride, do_rotate, center, st, CT_out, c_base, transposed, nullptr, extent);
     default: return DLPD_ERR_UNSUPPORTED;
   }
+}
+
+int dlpd_zfft_oriented(const float* vol, const float* R, void* wsA, int nb, int CT, int CT_out, int c_base, int L,
+                       long long vol_bstride, int do_rotate, float center, int transposed, void* stream) {
+  return dlpd_zfft_oriented_ext(vol, R, wsA, nb, CT, CT_out, c_base, L, vol_bstride, do_rotate, center, transposed, 0, stream);
 }
 
 size_t dlpd_quads_floats(int nvol, int L) { return (size_t)nvol * L * (L - 1) * (L - 1) * 4; }
@@ -1452,19 +1464,24 @@ int dlpd_make_channels_last(const float* vol, float* cl, int C, int L, void* str
 }
 
 // rotation + z FFT of the C score channels of ONE ligand shared by all rotations, gathered from its channels-last copy
-int dlpd_zfft_channels_last(const float* cl, const float* R, void* wsA, int nb, int C, int CT_out, int c_base, int L,
-                            float center, void* stream) {
-  if (!cl || !R || !wsA || nb <= 0 || C <= 0 || c_base < 0 || c_base + C > CT_out) return DLPD_ERR_ARG;
+int dlpd_zfft_channels_last_ext(const float* cl, const float* R, void* wsA, int nb, int C, int CT_out, int c_base, int L,
+                                float center, int extent, void* stream) {
+  if (!cl || !R || !wsA || nb <= 0 || C <= 0 || c_base < 0 || c_base + C > CT_out || extent < 0 || extent > L) return DLPD_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   cplx* A = (cplx*)wsA;
   const float4* c4 = (const float4*)cl;
   switch (L) {
-    case 32: return launch_k1_cl<64>(c4, R, A, C, nb, center, st, CT_out, c_base);
-    case 40: return launch_k1_cl<80>(c4, R, A, C, nb, center, st, CT_out, c_base);
-    case 64: return launch_k1_cl<128>(c4, R, A, C, nb, center, st, CT_out, c_base);
-    case 80: return launch_k1_cl<160>(c4, R, A, C, nb, center, st, CT_out, c_base);
+    case 32: return launch_k1_cl<64>(c4, R, A, C, nb, center, st, CT_out, c_base, extent);
+    case 40: return launch_k1_cl<80>(c4, R, A, C, nb, center, st, CT_out, c_base, extent);
+    case 64: return launch_k1_cl<128>(c4, R, A, C, nb, center, st, CT_out, c_base, extent);
+    case 80: return launch_k1_cl<160>(c4, R, A, C, nb, center, st, CT_out, c_base, extent);
     default: return DLPD_ERR_UNSUPPORTED;
   }
+}
+
+int dlpd_zfft_channels_last(const float* cl, const float* R, void* wsA, int nb, int C, int CT_out, int c_base, int L,
+                            float center, void* stream) {
+  return dlpd_zfft_channels_last_ext(cl, R, wsA, nb, C, CT_out, c_base, L, center, 0, stream);
 }
 
 int dlpd_zfft_into(const float* vol, const float* R, void* wsA, int nb, int CT, int CT_out, int c_base, int L,

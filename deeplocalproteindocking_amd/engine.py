@@ -126,9 +126,12 @@ class DockingEngine:
 
     def __init__(self, L, C, W1, b1, W2, b2, clip=5.0, threshold_clash=300.0, has_clash=True,
                  max_conf=1000, batch=8, device="cuda", lib=None, center=None, coarse_channels=0,
-                 fine_unfused=None, channels_last=None, k3_form=0, coarse_center=None):
+                 fine_unfused=None, channels_last=None, k3_form=0, coarse_center=None, extent=None):
         """coarse_channels > 0: the reference's two-resolution layout -- C channels at L^3 plus
-        ``coarse_channels`` at (L/2)^3 (ProteinRepresentationModels.py:72-76); W1 is (H, C+coarse)."""
+        ``coarse_channels`` at (L/2)^3 (ProteinRepresentationModels.py:72-76); W1 is (H, C+coarse).
+        extent < L: the volumes are extent^3 boxes in the corner of the L^3 ones (a box size without a compiled plan
+        inside this one, Docker._dock_volumes_embedded): rotated ligand volumes are cropped to that box (coarse grid:
+        extent / 2), ``center`` / ``coarse_center`` are the pivots of the small boxes."""
         self.device = torch.device(device)
         if lib is None:
             if self.device.type != "cuda":
@@ -165,11 +168,21 @@ class DockingEngine:
         if channels_last is None:
             channels_last = os.environ.get("DLPD_NO_CHANNELS_LAST", "") == "" and self.C >= 8
         self.use_cl = bool(channels_last)
+        self.extent = int(extent) if extent and int(extent) < int(L) else 0
+        self.extent1 = self.extent // 2
         self.orient = os.environ.get("DLPD_NO_ORIENT", "") == "" and not self.use_cl
-        self.use_quads = os.environ.get("DLPD_NO_QUADS", "") == "" and not self.use_cl
+        self.use_quads = os.environ.get("DLPD_NO_QUADS", "") == "" and not self.use_cl and not self.extent
         if self.use_cl:
             self.ligcl = torch.empty(lib.call("dlpd_channels_last_floats", self.C, int(L)), dtype=f32, device=dev)
         self.prefilter = os.environ.get("DLPD_NO_PREFILTER", "") == ""   # diagnostic switch (top-K candidate lists from K3)
+        self.window = None
+        if self.extent:
+            # the reference's (2 extent)^3 translation grid inside this engine's (2L)^3 one: index t for 0 <= t <= extent
+            # (t = extent: no overlap), 2L + t for -extent < t < 0 -- monotonic, so equal scores keep the reference's order.
+            # The top-K takes the gathered grid; K3's candidate lists carry indices of the large grid and are not used.
+            e = self.extent
+            self.window = torch.tensor(list(range(0, e + 1)) + list(range(2 * int(L) - (e - 1), 2 * int(L))), dtype=torch.long, device=dev)
+            self.prefilter = False
         if self.use_quads:
             self.ligq = torch.empty(lib.call("dlpd_quads_floats", CT, int(L)), dtype=f32, device=dev)
         if self.C1:
@@ -302,7 +315,8 @@ class DockingEngine:
         V = self.V if out is None else out
         call, st, L = self.lib.call, _stream(self.device), self.L
         provider = self.clash_provider if self.has_clash else None
-        if not (self.C1 or provider or self.fine_unfused or mark or use_quads or self.use_cl or cset is not None or self.k3_form):
+        if not (self.C1 or provider or self.fine_unfused or mark or use_quads or self.use_cl or cset is not None or self.k3_form
+                or self.extent):
             call("dlpd_score_rotations_oriented", _ptr(self.lig), _ptr(self.recF), _ptr(R), nb, self.C,
                  int(self.has_clash), L, self.center, _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2), self.b2,
                  self.HP, has_clip, clip, self.threshold, _ptr(self.wsA), _ptr(self.wsB), _ptr(V), tr, st)
@@ -313,14 +327,14 @@ class DockingEngine:
             # coarse resolution first: rotate + correlate + clip -> real volumes the fine filter reads
             L1 = self.L1
             if self.use_cl:
-                call("dlpd_zfft_channels_last", _ptr(self.ligcl1), _ptr(R), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1,
-                     self.center1, st)
+                call("dlpd_zfft_channels_last_ext", _ptr(self.ligcl1), _ptr(R), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1,
+                     self.center1, self.extent1, st)
             elif use_quads:
                 call("dlpd_zfft_quads", _ptr(self.ligq1), _ptr(R), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1,
                      self.center1, tr, st)
             else:
-                call("dlpd_zfft_oriented", _ptr(self.lig1), _ptr(R), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1, 0, 1,
-                     self.center1, tr, st)
+                call("dlpd_zfft_oriented_ext", _ptr(self.lig1), _ptr(R), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1, 0, 1,
+                     self.center1, tr, self.extent1, st)
             call("dlpd_xy_correlate_oriented", _ptr(self.wsA1), _ptr(self.recF1), _ptr(self.wsB1), nb, self.C1, L1, 0,
                  tr, st)
             self._coarse_preact(nb, has_clip, clip, st)
@@ -329,28 +343,28 @@ class DockingEngine:
             # clash channel from re-projected rotated ATOMS (Docker.py:221-224), scores from rotated volumes
             forb = provider(R).reshape(nb, L, L, L).contiguous()
             if self.use_cl:
-                call("dlpd_zfft_channels_last", _ptr(self.ligcl), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0, L,
-                     self.center, st)
+                call("dlpd_zfft_channels_last_ext", _ptr(self.ligcl), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0, L,
+                     self.center, self.extent, st)
             elif use_quads:
                 call("dlpd_zfft_quads", _ptr(self.ligq), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0, L,
                      self.center, tr, st)
             else:
-                call("dlpd_zfft_oriented", _ptr(self.lig), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0, L, 0, 1,
-                     self.center, tr, st)
+                call("dlpd_zfft_oriented_ext", _ptr(self.lig), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0, L, 0, 1,
+                     self.center, tr, self.extent, st)
             call("dlpd_zfft_oriented", _ptr(forb), 0, _ptr(self.wsA), nb, 1, self.CT, self.C, L, L ** 3, 0, 0.0,
                  tr, st)                      # same orientation as the score channels
         elif self.use_cl:
-            call("dlpd_zfft_channels_last", _ptr(self.ligcl), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0, L,
-                 self.center, st)
+            call("dlpd_zfft_channels_last_ext", _ptr(self.ligcl), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0, L,
+                 self.center, self.extent, st)
             if self.has_clash:                # the ligand's forbidden volume: one channel, per-channel kernel
-                call("dlpd_zfft_oriented", self.lig.data_ptr() + self.C * L ** 3 * 4, _ptr(R), _ptr(self.wsA), nb, 1,
-                     self.CT, self.C, L, 0, 1, self.center, 0, st)
+                call("dlpd_zfft_oriented_ext", self.lig.data_ptr() + self.C * L ** 3 * 4, _ptr(R), _ptr(self.wsA), nb, 1,
+                     self.CT, self.C, L, 0, 1, self.center, 0, self.extent, st)
         elif use_quads:
             call("dlpd_zfft_quads", _ptr(self.ligq), _ptr(R), _ptr(self.wsA), nb, self.CT, self.CT, 0, L,
                  self.center, tr, st)
         else:
-            call("dlpd_zfft_oriented", _ptr(self.lig), _ptr(R), _ptr(self.wsA), nb, self.CT, self.CT, 0, L, 0, 1,
-                 self.center, tr, st)
+            call("dlpd_zfft_oriented_ext", _ptr(self.lig), _ptr(R), _ptr(self.wsA), nb, self.CT, self.CT, 0, L, 0, 1,
+                 self.center, tr, self.extent, st)
         mark("k1_rotate_zfft")
         return self._correlate_and_filter(nb, V, mark, tr, cset)
 
@@ -423,7 +437,14 @@ class DockingEngine:
         """Per-rotation picks of Docker.update_top (Docker.py:89-98) for V (nb, N^3).  cset: the candidate set the
         scoring kernel filled for this batch -- then the rows hold only the picks that can still enter the running list
         (+inf padded) and the cset is consumed; see ``DeviceTopList.select``."""
+        if self.window is not None:
+            V = self.gather_window(V, nb)
         return self.top.select(V.reshape(nb, -1), nb, cset)
+
+    def gather_window(self, V, nb):
+        """(nb, N^3) scores of this engine's grid -> (nb, (2 extent)^3): the reference's grid of the embedded box."""
+        w, N = self.window, self.N
+        return V.reshape(nb, N, N, N).index_select(1, w).index_select(2, w).index_select(3, w).contiguous()
 
     def merge_batch(self, rot_ids, nb):
         """Docker.py:100-105 on the device-resident list.  rot_ids int32 (nb,) ascending."""

@@ -86,6 +86,16 @@ int dlpd_make_channels_last(const float* vol, float* cl, int C, int L, void* str
 int dlpd_zfft_channels_last(const float* cl, const float* R, void* wsA, int nb, int C, int CT_out, int c_base, int L,
                             float center, void* stream);
 
+/* The same two rotation + z-transform entries for a volume that is an extent^3 box in the corner of the L^3 one (zeros
+ * around it): a box_size without a compiled plan inside the next compiled box (box_size is a free argument of
+ * Docker.py:18; Docker._dock_volumes_embedded).  `center` is the pivot of the SMALL box; output voxels with any index
+ * >= extent are written as zero -- the reference crops the rotated volume to its own box (Docker.py:218).
+ * extent = 0 or L: the plain entries above. */
+int dlpd_zfft_oriented_ext(const float* vol, const float* R, void* wsA, int nb, int CT, int CT_out, int c_base, int L,
+                           long long vol_bstride, int do_rotate, float center, int transposed, int extent, void* stream);
+int dlpd_zfft_channels_last_ext(const float* cl, const float* R, void* wsA, int nb, int C, int CT_out, int c_base, int L,
+                                float center, int extent, void* stream);
+
 /* CoordsRotate + CoordsTranslate + TypedCoords2Volume (+ channel sum) of src/Docker/Docker.py:204,
  * 208,221-224 in one kernel: p' = R_b p + shift, density exp(-|r - p'|^2 / 2) on the 5^3 voxels
  * around each atom (build-defined shape).  coords (B, 3*stride_atoms) ordered by type,
