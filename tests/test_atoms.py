@@ -531,13 +531,12 @@ def test_rotation_pivot_is_switchable_from_docker_emulated(emu):
     assert _run_rotation_pivot(emu, "cpu", 12) == "embedded"      # (rotated at its own size about its own pivot)
 
 
-def _run_uncompiled_box(lib, device, L, K):
+def _run_uncompiled_box(lib, device, L, K, C=4):
     """A box size without a compiled FFT plan (the reference's box_size is a free argument, Docker.py:18,22-24,31):
     Docker must run the search through the stand-alone ops -- generic plan-free correlation, HIP filter kernel, device
     top-K -- instead of raising; ranked list against the oracle."""
     from deeplocalproteindocking_amd.Docker import Docker
     from deeplocalproteindocking_amd.Models import GlobalDockingModel, SimpleFilter, SyntheticRepr
-    C = 4
     thr = 0.12 * L ** 3
     rec, lig, recf, ligf, R = _volume_case(33, C, L)
     torch.manual_seed(6)
@@ -555,6 +554,7 @@ def _run_uncompiled_box(lib, device, L, K):
     dk2 = Docker(model.to(device), box_size=L, max_conf=K, rotations=R, device=device, lib=lib)
     got2 = dk2.dock_volumes([rec], [lig], recf, ligf, write=False)
     assert dk2.path == "embedded" and dk2.engine is not None and dk2.engine.L == dk2.engine_box > L
+    assert dk2.engine.extent == L and dk2.engine.use_cl == (C >= 8)
     _check_lists(got2, want[0], scale, K)
 
 
@@ -562,6 +562,7 @@ def test_uncompiled_box_size_takes_the_generic_path_emulated(emu):
     assert not emu.call("dlpd_grid_supported", 12) and emu.call("dlpd_generic_box_supported", 12)
     assert not emu.call("dlpd_generic_box_supported", 129)
     _run_uncompiled_box(emu, "cpu", 12, 20)
+    _run_uncompiled_box(emu, "cpu", 20, 20, C=8)          # eight channels: the channels-last K1 with its crop
 
 
 @pytest.mark.gpu
