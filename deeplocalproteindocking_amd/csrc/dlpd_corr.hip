@@ -324,10 +324,9 @@ k_rotate_zfft_cl(const float4* __restrict__ cl, const float* __restrict__ R, cpl
       float4 acc[2];
 #pragma unroll
       for (int u = 0; u < 2; u++) {
-        if (max(x, max(yg * YG + 2 * m + u, z)) >= ext) {      // outside the embedded box (ext < L): cropped
-          acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          continue;
-        }
+        // outside the embedded box (ext < L) the sample is cropped: all eight weights zero (no branch: the loads of both
+        // rows stay batched; a branch here cost 0.06 ms at N = 128)
+        const bool live = max(x, max(yg * YG + 2 * m + u, z)) < ext;
         const float dy = (yg * YG + 2 * m + u) - c0;
         const float px = c0 + (r0 * dx + r3 * dy + r6 * dz);
         const float py = c0 + (r1 * dx + r4 * dy + r7 * dz);
@@ -335,7 +334,7 @@ k_rotate_zfft_cl(const float4* __restrict__ cl, const float* __restrict__ R, cpl
         const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
         const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
         const float ax = px - fx, ay = py - fy, az = pz - fz;
-        const bool x0 = (ix >= 0) & (ix <= hi), x1 = (ix + 1 >= 0) & (ix + 1 <= hi);
+        const bool x0 = live & (ix >= 0) & (ix <= hi), x1 = live & (ix + 1 >= 0) & (ix + 1 <= hi);
         const bool y0 = (iy >= 0) & (iy <= hi), y1 = (iy + 1 >= 0) & (iy + 1 <= hi);
         const bool z0 = (iz >= 0) & (iz <= hi), z1 = (iz + 1 >= 0) & (iz + 1 <= hi);
         const float wx0 = x0 ? 1.f - ax : 0.f, wx1 = x1 ? ax : 0.f;
