@@ -377,6 +377,14 @@ class Docker:
         eng.set_receptor(rec[0], receptor_forbidden, rec[1] if two_res else None)
         return eng
 
+    @staticmethod
+    def _embed(v, Le):
+        """v (..., l, l, l) in the corner of a zero (..., Le, Le, Le) volume."""
+        out = torch.zeros(tuple(v.shape[:-3]) + (Le, Le, Le), dtype=torch.float32, device=v.device)
+        l = v.shape[-1]
+        out[..., :l, :l, :l] = v
+        return out
+
     def _embedding_box(self, L, two_res):
         """The smallest box WITH a compiled plan that holds an L^3 volume (and, for the reference's two
         resolutions, whose half holds the L/2 grid); None if there is none."""
@@ -408,12 +416,7 @@ class Docker:
             return None
         dev = self.device
 
-        def embed(v, Le):
-            out = torch.zeros(tuple(v.shape[:-3]) + (Le, Le, Le), dtype=torch.float32, device=v.device)
-            l = v.shape[-1]
-            out[..., :l, :l, :l] = v
-            return out
-
+        embed = self._embed
         has_clash = rec_forb is not None
         rec_e = [embed(rec[0], Lc)] + ([embed(rec[1], Lc // 2)] if two_res else [])
         rf_e = embed(torch.as_tensor(rec_forb, dtype=torch.float32).reshape(L, L, L), Lc) if has_clash else None
@@ -611,7 +614,19 @@ class Docker:
             rec = [v.reshape((-1,) + tuple(v.shape[-3:])) for v in receptor_volumes]
             params = fused_filter_parameters(model)
             eng = self._make_engine(rec, receptor.sum(dim=1)[0], self.launch_batch, params)
-            self.path = "fused" if eng is not None else ("ops" if self._ops_path_ok(rec, params) else "call")
+            Lc = None
+            if eng is None and params is not None and self.embed_uncompiled_boxes and \
+                    not self._library().call("dlpd_grid_supported", int(L)):
+                # a box without a compiled plan: the batch's volumes in the corner of the next compiled box, scored by
+                # the same engine; its top-K stage gathers the reference's grid (see _dock_volumes_embedded)
+                two_res = len(rec) == 2 and rec[1].shape[-1] * 2 == L
+                Lc = self._embedding_box(L, two_res) if (len(rec) == 1 or two_res) else None
+                if Lc is not None:
+                    eng = self._make_engine([self._embed(rec[0], Lc)] + ([self._embed(rec[1], Lc // 2)] if two_res else []),
+                                            self._embed(receptor.sum(dim=1)[0], Lc), self.launch_batch, params, inner_box=L)
+                    Lc = Lc if eng is not None else None
+                    self.engine_box = Lc
+            self.path = ("embedded" if Lc else "fused") if eng is not None else ("ops" if self._ops_path_ok(rec, params) else "call")
             nbatch = self.launch_batch if self.path != "call" else int(batch_size)
             if eng is not None:
                 eng.reset_top()
@@ -634,8 +649,11 @@ class Docker:
                 ligand_volumes = model.representation(ligand)
                 bid_dev = torch.as_tensor(bid, dtype=torch.int32).to(dev)
                 if eng is not None:
-                    eng.step(None, bid_dev, volumes=(ligand_volumes[0], ligand.sum(dim=1),
-                                                     ligand_volumes[1] if eng.C1 else None))
+                    vols = (ligand_volumes[0], ligand.sum(dim=1), ligand_volumes[1] if eng.C1 else None)
+                    if Lc:
+                        vols = (self._embed(vols[0], Lc), self._embed(vols[1], Lc),
+                                self._embed(vols[2], Lc // 2) if eng.C1 else None)
+                    eng.step(None, bid_dev, volumes=vols)
                     continue
                 ligand_forbidden = ligand.sum(dim=1).unsqueeze(dim=1).contiguous()
                 norm = conv_noclip(receptor_forbidden.expand(nb, -1, -1, -1, -1).contiguous(), ligand_forbidden)

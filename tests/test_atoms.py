@@ -747,3 +747,12 @@ def test_dockE3_reference_configuration_on_gpu(tmp_path):
         dk.dockE3(frec, flig, batch_size=2)
     assert max(abs(a[4] - b[4]) for a, b in zip(dk.top_list, want)) <= 1e-4 * scale
     assert sum(a[:4] == b[:4] for a, b in zip(dk.top_list, want)) >= K - 2
+    assert dk.path == "fused"
+    # the same at box 72 (no compiled plan): every batch's volumes inside the 80 / 40 engine
+    L2 = 72
+    want2, scale2 = _dock_reference_shape_e3(be, model.cpu(), frec, flig, R, L2, res, K)
+    dk2 = Docker(model.to(dev), box_size=L2, resolution=res, max_conf=K, rotations=R, device=dev, coords_backend=be)
+    with torch.no_grad():
+        dk2.dockE3(frec, flig, batch_size=2)
+    assert dk2.path == "embedded" and dk2.engine_box == 80
+    assert _check_lists_band(dk2.top_list, want2, scale2, K) <= 2
