@@ -22,7 +22,8 @@ typedef unsigned long long u64;
 #define TOPK_BINS 2048
 #define TOPK_HIST_BLOCKS 64
 #define TOPK_HIST_THREADS 256
-#define TOPK_MAXK 4096
+#define TOPK_LDSK 4096          // up to this many conformations the sorts run in one block's LDS ...
+#define TOPK_MAXK 65536         // ... above it in global scratch (same kernels, same results, slower: Docker.py:18 accepts any max_conf)
 
 struct TopkState {           // one per rotation in the batch
   u64 kth;                   // decided high bits of the K-th key, finally the K-th key itself
@@ -160,10 +161,11 @@ DLPD_D void bitonic_sort_u64(u64* a, int n, int tid, int nt) {
 }
 
 // one block per rotation: sort the K survivors, apply the zero-fill quirk, write (score, idx)
-__global__ void __launch_bounds__(1024)
+template <bool LARGE> __global__ void __launch_bounds__(1024)
 k_topk_sort(const float* __restrict__ V, long long nvox, const TopkState* st, const u64* __restrict__ cand, int K,
-            float* __restrict__ out_score, int* __restrict__ out_idx) {
-  __shared__ u64 keys[TOPK_MAXK];
+            float* __restrict__ out_score, int* __restrict__ out_idx, u64* __restrict__ sortbuf, int KPs) {
+  __shared__ u64 keys_lds[LARGE ? 1 : TOPK_LDSK];
+  u64* keys = LARGE ? sortbuf + (size_t)blockIdx.x * KPs : keys_lds;      // LARGE: K > TOPK_LDSK, sorted in global scratch
   __shared__ int nneg_s;
   __shared__ unsigned pmin_s;
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
@@ -266,7 +268,7 @@ DLPD_D void bitonic_sort_pairs(u64* hi, u64* lo, int n, int tid, int nt) {
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(1024)
+template <bool LARGE> __global__ void __launch_bounds__(1024)
 k_topk_merge(const float* __restrict__ cs, const int* __restrict__ ci, const int* __restrict__ rot_ids, int nb, int K,
              u64* __restrict__ glist, unsigned* __restrict__ tau_out) {
   DLPD_DYN_SHARED(u64, sm);
@@ -274,8 +276,8 @@ k_topk_merge(const float* __restrict__ cs, const int* __restrict__ ci, const int
   int KP = 1;
   while (KP < K) KP <<= 1;
   const int CAP = 2 * KP;
-  u64* hi = sm;
-  u64* lo = sm + CAP;
+  u64* hi = LARGE ? glist + 2 + 2 * (size_t)K : sm;      // LARGE: the pair arrays live behind the list (dlpd_topk_glist_bytes)
+  u64* lo = hi + CAP;
   __shared__ int s_cnt, s_new;
   u64* ghi = glist + 2;
   u64* glo = glist + 2 + K;
@@ -350,10 +352,19 @@ k_topk_merge(const float* __restrict__ cs, const int* __restrict__ ci, const int
 
 extern "C" {
 
-size_t dlpd_topk_workspace_bytes(int nb, int K) {
-  return (size_t)nb * sizeof(TopkState) + (size_t)nb * (size_t)K * sizeof(u64) + 256;
+static size_t topk_pow2(int K) {
+  size_t KP = 1;
+  while (KP < (size_t)K) KP <<= 1;
+  return KP;
 }
-size_t dlpd_topk_glist_bytes(int K) { return (size_t)(2 + 2 * (size_t)K) * sizeof(u64); }
+size_t dlpd_topk_workspace_bytes(int nb, int K) {
+  const size_t sortbuf = (K > TOPK_LDSK) ? (size_t)nb * topk_pow2(K) * sizeof(u64) : 0;
+  return (size_t)nb * sizeof(TopkState) + (size_t)nb * (size_t)K * sizeof(u64) + sortbuf + 256;
+}
+// header + hi[K] + lo[K] (+ the merge's 2 x 2 KP pair scratch when it does not fit a block's LDS)
+size_t dlpd_topk_glist_bytes(int K) {
+  return (size_t)(2 + 2 * (size_t)K + (K > TOPK_LDSK ? 4 * topk_pow2(K) : 0)) * sizeof(u64);
+}
 
 int dlpd_topk_glist_reset(void* glist, int K, void* stream) {
   if (!glist || K <= 0) return DLPD_ERR_ARG;
@@ -396,8 +407,15 @@ int dlpd_topk_select_cand(const float* V, int nb, long long nvox, int K, float* 
     DLPD_LAUNCH(k_topk_scan, dim3(nb), dim3(256), 0, st, state, pass);
   }
   DLPD_LAUNCH(k_topk_collect, dim3(TOPK_HIST_BLOCKS, nb), dim3(TOPK_HIST_THREADS), 0, st, V, nvox, state, cand, K);
-  DLPD_LAUNCH(k_topk_sort, dim3(nb), dim3(1024), 0, st, V, nvox, (const TopkState*)state, (const u64*)cand, K,
-              out_score, out_idx);
+  int KP = 1;
+  while (KP < K) KP <<= 1;
+  u64* sortbuf = cand + (size_t)nb * K;                 // (nb, KP), allocated for K > TOPK_LDSK only
+  if (K > TOPK_LDSK)
+    DLPD_LAUNCH(k_topk_sort<true>, dim3(nb), dim3(1024), 0, st, V, nvox, (const TopkState*)state, (const u64*)cand, K,
+                out_score, out_idx, sortbuf, KP);
+  else
+    DLPD_LAUNCH(k_topk_sort<false>, dim3(nb), dim3(1024), 0, st, V, nvox, (const TopkState*)state, (const u64*)cand, K,
+                out_score, out_idx, (u64*)nullptr, 0);
   return dlpd_check_launch();
 }
 
@@ -418,10 +436,15 @@ int dlpd_topk_merge_tau(const float* cand_score, const int* cand_idx, const int*
   if (K > TOPK_MAXK) return DLPD_ERR_UNSUPPORTED;
   int KP = 1;
   while (KP < K) KP <<= 1;
+  if (K > TOPK_LDSK) {
+    DLPD_LAUNCH(k_topk_merge<true>, dim3(1), dim3(1024), 0, (hipStream_t)stream, cand_score, cand_idx, rot_ids, nb, K,
+                (u64*)glist, (unsigned*)tau_out);
+    return dlpd_check_launch();
+  }
   const size_t shmem = (size_t)4 * KP * sizeof(u64);
-  int rc = dlpd_set_max_dyn_shared((const void*)k_topk_merge, shmem);
+  int rc = dlpd_set_max_dyn_shared((const void*)k_topk_merge<false>, shmem);
   if (rc) return rc;
-  DLPD_LAUNCH(k_topk_merge, dim3(1), dim3(1024), shmem, (hipStream_t)stream, cand_score, cand_idx, rot_ids, nb, K,
+  DLPD_LAUNCH(k_topk_merge<false>, dim3(1), dim3(1024), shmem, (hipStream_t)stream, cand_score, cand_idx, rot_ids, nb, K,
               (u64*)glist, (unsigned*)tau_out);
   return dlpd_check_launch();
 }

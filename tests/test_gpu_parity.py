@@ -153,8 +153,13 @@ def test_topk_full_size_exact(dev):
         assert np.array_equal(ci[j], idx) and np.array_equal(cs[j].view(np.uint32), sc.view(np.uint32))
 
 
+def get_lib_for_tests():
+    from deeplocalproteindocking_amd._lib import get_lib
+    return get_lib()
+
+
 def test_topk_and_merge_with_4096_conformations(dev):
-    """max_conf = 4096 (the device limit; the reference uses 2000): per-rotation picks exact against the vectorised oracle
+    """max_conf = 4096 (the largest list sorted in LDS; the reference uses 2000): per-rotation picks exact against the vectorised oracle
     at 128^3 and the merged running list of three rotations against the faithful sequence of update_top calls' closed
     form (sort of all picks by (score, rotation, pick))."""
     from deeplocalproteindocking_amd.engine import DeviceTopList
@@ -179,7 +184,14 @@ def test_topk_and_merge_with_4096_conformations(dev):
     assert rot.tolist() == [p[1] for p in want] and idx.tolist() == [p[3] for p in want]
     assert np.array_equal(np.asarray(score, dtype=np.float32), np.asarray([p[0] for p in want], dtype=np.float32))
     with pytest.raises(RuntimeError):
-        DeviceTopList(4097, 1, dev, get_lib()).select(V.to(dev).reshape(nb, -1)[:1], 1)
+        DeviceTopList(65537, 1, dev, get_lib()).select(V.to(dev).reshape(nb, -1)[:1], 1)
+
+
+def test_topk_and_merge_with_20000_conformations(dev):
+    """max_conf above 4096: the same kernels with their sorts in global scratch (128^3 grid, K = 20,000, three rotations
+    with ties and a zero-fill case)."""
+    from test_kernels_emu import _topk_large_k
+    _topk_large_k(get_lib_for_tests(), dev, 128, 20000, 3)
 
 
 @pytest.mark.parametrize("tag,nres", [("multires", 2), ("single", 1)])

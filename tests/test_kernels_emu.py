@@ -148,6 +148,36 @@ def test_topk_many_rotations_with_flushes(emu):
     assert got == [(r, x, y, z, float(np.float32(s))) for r, x, y, z, s in want]
 
 
+def _topk_large_k(lib, device, N, K, nrot):
+    """max_conf above 4096 (Docker.py:18 accepts any): the sorts of select and merge run in global scratch instead of
+    LDS -- per-rotation picks against the vectorised oracle, the merged list against the closed form of the update_top
+    sequence (all picks sorted by (score, rotation, pick)), with ties and a rotation that forces zero-fill."""
+    g = torch.Generator().manual_seed(19)
+    V = torch.randn(nrot, N, N, N, generator=g)
+    V[1] = torch.round(V[1] * 4) / 4                                         # ties
+    if nrot > 2:
+        V[2] = V[2].abs() * (torch.rand(N, N, N, generator=g) > 0.999)       # almost no negative score: zero-fill
+    top = DeviceTopList(K, nrot, device, lib)
+    top.reset()
+    cs, ci = top.select(V.to(device).reshape(nrot, -1).contiguous(), nrot)
+    cs, ci = cs.cpu().numpy().copy(), ci.cpu().numpy().copy()
+    picks = []
+    for j in range(nrot):
+        idx, sc = orc.rotation_picks_fast(V[j].numpy(), K)
+        assert np.array_equal(ci[j], idx) and np.array_equal(cs[j].view(np.uint32), sc.view(np.uint32))
+        picks += [(float(sc[i]), j, i, int(idx[i])) for i in range(K)]
+    top.merge(torch.arange(nrot, dtype=torch.int32, device=device), nrot)
+    rot, idx, score, pick = top.entries()
+    picks.sort(key=lambda p: (p[0], p[1], p[2]))
+    want = picks[:K]
+    assert rot.tolist() == [p[1] for p in want] and idx.tolist() == [p[3] for p in want]
+    assert np.array_equal(np.asarray(score, dtype=np.float32), np.asarray([p[0] for p in want], dtype=np.float32))
+
+
+def test_topk_with_more_than_4096_conformations_emulated(emu):
+    _topk_large_k(emu, "cpu", 20, 4500, 3)
+
+
 def test_rotate_kernel_matches_oracle(emu):
     torch.manual_seed(2)
     B, C, L = 2, 3, 10
