@@ -268,6 +268,46 @@ DLPD_D void bitonic_sort_pairs(u64* hi, u64* lo, int n, int tid, int nt) {
   __syncthreads();
 }
 
+// Large lists (pair arrays in global memory): the running list [0, count) is sorted and the pending entries
+// [KP, KP + nnew) are few in the steady state -- sort those in LDS (<= TOPK_LDSK of them), give every old and every new
+// entry its rank in the union by a binary search in the other run, write the K smallest behind the old list and copy
+// them back.  Keys are unique (score, rotation | pick, index), so ranks never collide.  sm: 2 x TOPK_LDSK u64 of LDS.
+DLPD_D void rank_merge_pairs(u64* hi, u64* lo, int KP, int count, int nnew, int K, u64* sm, int tid, int nt) {
+  u64* nh = sm;
+  u64* nl = sm + TOPK_LDSK;
+  int NP = 64;
+  while (NP < nnew) NP <<= 1;
+  for (int i = tid; i < NP; i += nt) {
+    nh[i] = (i < nnew) ? hi[KP + i] : ~(u64)0;
+    nl[i] = (i < nnew) ? lo[KP + i] : ~(u64)0;
+  }
+  bitonic_sort_pairs(nh, nl, NP, tid, nt);              // (ends with a block barrier: the pending slots may be overwritten)
+  for (int i = tid; i < count; i += nt) {               // old entry i: how many new ones sort before it
+    const u64 h = hi[i], l = lo[i];
+    int a = 0, b = nnew;
+    while (a < b) {
+      const int m = (a + b) >> 1;
+      if (pair_gt(h, l, nh[m], nl[m])) a = m + 1; else b = m;
+    }
+    const int pos = i + a;
+    if (pos < K) { hi[KP + pos] = h; lo[KP + pos] = l; }
+  }
+  for (int j = tid; j < nnew; j += nt) {                // new entry j: how many old ones sort before it
+    const u64 h = nh[j], l = nl[j];
+    int a = 0, b = count;
+    while (a < b) {
+      const int m = (a + b) >> 1;
+      if (pair_gt(h, l, hi[m], lo[m])) a = m + 1; else b = m;
+    }
+    const int pos = j + a;
+    if (pos < K) { hi[KP + pos] = h; lo[KP + pos] = l; }
+  }
+  __syncthreads();
+  const int total = (count + nnew < K) ? count + nnew : K;
+  for (int i = tid; i < total; i += nt) { hi[i] = hi[KP + i]; lo[i] = lo[KP + i]; }
+  __syncthreads();
+}
+
 template <bool LARGE> __global__ void __launch_bounds__(1024)
 k_topk_merge(const float* __restrict__ cs, const int* __restrict__ ci, const int* __restrict__ rot_ids, int nb, int K,
              u64* __restrict__ glist, unsigned* __restrict__ tau_out) {
@@ -309,7 +349,8 @@ k_topk_merge(const float* __restrict__ cs, const int* __restrict__ ci, const int
       if (tid == 0) s_cnt = 0;
       if (nnew + nsurv <= CAP - KP || attempt == 1) break;
       // flush: merge what is pending so the new rotation fits
-      bitonic_sort_pairs(hi, lo, CAP, tid, nt);
+      if (LARGE && nnew <= TOPK_LDSK) rank_merge_pairs(hi, lo, KP, count, nnew, K, sm, tid, nt);
+      else bitonic_sort_pairs(hi, lo, CAP, tid, nt);
       count = (count + nnew < K) ? count + nnew : K;
       nnew = 0;
       for (int i = KP + tid; i < CAP; i += nt) { hi[i] = ~(u64)0; lo[i] = ~(u64)0; }
@@ -334,7 +375,8 @@ k_topk_merge(const float* __restrict__ cs, const int* __restrict__ ci, const int
     __syncthreads();
   }
   if (nnew > 0) {
-    bitonic_sort_pairs(hi, lo, CAP, tid, nt);
+    if (LARGE && nnew <= TOPK_LDSK) rank_merge_pairs(hi, lo, KP, count, nnew, K, sm, tid, nt);
+    else bitonic_sort_pairs(hi, lo, CAP, tid, nt);
     count = (count + nnew < K) ? count + nnew : K;
   }
   __syncthreads();
@@ -437,7 +479,10 @@ int dlpd_topk_merge_tau(const float* cand_score, const int* cand_idx, const int*
   int KP = 1;
   while (KP < K) KP <<= 1;
   if (K > TOPK_LDSK) {
-    DLPD_LAUNCH(k_topk_merge<true>, dim3(1), dim3(1024), 0, (hipStream_t)stream, cand_score, cand_idx, rot_ids, nb, K,
+    const size_t shl = (size_t)2 * TOPK_LDSK * sizeof(u64);
+    int rcl = dlpd_set_max_dyn_shared((const void*)k_topk_merge<true>, shl);
+    if (rcl) return rcl;
+    DLPD_LAUNCH(k_topk_merge<true>, dim3(1), dim3(1024), shl, (hipStream_t)stream, cand_score, cand_idx, rot_ids, nb, K,
                 (u64*)glist, (unsigned*)tau_out);
     return dlpd_check_launch();
   }

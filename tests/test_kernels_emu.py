@@ -167,9 +167,20 @@ def _topk_large_k(lib, device, N, K, nrot):
         assert np.array_equal(ci[j], idx) and np.array_equal(cs[j].view(np.uint32), sc.view(np.uint32))
         picks += [(float(sc[i]), j, i, int(idx[i])) for i in range(K)]
     top.merge(torch.arange(nrot, dtype=torch.int32, device=device), nrot)
+    # a second batch whose scores mostly lose against the full list: few survivors, the steady-state merge (sorted run of
+    # new entries ranked into the sorted list)
+    V2 = torch.randn(nrot, N, N, N, generator=g) + 2.0
+    cs, ci = top.select(V2.to(device).reshape(nrot, -1).contiguous(), nrot)
+    cs, ci = cs.cpu().numpy().copy(), ci.cpu().numpy().copy()
+    for j in range(nrot):
+        idx, sc = orc.rotation_picks_fast(V2[j].numpy(), K)
+        assert np.array_equal(ci[j], idx) and np.array_equal(cs[j].view(np.uint32), sc.view(np.uint32))
+        picks += [(float(sc[i]), nrot + j, i, int(idx[i])) for i in range(K)]
+    top.merge(torch.arange(nrot, 2 * nrot, dtype=torch.int32, device=device), nrot)
     rot, idx, score, pick = top.entries()
     picks.sort(key=lambda p: (p[0], p[1], p[2]))
     want = picks[:K]
+    assert 0 < sum(p[1] >= nrot for p in want) < K // 4                      # some, but few, of the second batch made it
     assert rot.tolist() == [p[1] for p in want] and idx.tolist() == [p[3] for p in want]
     assert np.array_equal(np.asarray(score, dtype=np.float32), np.asarray([p[0] for p in want], dtype=np.float32))
 
