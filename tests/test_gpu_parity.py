@@ -754,3 +754,6 @@ def test_topk_candidate_lists_from_k3_equal_the_full_select(dev, monkeypatch):
     from test_kernels_emu import _search_with_and_without_candidate_lists
     _search_with_and_without_candidate_lists(None, dev, 64, 48, 2000, 60, 16, monkeypatch)
     _search_with_and_without_candidate_lists(None, dev, 80, 16, 500, 20, 8, monkeypatch, seed=4)
+    # max_conf above 4096: K3's lists (4096 slots per rotation) overflow until the threshold has tightened, the large-list
+    # select and merge run in global scratch; both routes must still agree entry for entry
+    _search_with_and_without_candidate_lists(None, dev, 64, 48, 6000, 60, 16, monkeypatch, seed=6)
