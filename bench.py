@@ -71,10 +71,20 @@ def parse_args():
     ap.add_argument("--no_real_shapes", action="store_true", help="skip the short N = 160 measurement")
     ap.add_argument("--no_pmc", action="store_true",
                     help="roofline.traffic from the committed profiles/ file instead of two rocprofv3 --pmc child passes of this run")
-    ap.add_argument("--sustained_s", type=float, default=2.5,
+    ap.add_argument("--sustained_s", type=float, default=8.0,
                     help="untimed extra: seconds of CONSECUTIVE batches from the head of the visiting sequence (0: skip)")
+    ap.add_argument("--strong_s", type=float, default=12.0,
+                    help="untimed extra `strong`: the COMPLETE rotation set sharded r::W over the W ranks if the estimate fits these "
+                         "seconds, else the prefix of the visiting sequence that does (0: skip)")
+    ap.add_argument("--gather_rotations", type=int, default=1024,
+                    help="untimed extra `gather_check`: the first n rotations of the visiting sequence, sharded r::W, one "
+                         "all-gather + merge; the list hash must not depend on the world size (0: skip)")
+    ap.add_argument("--no_extras", action="store_true", help="skip the c48l80 and e3 extra objects of the default line")
     ap.add_argument("--k3_form", type=int, default=0, choices=(0, 1, 2),
                     help="kernel formulation of the fused K3 (include/dlpd.h, dlpd_zifft_filter_form): 0 = library default")
+    ap.add_argument("--preact_layout", default="auto", choices=("auto", "planes", "channels_last"),
+                    help="two-resolution workloads: layout of the coarse grid's first-layer pre-activations (auto = the engine's "
+                         "default: planes; channels-last measured slower, DESIGN.md section 4)")
     ap.add_argument("--dry_run", action="store_true",
                     help="launch plumbing only (gloo, no GPU): every rank joins the group, rank 0 prints a JSON line")
     return ap.parse_args()
@@ -268,7 +278,8 @@ def build_workload(name, args, dev):
     thr = clash_threshold(recf, ligf)
     W = filt.parameters_tuple()
     eng = DockingEngine(L, C, *W, clip=5.0, threshold_clash=thr, has_clash=True, max_conf=args.max_conf,
-                        batch=args.batch, device=dev, coarse_channels=C1, k3_form=args.k3_form)
+                        batch=args.batch, device=dev, coarse_channels=C1, k3_form=args.k3_form,
+                        preact_channels_last={"auto": None, "planes": False, "channels_last": True}[args.preact_layout] if C1 else None)
     eng.set_receptor(rec[0], recf, rec[1] if C1 else None)
     eng.set_ligand(lig[0], ligf, lig[1] if C1 else None)
     return eng, dict(C=C, L=L, C1=C1, angle=angle, desc=desc, rec=rec, lig=lig, recf=recf, ligf=ligf, W=W, thr=thr)
@@ -295,6 +306,44 @@ def dry_run(args):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def list_sha256(ent):
+    """sha256 of a ranked list (rot, flat index, score, pick) in fixed dtypes: two runs compare entry for entry."""
+    import hashlib
+    import numpy as np
+    h = hashlib.sha256()
+    for a, ty in zip(ent, (np.int64, np.int64, np.float32, np.int64)):
+        h.update(np.ascontiguousarray(a, dtype=ty).tobytes())
+    return h.hexdigest()
+
+
+def sharded_search(eng, R_all, ids_global, rank, world, K, dist, dev):
+    """The search as Docker runs it on W ranks (Docker.py:211-236; SURVEY 8e): rank r scores ``ids_global[r::W]``
+    (ascending), then ONE all-gather of the per-rank lists and the deterministic merge.  -> (merged entries,
+    seconds = max over ranks, barrier to barrier)."""
+    import numpy as np
+    import torch
+    from deeplocalproteindocking_amd.Docker.Docker import all_gather_top_entries
+    mine = np.sort(np.asarray(ids_global)[rank::world])
+    eng.reset_top()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    if len(mine):
+        eng.search(R_all[mine], rot_ids=mine)
+    ent = eng.top_entries()
+    if world > 1:
+        ent = all_gather_top_entries(ent, K, world, None, dev)
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0].item())
+    return ent, dt
 
 
 def run_rank(args):
@@ -423,11 +472,48 @@ def run_rank(args):
     if rank == 0 and world == 1 and args.sustained_s > 0:
         sustained = sustained_measurement(eng, R_all, seq_ids, seq_key, nb, N, elapsed / args.steps, args.sustained_s, dev)
 
-    real_shapes = None
+    # untimed extras that EVERY world size runs, so that the driver's N = 1 and N = 8 lines can be compared:
+    # (i) gather_check: a fixed subset of the set (the first n rotations of the single-process visiting sequence),
+    #     sharded r::W, through the one all-gather + merge -- the list hash must not depend on W;
+    # (ii) strong: the complete set sharded over the ranks (seconds, rotations/s, list hash, the set-up beside it), or,
+    #     where that would not fit --strong_s (N = 1), the prefix of the sequence that does.
+    switches = eng.switches()
+    gather_check = strong = None
+    all_ids = np.arange(nrot_total)
+    seq_all, _ = visiting_sequence(DockingEngine, R_all, all_ids, nb)
+    if args.gather_rotations > 0:
+        sub = seq_all[:min(args.gather_rotations, len(seq_all))]
+        ent, dt = sharded_search(eng, R_all, sub, rank, world, K, dist, dev)
+        gather_check = {"rotations": int(len(sub)), "list_sha256": list_sha256(ent), "list_entries": int(len(ent[0])),
+                        "world_size_seen": (dist.get_world_size() if world > 1 else 1),
+                        "backend": (dist.get_backend() if world > 1 else None), "seconds": dt,
+                        "sample": "the first %d rotations of the single-process visiting sequence, sharded r::W, one "
+                                  "all-gather + deterministic merge; the hash is the same at every world size" % len(sub)}
+    if args.strong_s > 0:
+        s_per_rot = elapsed / args.steps / nb
+        complete = nrot_total / world * s_per_rot <= args.strong_s
+        ids_strong = all_ids if complete else seq_all[:max(nb, int(args.strong_s / s_per_rot) // nb * nb)]
+        ent, dt = sharded_search(eng, R_all, ids_strong, rank, world, K, dist, dev)
+        strong = {"complete_set": bool(complete), "rotations": int(len(ids_strong)), "world_size": world, "seconds": dt,
+                  "rot_per_s": len(ids_strong) / dt, "value": len(ids_strong) * float(N) ** 3 / dt, "unit": "pose scores/s",
+                  "list_sha256": list_sha256(ent), "list_entries": int(len(ent[0])), "per_rank_setup_s": setup_s,
+                  "seconds_incl_setup": dt + setup_s,
+                  "sample": ("the complete %d-rotation set, rank r scoring rotations r::W (Docker.shard), ending with the one "
+                             "all-gather + merge" % nrot_total) if complete else
+                            ("the first %d rotations of the visiting sequence: the complete set would exceed --strong_s %.0f s "
+                             "at this world size" % (len(ids_strong), args.strong_s))}
+
+    real_shapes = c48l80 = e3 = None
     if rank == 0 and world == 1 and args.workload == "config2" and not args.no_real_shapes:
         del eng
         torch.cuda.empty_cache()
         real_shapes = short_measurement("real", args, dev, R_all, nb)
+        if not args.no_extras:
+            c48l80 = short_measurement("c48l80", args, dev, R_all, nb, nsteps=12)
+            try:
+                e3 = e3_measurement(dev, nb)
+            except Exception as exc:                             # an extra must never cost the headline line
+                e3 = {"error": repr(exc)}
 
     if rank == 0:
         poses = float(args.steps) * nb * N ** 3 * world
@@ -482,6 +568,8 @@ def run_rank(args):
                        "translations_per_rotation": N ** 3, "sharding": "rotations interleaved over %d rank(s)" % world,
                        "world_size_seen_by_the_collective": (dist.get_world_size() if world > 1 else 1),
                        "collective_backend": (dist.get_backend() if world > 1 else None),
+                       "kernel_switches": switches,
+                       "environment": {k: v for k, v in os.environ.items() if k.startswith("DLPD_")},
                        "clip": 5.0, "threshold_clash": wl["thr"],
                        "masked_fraction": None if V_first is None else float((V_first == 0).float().mean())},
             "rot_per_s": args.steps * nb * world / elapsed,
@@ -498,8 +586,16 @@ def run_rank(args):
         out["per_rank_setup_s"] = setup_s
         if sustained is not None:
             out["sustained"] = sustained
+        if gather_check is not None:
+            out["gather_check"] = gather_check
+        if strong is not None:
+            out["strong"] = strong
         if real_shapes is not None:
             out["real_shapes"] = real_shapes
+        if c48l80 is not None:
+            out["c48l80"] = c48l80
+        if e3 is not None:
+            out["e3"] = e3
         if world == 1 and args.cpu_rotations > 0 and V_first is not None:
             out["cpu_baseline"] = cpu_baseline(wl["rec"], wl["lig"], wl["recf"], wl["ligf"], [w.cpu() for w in wl["W"]],
                                                R_cpu, grp_cpu, wl["thr"], K, V_first)
@@ -513,7 +609,6 @@ def sustained_measurement(eng, R_all, seq_ids, seq_key, nb, N, s_per_step, secon
     """Untimed extra of the default line: `seconds` worth of CONSECUTIVE batches (the search as Docker runs it, from the
     head of the visiting sequence) -- long enough for the power-limited steady-state clock -- with the sha256 of the
     resulting ranked list, so that two driver runs can be compared entry for entry."""
-    import hashlib
     import numpy as np
     import torch
     nsteps = int(min(len(seq_ids) // nb, max(32, seconds / max(s_per_step, 1e-6))))
@@ -528,11 +623,8 @@ def sustained_measurement(eng, R_all, seq_ids, seq_key, nb, N, s_per_step, secon
     ent = eng.top_entries()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    h = hashlib.sha256()
-    for a, ty in zip(ent, (np.int64, np.int64, np.float32, np.int64)):
-        h.update(np.ascontiguousarray(a, dtype=ty).tobytes())
     return {"steps": nsteps, "seconds": dt, "ms_per_step": dt / nsteps * 1e3, "value": nsteps * nb * N ** 3 / dt,
-            "unit": "pose scores/s", "rotations": nsteps * nb, "list_sha256": h.hexdigest(), "list_entries": int(len(ent[0])),
+            "unit": "pose scores/s", "rotations": nsteps * nb, "list_sha256": list_sha256(ent), "list_entries": int(len(ent[0])),
             "sample": "the first %d batches of the visiting sequence, consecutively (untimed extra, NOT the headline)" % nsteps}
 
 
@@ -569,13 +661,87 @@ def short_measurement(name, args, dev, R_all, nb, nsteps=24):
     rps = nb / (ms * 1e-3)
     del eng
     torch.cuda.empty_cache()
-    return {"workload": wl["desc"], "steps": nsteps, "ms_per_step": ms, "rot_per_s": rps,
+    return {"workload": wl["desc"], "kernel_switches": sw, "steps": nsteps, "ms_per_step": ms, "rot_per_s": rps,
             "value": rps * N ** 3, "unit": "pose scores/s",
             "stages": {k: {"ms_per_launch": v, "alg_GBps": (alg[k] / (v * 1e-3) / 1e9 if k in alg else None),
                            "frac_of_peak": (alg[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS if k in alg else None)}
                        for k, v in stages.items()},
             "frac_of_peak_on_compulsory_floor": rps * floor_mb * 1e6 / 1e9 / HBM_PEAK_GBS,
             "stage_boundary_model_GBps_nominal": rps * sb_mb * 1e6 / 1e9}
+
+
+def e3_measurement(dev, nb, nsteps=6):
+    """`e3` extra: what a batch of Docker.dockE3 (Docker.py:135-182) costs at the reference's box 80 -- the ligand
+    rotated in coordinate space and re-projected (Docker.py:163-165), re-represented by the plugin
+    (E3MultiResRepr4x4(multiplier=8): every convolution on dlpd_conv3d, Docker.py:166-167) and scored by the fused
+    engine from the batch's own volumes -- on a synthetic protein-sized pair, per launch of `nb` rotations."""
+    import tempfile
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from synth_pdb import write_protein_like_pdb
+    from deeplocalproteindocking_amd.Docker import Docker
+    from deeplocalproteindocking_amd.Models import E3MultiResRepr4x4, GlobalDockingModel, SimpleFilter
+    from deeplocalproteindocking_amd.Utils.FullAtom import CoordsBackend
+    from deeplocalproteindocking_amd.Utils.Rotations import Rotations
+    with tempfile.TemporaryDirectory(prefix="dlpd_e3_") as tmp, torch.no_grad():
+        rec_pdb, lig_pdb = os.path.join(tmp, "rec.pdb"), os.path.join(tmp, "lig.pdb")
+        write_protein_like_pdb(rec_pdb, 160, 31)
+        write_protein_like_pdb(lig_pdb, 110, 32)
+        torch.manual_seed(3)
+        repr_ = E3MultiResRepr4x4(multiplier=8)
+        model = GlobalDockingModel(repr_, SimpleFilter(repr_.get_num_outputs()), threshold_clash=3.0).to(dev)
+        model.eval()
+        be = CoordsBackend()
+        rot = Rotations(20, allow_generated=True, verbose=False)
+        dk = Docker(model, angle_inc=20, box_size=80, resolution=1.25, max_conf=2000, device=dev, coords_backend=be,
+                    rotations=rot.R.numpy())
+        L, res = 80, 1.25
+        lcoords, lnat, loff, _, _ = dk.load_batch([lig_pdb], bbox_center=False)
+        rcoords, rnat, roff, _, rnatoms = dk.load_batch([rec_pdb], bbox_center=False)
+        rcoords = be.translate(rcoords, dk.box_center, rnatoms)
+        lc, ln, lo = be.to_device(lcoords, lnat, loff, dev)
+        receptor = be.project(rcoords, rnat, roff, L, res, dev)
+        rv = model.representation(receptor)
+        from deeplocalproteindocking_amd.Models.DockingModels import fused_filter_parameters
+        eng = dk._make_engine([v.reshape((-1,) + tuple(v.shape[-3:])) for v in rv], receptor.sum(dim=1)[0], nb,
+                              fused_filter_parameters(model))
+        eng.reset_top()
+        Rb = rot.R[:nb].to(device=dev, dtype=torch.float32).contiguous()
+        ids = torch.arange(nb, dtype=torch.int32, device=dev)
+
+        def timed(fn, n=nsteps):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                r = fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3, r
+        ms_proj, lig = timed(lambda: be.project(lc, ln, lo, L, res, dev, R=Rb, shift=dk.box_center))
+        ms_repr, vols = timed(lambda: model.representation(lig))
+        forb = lig.sum(dim=1)
+
+        def engine_step():
+            eng.step(None, ids, volumes=(vols[0], forb, vols[1] if eng.C1 else None))
+            eng.finish()
+        ms_eng, _ = timed(engine_step)
+
+        def body():
+            l = be.project(lc, ln, lo, L, res, dev, R=Rb, shift=dk.box_center)
+            v = model.representation(l)
+            eng.step(None, ids, volumes=(v[0], l.sum(dim=1), v[1] if eng.C1 else None))
+        ms_all, _ = timed(body, n=2 * nsteps)
+        eng.finish()
+        natoms = int(lnat.sum()) if hasattr(lnat, "sum") else None
+        out = {"workload": "Docker.dockE3 at box 80, E3MultiResRepr4x4(multiplier=8) -> %s channels, synthetic %d / %d-residue pair"
+                           % (repr_.get_num_outputs(), 160, 110),
+               "rotations_per_launch": nb, "ms_projection": ms_proj, "ms_representation": ms_repr, "ms_engine": ms_eng,
+               "ms_per_launch": ms_all, "rot_per_s": nb / (ms_all * 1e-3), "value": nb / (ms_all * 1e-3) * (2.0 * L) ** 3,
+               "unit": "pose scores/s", "ligand_atoms": natoms, "path": "fused engine on the batch's own volumes"}
+        dk.release_engine()
+        del eng
+        torch.cuda.empty_cache()
+        return out
 
 
 def pmc_traffic(workload, C, L, nb, kernel):

@@ -35,7 +35,11 @@ def read_pdb_list(benchmark_dir, pdb_list_file, struct_folder="structures"):
                 continue
             if cls == 0:
                 continue
-            pdb = line.split("\t")[0].split("_")[0]
+            # (the reference appends a target for EVERY line of a section, an empty one included -- its name is then the
+            #  line break; such rows, and the CR of a CRLF table, are dropped here instead of becoming file names)
+            pdb = line.split("\t")[0].split("_")[0].strip()
+            if not pdb:
+                continue
             s = lambda suffix: os.path.join(benchmark_dir, struct_folder, pdb + suffix)
             targets.append((pdb, os.path.join(benchmark_dir, "Matched", pdb + "_b.pdb"),
                             s("_r_u.pdb"), s("_l_u.pdb"), s("_r_b.pdb"), s("_l_b.pdb"), cls))

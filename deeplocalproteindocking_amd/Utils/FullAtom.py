@@ -68,24 +68,66 @@ def atom_type(resname, atomname):
     return -1
 
 
+_HEAVY_ELEMENTS = {"C", "N", "O", "S", "SE", "P"}
+
+
+def _residue_number(field):
+    """Columns 23-26: a decimal number; files with more than 9,999 residues carry hybrid-36 there ("A000" = 10000):
+    decoded, and anything unreadable becomes 0 (the number only labels the atom, Docker never computes with it)."""
+    f = field.strip()
+    try:
+        return int(f)
+    except ValueError:
+        pass
+    digits = "0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZ"
+    if len(f) == 4 and f[0].isalpha() and all(ch.upper() in digits for ch in f):
+        up = f[0].isupper()
+        v = 0
+        for ch in f.upper():
+            v = v * 36 + digits.index(ch)
+        return v - 10 * 36 ** 3 + 10 ** 4 + (0 if up else 26 * 36 ** 3)
+    return 0
+
+
 def read_pdb_atoms(filename):
     """ATOM records -> (xyz float64 (n,3), chains, resnames, resnums, atomnames); first model only,
-    alternate locations other than ' '/'A' dropped."""
+    alternate locations other than ' '/'A' dropped.
+
+    What real PDB entries have and the synthetic test files may not: CRLF line ends and lines without trailing
+    blanks (records are padded to 80 columns before slicing), TER / END / CONECT / ANISOU / HETATM records (skipped: the
+    reference types protein atoms only), hybrid-36 serial and residue numbers, blank chain identifiers, an element
+    column (77-78) that is present, blank or absent -- when it names an element the record is kept only for C, N, O, S,
+    Se, P (hydrogen and deuterium records are dropped here, whatever their atom name looks like; metals written as
+    ATOM too), otherwise the atom name decides (``atom_type``).  A file without a usable ATOM record, a record with a
+    non-numeric or non-finite coordinate: ValueError naming the file and line."""
     xyz, chains, resnames, resnums, atomnames = [], [], [], [], []
-    with open(filename) as fin:
-        for line in fin:
+    with open(filename, newline=None, errors="replace") as fin:
+        for lineno, raw in enumerate(fin, 1):
+            line = raw.rstrip("\r\n")
             rec = line[:6]
             if rec.startswith("ENDMDL"):
                 break
             if not rec.startswith("ATOM"):
                 continue
+            line = line.ljust(80)
             if line[16] not in (" ", "A"):
                 continue
+            elem = line[76:78].strip().upper()
+            if elem.isalpha() and elem not in _HEAVY_ELEMENTS:
+                continue                                        # H, D, metals
+            try:
+                pos = (float(line[30:38]), float(line[38:46]), float(line[46:54]))
+            except ValueError:
+                raise ValueError("%s:%d: ATOM record without numeric coordinates in columns 31-54" % (filename, lineno))
+            if not all(np.isfinite(pos)):
+                raise ValueError("%s:%d: non-finite coordinate" % (filename, lineno))
             atomnames.append(line[12:16].strip())
             resnames.append(line[17:20].strip())
             chains.append(line[21])
-            resnums.append(int(line[22:26]))
-            xyz.append((float(line[30:38]), float(line[38:46]), float(line[46:54])))
+            resnums.append(_residue_number(line[22:26]))
+            xyz.append(pos)
+    if not xyz:
+        raise ValueError("%s: no ATOM records" % filename)
     return np.asarray(xyz, dtype=np.float64).reshape(-1, 3), chains, resnames, resnums, atomnames
 
 

@@ -56,6 +56,10 @@ template <int N> DLPD_D void init_twiddles_k3r(cplx* tw, int tid, int nthreads) 
 #ifndef DLPD_K3R_RAWBUF128
 #define DLPD_K3R_RAWBUF128 1
 #endif
+#ifndef DLPD_K3R_MATRIX
+#define DLPD_K3R_MATRIX 1                   // the filter waves' first layer on the matrix pipe (4x4x1 blocks); 0: vector FMAs
+#endif
+static constexpr bool K3R_MATRIX = DLPD_K3R_MATRIX != 0;
 #ifndef DLPD_K3R_FFT_PRIO
 #define DLPD_K3R_FFT_PRIO 0
 #endif
@@ -174,12 +178,44 @@ template <int N> DLPD_D void k3r_second_pass(cplx* S, int rowoff, int t, const c
   }
 }
 
+// the NQ weight quads of one channel for the matrix pipe's 4x4x1 blocks, from the LDS table (k_zifft_filter_rs): p points at
+// this lane's run (row 4 c + (lane & 3), HPQP floats, 16-byte aligned)
+template <int NQ, int HPQP> DLPD_D void k3r_load_quadw(const float* p, dlpd_quadw (&w)[NQ]) {
+#if DLPD_QUADW_IS_SCALAR
+  if constexpr (NQ % 4 == 0) {
+#pragma unroll
+    for (int q = 0; q < NQ; q += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(p + q);
+      w[q] = v.x; w[q + 1] = v.y; w[q + 2] = v.z; w[q + 3] = v.w;
+    }
+  } else if constexpr (NQ % 2 == 0) {
+#pragma unroll
+    for (int q = 0; q + 4 <= NQ; q += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(p + q);
+      w[q] = v.x; w[q + 1] = v.y; w[q + 2] = v.z; w[q + 3] = v.w;
+    }
+    const float2 v = *reinterpret_cast<const float2*>(p + NQ / 4 * 4);
+    w[NQ / 4 * 4] = v.x; w[NQ / 4 * 4 + 1] = v.y;
+  } else {
+#pragma unroll
+    for (int q = 0; q < NQ; q++) w[q] = p[q];
+  }
+#else
+  // emulated lane: keeps all four values of the quad (rows 4 c .. 4 c + 3 of the table)
+#pragma unroll
+  for (int q = 0; q < NQ; q++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) w[q].w[i] = p[i * HPQP + q];
+#endif
+}
+
 //   Bw   (nb, CT, NZ, N, N) complex [kz][x'][y']
 //   MODE 1: V (nb, N,N,N) = mask * (W2 . relu(W1 . clamp(corr) + b1) + b2); score channels [0,C), clash channel C
 //           if has_clash (mask = corr_C < thr); aux: HP first-layer pre-activation planes on the coarse grid (or none)
 //   MODE 2: out (nb, HP, N,N,N) = b1 + W1rows^T clamp(corr): the coarse resolution's half of the first layer
 //   W1t  (C, HP) transposed + zero padded, b1 (HP), W2 (HP);  G channels per group (<= F * CPW)
-template <int N, int HP, int MODE> __global__ void __launch_bounds__(64 * (K3rCfg<N, (HP > 32)>::F + K3rCfg<N, (HP > 32)>::M))
+//   PCL  the pre-activation planes (MODE 1: aux, read; MODE 2: out, written) are CHANNELS-LAST, (nb, Naux^3 | N^3, HP)
+template <int N, int HP, int MODE, bool PCL> __global__ void __launch_bounds__(64 * (K3rCfg<N, (HP > 32)>::F + K3rCfg<N, (HP > 32)>::M))
 k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int C, int has_clash, int G,
                   const float* __restrict__ W1t, const float* __restrict__ b1, const float* __restrict__ W2,
                   float b2, int has_clip, float clip, float thr, K3Aux aux, int ntiles, int tpb, K3Cand cd) {
@@ -205,6 +241,17 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
   const int t_beg = blockIdx.x * tpb, t_end = (t_beg + tpb < ntiles) ? t_beg + tpb : ntiles;
   if (t_beg >= t_end) return;
   init_twiddles_k3r<N>(tw, tid, 64 * (F + M));
+  // first-layer weights for the matrix pipe (filter waves, below): wq[(c * 4 + i) * HPQP + q] = W1t[c][4 q + i], so that
+  // lane l reads the HP / 4 weights it multiplies with -- hidden units 4 q + (l & 3) of channel c -- as one contiguous,
+  // 16-byte aligned run (LDS latency, not a global load's, in front of every channel's products)
+  constexpr int HPQ = (HP + 3) / 4, HPQP = (HPQ + 3) / 4 * 4;
+  float* wq = reinterpret_cast<float*>(raw + RAWBUF * F * CPW * RAWC);
+  if constexpr (K3R_MATRIX && HP % 4 == 0) {
+    for (int i = tid; i < C * HP; i += 64 * (F + M)) {
+      const int c = i / HP, j = i % HP;
+      wq[(c * 4 + (j & 3)) * HPQP + (j >> 2)] = W1t[i];
+    }
+  }
   const unsigned cand_tau = (MODE == 1 && cd.keys) ? *cd.tau : 0u;
 
   // ---- transform role: this wave's channels of group `cb` of tile `t` -> raw staging buffer `buf`
@@ -287,7 +334,10 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
   } else {
     // ================= filter waves =================
     float nrm[EPT * 2];
-    float h[EPT * 2][HP];
+    // hidden pre-activations of the thread's voxels, in quads: the matrix pipe's 4x4x1 blocks accumulate four hidden
+    // units of a voxel per instruction (below); H(e, j) = hidden unit j of voxel e
+    dlpd_acc4 hq[EPT * 2][(HP + 3) / 4];
+#define H(e, j) DLPD_ACC4_AT(hq[e][(j) >> 2], (j) & 3)
     cplx vals[GMAX][EPT];
     int t = t_beg, cbase = 0;
 #pragma unroll 1
@@ -304,20 +354,41 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
           // rows 2m, 2m+1 and columns z, z^1 of the fine grid share one coarse voxel
           const int Na = aux.N;
           const size_t cstride = (size_t)Na * Na * Na;
-          const float* ab = aux.p + (size_t)b * HP * cstride + ((size_t)(xo >> 1) * Na + (y0 >> 1)) * Na + (zz >> 1);
+          if constexpr (PCL) {
+            // channels-last planes pre[b][x][y][z][HP]: the HP values of a coarse voxel are one contiguous run
+            // (HP / 4 16-byte loads instead of HP 4-byte loads at plane stride)
+            const float* ab = aux.p + (((size_t)b * Na + (xo >> 1)) * Na * Na + (size_t)(y0 >> 1) * Na + (zz >> 1)) * HP;
 #pragma unroll
-          for (int e = 0; e < EPT; e++)
+            for (int e = 0; e < EPT; e++) {
+              const float* av = ab + (size_t)(m0 + e * MSTEP) * Na * HP;
+              if constexpr (HP % 4 == 0) {
 #pragma unroll
-            for (int j = 0; j < HP; j++) {
-              const float v = ab[(size_t)j * cstride + (size_t)(m0 + e * MSTEP) * Na];
-              h[2 * e][j] = v;
-              h[2 * e + 1][j] = v;
+                for (int q = 0; q < HP / 4; q++) {
+                  const float4 v = reinterpret_cast<const float4*>(av)[q];
+                  H(2 * e, 4 * q) = v.x; H(2 * e, 4 * q + 1) = v.y; H(2 * e, 4 * q + 2) = v.z; H(2 * e, 4 * q + 3) = v.w;
+                  H(2 * e + 1, 4 * q) = v.x; H(2 * e + 1, 4 * q + 1) = v.y; H(2 * e + 1, 4 * q + 2) = v.z; H(2 * e + 1, 4 * q + 3) = v.w;
+                }
+              } else {
+#pragma unroll
+                for (int j = 0; j < HP; j++) { H(2 * e, j) = av[j]; H(2 * e + 1, j) = av[j]; }
+              }
             }
+          } else {
+            const float* ab = aux.p + (size_t)b * HP * cstride + ((size_t)(xo >> 1) * Na + (y0 >> 1)) * Na + (zz >> 1);
+#pragma unroll
+            for (int e = 0; e < EPT; e++)
+#pragma unroll
+              for (int j = 0; j < HP; j++) {
+                const float v = ab[(size_t)j * cstride + (size_t)(m0 + e * MSTEP) * Na];
+                H(2 * e, j) = v;
+                H(2 * e + 1, j) = v;
+              }
+          }
         } else {
 #pragma unroll
           for (int e = 0; e < EPT * 2; e++)
 #pragma unroll
-            for (int j = 0; j < HP; j++) h[e][j] = b1[j];
+            for (int j = 0; j < HP; j++) H(e, j) = b1[j];
         }
       }
       DLPD_STAMP(0);
@@ -342,7 +413,37 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
       }
       DLPD_LDS_BARRIER();                      // B2: values held in registers, pencils free for the next group
       DLPD_STAMP(2);
-      {
+      if constexpr (K3R_MATRIX && HP % 4 == 0) {
+        // FIRST LAYER ON THE MATRIX PIPE (v_mfma_f32_4x4x1_16b_f32: sixteen 4x4x1 blocks, one lane quad each): a lane
+        // multiplies ITS voxel's value with the four weights its quad holds -- hidden units 4q..4q+3, lane l holding
+        // W1t[c][4q + (l & 3)] -- and adds into four accumulators: exactly the fmaf(w, v, h) of the vector form, element
+        // by element (bit-identical), HP / 4 matrix instructions per voxel and channel instead of HP vector ones, on
+        // the pipe the transform waves do not use.  Channel g+1's weights are requested before channel g's products.
+        dlpd_quadw wcur[HP / 4], wnxt[HP / 4];
+        const float* wl = wq + DLPD_QUADW_LANE(lane) * HPQP;
+        if (gs > 0) k3r_load_quadw<HP / 4, HPQP>(wl + cbase * 4 * HPQP, wcur);
+#pragma unroll
+        for (int g = 0; g < GMAX; g++) {
+          if (g < gs) {
+            const int gn1 = (g + 1 < gs ? g + 1 : g);
+            k3r_load_quadw<HP / 4, HPQP>(wl + (cbase + gn1) * 4 * HPQP, wnxt);
+            DLPD_SCHED_FENCE();
+#pragma unroll
+            for (int e = 0; e < EPT; e++) {
+              float v0 = vals[g][e].x, v1 = vals[g][e].y;
+              if (has_clip) { v0 = DLPD_CLAMP(v0, clip); v1 = DLPD_CLAMP(v1, clip); }
+#pragma unroll
+              for (int q = 0; q < HP / 4; q++) {
+                hq[2 * e][q] = DLPD_MFMA_4x4x1_QW(wcur[q], v0, hq[2 * e][q]);
+                hq[2 * e + 1][q] = DLPD_MFMA_4x4x1_QW(wcur[q], v1, hq[2 * e + 1][q]);
+              }
+            }
+            DLPD_SCHED_FENCE();
+#pragma unroll
+            for (int q = 0; q < HP / 4; q++) wcur[q] = wnxt[q];
+          }
+        }
+      } else {
         // first-layer weights are wave-uniform (scalar loads): channel g+1's row is requested before channel g's FMAs
         float wcur[HP], wnxt[HP];
         if (gs > 0) {
@@ -362,8 +463,8 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
               if (has_clip) { v0 = DLPD_CLAMP(v0, clip); v1 = DLPD_CLAMP(v1, clip); }
 #pragma unroll
               for (int j = 0; j < HP; j++) {
-                h[2 * e][j] = fmaf(wcur[j], v0, h[2 * e][j]);
-                h[2 * e + 1][j] = fmaf(wcur[j], v1, h[2 * e + 1][j]);
+                H(2 * e, j) = fmaf(wcur[j], v0, H(2 * e, j));
+                H(2 * e + 1, j) = fmaf(wcur[j], v1, H(2 * e + 1, j));
               }
             }
             DLPD_SCHED_FENCE();
@@ -381,10 +482,25 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
           for (int e = 0; e < EPT; e++) {
             const int m = m0 + e * MSTEP;
 #pragma unroll
-            for (int u = 0; u < 2; u++)
+            for (int u = 0; u < 2; u++) {
+              if constexpr (PCL) {
+                // channels-last planes (see the MODE 1 prologue): one contiguous run of HP values per voxel
+                float* ov = out + ((((size_t)b * N + xo) * N + y0 + 2 * m + u) * N + zz) * HP;
+                if constexpr (HP % 4 == 0) {
 #pragma unroll
-              for (int j = 0; j < HP; j++)
-                out[((((size_t)b * HP + j) * N + xo) * N + y0 + 2 * m + u) * N + zz] = h[2 * e + u][j];
+                  for (int q = 0; q < HP / 4; q++)
+                    reinterpret_cast<float4*>(ov)[q] = make_float4(H(2 * e + u, 4 * q), H(2 * e + u, 4 * q + 1),
+                                                                   H(2 * e + u, 4 * q + 2), H(2 * e + u, 4 * q + 3));
+                } else {
+#pragma unroll
+                  for (int j = 0; j < HP; j++) ov[j] = H(2 * e + u, j);
+                }
+              } else {
+#pragma unroll
+                for (int j = 0; j < HP; j++)
+                  out[((((size_t)b * HP + j) * N + xo) * N + y0 + 2 * m + u) * N + zz] = H(2 * e + u, j);
+              }
+            }
           }
         } else {
 #pragma unroll
@@ -394,7 +510,7 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
             for (int u = 0; u < 2; u++) {
               float acc = b2;
 #pragma unroll
-              for (int j = 0; j < HP; j++) acc = fmaf(W2[j], fmaxf(h[2 * e + u][j], 0.f), acc);
+              for (int j = 0; j < HP; j++) acc = fmaf(W2[j], fmaxf(H(2 * e + u, j), 0.f), acc);
               if (has_clash) acc = acc * ((nrm[2 * e + u] < thr) ? 1.0f : 0.0f);
               out[(((size_t)b * N + xo) * N + y0 + 2 * m + u) * N + zz] = acc;
               if (cd.keys && cand_tau) k3_emit(cd, cand_tau, b, (unsigned)((xo * N + y0 + 2 * m + u) * N + zz), acc);
@@ -406,6 +522,7 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
       if (last_group) { cbase = 0; t++; } else cbase += G;
     }
   }
+#undef H
 #ifdef DLPD_STAMPS
   if (lane == 0 && (wave == 0 || wave == F)) {
     const int o = wave == 0 ? 0 : 16;
@@ -427,19 +544,21 @@ static int k3r_group(int CT, int maxg, bool balanced) {
 #ifndef DLPD_K3R_TPB_DIV
 #define DLPD_K3R_TPB_DIV 1                   // tiles per block = (y-tiles of an x' plane) / DIV
 #endif
-template <int N, int HP, int MODE> static int launch_k3r(const cplx* Bw, float* out, int CT, int C, int has_clash, int nb,
+template <int N, int HP, int MODE, bool PCL> static int launch_k3r(const cplx* Bw, float* out, int CT, int C, int has_clash, int nb,
                                                          const float* W1t, const float* b1, const float* W2, float b2,
                                                          int has_clip, float clip, float thr, hipStream_t st, K3Aux aux,
                                                          K3Cand cd) {
   typedef K3rCfg<N, (HP > 32)> Cfg;
   constexpr int RS = N + 8, NZ = N / 2 + 1, NPAIR = Cfg::TY / 2, CPW = 8 / NPAIR;
   constexpr int RAWC = ((NZ * NPAIR + 63) / 64) * 64;
-  const size_t shmem = (size_t)(Cfg::F * 8 * RS + N) * sizeof(cplx) + (size_t)Cfg::RAWBUF * Cfg::F * CPW * RAWC * 16;
-  int rc = dlpd_set_max_dyn_shared((const void*)k_zifft_filter_rs<N, HP, MODE>, shmem);
+  constexpr int HPQP = ((HP + 3) / 4 + 3) / 4 * 4;
+  const size_t shmem = (size_t)(Cfg::F * 8 * RS + N) * sizeof(cplx) + (size_t)Cfg::RAWBUF * Cfg::F * CPW * RAWC * 16 +
+                       ((K3R_MATRIX && HP % 4 == 0) ? (size_t)C * 4 * HPQP * sizeof(float) : 0);
+  int rc = dlpd_set_max_dyn_shared((const void*)k_zifft_filter_rs<N, HP, MODE, PCL>, shmem);
   if (rc) return rc;
   const int G = k3r_group(CT, Cfg::F * CPW, true);
   const int ntiles = (N / Cfg::TY) * N * nb, tpb = (N / Cfg::TY) / DLPD_K3R_TPB_DIV;
-  DLPD_LAUNCH((k_zifft_filter_rs<N, HP, MODE>), dim3((ntiles + tpb - 1) / tpb), dim3(64 * (Cfg::F + Cfg::M)), shmem, st, Bw,
+  DLPD_LAUNCH((k_zifft_filter_rs<N, HP, MODE, PCL>), dim3((ntiles + tpb - 1) / tpb), dim3(64 * (Cfg::F + Cfg::M)), shmem, st, Bw,
               out, CT, C, has_clash, G, W1t, b1, W2, b2, has_clip, clip, thr, aux, ntiles, tpb, cd);
   return dlpd_check_launch();
 }
@@ -452,17 +571,17 @@ int dlpd_k3r_supported(int L, int HP, int mode) {
   return 0;
 }
 
-template <int N, int MODE> static int k3r_dispatch(int HP, const cplx* Bw, float* out, int CT, int C, int has_clash, int nb,
+template <int N, int MODE, bool PCL = false> static int k3r_dispatch(int HP, const cplx* Bw, float* out, int CT, int C, int has_clash, int nb,
                                                    const float* W1t, const float* b1, const float* W2, float b2,
                                                    int has_clip, float clip, float thr, hipStream_t st, K3Aux aux, K3Cand cd) {
   switch (HP) {
-    case 2: return launch_k3r<N, 2, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
-    case 4: return launch_k3r<N, 4, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
-    case 8: return launch_k3r<N, 8, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
-    case 16: return launch_k3r<N, 16, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
-    case 24: return launch_k3r<N, 24, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
-    case 32: return launch_k3r<N, 32, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
-    case 48: return launch_k3r<N, 48, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 2: return launch_k3r<N, 2, MODE, PCL>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 4: return launch_k3r<N, 4, MODE, PCL>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 8: return launch_k3r<N, 8, MODE, PCL>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 16: return launch_k3r<N, 16, MODE, PCL>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 24: return launch_k3r<N, 24, MODE, PCL>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 32: return launch_k3r<N, 32, MODE, PCL>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 48: return launch_k3r<N, 48, MODE, PCL>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
     default: return DLPD_ERR_UNSUPPORTED;
   }
 }
@@ -473,18 +592,25 @@ int dlpd_k3r_filter(const cplx* Bw, float* V, int CT, int C, int has_clash, int 
                     hipStream_t st) {
   switch (L) {
     case 64: return k3r_dispatch<128, 1>(HP, Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
-    case 80: return k3r_dispatch<160, 1>(HP, Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 80:
+      if (aux.C > 0 && aux.is_preact == 2)
+        return k3r_dispatch<160, 1, true>(HP, Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+      return k3r_dispatch<160, 1>(HP, Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
     default: return DLPD_ERR_UNSUPPORTED;
   }
 }
 
 // wsB (nb, C, NZ, N, N) -> pre (nb, HP, N^3): z C2R fused with the (linear) first layer over these C channels
+// channels_last: pre (nb, N^3, HP) -- the layout the fine grid's role-split kernel reads with 16-byte loads
+// (K3Aux.is_preact == 2) -- instead of HP planes
 int dlpd_k3r_preact(const cplx* Bw, float* pre, int C, int nb, int L, const float* W1rows, int HP, const float* b1,
-                    int has_clip, float clip, hipStream_t st) {
-  const K3Aux ax = {nullptr, 0, 0, 0};
+                    int has_clip, float clip, int channels_last, hipStream_t st) {
+  const K3Aux ax = {nullptr, 0, 0, channels_last ? 2 : 0};
   const K3Cand cd = {nullptr, nullptr, nullptr, 0, 0};
   switch (L) {
-    case 40: return k3r_dispatch<80, 2>(HP, Bw, pre, C, C, 0, nb, W1rows, b1, b1, 0.f, has_clip, clip, 0.f, st, ax, cd);
+    case 40:
+      if (channels_last) return k3r_dispatch<80, 2, true>(HP, Bw, pre, C, C, 0, nb, W1rows, b1, b1, 0.f, has_clip, clip, 0.f, st, ax, cd);
+      return k3r_dispatch<80, 2>(HP, Bw, pre, C, C, 0, nb, W1rows, b1, b1, 0.f, has_clip, clip, 0.f, st, ax, cd);
     default: return DLPD_ERR_UNSUPPORTED;
   }
 }

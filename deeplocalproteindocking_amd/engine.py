@@ -6,8 +6,6 @@ volumes, clash correlation + threshold, GlobalDockingModel.forward, mask multipl
 for a single-resolution representation, without any host synchronisation inside the loop.
 torch is plumbing only (memory + streams); all arithmetic is in libdlpd.so.
 """
-import os
-
 import numpy as np
 import torch
 
@@ -126,7 +124,8 @@ class DockingEngine:
 
     def __init__(self, L, C, W1, b1, W2, b2, clip=5.0, threshold_clash=300.0, has_clash=True,
                  max_conf=1000, batch=8, device="cuda", lib=None, center=None, coarse_channels=0,
-                 fine_unfused=None, channels_last=None, k3_form=0, coarse_center=None, extent=None):
+                 fine_unfused=None, channels_last=None, k3_form=0, coarse_center=None, extent=None,
+                 preact_channels_last=None, orient=True, quads=True, prefilter=True):
         """coarse_channels > 0: the reference's two-resolution layout -- C channels at L^3 plus
         ``coarse_channels`` at (L/2)^3 (ProteinRepresentationModels.py:72-76); W1 is (H, C+coarse).
         extent < L: the volumes are extent^3 boxes in the corner of the L^3 ones (a box size without a compiled plan
@@ -165,16 +164,19 @@ class DockingEngine:
         # channels-last gather (include/dlpd.h): one 16-byte load serves four channels of a corner, so the rotation
         # costs the same for every rotation; slab orientation and the quad layout are the per-channel kernel's
         # remedies and stay for ligands with few channels (and as diagnostic switches)
+        # Kernel choices are CONSTRUCTOR ARGUMENTS only (no environment switches): channels_last (default: ligands with
+        # >= 8 channels), orient / quads (the per-channel K1's launch variants), prefilter (top-K candidate lists from
+        # K3).  They select equivalent kernels, never less work; ``switches()`` reports what is active.
         if channels_last is None:
-            channels_last = os.environ.get("DLPD_NO_CHANNELS_LAST", "") == "" and self.C >= 8
+            channels_last = self.C >= 8
         self.use_cl = bool(channels_last)
         self.extent = int(extent) if extent and int(extent) < int(L) else 0
         self.extent1 = self.extent // 2
-        self.orient = os.environ.get("DLPD_NO_ORIENT", "") == "" and not self.use_cl
-        self.use_quads = os.environ.get("DLPD_NO_QUADS", "") == "" and not self.use_cl and not self.extent
+        self.orient = bool(orient) and not self.use_cl
+        self.use_quads = bool(quads) and not self.use_cl and not self.extent
         if self.use_cl:
             self.ligcl = torch.empty(lib.call("dlpd_channels_last_floats", self.C, int(L)), dtype=f32, device=dev)
-        self.prefilter = os.environ.get("DLPD_NO_PREFILTER", "") == ""   # diagnostic switch (top-K candidate lists from K3)
+        self.prefilter = bool(prefilter)
         self.window = None
         if self.extent:
             # the reference's (2 extent)^3 translation grid inside this engine's (2L)^3 one: index t for 0 <= t <= extent
@@ -206,8 +208,19 @@ class DockingEngine:
         if self.fine_unfused:
             self.conv = torch.empty(nb, CT, N, N, N, dtype=f32, device=dev)
         if self.C1:
-            # first-layer pre-activations of the coarse channels on the coarse grid (dlpd_filter_preact)
+            # first-layer pre-activations of the coarse channels on the coarse grid (dlpd_zifft_preact): HP planes (the
+            # default), or -- opt-in, where both role-split kernels exist -- channels-last (nb, N1^3, HP), which the fine
+            # grid's K3 reads with 16-byte loads (include/dlpd.h, dlpd_zifft_preact_cl); same values, same V.  Measured
+            # (round 4, real shapes): the fine K3 is unchanged (1.97 vs 1.98 ms), the coarse kernel's 16-byte-per-lane
+            # stores at a 96-byte lane stride cost +0.07 ms -> planes stay the default.
             self.pre = torch.empty(nb, self.HP, 2 * self.L1, 2 * self.L1, 2 * self.L1, dtype=f32, device=dev)
+            can_cl = bool(lib.call("dlpd_preact_channels_last_supported", self.L, self.HP))
+            if preact_channels_last and not can_cl:
+                raise RuntimeError("dlpd: channels-last pre-activations need the role-split K3 at box %d / hidden %d" % (L, self.HP))
+            self.preact_channels_last = bool(preact_channels_last)
+            self.preact_channels_last_supported = can_cl
+        else:
+            self.preact_channels_last = self.preact_channels_last_supported = False
         self.top = DeviceTopList(self.K, nb, dev, lib)
         # optional: callable(R (nb,3,3) f32 device) -> (nb,L,L,L) f32 device ligand forbidden volumes
         # re-projected from rotated ATOMS (Docker.py:221-224) instead of the rotated volume
@@ -215,6 +228,20 @@ class DockingEngine:
         # kernel formulation of the fused K3 (include/dlpd.h, dlpd_zifft_filter_form): 0 = the library's default
         # (role-split transform / filter waves where compiled), 1 = channel-owning waves; same results bit for bit
         self.k3_form = int(k3_form)
+
+    @property
+    def pre_cl(self):
+        """The coarse grid's pre-activations are channels-last for THIS launch (the role-split K3 reads them)."""
+        return self.preact_channels_last and self.k3_form != 1 and not self.fine_unfused
+
+    def switches(self):
+        """Which of the equivalent kernel formulations this engine launches (recorded by bench.py)."""
+        return {"k1": "channels_last" if self.use_cl else "per_channel",
+                "k1_slab_orientation": bool(self.orient), "k1_quad_layout": bool(self.use_quads),
+                "k3_form": {0: "library default (role-split where compiled)", 1: "channel-owning", 2: "role-split"}[self.k3_form],
+                "k3_unfused": bool(self.fine_unfused), "topk_candidate_lists": bool(self.prefilter),
+                "preact_layout": (("channels_last" if self.pre_cl else "planes") if self.C1 else None),
+                "embedded_extent": self.extent or None}
 
     # ---- inputs ------------------------------------------------------------------------
     def set_filter(self, W1, b1, W2, b2):
@@ -397,6 +424,10 @@ class DockingEngine:
     def _coarse_preact(self, nb, has_clip, clip, st):
         """Coarse grid, last stage: z-inverse + clip fused with the coarse half of the (linear) first layer
         (DockingModels.py:74-83): HP pre-activation planes on the coarse grid instead of C1 correlation volumes."""
+        if self.pre_cl:
+            self.lib.call("dlpd_zifft_preact_cl", _ptr(self.wsB1), _ptr(self.pre), nb, self.C1, self.L1,
+                          self.W1t.data_ptr() + self.C * self.HP * 4, _ptr(self.b1), self.HP, has_clip, clip, st)
+            return
         self.lib.call("dlpd_zifft_preact_form", _ptr(self.wsB1), _ptr(self.pre), nb, self.C1, self.L1,
                       self.W1t.data_ptr() + self.C * self.HP * 4, _ptr(self.b1), self.HP, has_clip, clip, self.k3_form, st)
 
@@ -424,7 +455,7 @@ class DockingEngine:
             tau, ck, cc, cap = (_ptr(self.top.tau), _ptr(cset["keys"]), _ptr(cset["count"]), cset["cap"]) if cset else (0, 0, 0, 0)
             call("dlpd_zifft_filter_form", _ptr(self.wsB), _ptr(V), nb, self.C, int(self.has_clash), L,
                  _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2), self.b2, self.HP, has_clip, clip, self.threshold,
-                 aux, C1, int(C1 > 0), tau, ck, cc, cap, self.k3_form, st)
+                 aux, C1, (2 if self.pre_cl else 1) if C1 else 0, tau, ck, cc, cap, self.k3_form, st)
             self._cset_used = cset
             mark("k3_zifft_filter")
         return V[:nb]

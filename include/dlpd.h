@@ -207,6 +207,15 @@ int dlpd_zifft_preact(const void* wsB, float* pre, int nb, int C, int L, const f
 int dlpd_zifft_preact_form(const void* wsB, float* pre, int nb, int C, int L, const float* W1rows, const float* b1,
                            int HP, int has_clip, float clip, int form, void* stream);
 
+/* dlpd_zifft_preact writing the same values CHANNELS-LAST, pre (nb, N^3, HP): the HP pre-activations of a coarse
+ * voxel are one contiguous run, which the fine grid's role-split kernel -- dlpd_zifft_filter_form(aux = pre,
+ * aux_is_preact = 2) -- fetches with HP / 4 16-byte loads instead of HP 4-byte loads at plane stride (same values,
+ * bit-identical V).  Only where dlpd_preact_channels_last_supported(L_fine, HP) (both role-split kernels compiled);
+ * L is this (coarse) resolution's box.  Replaces DockingModels.py:74-77 like dlpd_zifft_preact. */
+int dlpd_preact_channels_last_supported(int L_fine, int HP);
+int dlpd_zifft_preact_cl(const void* wsB, float* pre, int nb, int C, int L, const float* W1rows, const float* b1, int HP,
+                         int has_clip, float clip, void* stream);
+
 /* dlpd_zifft_real with the clamp restricted to channels [0, nclip). */
 int dlpd_zifft_real_part(const void* wsB, float* out, int nb, int CT, int nclip, int L, int has_clip, float clip,
                          void* stream);

@@ -10,17 +10,29 @@ OUT = os.path.join(HERE, "libdlpd_emu.so")
 SRCS = ["dlpd_corr.hip", "dlpd_k2.hip", "dlpd_k2q.hip", "dlpd_k3r.hip", "dlpd_topk.hip", "dlpd_generic.hip", "dlpd_atoms.hip", "dlpd_conv.hip", "dlpd_version.hip"]
 
 
+def _fresh(deps):
+    return os.path.exists(OUT) and all(os.path.getmtime(OUT) > os.path.getmtime(d) for d in deps)
+
+
 def build(force=False):
+    import fcntl
     srcs = [os.path.join(CSRC, s) for s in SRCS]
     deps = srcs + [os.path.join(CSRC, h) for h in ("dlpd_fft.h", "dlpd_internal.h", "dlpd_k3.h")] + \
         [os.path.join(HERE, "dlpd_platform.h")]
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) > os.path.getmtime(d) for d in deps):
+    if not force and _fresh(deps):
         return OUT
-    cmd = ["g++", "-O2", "-g", "-std=c++17", "-shared", "-fPIC", "-fpermissive", "-w",
-           "-I", HERE, "-I", CSRC, "-o", OUT] + os.environ.get("DLPD_EMU_FLAGS", "").split()
-    for s in srcs:
-        cmd += ["-x", "c++", s]
-    subprocess.check_call(cmd)
+    # the ranks of a multi-process test must not compile concurrently (and never load a half-written file):
+    # one builder under a lock, output moved into place atomically
+    with open(OUT + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or not _fresh(deps):
+            tmp = OUT + ".tmp.%d" % os.getpid()
+            cmd = ["g++", "-O2", "-g", "-std=c++17", "-shared", "-fPIC", "-fpermissive", "-w",
+                   "-I", HERE, "-I", CSRC, "-o", tmp] + os.environ.get("DLPD_EMU_FLAGS", "").split()
+            for s in srcs:
+                cmd += ["-x", "c++", s]
+            subprocess.check_call(cmd)
+            os.replace(tmp, OUT)
     return OUT
 
 
