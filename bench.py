@@ -65,6 +65,8 @@ def parse_args():
     ap.add_argument("--channels", type=int, default=None, help="override the workload's channel count")
     ap.add_argument("--box", type=int, default=None, help="override the workload's box size")
     ap.add_argument("--angle_inc", type=int, default=None)
+    ap.add_argument("--hidden", type=int, default=None,
+                    help="hidden width of the filter (default: the reference's SimpleFilter, half the channel count)")
     ap.add_argument("--max_conf", type=int, default=2000)
     ap.add_argument("--cpu_rotations", type=int, default=16,
                     help="rotations of the CPU baseline sample, spread over the four search groups (0: skip)")
@@ -277,6 +279,12 @@ def build_workload(name, args, dev):
     filt = SimpleFilter([C] + ([C1] if C1 else []))
     thr = clash_threshold(recf, ligf)
     W = filt.parameters_tuple()
+    if args.hidden and name == args.workload:
+        # another hidden width (select_model's multiplier moves it: ProteinRepresentationModels.py:24,35-36): Xavier-like
+        g = torch.Generator().manual_seed(2)
+        Ct, H = C + C1, int(args.hidden)
+        W = (torch.randn(H, Ct, generator=g) * (2.0 / (H + Ct)) ** 0.5, torch.zeros(H), torch.randn(1, H, generator=g) * (2.0 / (H + 1)) ** 0.5,
+             torch.zeros(1))
     eng = DockingEngine(L, C, *W, clip=5.0, threshold_clash=thr, has_clash=True, max_conf=args.max_conf,
                         batch=args.batch, device=dev, coarse_channels=C1, k3_form=args.k3_form,
                         preact_channels_last={"auto": None, "planes": False, "channels_last": True}[args.preact_layout] if C1 else None)
@@ -771,6 +779,23 @@ STAGE_KERNELS = {"k1_rotate_zfft": ("k_rotate_zfft_cl<%d>", "k_rotate_zfft<%d>")
                  "k3_zifft_filter": ("k_zifft_filter_rs<%d,",)}
 
 
+def run_in_own_group(cmd, cwd, env, timeout):
+    """Run ``cmd`` as the leader of a new process group, output discarded; on a timeout the WHOLE group is killed.
+    -> return code (None after a timeout)."""
+    import signal
+    import subprocess
+    proc = subprocess.Popen(cmd, cwd=cwd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+    try:
+        return proc.wait(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        proc.wait()
+        return None
+
+
 def live_pmc_traffic(args, stage, N):
     """(bytes per launch, source) of the stage's kernels from two rocprofv3 child passes of this script, or (None, None)."""
     import csv, glob, shutil, subprocess, tempfile
@@ -783,9 +808,10 @@ def live_pmc_traffic(args, stage, N):
         return None, None
     pats = tuple(p % N for p in pats)
     child = [sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--cpu_rotations", "0", "--no_real_shapes",
-             "--sustained_s", "0", "--workload", args.workload, "--batch", str(args.batch), "--max_conf", str(args.max_conf),
-             "--k3_form", str(args.k3_form)]
-    for flag, val in (("--channels", args.channels), ("--box", args.box), ("--angle_inc", args.angle_inc)):
+             "--sustained_s", "0", "--strong_s", "0", "--gather_rotations", "0", "--workload", args.workload,
+             "--batch", str(args.batch), "--max_conf", str(args.max_conf), "--k3_form", str(args.k3_form),
+             "--preact_layout", args.preact_layout]
+    for flag, val in (("--channels", args.channels), ("--box", args.box), ("--angle_inc", args.angle_inc), ("--hidden", args.hidden)):
         if val is not None:
             child += [flag, str(val)]
     per_launch = {}
@@ -793,10 +819,12 @@ def live_pmc_traffic(args, stage, N):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             with tempfile.TemporaryDirectory(prefix="dlpd_pmc_") as tmp:
                 env = dict(os.environ, TMPDIR="/tmp")
-                r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", tmp, "--"] + child,
-                                   cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+                # the profiler and the benchmark under it in a process group of their own: a timeout ends BOTH (killing
+                # only rocprofv3 would leave its child on the GPU)
+                rc = run_in_own_group([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", tmp, "--"] + child,
+                                      cwd="/tmp", env=env, timeout=240)
                 files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
-                if r.returncode != 0 or not files:
+                if rc != 0 or not files:
                     return None, None
                 total, launches = 0.0, set()
                 for row in csv.DictReader(open(files[0])):
@@ -811,7 +839,9 @@ def live_pmc_traffic(args, stage, N):
         scale = FETCH_SCALE.get((stage, N), 2.0)
         return scale * per_launch["FETCH_SIZE"] + per_launch["WRITE_SIZE"], \
             ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two child passes of bench.py "
-             "--steps 6, per launch of %s...; FETCH_SIZE x %.0f: gfx950 tallies 128-byte read requests at 64 bytes)" % (pats[0], scale))
+             "--steps 6, per launch of %s...): raw FETCH_SIZE %.0f bytes x %.0f (gfx950 tallies a 128-byte read request at 64 "
+             "bytes; a kernel reading 64-byte runs is taken at face value: FETCH_SCALE in bench.py) + raw WRITE_SIZE %.0f bytes"
+             % (pats[0], per_launch["FETCH_SIZE"], scale, per_launch["WRITE_SIZE"]))
     except Exception:
         return None, None
 

@@ -39,6 +39,7 @@ import torch
 
 from deeplocalproteindocking_amd.engine import DeviceTopList, DockingEngine
 from deeplocalproteindocking_amd._lib import get_lib
+from deeplocalproteindocking_amd.Utils.Conventions import VolumeConventions
 from deeplocalproteindocking_amd.Utils.Rotations import Rotations, euler_to_matrices
 
 
@@ -48,7 +49,7 @@ def fused_filter_parameters(model):
 
 
 class _PivotRotation(object):
-    """ops.VolumeRotation per grid size, pivoted where the Docker's ``rotation_center`` says."""
+    """ops.VolumeRotation per grid size, with the Docker's rotation conventions (pivot, scale, axis order)."""
 
     def __init__(self, docker):
         self.docker, self.ops = docker, {}
@@ -57,7 +58,10 @@ class _PivotRotation(object):
         from deeplocalproteindocking_amd.ops import VolumeRotation
         L = volume.shape[-1]
         if L not in self.ops:
-            self.ops[L] = VolumeRotation(center=self.docker.rotation_pivot(L), lib=self.docker._lib)
+            cv = self.docker.conventions
+            self.ops[L] = VolumeRotation(center=self.docker.rotation_pivot(L), lib=self.docker._lib,
+                                         scale=cv.rotation_scale, axis_order=cv.rotation_axis_order,
+                                         transpose=cv.rotation_transpose)
         return self.ops[L](volume, R)
 
 
@@ -114,7 +118,8 @@ LAUNCH_BATCH = 16      # rotations per launch of the fused pipeline (DESIGN.md s
 class Docker:
     def __init__(self, docking_model, angle_inc=15.0, box_size=80, resolution=1.25, max_conf=1000,
                  randomize_rot=False, rotations=None, device="cuda", coords_backend=None,
-                 rank=0, world_size=1, process_group=None, lib=None, launch_batch=None, rotation_center=None):
+                 rank=0, world_size=1, process_group=None, lib=None, launch_batch=None, rotation_center=None,
+                 conventions=None):
         self.docking_model = docking_model
         self.log = None
 
@@ -142,7 +147,15 @@ class Docker:
         # VolumeRotation has no source here).  None: index L/2 of each grid (the box centre when voxel i spans
         # [i, i+1) * resolution, Docker.py:221-223); "grid_sample": (L-1)/2 of each grid (the centre of
         # torch's align_corners=False sampling grid); a number: that index on the fine grid, scaled to coarser ones.
-        self.rotation_center = rotation_center
+        # conventions: a Utils.Conventions.VolumeConventions (or the path of the JSON scripts/calibrate_tpl.py writes): the
+        # remaining build-defined choices -- rotation scale and axis order, what VolumeConvolution(clip) clamps, the
+        # density splat -- next to the pivot.  ``rotation_center`` given explicitly wins over the file's.
+        if isinstance(conventions, str):
+            conventions = VolumeConventions.load(conventions)
+        self.conventions = conventions if conventions is not None else VolumeConventions()
+        if rotation_center is not None:
+            self.conventions = VolumeConventions.from_dict(dict(self.conventions.to_dict(), rotation_center=rotation_center))
+        self._ops_cache = {}
         # box sizes without a compiled plan: on the fused kernels inside the next compiled box (_dock_volumes_embedded);
         # False: the plan-free stand-alone ops (ops.VolumeConvolution._forward_generic), any box up to 128
         self.embed_uncompiled_boxes = True
@@ -182,11 +195,16 @@ class Docker:
     @property
     def convolve(self):                     # VolumeConvolution()(volume1, volume2): no clip (Docker.py:32)
         from deeplocalproteindocking_amd.ops import VolumeConvolution
-        return VolumeConvolution(lib=self._lib)
+        key = ("convolve", self.embed_uncompiled_boxes)
+        if key not in self._ops_cache:      # one object per Docker, as the reference's attribute is
+            self._ops_cache[key] = VolumeConvolution(lib=self._lib, embed=self.embed_uncompiled_boxes)
+        return self._ops_cache[key]
 
     @property
-    def vol_rotate(self):                   # VolumeRotation()(volume, R), pivoted as ``rotation_center`` says
-        return _PivotRotation(self)
+    def vol_rotate(self):                   # VolumeRotation()(volume, R), with this Docker's rotation conventions
+        if "vol_rotate" not in self._ops_cache:
+            self._ops_cache["vol_rotate"] = _PivotRotation(self)
+        return self._ops_cache["vol_rotate"]
 
     # ------------------------------------------------------------------ logging (Docker.py:63-84)
     def new_log(self, log_file_name, rewrite=True):
@@ -255,16 +273,18 @@ class Docker:
             self.log.write("\n".join(rows) + "\n")
         self.log.flush()
 
+    @property
+    def rotation_center(self):
+        return self.conventions.rotation_center
+
+    @rotation_center.setter
+    def rotation_center(self, value):
+        self.conventions.rotation_center = value
+        self._ops_cache.pop("vol_rotate", None)          # (its per-size operators carry the pivot)
+
     def rotation_pivot(self, L):
         """Pivot index of the volume rotation on a grid of L voxels per edge (see ``rotation_center``)."""
-        rc = self.rotation_center
-        if rc is None:
-            return float(L) / 2.0
-        if isinstance(rc, str):
-            if rc != "grid_sample":
-                raise Exception("Unknown rotation_center", rc)
-            return (float(L) - 1.0) / 2.0
-        return float(rc) * float(L) / float(self.box_size)
+        return self.conventions.pivot(L, self.box_size)
 
     def release_engine(self):
         """Drop the cached fused engine and its device workspaces (several GB at box 80: wsB for 16 rotations,
@@ -360,15 +380,19 @@ class Docker:
         # inner_box: the volumes are inner_box^3 boxes in the corner of the L^3 ones (_dock_volumes_embedded): pivots and
         # crop of the rotation are the small box's
         Lp = int(inner_box or L)
+        cv = self.conventions
         key = (int(L), int(C), int(C1), has_clash, HP, int(self.max_conf),
-               int(batch_size), str(self.device), self.rotation_pivot(Lp), Lp)
+               int(batch_size), str(self.device), self.rotation_pivot(Lp), Lp, cv.scale(Lp), cv.rotation_axis_order, cv.clip_mode,
+               cv.rotation_transpose)
         eng = self.engine if getattr(self, "_engine_key", None) == key else None
         if eng is None:
             eng = DockingEngine(L, C, W1.cpu(), b1.cpu(), W2.cpu(), b2.cpu(), clip=getattr(model, "clip", 5.0),
                                 threshold_clash=model.threshold_clash, has_clash=has_clash, max_conf=self.max_conf,
                                 batch=batch_size, device=self.device, lib=self._lib, coarse_channels=C1,
                                 center=self.rotation_pivot(Lp), coarse_center=self.rotation_pivot(Lp // 2),
-                                extent=(Lp if Lp < L else None))
+                                extent=(Lp if Lp < L else None), rotation_scale=cv.scale(Lp),
+                                coarse_rotation_scale=cv.scale(Lp // 2), rotation_axis_order=cv.rotation_axis_order,
+                                clip_mode=cv.clip_mode, rotation_transpose=cv.rotation_transpose)
             self.engine, self._engine_key = eng, key
         else:
             eng.finish()
@@ -472,7 +496,7 @@ class Docker:
         rotate, conv_noclip = _PivotRotation(self), VolumeConvolution(lib=self._lib, embed=emb)
         convolve = getattr(model, "convolve", None) or VolumeConvolution(clip=getattr(model, "clip", 5.0), lib=self._lib)
         if isinstance(convolve, VolumeConvolution):        # the reference's op: same clip, this Docker's box policy
-            convolve = VolumeConvolution(clip=convolve.clip, lib=self._lib, embed=emb)
+            convolve = VolumeConvolution(clip=convolve.clip, lib=self._lib, embed=emb, clip_mode=self.conventions.clip_mode)
         rec_d, lig_d, rf, lf = self._batch_inputs(rec, lig, rec_forb, lig_forb, clash_provider)
         L = rec[0].shape[-1]
         top = DeviceTopList(self.max_conf, batch_size, dev, self._library())
@@ -542,7 +566,8 @@ class Docker:
         ``CoordsBackend`` unless the constructor was given another one."""
         if self.coords_backend is None:
             from deeplocalproteindocking_amd.Utils.FullAtom import CoordsBackend
-            self.coords_backend = CoordsBackend(lib=self._lib)
+            self.coords_backend = CoordsBackend(lib=self._lib, splat=self.conventions.splat,
+                                                atom_types=self.conventions.atom_types)
         return self.coords_backend
 
     def load_batch(self, filenames, bbox_center=True):
@@ -636,7 +661,8 @@ class Docker:
                 convolve = getattr(model, "convolve", None) or VolumeConvolution(clip=getattr(model, "clip", 5.0),
                                                                                  lib=self._lib)
                 if isinstance(convolve, VolumeConvolution):
-                    convolve = VolumeConvolution(clip=convolve.clip, lib=self._lib, embed=emb)
+                    convolve = VolumeConvolution(clip=convolve.clip, lib=self._lib, embed=emb,
+                                                 clip_mode=self.conventions.clip_mode)
                 top = DeviceTopList(self.max_conf, nbatch, dev, self._library())
                 top.reset()
                 receptor_forbidden = receptor.sum(dim=1).unsqueeze(dim=1).contiguous()

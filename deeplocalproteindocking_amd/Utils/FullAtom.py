@@ -134,8 +134,19 @@ def read_pdb_atoms(filename):
 class CoordsBackend:
     """Plug-in for ``Docker(coords_backend=...)``; method names follow Docker's calls."""
 
-    def __init__(self, lib=None):
+    def __init__(self, lib=None, splat=None, atom_types=None):
         self.lib = lib                 # None -> the product library (GPU); tests pass the emulated one
+        # density shape of the projection (build-defined; Utils/Conventions.py): sigma, window, voxel_offset, norm
+        self.splat = dict({"sigma": 1.0, "window": 2, "voxel_offset": 0.0, "norm": 1.0}, **(splat or {}))
+        # optional typing table {"RES:ATOM": type 0..10 | -1} that overrides ``atom_type`` entry by entry
+        # (scripts/calibrate_tpl.py reads TorchProteinLibrary's own assignment off a probe structure)
+        self.atom_types = dict(atom_types or {})
+
+    def type_of(self, resname, atomname):
+        key = "%s:%s" % (resname.strip().upper(), atomname.strip().upper())
+        if key in self.atom_types:
+            return int(self.atom_types[key])
+        return atom_type(resname, atomname)
 
     # ---- PDB2CoordsUnordered (Docker.py:51)
     def pdb2coords(self, filenames):
@@ -157,7 +168,7 @@ class CoordsBackend:
         for b in range(B):
             n = int(num_atoms[b])
             xyz = coords[b, :3 * n].reshape(n, 3)
-            ty = np.array([atom_type(resnames[b][i], atomnames[b][i]) for i in range(n)], dtype=np.int64)
+            ty = np.array([self.type_of(resnames[b][i], atomnames[b][i]) for i in range(n)], dtype=np.int64)
             order = [np.nonzero(ty == t)[0] for t in range(NUM_ATOM_TYPES)]
             for t in range(NUM_ATOM_TYPES):
                 counts[b, t] = len(order[t])
@@ -224,6 +235,7 @@ class CoordsBackend:
         sx, sy, sz = (0.0, 0.0, 0.0) if shift is None else [float(v) for v in torch.as_tensor(shift).reshape(-1)[:3]]
         nch = 1 if sum_types else NUM_ATOM_TYPES
         out = torch.empty(nb, nch, box_size, box_size, box_size, dtype=torch.float32, device=device)
-        lib.call("dlpd_project_atoms", _ptr(c), _ptr(nt), _ptr(of), _ptr(R), sx, sy, sz, _ptr(out), nb, stride,
-                 NUM_ATOM_TYPES, box_size, float(resolution), int(sum_types), _stream(device))
+        lib.call("dlpd_project_atoms_ext", _ptr(c), _ptr(nt), _ptr(of), _ptr(R), sx, sy, sz, _ptr(out), nb, stride,
+                 NUM_ATOM_TYPES, box_size, float(resolution), int(sum_types), float(self.splat["sigma"]),
+                 int(self.splat["window"]), float(self.splat["voxel_offset"]), float(self.splat["norm"]), _stream(device))
         return out

@@ -4,22 +4,26 @@
 //                                                  TorchProteinLibrary TypedCoords2Volume, channel sum
 //   /root/reference/src/Docker/Docker.py:204,208  TypedCoords2Volume of receptor / ligand
 // by ONE kernel that rotates on the fly (no per-batch host round trip).
-// TorchProteinLibrary's source is absent: the density shape is BUILD-DEFINED (parity unpinned):
-// every atom adds exp(-|r - x|^2 / 2) (Angstrom^2) to the (2d+1)^3 voxels around it, d = 2, voxel
-// (i,j,k) sitting at (i,j,k) * resolution.
+// TorchProteinLibrary's source is absent: the density shape is BUILD-DEFINED (parity unpinned) and therefore a
+// PARAMETER (dlpd_project_atoms_ext; deeplocalproteindocking_amd/Utils/Conventions.py; scripts/calibrate_tpl.py finds the
+// values on a machine that has the library): every atom adds exp(-|r - x|^2 / (2 sigma^2)) (Angstrom^2) to the
+// (2d+1)^3 voxels around it (times a prefactor `norm`), voxel (i,j,k) sitting at (i,j,k + voxel_offset) * resolution.
+// Defaults: sigma 1, d 2, voxel_offset 0, norm 1.
 //
-// DETERMINISTIC: the contributions are accumulated as 2^-20 fixed-point UNSIGNED integers (integer atomic adds
+// DETERMINISTIC: the contributions are accumulated as 2^-22 fixed-point UNSIGNED integers (integer atomic adds
 // commute, float ones do not; every contribution is positive), then converted to float in place.  Two runs -- and
 // two ranks projecting the same receptor -- produce bit-identical volumes, so the clash mask `corr < threshold`
-// (Docker.py:226) and with it the ranked list never depends on the order in which atoms happen to be added.  A
-// unit-sigma Gaussian per atom at protein packing density (~0.1 heavy atoms / A^3) sums to < 2 per voxel at any
-// resolution; the 32-bit accumulator holds 4095 -- thousands of atoms stacked on one site (duplicated records,
-// multi-model files summed into one channel) before it could wrap; the resolution 2^-20 is below the float
-// spacing of such sums.
+// (Docker.py:226) and with it the ranked list never depends on the order in which atoms happen to be added.
+// Resolution and range: a contribution is rounded to a multiple of 2^-22, i.e. by at most 2^-23 = 1.2e-7 -- one ulp of
+// 1.0f, what a float sum of such contributions (a unit-sigma Gaussian per atom at protein packing density, ~0.1 heavy
+// atoms / A^3, sums to 1-2 per voxel) loses per addition anyway; the 32-bit accumulator holds 1023 per voxel --
+// a thousand atoms stacked on one site (duplicated records, multi-model files summed into one channel) before it could
+// wrap.  (Round 3 used 2^-20: four times the range for four times the rounding step; round 2 2^-24 signed: 127.)
 #include <dlpd_platform.h>
 #include "dlpd_internal.h"
 
-#define DLPD_SPLAT_SCALE 1048576.0f           // 2^20
+#define DLPD_SPLAT_SCALE 4194304.0f           // 2^22
+#define DLPD_SPLAT_MAX_WINDOW 6
 
 // coords (B, 3*stride_atoms) f32 [x0 y0 z0 x1 ...] ordered by atom type; ntype (B, T) counts,
 // offs (B, T) first atom of each type.  p' = R_b p + shift (R row-major, may be null).
@@ -27,7 +31,7 @@
 __global__ void __launch_bounds__(256)
 k_project_atoms(const float* __restrict__ coords, const int* __restrict__ ntype, const int* __restrict__ offs,
                 const float* __restrict__ R, float sx, float sy, float sz, unsigned* __restrict__ out, int B,
-                int stride_atoms, int T, int L, float res, int sum_types) {
+                int stride_atoms, int T, int L, float res, int sum_types, float inv2s2, int d, float voff, float norm) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = gid / stride_atoms, a = gid % stride_atoms;
   if (b >= B) return;
@@ -47,19 +51,20 @@ k_project_atoms(const float* __restrict__ coords, const int* __restrict__ ntype,
     x = rx; y = ry; z = rz;
   }
   x += sx; y += sy; z += sz;
-  const int ci = (int)floorf(x / res), cj = (int)floorf(y / res), ck = (int)floorf(z / res);
+  // (voff = 0 leaves every expression below at the value it had without the parameter)
+  const int ci = (int)floorf(x / res - voff), cj = (int)floorf(y / res - voff), ck = (int)floorf(z / res - voff);
   const int ch = sum_types ? 0 : ty, nch = sum_types ? 1 : T;
   unsigned* vol = out + ((size_t)b * nch + ch) * L * L * L;
-  for (int i = ci - 2; i <= ci + 2; i++) {
+  for (int i = ci - d; i <= ci + d; i++) {
     if (i < 0 || i >= L) continue;
-    const float dx = x - i * res;
-    for (int j = cj - 2; j <= cj + 2; j++) {
+    const float dx = x - (i + voff) * res;
+    for (int j = cj - d; j <= cj + d; j++) {
       if (j < 0 || j >= L) continue;
-      const float dy = y - j * res;
-      for (int k = ck - 2; k <= ck + 2; k++) {
+      const float dy = y - (j + voff) * res;
+      for (int k = ck - d; k <= ck + d; k++) {
         if (k < 0 || k >= L) continue;
-        const float dz = z - k * res;
-        const float w = expf(-0.5f * (dx * dx + dy * dy + dz * dz));
+        const float dz = z - (k + voff) * res;
+        const float w = norm * expf(-inv2s2 * (dx * dx + dy * dy + dz * dz));      // (norm = 1: the same value)
         atomicAdd(&vol[((size_t)i * L + j) * L + k], (unsigned)rintf(w * DLPD_SPLAT_SCALE));
       }
     }
@@ -78,23 +83,32 @@ __global__ void __launch_bounds__(256) k_splat_to_float(unsigned* __restrict__ a
 extern "C" {
 
 // Clears `out`, accumulates the densities in fixed point, converts to float: bit-reproducible.
-int dlpd_project_atoms(const float* coords, const int* num_atoms_of_type, const int* offsets, const float* R,
-                       float shift_x, float shift_y, float shift_z, float* out, int B, int stride_atoms,
-                       int ntypes, int L, float resolution, int sum_types, void* stream) {
+int dlpd_project_atoms_ext(const float* coords, const int* num_atoms_of_type, const int* offsets, const float* R,
+                           float shift_x, float shift_y, float shift_z, float* out, int B, int stride_atoms,
+                           int ntypes, int L, float resolution, int sum_types, float sigma, int window,
+                           float voxel_offset, float norm, void* stream) {
   if (!coords || !num_atoms_of_type || !offsets || !out || B <= 0 || stride_atoms <= 0 || ntypes <= 0 || L <= 0 ||
-      resolution <= 0.f)
+      resolution <= 0.f || !(sigma > 0.f) || window < 0 || window > DLPD_SPLAT_MAX_WINDOW || !(norm > 0.f) || norm > 64.f)
     return DLPD_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const size_t bytes = (size_t)B * (sum_types ? 1 : ntypes) * L * L * L * sizeof(float);
   if (hipMemsetAsync(out, 0, bytes, st) != hipSuccess) return DLPD_ERR_LAUNCH;
   const int total = B * stride_atoms;
   DLPD_LAUNCH(k_project_atoms, dim3((total + 255) / 256), dim3(256), 0, st, coords, num_atoms_of_type, offsets, R,
-              shift_x, shift_y, shift_z, reinterpret_cast<unsigned*>(out), B, stride_atoms, ntypes, L, resolution, sum_types);
+              shift_x, shift_y, shift_z, reinterpret_cast<unsigned*>(out), B, stride_atoms, ntypes, L, resolution, sum_types,
+              0.5f / (sigma * sigma), window, voxel_offset, norm);
   const size_t n = bytes / sizeof(float);
   size_t nblk = (n + 255) / 256;
   if (nblk > 16384) nblk = 16384;
   DLPD_LAUNCH(k_splat_to_float, dim3((unsigned)nblk), dim3(256), 0, st, reinterpret_cast<unsigned*>(out), n);
   return dlpd_check_launch();
+}
+
+int dlpd_project_atoms(const float* coords, const int* num_atoms_of_type, const int* offsets, const float* R,
+                       float shift_x, float shift_y, float shift_z, float* out, int B, int stride_atoms,
+                       int ntypes, int L, float resolution, int sum_types, void* stream) {
+  return dlpd_project_atoms_ext(coords, num_atoms_of_type, offsets, R, shift_x, shift_y, shift_z, out, B, stride_atoms,
+                                ntypes, L, resolution, sum_types, 1.0f, 2, 0.0f, 1.0f, stream);
 }
 
 }  // extern "C"

@@ -47,7 +47,10 @@ __global__ void __launch_bounds__(256) k_gdft_mid(const cplx* __restrict__ in, c
         const cplx w = tw[idx[u]];
         ar[u] = fmaf(v.x, w.x, fmaf(-v.y, w.y, ar[u]));
         ai[u] = fmaf(v.x, w.y, fmaf(v.y, w.x, ai[u]));
-        idx[u] += k0 + u;                 // (j k) mod N, incrementally
+        // (j k) mod N, incrementally.  The step is reduced mod N first: for an odd box N = 2L is not a multiple of 4
+        // and the lanes k0 + u >= N of the last round (their results are discarded below) would otherwise walk idx past
+        // the table -- a read beyond the LDS allocation (harmless zeros on the GPU, a heap over-read in the emulator)
+        idx[u] += (k0 + u < N) ? (k0 + u) : (k0 + u - N);
         if (idx[u] >= N) idx[u] -= N;
       }
     }

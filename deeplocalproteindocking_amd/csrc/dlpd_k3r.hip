@@ -56,16 +56,15 @@ template <int N> DLPD_D void init_twiddles_k3r(cplx* tw, int tid, int nthreads) 
 #ifndef DLPD_K3R_RAWBUF128
 #define DLPD_K3R_RAWBUF128 1
 #endif
-#ifndef DLPD_K3R_MATRIX
-#define DLPD_K3R_MATRIX 1                   // the filter waves' first layer on the matrix pipe (4x4x1 blocks); 0: vector FMAs
-#endif
-static constexpr bool K3R_MATRIX = DLPD_K3R_MATRIX != 0;
 #ifndef DLPD_K3R_FFT_PRIO
 #define DLPD_K3R_FFT_PRIO 0
 #endif
 // WIDE: hidden widths 33..48 (the reference class default: multiplier 16 -> [32, 64] channels -> hidden 48,
 // ProteinRepresentationModels.py:24,35-36): 96 accumulators are two voxels x 48 hidden units, so the filter waves
 // take two voxels per thread and the tile shrinks to 8 rows where 16 rows would need 16 filter waves.
+#ifndef DLPD_K3R_WIDE_ABOVE
+#define DLPD_K3R_WIDE_ABOVE 32               // hidden widths above this take two voxels per filter thread
+#endif
 template <int N, bool WIDE> struct K3rCfg;
 template <> struct K3rCfg<64, false> { static constexpr int F = 4, M = 4, TY = 16, RAWBUF = 2; };
 template <> struct K3rCfg<80, false> { static constexpr int F = 5, M = 5, TY = 16, RAWBUF = 2; };
@@ -178,48 +177,17 @@ template <int N> DLPD_D void k3r_second_pass(cplx* S, int rowoff, int t, const c
   }
 }
 
-// the NQ weight quads of one channel for the matrix pipe's 4x4x1 blocks, from the LDS table (k_zifft_filter_rs): p points at
-// this lane's run (row 4 c + (lane & 3), HPQP floats, 16-byte aligned)
-template <int NQ, int HPQP> DLPD_D void k3r_load_quadw(const float* p, dlpd_quadw (&w)[NQ]) {
-#if DLPD_QUADW_IS_SCALAR
-  if constexpr (NQ % 4 == 0) {
-#pragma unroll
-    for (int q = 0; q < NQ; q += 4) {
-      const float4 v = *reinterpret_cast<const float4*>(p + q);
-      w[q] = v.x; w[q + 1] = v.y; w[q + 2] = v.z; w[q + 3] = v.w;
-    }
-  } else if constexpr (NQ % 2 == 0) {
-#pragma unroll
-    for (int q = 0; q + 4 <= NQ; q += 4) {
-      const float4 v = *reinterpret_cast<const float4*>(p + q);
-      w[q] = v.x; w[q + 1] = v.y; w[q + 2] = v.z; w[q + 3] = v.w;
-    }
-    const float2 v = *reinterpret_cast<const float2*>(p + NQ / 4 * 4);
-    w[NQ / 4 * 4] = v.x; w[NQ / 4 * 4 + 1] = v.y;
-  } else {
-#pragma unroll
-    for (int q = 0; q < NQ; q++) w[q] = p[q];
-  }
-#else
-  // emulated lane: keeps all four values of the quad (rows 4 c .. 4 c + 3 of the table)
-#pragma unroll
-  for (int q = 0; q < NQ; q++)
-#pragma unroll
-    for (int i = 0; i < 4; i++) w[q].w[i] = p[i * HPQP + q];
-#endif
-}
-
 //   Bw   (nb, CT, NZ, N, N) complex [kz][x'][y']
 //   MODE 1: V (nb, N,N,N) = mask * (W2 . relu(W1 . clamp(corr) + b1) + b2); score channels [0,C), clash channel C
 //           if has_clash (mask = corr_C < thr); aux: HP first-layer pre-activation planes on the coarse grid (or none)
 //   MODE 2: out (nb, HP, N,N,N) = b1 + W1rows^T clamp(corr): the coarse resolution's half of the first layer
 //   W1t  (C, HP) transposed + zero padded, b1 (HP), W2 (HP);  G channels per group (<= F * CPW)
 //   PCL  the pre-activation planes (MODE 1: aux, read; MODE 2: out, written) are CHANNELS-LAST, (nb, Naux^3 | N^3, HP)
-template <int N, int HP, int MODE, bool PCL> __global__ void __launch_bounds__(64 * (K3rCfg<N, (HP > 32)>::F + K3rCfg<N, (HP > 32)>::M))
+template <int N, int HP, int MODE, bool PCL> __global__ void __launch_bounds__(64 * (K3rCfg<N, (HP > DLPD_K3R_WIDE_ABOVE)>::F + K3rCfg<N, (HP > DLPD_K3R_WIDE_ABOVE)>::M))
 k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int C, int has_clash, int G,
                   const float* __restrict__ W1t, const float* __restrict__ b1, const float* __restrict__ W2,
                   float b2, int has_clip, float clip, float thr, K3Aux aux, int ntiles, int tpb, K3Cand cd) {
-  typedef K3rCfg<N, (HP > 32)> Cfg;
+  typedef K3rCfg<N, (HP > DLPD_K3R_WIDE_ABOVE)> Cfg;
   constexpr int F = Cfg::F, M = Cfg::M, TY = Cfg::TY, RAWBUF = Cfg::RAWBUF;
   constexpr int NZ = N / 2 + 1, RS = N + 8, NPAIR = TY / 2, NYT = N / TY;
   constexpr int CPW = 8 / NPAIR;               // channels per transform wave: its 8 pencils = CPW channels x NPAIR row pairs
@@ -241,17 +209,6 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
   const int t_beg = blockIdx.x * tpb, t_end = (t_beg + tpb < ntiles) ? t_beg + tpb : ntiles;
   if (t_beg >= t_end) return;
   init_twiddles_k3r<N>(tw, tid, 64 * (F + M));
-  // first-layer weights for the matrix pipe (filter waves, below): wq[(c * 4 + i) * HPQP + q] = W1t[c][4 q + i], so that
-  // lane l reads the HP / 4 weights it multiplies with -- hidden units 4 q + (l & 3) of channel c -- as one contiguous,
-  // 16-byte aligned run (LDS latency, not a global load's, in front of every channel's products)
-  constexpr int HPQ = (HP + 3) / 4, HPQP = (HPQ + 3) / 4 * 4;
-  float* wq = reinterpret_cast<float*>(raw + RAWBUF * F * CPW * RAWC);
-  if constexpr (K3R_MATRIX && HP % 4 == 0) {
-    for (int i = tid; i < C * HP; i += 64 * (F + M)) {
-      const int c = i / HP, j = i % HP;
-      wq[(c * 4 + (j & 3)) * HPQP + (j >> 2)] = W1t[i];
-    }
-  }
   const unsigned cand_tau = (MODE == 1 && cd.keys) ? *cd.tau : 0u;
 
   // ---- transform role: this wave's channels of group `cb` of tile `t` -> raw staging buffer `buf`
@@ -334,10 +291,7 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
   } else {
     // ================= filter waves =================
     float nrm[EPT * 2];
-    // hidden pre-activations of the thread's voxels, in quads: the matrix pipe's 4x4x1 blocks accumulate four hidden
-    // units of a voxel per instruction (below); H(e, j) = hidden unit j of voxel e
-    dlpd_acc4 hq[EPT * 2][(HP + 3) / 4];
-#define H(e, j) DLPD_ACC4_AT(hq[e][(j) >> 2], (j) & 3)
+    float h[EPT * 2][HP];
     cplx vals[GMAX][EPT];
     int t = t_beg, cbase = 0;
 #pragma unroll 1
@@ -365,12 +319,12 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
 #pragma unroll
                 for (int q = 0; q < HP / 4; q++) {
                   const float4 v = reinterpret_cast<const float4*>(av)[q];
-                  H(2 * e, 4 * q) = v.x; H(2 * e, 4 * q + 1) = v.y; H(2 * e, 4 * q + 2) = v.z; H(2 * e, 4 * q + 3) = v.w;
-                  H(2 * e + 1, 4 * q) = v.x; H(2 * e + 1, 4 * q + 1) = v.y; H(2 * e + 1, 4 * q + 2) = v.z; H(2 * e + 1, 4 * q + 3) = v.w;
+                  h[2 * e][4 * q] = v.x; h[2 * e][4 * q + 1] = v.y; h[2 * e][4 * q + 2] = v.z; h[2 * e][4 * q + 3] = v.w;
+                  h[2 * e + 1][4 * q] = v.x; h[2 * e + 1][4 * q + 1] = v.y; h[2 * e + 1][4 * q + 2] = v.z; h[2 * e + 1][4 * q + 3] = v.w;
                 }
               } else {
 #pragma unroll
-                for (int j = 0; j < HP; j++) { H(2 * e, j) = av[j]; H(2 * e + 1, j) = av[j]; }
+                for (int j = 0; j < HP; j++) { h[2 * e][j] = av[j]; h[2 * e + 1][j] = av[j]; }
               }
             }
           } else {
@@ -380,15 +334,15 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
 #pragma unroll
               for (int j = 0; j < HP; j++) {
                 const float v = ab[(size_t)j * cstride + (size_t)(m0 + e * MSTEP) * Na];
-                H(2 * e, j) = v;
-                H(2 * e + 1, j) = v;
+                h[2 * e][j] = v;
+                h[2 * e + 1][j] = v;
               }
           }
         } else {
 #pragma unroll
           for (int e = 0; e < EPT * 2; e++)
 #pragma unroll
-            for (int j = 0; j < HP; j++) H(e, j) = b1[j];
+            for (int j = 0; j < HP; j++) h[e][j] = b1[j];
         }
       }
       DLPD_STAMP(0);
@@ -413,63 +367,40 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
       }
       DLPD_LDS_BARRIER();                      // B2: values held in registers, pencils free for the next group
       DLPD_STAMP(2);
-      if constexpr (K3R_MATRIX && HP % 4 == 0) {
-        // FIRST LAYER ON THE MATRIX PIPE (v_mfma_f32_4x4x1_16b_f32: sixteen 4x4x1 blocks, one lane quad each): a lane
-        // multiplies ITS voxel's value with the four weights its quad holds -- hidden units 4q..4q+3, lane l holding
-        // W1t[c][4q + (l & 3)] -- and adds into four accumulators: exactly the fmaf(w, v, h) of the vector form, element
-        // by element (bit-identical), HP / 4 matrix instructions per voxel and channel instead of HP vector ones, on
-        // the pipe the transform waves do not use.  Channel g+1's weights are requested before channel g's products.
-        dlpd_quadw wcur[HP / 4], wnxt[HP / 4];
-        const float* wl = wq + DLPD_QUADW_LANE(lane) * HPQP;
-        if (gs > 0) k3r_load_quadw<HP / 4, HPQP>(wl + cbase * 4 * HPQP, wcur);
-#pragma unroll
-        for (int g = 0; g < GMAX; g++) {
-          if (g < gs) {
-            const int gn1 = (g + 1 < gs ? g + 1 : g);
-            k3r_load_quadw<HP / 4, HPQP>(wl + (cbase + gn1) * 4 * HPQP, wnxt);
-            DLPD_SCHED_FENCE();
-#pragma unroll
-            for (int e = 0; e < EPT; e++) {
-              float v0 = vals[g][e].x, v1 = vals[g][e].y;
-              if (has_clip) { v0 = DLPD_CLAMP(v0, clip); v1 = DLPD_CLAMP(v1, clip); }
-#pragma unroll
-              for (int q = 0; q < HP / 4; q++) {
-                hq[2 * e][q] = DLPD_MFMA_4x4x1_QW(wcur[q], v0, hq[2 * e][q]);
-                hq[2 * e + 1][q] = DLPD_MFMA_4x4x1_QW(wcur[q], v1, hq[2 * e + 1][q]);
-              }
-            }
-            DLPD_SCHED_FENCE();
-#pragma unroll
-            for (int q = 0; q < HP / 4; q++) wcur[q] = wnxt[q];
-          }
-        }
-      } else {
-        // first-layer weights are wave-uniform (scalar loads): channel g+1's row is requested before channel g's FMAs
-        float wcur[HP], wnxt[HP];
+      {
+        // first-layer weights are wave-uniform (scalar loads): the next piece's weights are requested before this
+        // piece's FMAs.  A piece is a channel's whole row up to hidden width 24; from 32 on it is HALF a row, so that the
+        // two buffers together take HP scalar registers instead of 2 HP (64 / 96 of the wave's ~100: they used to
+        // spill into vector registers, and those into scratch).  Same fmaf per accumulator and channel, same order.
+        constexpr int NH = HP >= 32 ? 2 : 1, HH = HP / NH;
+        float wcur[HH], wnxt[HH];
         if (gs > 0) {
 #pragma unroll
-          for (int j = 0; j < HP; j++) wcur[j] = W1t[(size_t)cbase * HP + j];
+          for (int j = 0; j < HH; j++) wcur[j] = W1t[(size_t)cbase * HP + j];
         }
 #pragma unroll
         for (int g = 0; g < GMAX; g++) {
           if (g < gs) {
-            const int gn1 = (g + 1 < gs ? g + 1 : g);
 #pragma unroll
-            for (int j = 0; j < HP; j++) wnxt[j] = W1t[(size_t)(cbase + gn1) * HP + j];
-            DLPD_SCHED_FENCE();
+            for (int hf = 0; hf < NH; hf++) {
+              const int gn1 = (hf + 1 < NH) ? g : (g + 1 < gs ? g + 1 : g), hn1 = (hf + 1 < NH) ? hf + 1 : 0;
 #pragma unroll
-            for (int e = 0; e < EPT; e++) {
-              float v0 = vals[g][e].x, v1 = vals[g][e].y;
-              if (has_clip) { v0 = DLPD_CLAMP(v0, clip); v1 = DLPD_CLAMP(v1, clip); }
+              for (int j = 0; j < HH; j++) wnxt[j] = W1t[(size_t)(cbase + gn1) * HP + hn1 * HH + j];
+              DLPD_SCHED_FENCE();
 #pragma unroll
-              for (int j = 0; j < HP; j++) {
-                H(2 * e, j) = fmaf(wcur[j], v0, H(2 * e, j));
-                H(2 * e + 1, j) = fmaf(wcur[j], v1, H(2 * e + 1, j));
+              for (int e = 0; e < EPT; e++) {
+                float v0 = vals[g][e].x, v1 = vals[g][e].y;
+                if (has_clip) { v0 = DLPD_CLAMP(v0, clip); v1 = DLPD_CLAMP(v1, clip); }
+#pragma unroll
+                for (int j = 0; j < HH; j++) {
+                  h[2 * e][hf * HH + j] = fmaf(wcur[j], v0, h[2 * e][hf * HH + j]);
+                  h[2 * e + 1][hf * HH + j] = fmaf(wcur[j], v1, h[2 * e + 1][hf * HH + j]);
+                }
               }
-            }
-            DLPD_SCHED_FENCE();
+              DLPD_SCHED_FENCE();
 #pragma unroll
-            for (int j = 0; j < HP; j++) wcur[j] = wnxt[j];
+              for (int j = 0; j < HH; j++) wcur[j] = wnxt[j];
+            }
           }
         }
       }
@@ -489,16 +420,16 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
                 if constexpr (HP % 4 == 0) {
 #pragma unroll
                   for (int q = 0; q < HP / 4; q++)
-                    reinterpret_cast<float4*>(ov)[q] = make_float4(H(2 * e + u, 4 * q), H(2 * e + u, 4 * q + 1),
-                                                                   H(2 * e + u, 4 * q + 2), H(2 * e + u, 4 * q + 3));
+                    reinterpret_cast<float4*>(ov)[q] = make_float4(h[2 * e + u][4 * q], h[2 * e + u][4 * q + 1],
+                                                                   h[2 * e + u][4 * q + 2], h[2 * e + u][4 * q + 3]);
                 } else {
 #pragma unroll
-                  for (int j = 0; j < HP; j++) ov[j] = H(2 * e + u, j);
+                  for (int j = 0; j < HP; j++) ov[j] = h[2 * e + u][j];
                 }
               } else {
 #pragma unroll
                 for (int j = 0; j < HP; j++)
-                  out[((((size_t)b * HP + j) * N + xo) * N + y0 + 2 * m + u) * N + zz] = H(2 * e + u, j);
+                  out[((((size_t)b * HP + j) * N + xo) * N + y0 + 2 * m + u) * N + zz] = h[2 * e + u][j];
               }
             }
           }
@@ -510,7 +441,7 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
             for (int u = 0; u < 2; u++) {
               float acc = b2;
 #pragma unroll
-              for (int j = 0; j < HP; j++) acc = fmaf(W2[j], fmaxf(H(2 * e + u, j), 0.f), acc);
+              for (int j = 0; j < HP; j++) acc = fmaf(W2[j], fmaxf(h[2 * e + u][j], 0.f), acc);
               if (has_clash) acc = acc * ((nrm[2 * e + u] < thr) ? 1.0f : 0.0f);
               out[(((size_t)b * N + xo) * N + y0 + 2 * m + u) * N + zz] = acc;
               if (cd.keys && cand_tau) k3_emit(cd, cand_tau, b, (unsigned)((xo * N + y0 + 2 * m + u) * N + zz), acc);
@@ -522,7 +453,6 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
       if (last_group) { cbase = 0; t++; } else cbase += G;
     }
   }
-#undef H
 #ifdef DLPD_STAMPS
   if (lane == 0 && (wave == 0 || wave == F)) {
     const int o = wave == 0 ? 0 : 16;
@@ -548,12 +478,10 @@ template <int N, int HP, int MODE, bool PCL> static int launch_k3r(const cplx* B
                                                          const float* W1t, const float* b1, const float* W2, float b2,
                                                          int has_clip, float clip, float thr, hipStream_t st, K3Aux aux,
                                                          K3Cand cd) {
-  typedef K3rCfg<N, (HP > 32)> Cfg;
+  typedef K3rCfg<N, (HP > DLPD_K3R_WIDE_ABOVE)> Cfg;
   constexpr int RS = N + 8, NZ = N / 2 + 1, NPAIR = Cfg::TY / 2, CPW = 8 / NPAIR;
   constexpr int RAWC = ((NZ * NPAIR + 63) / 64) * 64;
-  constexpr int HPQP = ((HP + 3) / 4 + 3) / 4 * 4;
-  const size_t shmem = (size_t)(Cfg::F * 8 * RS + N) * sizeof(cplx) + (size_t)Cfg::RAWBUF * Cfg::F * CPW * RAWC * 16 +
-                       ((K3R_MATRIX && HP % 4 == 0) ? (size_t)C * 4 * HPQP * sizeof(float) : 0);
+  const size_t shmem = (size_t)(Cfg::F * 8 * RS + N) * sizeof(cplx) + (size_t)Cfg::RAWBUF * Cfg::F * CPW * RAWC * 16;
   int rc = dlpd_set_max_dyn_shared((const void*)k_zifft_filter_rs<N, HP, MODE, PCL>, shmem);
   if (rc) return rc;
   const int G = k3r_group(CT, Cfg::F * CPW, true);

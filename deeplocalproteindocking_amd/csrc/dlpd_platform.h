@@ -147,14 +147,4 @@ typedef float dlpd_acc4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ dlpd_acc4 dlpd_acc4_zero() { dlpd_acc4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
 __device__ __forceinline__ float dlpd_acc4_get(dlpd_acc4 v, int j) { return v[j]; }
 __device__ __forceinline__ dlpd_acc4 dlpd_acc4_make(float a, float b, float c, float d) { dlpd_acc4 z = {a, b, c, d}; return z; }
-#define DLPD_ACC4_AT(acc, j) ((acc)[(j)])            // element j as an lvalue
 #define DLPD_MFMA_16x16x4(a, b, acc) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (acc), 0, 0, 0)
-// sixteen 4x4x1 blocks (v_mfma_f32_4x4x1_16b_f32): block B = lane / 4; lane 4B + j holds A_B[j] and B_B[j]; element i of
-// its accumulator is D_B[i][j] = fma(A_B[i], B_B[j], C_B[i][j]) -- i.e. every lane multiplies ITS OWN b with the four a
-// values of its lane quad: one exact fmaf per element, at the matrix pipe's rate (256 fma per 8 cycles and SIMD)
-#define DLPD_MFMA_4x4x1(a, b, acc) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (acc), 0, 0, 0)
-// the A operand when every lane quad holds the SAME four values p[0..3] (a weight quad): lane l keeps p[l & 3]
-typedef float dlpd_quadw;
-#define DLPD_QUADW_IS_SCALAR 1
-#define DLPD_QUADW_LANE(lane) ((lane) & 3)           // which of the quad's four values this lane keeps
-#define DLPD_MFMA_4x4x1_QW(qw, b, acc) DLPD_MFMA_4x4x1((qw), (b), (acc))

@@ -125,7 +125,9 @@ class DockingEngine:
     def __init__(self, L, C, W1, b1, W2, b2, clip=5.0, threshold_clash=300.0, has_clash=True,
                  max_conf=1000, batch=8, device="cuda", lib=None, center=None, coarse_channels=0,
                  fine_unfused=None, channels_last=None, k3_form=0, coarse_center=None, extent=None,
-                 preact_channels_last=None, orient=True, quads=True, prefilter=True):
+                 preact_channels_last=None, orient=True, quads=True, prefilter=True,
+                 rotation_scale=1.0, coarse_rotation_scale=None, rotation_axis_order="xyz", clip_mode="output",
+                 rotation_transpose=False):
         """coarse_channels > 0: the reference's two-resolution layout -- C channels at L^3 plus
         ``coarse_channels`` at (L/2)^3 (ProteinRepresentationModels.py:72-76); W1 is (H, C+coarse).
         extent < L: the volumes are extent^3 boxes in the corner of the L^3 ones (a box size without a compiled plan
@@ -145,6 +147,18 @@ class DockingEngine:
         self.has_clash = bool(has_clash)
         self.CT = self.C + (1 if self.has_clash else 0)
         self.center = float(L) / 2.0 if center is None else float(center)
+        # Conventions of the volume rotation and of VolumeConvolution(clip) that TorchProteinLibrary may define
+        # differently (Utils/Conventions.py): scale + axis order are folded into the 3x3 maps K1 samples with (the clash
+        # provider keeps the true rotations: atoms are rotated geometrically); clip_mode "input" clamps the receptor once
+        # and every rotated ligand batch before its transform (through the volumes path: exact, one extra round trip of
+        # the rotated volumes -- the price of a convention nobody has confirmed), "none" drops the clamp.
+        self.rot_scale = float(rotation_scale)
+        self.rot_scale1 = float(rotation_scale if coarse_rotation_scale is None else coarse_rotation_scale)
+        self.rot_axis_order, self.rot_transpose = rotation_axis_order, bool(rotation_transpose)
+        self._rot_mapped = self.rot_scale != 1.0 or self.rot_scale1 != 1.0 or rotation_axis_order != "xyz" or self.rot_transpose
+        if clip_mode not in ("output", "input", "none"):
+            raise RuntimeError("dlpd: clip_mode %r" % (clip_mode,))
+        self.clip_mode = clip_mode
         self.clip = clip
         self.threshold = float(threshold_clash)
         self.K = int(max_conf)
@@ -230,6 +244,23 @@ class DockingEngine:
         self.k3_form = int(k3_form)
 
     @property
+    def _out_clip(self):
+        """(has_clip, clip) of the kernels' clamp on the correlation OUTPUT."""
+        on = self.clip is not None and self.clip_mode == "output"
+        return (1 if on else 0), float(self.clip if on else 0.0)
+
+    @property
+    def _in_clip(self):
+        return float(self.clip) if (self.clip is not None and self.clip_mode == "input") else None
+
+    def _kernel_R(self, R, coarse=False):
+        """The 3x3 maps K1 samples with: R itself, or scale * P R P (Utils/Conventions.kernel_matrices)."""
+        if not self._rot_mapped:
+            return R
+        from .Utils.Conventions import kernel_matrices
+        return kernel_matrices(R, self.rot_scale1 if coarse else self.rot_scale, self.rot_axis_order, self.rot_transpose)
+
+    @property
     def pre_cl(self):
         """The coarse grid's pre-activations are channels-last for THIS launch (the role-split K3 reads them)."""
         return self.preact_channels_last and self.k3_form != 1 and not self.fine_unfused
@@ -241,7 +272,10 @@ class DockingEngine:
                 "k3_form": {0: "library default (role-split where compiled)", 1: "channel-owning", 2: "role-split"}[self.k3_form],
                 "k3_unfused": bool(self.fine_unfused), "topk_candidate_lists": bool(self.prefilter),
                 "preact_layout": (("channels_last" if self.pre_cl else "planes") if self.C1 else None),
-                "embedded_extent": self.extent or None}
+                "embedded_extent": self.extent or None,
+                "rotation": {"center": self.center, "scale": self.rot_scale, "axis_order": self.rot_axis_order,
+                             "transpose": self.rot_transpose},
+                "clip_mode": self.clip_mode}
 
     # ---- inputs ------------------------------------------------------------------------
     def set_filter(self, W1, b1, W2, b2):
@@ -275,10 +309,14 @@ class DockingEngine:
         if self.C1:
             L1 = self.L1
             r1 = torch.as_tensor(rec_coarse, dtype=torch.float32).reshape(self.C1, L1, L1, L1).to(self.device).contiguous()
+            if self._in_clip is not None:
+                r1 = r1.clamp(-self._in_clip, self._in_clip)
             self.lib.call("dlpd_rfft3d_padded", _ptr(r1), _ptr(self.recF1), _ptr(self.wsA1), self.C1, L1,
                           1.0 / float(2 * L1) ** 3, _stream(self.device))
         rec = torch.zeros(CT, L, L, L, dtype=torch.float32, device=self.device)
         rec[: self.C] = torch.as_tensor(rec_volumes, dtype=torch.float32).reshape(self.C, L, L, L).to(self.device)
+        if self._in_clip is not None:
+            rec[: self.C].clamp_(-self._in_clip, self._in_clip)
         if self.has_clash:
             rec[self.C] = torch.as_tensor(rec_forbidden, dtype=torch.float32).reshape(L, L, L).to(self.device)
         scale = 1.0 / float(N) ** 3
@@ -338,10 +376,14 @@ class DockingEngine:
         assert nb <= self.batch and R.dtype == torch.float32 and R.is_contiguous()
         tr = int(bool(transposed) and self.orient)
         use_quads = bool(quads) and self.use_quads
-        has_clip, clip = (0 if self.clip is None else 1), float(self.clip or 0.0)
+        has_clip, clip = self._out_clip
         V = self.V if out is None else out
         call, st, L = self.lib.call, _stream(self.device), self.L
         provider = self.clash_provider if self.has_clash else None
+        if self._in_clip is not None:
+            return self._score_rotated_then_clamped(R, mark, out, cset, provider)
+        R_true, R, R1 = R, self._kernel_R(R), (self._kernel_R(R, coarse=True) if self.C1 else None)
+        self._keepR = (R, R1)                          # mapped copies stay alive until the stream has consumed them
         if not (self.C1 or provider or self.fine_unfused or mark or use_quads or self.use_cl or cset is not None or self.k3_form
                 or self.extent):
             call("dlpd_score_rotations_oriented", _ptr(self.lig), _ptr(self.recF), _ptr(R), nb, self.C,
@@ -354,13 +396,13 @@ class DockingEngine:
             # coarse resolution first: rotate + correlate + clip -> real volumes the fine filter reads
             L1 = self.L1
             if self.use_cl:
-                call("dlpd_zfft_channels_last_ext", _ptr(self.ligcl1), _ptr(R), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1,
+                call("dlpd_zfft_channels_last_ext", _ptr(self.ligcl1), _ptr(R1), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1,
                      self.center1, self.extent1, st)
             elif use_quads:
-                call("dlpd_zfft_quads", _ptr(self.ligq1), _ptr(R), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1,
+                call("dlpd_zfft_quads", _ptr(self.ligq1), _ptr(R1), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1,
                      self.center1, tr, st)
             else:
-                call("dlpd_zfft_oriented_ext", _ptr(self.lig1), _ptr(R), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1, 0, 1,
+                call("dlpd_zfft_oriented_ext", _ptr(self.lig1), _ptr(R1), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1, 0, 1,
                      self.center1, tr, self.extent1, st)
             call("dlpd_xy_correlate_oriented", _ptr(self.wsA1), _ptr(self.recF1), _ptr(self.wsB1), nb, self.C1, L1, 0,
                  tr, st)
@@ -368,7 +410,7 @@ class DockingEngine:
             mark("coarse")
         if provider is not None:
             # clash channel from re-projected rotated ATOMS (Docker.py:221-224), scores from rotated volumes
-            forb = provider(R).reshape(nb, L, L, L).contiguous()
+            forb = provider(R_true).reshape(nb, L, L, L).contiguous()
             if self.use_cl:
                 call("dlpd_zfft_channels_last_ext", _ptr(self.ligcl), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0, L,
                      self.center, self.extent, st)
@@ -401,10 +443,13 @@ class DockingEngine:
         assert nb <= self.batch
         f32c = lambda t: t.to(device=self.device, dtype=torch.float32).contiguous()
         call, st = self.lib.call, _stream(self.device)
-        has_clip, clip = (0 if self.clip is None else 1), float(self.clip or 0.0)
+        has_clip, clip = self._out_clip
         V = self.V if out is None else out
         mark = mark or (lambda name: None)
         mark("begin")
+        if self._in_clip is not None:                  # VolumeConvolution(clip) clamping its INPUTS (clip_mode "input")
+            vl = f32c(vl).clamp(-self._in_clip, self._in_clip)
+            vc = f32c(vc).clamp(-self._in_clip, self._in_clip) if self.C1 else vc
         if self.C1:
             L1 = self.L1
             vc = f32c(vc).reshape(nb, self.C1, L1, L1, L1)
@@ -421,6 +466,34 @@ class DockingEngine:
         self._keep = (vl, vf, vc)                      # inputs stay alive until the stream has consumed them
         return self._correlate_and_filter(nb, V, mark, 0, cset)
 
+    def _score_rotated_then_clamped(self, R, mark, out, cset, provider):
+        """clip_mode "input": the reference order is rotate (Docker.py:218) -> VolumeConvolution(clip) (DockingModels.py:71),
+        so the clamp acts on the ROTATED ligand volumes: they are materialised by the stand-alone rotation kernel, clamped
+        (in _score_volumes) and fed to the pipeline as given volumes.  The clash channel is never clamped (Docker.py:32,225:
+        VolumeConvolution() without clip)."""
+        nb, L, call, st = R.shape[0], self.L, self.lib.call, _stream(self.device)
+        f32 = torch.float32
+        Rk, Rk1 = self._kernel_R(R), (self._kernel_R(R, coarse=True) if self.C1 else None)
+        self._keepR = (Rk, Rk1)                        # alive until the stream has consumed them
+        vl = torch.empty(nb, self.C, L, L, L, dtype=f32, device=self.device)
+        call("dlpd_rotate_trilinear", _ptr(self.lig), _ptr(Rk), _ptr(vl), nb, self.C, L, 0, self.center, st)
+        vf = vc = None
+        if self.has_clash:
+            if provider is not None:
+                vf = provider(R).reshape(nb, L, L, L).contiguous()
+            else:
+                vf = torch.empty(nb, 1, L, L, L, dtype=f32, device=self.device)
+                call("dlpd_rotate_trilinear", self.lig.data_ptr() + self.C * L ** 3 * 4, _ptr(Rk), _ptr(vf), nb, 1, L, 0,
+                     self.center, st)
+        if self.C1:
+            L1 = self.L1
+            vc = torch.empty(nb, self.C1, L1, L1, L1, dtype=f32, device=self.device)
+            call("dlpd_rotate_trilinear", _ptr(self.lig1), _ptr(Rk1), _ptr(vc), nb, self.C1, L1, 0,
+                 self.center1, st)
+        if self.extent:
+            raise RuntimeError("dlpd: clip_mode 'input' is not combined with embedded boxes (use a compiled box size)")
+        return self._score_volumes((vl, vf, vc), mark, out, cset)
+
     def _coarse_preact(self, nb, has_clip, clip, st):
         """Coarse grid, last stage: z-inverse + clip fused with the coarse half of the (linear) first layer
         (DockingModels.py:74-83): HP pre-activation planes on the coarse grid instead of C1 correlation volumes."""
@@ -434,7 +507,7 @@ class DockingEngine:
     def _correlate_and_filter(self, nb, V, mark, tr, cset=None):
         """K2 + K3 (+ filter) on whatever K1 left in wsA (and the coarse result in aux); tr: the slab
         orientation K1 used."""
-        has_clip, clip = (0 if self.clip is None else 1), float(self.clip or 0.0)
+        has_clip, clip = self._out_clip
         call, st, L = self.lib.call, _stream(self.device), self.L
         call("dlpd_xy_correlate_oriented", _ptr(self.wsA), _ptr(self.recF), _ptr(self.wsB), nb, self.CT, L, 0,
              tr, st)

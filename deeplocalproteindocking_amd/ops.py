@@ -16,6 +16,7 @@ from torch import nn
 
 from ._lib import get_lib
 from .engine import _ptr, _stream
+from .Utils.Conventions import CLIP_MODES, kernel_matrices, rotation_scale
 
 
 def _check(t, name, lib=None):
@@ -27,10 +28,16 @@ def _check(t, name, lib=None):
 
 
 class VolumeRotation(nn.Module):
-    def __init__(self, center=None, lib=None):
+    """``center`` / ``scale`` / ``axis_order``: the conventions of Utils/Conventions.py (pivot index; stretch of the
+    sample offset -- a number or "(L-1)/L" / "L/(L-1)"; "xyz" | "zyx"), folded into the 3x3 maps the kernel samples with."""
+
+    def __init__(self, center=None, lib=None, scale=None, axis_order="xyz", transpose=False):
         super().__init__()
         self.center = center
         self.lib = lib
+        self.scale = scale
+        self.axis_order = axis_order
+        self.transpose = bool(transpose)
 
     def forward(self, volume, R):
         volume, R = _check(volume, "volume", self.lib), _check(R, "R", self.lib)
@@ -39,6 +46,8 @@ class VolumeRotation(nn.Module):
             raise RuntimeError("dlpd: VolumeRotation batch mismatch: volume %d vs R %d" % (B, R.shape[0]))
         out = torch.empty_like(volume)
         c0 = float(L) / 2.0 if self.center is None else float(self.center)
+        if self.scale is not None or self.axis_order != "xyz" or self.transpose:
+            R = kernel_matrices(R, rotation_scale(self.scale, L), self.axis_order, self.transpose)
         (self.lib or get_lib()).call("dlpd_rotate_trilinear", _ptr(volume), _ptr(R), _ptr(out), B, C, L, C * L ** 3, c0,
                        _stream(volume.device))
         return out
@@ -48,16 +57,29 @@ class VolumeConvolution(nn.Module):
     """Per-channel circular cross-correlation on the 2L zero-padded grid:
     out[b,c,t mod 2L] = sum_r v1[b,c,r+t] * v2[b,c,r]  (semantics: MultiplyVolumes.py:13-47)."""
 
-    def __init__(self, clip=None, lib=None, embed=True):
+    def __init__(self, clip=None, lib=None, embed=True, clip_mode="output"):
+        """clip_mode (Utils/Conventions.py): "output" clamps the correlation to +-clip (this build's definition),
+        "input" clamps both input volumes instead, "none" ignores ``clip``."""
         super().__init__()
+        if clip_mode not in CLIP_MODES:
+            raise RuntimeError("dlpd: clip_mode must be one of %s" % (CLIP_MODES,))
+        self.clip_mode = clip_mode
         self.clip = clip
         self.lib = lib
         self.embed = embed          # boxes without a compiled plan: inside the next compiled box (False: plan-free transforms)
+
+    @property
+    def out_clip(self):
+        """The clamp the kernels apply to the correlation OUTPUT (None: no clamp)."""
+        return self.clip if self.clip_mode == "output" else None
 
     def forward(self, input_volume1, input_volume2):
         v1, v2 = _check(input_volume1, "volume1", self.lib), _check(input_volume2, "volume2", self.lib)
         if v1.shape != v2.shape:
             raise RuntimeError("dlpd: VolumeConvolution shape mismatch %s vs %s" % (tuple(v1.shape), tuple(v2.shape)))
+        if self.clip is not None and self.clip_mode == "input":
+            c = float(self.clip)
+            v1, v2 = v1.clamp(-c, c), v2.clamp(-c, c)
         B, C, L = v1.shape[0], v1.shape[1], v1.shape[2]
         lib = self.lib or get_lib()
         if not lib.call("dlpd_grid_supported", L):
@@ -81,8 +103,8 @@ class VolumeConvolution(nn.Module):
         wsB = torch.empty(nvol * NZ * N * N * 2, dtype=torch.float32, device=dev)
         lib.call("dlpd_xy_correlate", _ptr(wsA), _ptr(spec), _ptr(wsB), 1, nvol, L, 0, st)
         out = torch.empty(B, C, N, N, N, dtype=torch.float32, device=dev)
-        lib.call("dlpd_zifft_real", _ptr(wsB), _ptr(out), 1, nvol, L, 0 if self.clip is None else 1,
-                 float(self.clip or 0.0), st)
+        oc = self.out_clip
+        lib.call("dlpd_zifft_real", _ptr(wsB), _ptr(out), 1, nvol, L, 0 if oc is None else 1, float(oc or 0.0), st)
         return out
 
 
@@ -101,8 +123,8 @@ def _vc_generic(self, v1, v2, lib):
     a, b, o = v1.reshape(nvol, -1), v2.reshape(nvol, -1), out.reshape(nvol, -1)
     for beg in range(0, nvol, chunk):
         n = min(chunk, nvol - beg)
-        lib.call("dlpd_correlate_generic", _ptr(a[beg]), _ptr(b[beg]), _ptr(o[beg]), n, L, 0 if self.clip is None else 1,
-                 float(self.clip or 0.0), _ptr(ws), st)
+        lib.call("dlpd_correlate_generic", _ptr(a[beg]), _ptr(b[beg]), _ptr(o[beg]), n, L, 0 if self.out_clip is None else 1,
+                 float(self.out_clip or 0.0), _ptr(ws), st)
     return out
 
 

@@ -39,6 +39,10 @@ int dlpd_fused_hidden_pad(int H, int L, int two_res);
 
 /* TPL VolumeRotation call, src/Docker/Docker.py:218 (ctor :40; DockingModels.py:49).
  * out[b,c](i) = trilinear vol[b,c]( center + R_b^T (i - center) ), zeros outside.
+ * R_b is used as a GENERAL 3x3 map by every rotation entry point of this header (nothing assumes orthonormality): a
+ * sampling scale s and a reversed axis order (matrix axis 0 <-> last spatial index) -- conventions TorchProteinLibrary's
+ * VolumeRotation may have (its source is absent) -- are passed as R' = s P R P, P the axis reversal
+ * (deeplocalproteindocking_amd/Utils/Conventions.py: kernel_matrices), the pivot as `center`.
  * vol (B,C,L^3) with batch stride vol_bstride floats (0: one volume set shared by all b). */
 int dlpd_rotate_trilinear(const float* vol, const float* R, float* out, int B, int C, int L,
                           long long vol_bstride, float center, void* stream);
@@ -103,6 +107,15 @@ int dlpd_zfft_channels_last_ext(const float* cl, const float* R, void* wsA, int 
 int dlpd_project_atoms(const float* coords, const int* num_atoms_of_type, const int* offsets, const float* R,
                        float shift_x, float shift_y, float shift_z, float* out, int B, int stride_atoms,
                        int ntypes, int L, float resolution, int sum_types, void* stream);
+/* The same with the density shape as parameters (TypedCoords2Volume's is not known: TorchProteinLibrary is absent from
+ * the reference tree; scripts/calibrate_tpl.py determines them where it is installed): exp(-|r - p'|^2 / (2 sigma^2)) on
+ * the (2 window + 1)^3 voxels around each atom, times `norm` (0 < norm <= 64; the fixed-point accumulator holds
+ * 1023 per voxel), voxel (i,j,k) at ((i,j,k) + voxel_offset) * resolution; window <= 6.
+ * dlpd_project_atoms = (sigma 1, window 2, voxel_offset 0, norm 1). */
+int dlpd_project_atoms_ext(const float* coords, const int* num_atoms_of_type, const int* offsets, const float* R,
+                           float shift_x, float shift_y, float shift_z, float* out, int B, int stride_atoms,
+                           int ntypes, int L, float resolution, int sum_types, float sigma, int window,
+                           float voxel_offset, float norm, void* stream);
 
 /* Zero-padded 3-D R2C spectrum (receptor side of VolumeConvolution, DockingModels.py:71):
  * spec (nvol, NZ, N, N) = scale * rfftn(pad(vol)).  wsA: nvol*NZ*L*L complex64 scratch. */

@@ -66,27 +66,43 @@ def load_eul(filename):
 # Volume rotation (TPL VolumeRotation at Docker.py:218) -- build-defined conventions
 # --------------------------------------------------------------------------------------
 
-def rotate_volume(vol, R, center=None, dtype=torch.float32):
+def rotate_volume(vol, R, center=None, dtype=torch.float32, scale=1.0, axis_order="xyz", transpose=False):
     """Trilinear resampling of ``vol`` (B,C,L,L,L) under rotation ``R`` (B,3,3).
 
-    out[b,c,i] = vol[b,c]( c0 + R_b^T (i - c0) ), zero outside the box, i = (x,y,z) index
+    out[b,c,i] = vol[b,c]( c0 + s R_b^T (i - c0) ), zero outside the box, i = (x,y,z) index
     vector, axis 0 of the matrix <-> first spatial index.  ``c0`` defaults to L/2 in index
     units: the reference rotates ligand coordinates about the origin and then translates them
     to box_length/2 (Docker.py:199-201,221-222), i.e. about the box centre.
     Weights are computed in ``dtype``.
+
+    The conventions TorchProteinLibrary's VolumeRotation may differ in (its source is absent; they are what
+    scripts/calibrate_tpl.py determines on a machine that has it), each written out here, not folded into R:
+      center      pivot index c0 (L/2; (L-1)/2 for a grid_sample(align_corners=True)-style sampler; any number)
+      scale       s: the sample offset is stretched by s -- (L-1)/L when normalised coordinates are GENERATED with one
+                  align_corners convention and SAMPLED with the other (PyTorch 1.1, README.md:4, has only one)
+      axis_order  "xyz": matrix axis 0 <-> first spatial index; "zyx": matrix axis 0 <-> LAST spatial index
+                  (grid_sample's own convention: its grid's last dimension is (x, y, z) = (W, H, D) order)
+      transpose   True: R^T in place of R (the inverse rotation)
     """
     vol = torch.as_tensor(vol)
     B, C, L = vol.shape[0], vol.shape[1], vol.shape[2]
     R = torch.as_tensor(R).to(dtype)
+    if transpose:
+        R = R.transpose(-1, -2)
     c0 = (L / 2.0) if center is None else float(center)
+    if axis_order not in ("xyz", "zyx"):
+        raise ValueError("axis_order must be 'xyz' or 'zyx'")
     ar = torch.arange(L, dtype=dtype) - c0
     gx, gy, gz = torch.meshgrid(ar, ar, ar, indexing="ij")
-    d = torch.stack([gx, gy, gz], dim=-1).reshape(-1, 3)          # (L^3, 3)
+    d = torch.stack([gx, gy, gz], dim=-1).reshape(-1, 3)          # (L^3, 3) offsets in (first, second, third) index order
     out = torch.empty(B, C, L, L, L, dtype=dtype)
     v = vol.to(dtype)
     for b in range(B):
-        # p = c0 + R^T d  ->  row-vector form d @ R
-        p = d @ R[b] + c0
+        # p = c0 + s R^T d  ->  row-vector form d @ R; "zyx": the matrix acts on (third, second, first)
+        if axis_order == "zyx":
+            p = (d.flip(-1) @ R[b]).flip(-1) * float(scale) + c0
+        else:
+            p = (d @ R[b]) * float(scale) + c0
         p0 = torch.floor(p)
         f = p - p0
         i0 = p0.to(torch.int64)
@@ -140,20 +156,30 @@ def correlate_direct(v1, v2):
     return out
 
 
-def correlate_fft(v1, v2, clip=None, dtype=torch.float32):
+CLIP_MODES = ("output", "input", "none")
+
+
+def correlate_fft(v1, v2, clip=None, dtype=torch.float32, clip_mode="output"):
     """Per-channel circular cross-correlation on the 2L zero-padded grid (B,C,2L,2L,2L).
 
     irfftn( rfftn(v1, 2L) * conj(rfftn(v2, 2L)) ).  ``clip``: build-defined as clamping the
     OUTPUT to [-clip, clip] (TPL source absent; parity unpinned, see module docstring).
+    ``clip_mode``: what VolumeConvolution(clip) (DockingModels.py:48) may mean instead -- "input": both input volumes
+    are clamped to [-clip, clip] before they are correlated; "none": the argument is ignored
+    (scripts/calibrate_tpl.py tells which one a TorchProteinLibrary build implements).
     """
+    if clip_mode not in CLIP_MODES:
+        raise ValueError("clip_mode must be one of %s" % (CLIP_MODES,))
     v1 = torch.as_tensor(v1).to(dtype)
     v2 = torch.as_tensor(v2).to(dtype)
+    if clip is not None and clip_mode == "input":
+        v1, v2 = torch.clamp(v1, -float(clip), float(clip)), torch.clamp(v2, -float(clip), float(clip))
     L = v1.shape[2]
     N = 2 * L
     f1 = torch.fft.rfftn(v1, s=(N, N, N), dim=(2, 3, 4))
     f2 = torch.fft.rfftn(v2, s=(N, N, N), dim=(2, 3, 4))
     out = torch.fft.irfftn(f1 * torch.conj(f2), s=(N, N, N), dim=(2, 3, 4))
-    if clip is not None:
+    if clip is not None and clip_mode == "output":
         out = torch.clamp(out, -float(clip), float(clip))
     return out
 
@@ -169,7 +195,7 @@ def filter_mlp(feat, W1, b1, W2, b2):
 
 
 def score_volumes(receptor_volumes, ligand_volumes, W1, b1, W2, b2, clip=5.0,
-                  dtype=torch.float32):
+                  dtype=torch.float32, clip_mode="output"):
     """GlobalDockingModel.forward: list of (B,C_i,L_i^3) pairs -> V (B,N,N,N), N = 2*L_0.
 
     Per-resolution correlation (:70-71), nearest upsample of smaller grids to N (:74-76,
@@ -179,7 +205,7 @@ def score_volumes(receptor_volumes, ligand_volumes, W1, b1, W2, b2, clip=5.0,
     N = 2 * receptor_volumes[0].shape[2]
     conv = []
     for r, l in zip(receptor_volumes, ligand_volumes):
-        c = correlate_fft(r, l, clip=clip, dtype=dtype)
+        c = correlate_fft(r, l, clip=clip, dtype=dtype, clip_mode=clip_mode)
         if c.shape[2] < N:
             s = N // c.shape[2]
             assert c.shape[2] * s == N
@@ -298,9 +324,11 @@ def format_conformations(top_list, R_all, box_size, resolution, randR=None):
 # Atom projection (TPL TypedCoords2Volume at Docker.py:204,208,223) -- build-defined shape
 # --------------------------------------------------------------------------------------
 
-def project_atoms(coords, num_atoms_of_type, offsets, L, resolution, R=None, shift=None, sum_types=False):
-    """coords (3*Nmax,) ordered by type; every atom adds exp(-|r - p'|^2 / 2) to the 5^3 voxels
-    around p' = R p + shift (voxel (i,j,k) at (i,j,k)*resolution).  float64.  -> (T or 1, L,L,L)."""
+def project_atoms(coords, num_atoms_of_type, offsets, L, resolution, R=None, shift=None, sum_types=False,
+                  sigma=1.0, window=2, voxel_offset=0.0, norm=1.0):
+    """coords (3*Nmax,) ordered by type; every atom adds exp(-|r - p'|^2 / (2 sigma^2)) to the (2 window + 1)^3 voxels
+    around p' = R p + shift (voxel (i,j,k) at ((i,j,k) + voxel_offset)*resolution).  float64.  -> (T or 1, L,L,L).
+    Defaults (sigma 1, window 2, offset 0) are this build's definition; TypedCoords2Volume's is unknown."""
     T = len(num_atoms_of_type)
     out = np.zeros((1 if sum_types else T, L, L, L), dtype=np.float64)
     xyz = np.asarray(coords, dtype=np.float64).reshape(-1, 3)
@@ -309,13 +337,14 @@ def project_atoms(coords, num_atoms_of_type, offsets, L, resolution, R=None, shi
     for t in range(T):
         for a in range(int(offsets[t]), int(offsets[t]) + int(num_atoms_of_type[t])):
             p = R @ xyz[a] + shift
-            c = np.floor(p / resolution).astype(int)
-            for i in range(c[0] - 2, c[0] + 3):
-                for j in range(c[1] - 2, c[1] + 3):
-                    for k in range(c[2] - 2, c[2] + 3):
+            c = np.floor(p / resolution - voxel_offset).astype(int)
+            w = int(window)
+            for i in range(c[0] - w, c[0] + w + 1):
+                for j in range(c[1] - w, c[1] + w + 1):
+                    for k in range(c[2] - w, c[2] + w + 1):
                         if 0 <= i < L and 0 <= j < L and 0 <= k < L:
-                            d = p - np.array([i, j, k]) * resolution
-                            out[0 if sum_types else t, i, j, k] += np.exp(-0.5 * d @ d)
+                            d = p - (np.array([i, j, k]) + voxel_offset) * resolution
+                            out[0 if sum_types else t, i, j, k] += norm * np.exp(-0.5 * (d @ d) / sigma ** 2)
     return out
 
 
@@ -346,9 +375,24 @@ def project_atoms_fast(coords, num_atoms_of_type, offsets, L, resolution, R=None
 # Whole search (Docker.dockSE3 loop, Docker.py:211-238) on volumes
 # --------------------------------------------------------------------------------------
 
+def rotation_scale(rule, L):
+    """Scale of the volume rotation on a grid of L voxels per edge: a number, or "(L-1)/L" / "L/(L-1)" (the two ways a
+    generate / sample mismatch of grid_sample's align_corners convention can go)."""
+    if rule is None:
+        return 1.0
+    if isinstance(rule, str):
+        if rule == "(L-1)/L":
+            return (float(L) - 1.0) / float(L)
+        if rule == "L/(L-1)":
+            return float(L) / (float(L) - 1.0)
+        raise ValueError("unknown rotation scale rule %r" % (rule,))
+    return float(rule)
+
+
 def dock_volumes(receptor_volumes, ligand_volumes, receptor_forbidden, ligand_forbidden,
                  rotations, W1, b1, W2, b2, threshold_clash, max_conf, clip=5.0,
-                 rot_indices=None, faithful_topk=True, dtype=torch.float32, return_V=False):
+                 rot_indices=None, faithful_topk=True, dtype=torch.float32, return_V=False,
+                 clip_mode="output", rotation_center_offset=0.0, rotation_scale_rule=None, axis_order="xyz", transpose=False):
     """Run the reference loop for the given rotations on single-sample volumes.
 
     receptor_volumes / ligand_volumes: lists of (1,C_i,L_i^3); *_forbidden: (1,1,L^3).
@@ -364,10 +408,14 @@ def dock_volumes(receptor_volumes, ligand_volumes, receptor_forbidden, ligand_fo
     N = 2 * receptor_volumes[0].shape[2]
     for ri in rot_indices:
         Rb = torch.from_numpy(rotations[ri:ri + 1]).to(dtype)
-        lig_rot = [rotate_volume(v, Rb, dtype=dtype) for v in ligand_volumes]
-        lig_forb_rot = rotate_volume(ligand_forbidden, Rb, dtype=dtype)
+        def rot(v):
+            Lv = v.shape[2]
+            return rotate_volume(v, Rb, center=Lv / 2.0 + rotation_center_offset, dtype=dtype,
+                                 scale=rotation_scale(rotation_scale_rule, Lv), axis_order=axis_order, transpose=transpose)
+        lig_rot = [rot(v) for v in ligand_volumes]
+        lig_forb_rot = rot(ligand_forbidden)
         mask, _ = clash_mask(receptor_forbidden, lig_forb_rot, threshold_clash, dtype=dtype)
-        V = score_volumes(receptor_volumes, lig_rot, W1, b1, W2, b2, clip=clip, dtype=dtype)
+        V = score_volumes(receptor_volumes, lig_rot, W1, b1, W2, b2, clip=clip, dtype=dtype, clip_mode=clip_mode)
         V = (mask * V)[0].contiguous()
         if return_V:
             Vs.append(V.clone())

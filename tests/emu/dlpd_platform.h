@@ -260,31 +260,4 @@ static inline dlpd_acc4 dlpd_emu_mfma_16x16x4(float a, float b, dlpd_acc4 acc) {
   emu::wave_sync();
   return acc;
 }
-#define DLPD_ACC4_AT(acc, j) ((acc).v[(j)])
 #define DLPD_MFMA_16x16x4(a, b, acc) dlpd_emu_mfma_16x16x4((a), (b), (acc))
-// sixteen 4x4x1 blocks: lane 4B + j, accumulator element i: fma(a of lane 4B + i, own b, c)
-static inline dlpd_acc4 dlpd_emu_mfma_4x4x1(float a, float b, dlpd_acc4 acc) {
-  emu::State& s = emu::S();
-  const int w = s.cur / 64, l = s.cur % 64;
-  float ab[2] = {a, b};
-  memcpy(&s.wave_buf[w][l], ab, 8);
-  emu::wave_sync();
-  for (int i = 0; i < 4; i++) {
-    float fa[2];
-    memcpy(fa, &s.wave_buf[w][(l & ~3) + i], 8);
-    acc.v[i] = fmaf(fa[0], b, acc.v[i]);
-  }
-  emu::wave_sync();
-  return acc;
-}
-#define DLPD_MFMA_4x4x1(a, b, acc) dlpd_emu_mfma_4x4x1((a), (b), (acc))
-// weight-quad form (every lane quad holds the same four a values): the emulated lane keeps all four, so the block
-// product needs no wave collective (the lane map itself is checked by DLPD_MFMA_4x4x1 users and by the GPU tests)
-struct dlpd_quadw { float w[4]; };
-static inline dlpd_acc4 dlpd_emu_mfma_4x4x1_qw(const dlpd_quadw& q, float b, dlpd_acc4 acc) {
-  for (int i = 0; i < 4; i++) acc.v[i] = fmaf(q.w[i], b, acc.v[i]);
-  return acc;
-}
-#define DLPD_QUADW_IS_SCALAR 0
-#define DLPD_QUADW_LANE(lane) 0                      // (the emulated lane reads all four rows itself)
-#define DLPD_MFMA_4x4x1_QW(qw, b, acc) dlpd_emu_mfma_4x4x1_qw((qw), (b), (acc))

@@ -757,3 +757,38 @@ def test_topk_candidate_lists_from_k3_equal_the_full_select(dev, monkeypatch):
     # max_conf above 4096: K3's lists (4096 slots per rotation) overflow until the threshold has tightened, the large-list
     # select and merge run in global scratch; both routes must still agree entry for entry
     _search_with_and_without_candidate_lists(None, dev, 64, 48, 6000, 60, 16, monkeypatch, seed=6)
+
+
+def test_four_degree_rotation_set_head_and_tail_match_the_oracle(dev):
+    """BASELINE config 3's rotation set (``angle_inc=4``: data/oim04.eul is absent from the reference tree,
+    .MISSING_LARGE_BLOBS:1, and from the table at src/Utils/Rotations.py:42-55; the SOI-sized generated substitute of
+    232,020 rotations stands in) on config 3's 48-channel 64^3 pair: the first 32 and the last 32 rotations of the set,
+    searched under their GLOBAL indices as a rank of the sharded search would (rot_ids), K = 200, against the oracle."""
+    import bench
+    from deeplocalproteindocking_amd.engine import DockingEngine
+    from deeplocalproteindocking_amd.Utils.Rotations import Rotations, generated_set_size
+    rot = Rotations(4, allow_generated=True, verbose=False)
+    nsphere, nphi = generated_set_size(4)
+    nrot = rot.R.shape[0]
+    assert nrot == nsphere * nphi == 232020 or rot.source != "generated"
+    ids = np.concatenate([np.arange(32), np.arange(nrot - 32, nrot)])
+    R = rot.R[ids].numpy()
+    L, C, K = 64, 48, 200
+    rec, lig, recf, ligf, filt = bench.synthetic_pair(C, L)
+    W = filt.parameters_tuple()
+    thr = bench.clash_threshold(recf, ligf)
+    eng = DockingEngine(L, C, *W, clip=5.0, threshold_clash=thr, max_conf=K, batch=16, device=dev)
+    eng.set_receptor(rec, recf)
+    eng.set_ligand(lig, ligf)
+    eng.reset_top()
+    eng.search(rot.R[ids], rot_ids=ids)
+    got = eng.top_list()
+    want, Vs = orc.dock_volumes([rec[None]], [lig[None]], recf[None, None], ligf[None, None], R, *[w.cpu() for w in W], thr, K,
+                                clip=5.0, faithful_topk=False, return_V=True)
+    want = [(int(ids[w[0]]),) + w[1:] for w in want]            # oracle indices are positions in R: -> global indices
+    scale = max(float(v.abs().max()) for v in Vs)
+    band = TOL * scale
+    assert len(got) == len(want) == K and {g[0] for g in got} <= set(ids.tolist())
+    assert max(abs(a[4] - b[4]) for a, b in zip(got, want)) <= band
+    assert sum(a[:4] == b[:4] for a, b in zip(got, want)) >= int(0.97 * K)
+    assert any(g[0] >= nrot - 32 for g in got) and any(g[0] < 32 for g in got)

@@ -223,7 +223,7 @@ def test_bench_reads_the_dominant_kernels_traffic_from_a_counter_pass(tmp_path, 
     import subprocess
     import bench
 
-    def fake_run(cmd, **kw):
+    def fake_run(cmd, cwd=None, env=None, timeout=None):
         out = cmd[cmd.index("-d") + 1]
         counter = cmd[cmd.index("--pmc") + 1]
         os.makedirs(os.path.join(out, "host"), exist_ok=True)
@@ -234,13 +234,14 @@ def test_bench_reads_the_dominant_kernels_traffic_from_a_counter_pass(tmp_path, 
         rows.append('3,"void k_xy_corr<128, 0>(float2 const*, int)",%s,77777' % counter)     # receptor prep: not the stage
         rows.append('4,"void k_zifft_filter_rs<128, 24, 1>(void const*)",%s,55555' % counter)
         open(os.path.join(out, "host", "1_counter_collection.csv"), "w").write("\n".join(rows) + "\n")
-        return subprocess.CompletedProcess(cmd, 0, "", "")
+        return 0
 
-    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(bench, "run_in_own_group", fake_run)
     monkeypatch.setattr(os.path, "exists", lambda p: True)
     import sys
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     args = bench.parse_args()
     traffic, src = bench.live_pmc_traffic(args, "k2_xy_corr", 128)
     assert traffic == (2.0 * 1000.0 + 3000.0) * 1024.0 and "measured in this run" in src
+    assert "raw FETCH_SIZE 1024000 bytes x 2" in src and "raw WRITE_SIZE 3072000 bytes" in src      # auditable
     assert bench.live_pmc_traffic(args, "topk_select", 128) == (None, None)

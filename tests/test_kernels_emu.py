@@ -278,6 +278,9 @@ def _volume_convolution_uncompiled_box(lib, device, L, B=2, C=3):
 
 def test_volume_convolution_at_an_uncompiled_box_emulated(emu):
     _volume_convolution_uncompiled_box(emu, "cpu", 10, B=1, C=2)
+    # an ODD box: N = 2 L = 18 is not a multiple of the plan-free transform's 4-wide unroll (its spare lanes used to
+    # step past the twiddle table)
+    _volume_convolution_uncompiled_box(emu, "cpu", 9, B=1, C=1)
 
 
 @pytest.mark.parametrize("tag,nres", [("multires", 2), ("single", 1)])
