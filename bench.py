@@ -84,9 +84,6 @@ def parse_args():
     ap.add_argument("--no_extras", action="store_true", help="skip the c48l80 and e3 extra objects of the default line")
     ap.add_argument("--k3_form", type=int, default=0, choices=(0, 1, 2),
                     help="kernel formulation of the fused K3 (include/dlpd.h, dlpd_zifft_filter_form): 0 = library default")
-    ap.add_argument("--preact_layout", default="auto", choices=("auto", "planes", "channels_last"),
-                    help="two-resolution workloads: layout of the coarse grid's first-layer pre-activations (auto = the engine's "
-                         "default: planes; channels-last measured slower, DESIGN.md section 4)")
     ap.add_argument("--dry_run", action="store_true",
                     help="launch plumbing only (gloo, no GPU): every rank joins the group, rank 0 prints a JSON line")
     return ap.parse_args()
@@ -279,15 +276,14 @@ def build_workload(name, args, dev):
     filt = SimpleFilter([C] + ([C1] if C1 else []))
     thr = clash_threshold(recf, ligf)
     W = filt.parameters_tuple()
-    if args.hidden and name == args.workload:
+    if getattr(args, "hidden", None) and name == args.workload:
         # another hidden width (select_model's multiplier moves it: ProteinRepresentationModels.py:24,35-36): Xavier-like
         g = torch.Generator().manual_seed(2)
         Ct, H = C + C1, int(args.hidden)
         W = (torch.randn(H, Ct, generator=g) * (2.0 / (H + Ct)) ** 0.5, torch.zeros(H), torch.randn(1, H, generator=g) * (2.0 / (H + 1)) ** 0.5,
              torch.zeros(1))
     eng = DockingEngine(L, C, *W, clip=5.0, threshold_clash=thr, has_clash=True, max_conf=args.max_conf,
-                        batch=args.batch, device=dev, coarse_channels=C1, k3_form=args.k3_form,
-                        preact_channels_last={"auto": None, "planes": False, "channels_last": True}[args.preact_layout] if C1 else None)
+                        batch=args.batch, device=dev, coarse_channels=C1, k3_form=args.k3_form)
     eng.set_receptor(rec[0], recf, rec[1] if C1 else None)
     eng.set_ligand(lig[0], ligf, lig[1] if C1 else None)
     return eng, dict(C=C, L=L, C1=C1, angle=angle, desc=desc, rec=rec, lig=lig, recf=recf, ligf=ligf, W=W, thr=thr)
@@ -667,6 +663,7 @@ def short_measurement(name, args, dev, R_all, nb, nsteps=24):
     alg = algorithmic_bytes(C, L, C1, nb, args.max_conf, unfused=eng.fine_unfused, HP=eng.HP)
     sb_mb, floor_mb = SURVEY_MB_PER_ROT[name]
     rps = nb / (ms * 1e-3)
+    sw = eng.switches()
     del eng
     torch.cuda.empty_cache()
     return {"workload": wl["desc"], "kernel_switches": sw, "steps": nsteps, "ms_per_step": ms, "rot_per_s": rps,
@@ -809,8 +806,7 @@ def live_pmc_traffic(args, stage, N):
     pats = tuple(p % N for p in pats)
     child = [sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--cpu_rotations", "0", "--no_real_shapes",
              "--sustained_s", "0", "--strong_s", "0", "--gather_rotations", "0", "--workload", args.workload,
-             "--batch", str(args.batch), "--max_conf", str(args.max_conf), "--k3_form", str(args.k3_form),
-             "--preact_layout", args.preact_layout]
+             "--batch", str(args.batch), "--max_conf", str(args.max_conf), "--k3_form", str(args.k3_form)]
     for flag, val in (("--channels", args.channels), ("--box", args.box), ("--angle_inc", args.angle_inc), ("--hidden", args.hidden)):
         if val is not None:
             child += [flag, str(val)]

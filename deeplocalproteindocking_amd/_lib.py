@@ -20,6 +20,7 @@ SIGNATURES = {
     "dlpd_version": (_i, []),
     "dlpd_source_hash": (ctypes.c_char_p, []),
     "dlpd_grid_supported": (_i, [_i]),
+    "dlpd_orientation_supported": (_i, [_i]),
     "dlpd_hidden_pad": (_i, [_i]),
     "dlpd_fused_hidden_pad": (_i, [_i, _i, _i]),
     "dlpd_generic_box_supported": (_i, [_i]),
@@ -56,8 +57,6 @@ SIGNATURES = {
     "dlpd_filter_volumes": (_i, [_p, _i, _ll, _i, _p, _i, _i, _i, _p, _ll, _f, _i, _p, _p, _p, _f, _i, _p, _i, _p]),
     "dlpd_zifft_preact": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _f, _p]),
     "dlpd_zifft_preact_form": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _f, _i, _p]),
-    "dlpd_preact_channels_last_supported": (_i, [_i, _i]),
-    "dlpd_zifft_preact_cl": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _f, _p]),
     "dlpd_zifft_real_part": (_i, [_p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "dlpd_maxpool3d_5s2": (_i, [_p, _p, _i, _i, _p]),
     "dlpd_conv3d_supported": (_i, [_i, _i, _i, _i]),
@@ -103,9 +102,8 @@ class DlpdLib:
 
     def call(self, name, *args):
         rc = getattr(self, "_" + name)(*args)
-        if SIGNATURES[name][0] is _i and name not in ("dlpd_version", "dlpd_grid_supported", "dlpd_conv3d_supported",
-                                                      "dlpd_hidden_pad", "dlpd_fused_hidden_pad", "dlpd_generic_box_supported",
-                                                      "dlpd_preact_channels_last_supported") and rc != 0:
+        if SIGNATURES[name][0] is _i and name not in ("dlpd_version", "dlpd_grid_supported", "dlpd_conv3d_supported", "dlpd_orientation_supported",
+                                                      "dlpd_hidden_pad", "dlpd_fused_hidden_pad", "dlpd_generic_box_supported") and rc != 0:
             raise RuntimeError("dlpd: %s failed: %s" % (name, ERRORS.get(rc, rc)))
         return rc
 

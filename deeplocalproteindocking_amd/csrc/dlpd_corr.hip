@@ -1274,7 +1274,7 @@ int dlpd_k3r_filter(const cplx* Bw, float* V, int CT, int C, int has_clash, int 
                     const float* b1, const float* W2, float b2, int has_clip, float clip, float thr, K3Aux aux, K3Cand cd,
                     hipStream_t st);
 int dlpd_k3r_preact(const cplx* Bw, float* pre, int C, int nb, int L, const float* W1rows, int HP, const float* b1,
-                    int has_clip, float clip, int channels_last, hipStream_t st);
+                    int has_clip, float clip, hipStream_t st);
 // which formulation the un-suffixed entry points take where both exist (variant builds: -DDLPD_K3_DEFAULT_FORM=1)
 #ifndef DLPD_K3_DEFAULT_FORM
 #define DLPD_K3_DEFAULT_FORM 2               // 1: channel-owning waves (this file), 2: role-split waves (dlpd_k3r.hip)
@@ -1284,6 +1284,7 @@ int dlpd_k3r_preact(const cplx* Bw, float* pre, int C, int nb, int L, const floa
 int dlpd_k2_forward(const cplx* A, cplx* out, int CT, int nb, int L, float scale, hipStream_t st);
 int dlpd_k2_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, int L, long long rbs, hipStream_t st,
                       int transposed = 0);
+int dlpd_k2_orientation_supported(int L);
 
 // channels per group.  One channel per wave (16-row tiles, N <= 128): as many as there are channel-owning waves -- 49
 // channels on 8 waves are six full groups and one with the clash channel alone, 1 % faster than seven groups of seven,
@@ -1502,6 +1503,8 @@ int dlpd_rfft3d_padded(const float* vol, void* spec, void* wsA, int nvol, int L,
   return dlpd_k2_forward((const cplx*)wsA, (cplx*)spec, nvol, 1, L, scale, st);
 }
 
+int dlpd_orientation_supported(int L) { return dlpd_k2_orientation_supported(L); }
+
 // wsA (nb, CT, NZ, L, L) x rec (CT or nb*CT spectra) -> wsB (nb, CT, NZ, N, N)
 int dlpd_xy_correlate_oriented(const void* wsA, const void* rec, void* wsB, int nb, int CT, int L,
                                long long rec_bstride, int transposed, void* stream) {
@@ -1544,31 +1547,21 @@ int dlpd_zifft_preact_form(const void* wsB, float* pre, int nb, int C, int L, co
   hipStream_t st = (hipStream_t)stream;
   const cplx* B = (const cplx*)wsB;
   if (form == 0) form = DLPD_K3_DEFAULT_FORM;
-  if (form == 2 && dlpd_k3r_supported(L, HP, 2)) return dlpd_k3r_preact(B, pre, C, nb, L, W1rows, HP, b1, has_clip, clip, 0, st);
+  if (form == 2 && dlpd_k3r_supported(L, HP, 2)) return dlpd_k3r_preact(B, pre, C, nb, L, W1rows, HP, b1, has_clip, clip, st);
 #define DLPD_ZP(NN, H) case H: return launch_k3<NN, H, 2>(B, pre, C, C, 0, nb, W1rows, b1, b1, 0.f, has_clip, clip, 0.f, st)
 #define DLPD_ZPN(NN) switch (HP) { DLPD_ZP(NN, 2); DLPD_ZP(NN, 4); DLPD_ZP(NN, 8); DLPD_ZP(NN, 16); DLPD_ZP(NN, 24); DLPD_ZP(NN, 32); \
                                    default: return DLPD_ERR_UNSUPPORTED; }
   switch (L) {
     case 32: DLPD_ZPN(64)
-    case 40: DLPD_ZPN(80)
+#ifdef DLPD_TEST_VARIANTS
+    case 40: DLPD_ZPN(80)                      // (product: the role-split kernel above; coarse grids of 64 / 80 have no fine grid)
     case 64: DLPD_ZPN(128)
     case 80: DLPD_ZPN(160)
+#endif
     default: return DLPD_ERR_UNSUPPORTED;
   }
 #undef DLPD_ZPN
 #undef DLPD_ZP
-}
-
-// The same planes CHANNELS-LAST, pre (nb, N^3, HP): producer and consumer are the role-split kernels only
-// (dlpd_zifft_filter_form with aux_is_preact = 2); L here is the COARSE box, the query takes the fine one.
-int dlpd_preact_channels_last_supported(int L_fine, int HP) {
-  return (L_fine % 2 == 0 && dlpd_k3r_supported(L_fine, HP, 1) && dlpd_k3r_supported(L_fine / 2, HP, 2)) ? 1 : 0;
-}
-int dlpd_zifft_preact_cl(const void* wsB, float* pre, int nb, int C, int L, const float* W1rows, const float* b1, int HP,
-                         int has_clip, float clip, void* stream) {
-  if (!wsB || !pre || !W1rows || !b1 || nb <= 0 || C <= 0) return DLPD_ERR_ARG;
-  if (!dlpd_k3r_supported(L, HP, 2)) return DLPD_ERR_UNSUPPORTED;
-  return dlpd_k3r_preact((const cplx*)wsB, pre, C, nb, L, W1rows, HP, b1, has_clip, clip, 1, (hipStream_t)stream);
 }
 
 int dlpd_zifft_real(const void* wsB, float* out, int nb, int CT, int L, int has_clip, float clip, void* stream) {
@@ -1615,18 +1608,20 @@ int dlpd_zifft_filter_form(const void* wsB, float* V, int nb, int C, int has_cla
   if (cand_keys && (!tau || !cand_count || cap <= 0)) return DLPD_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int CT = C + (has_clash ? 1 : 0);
-  const K3Aux ax = {aux, Caux, L, (Caux > 0 && aux_is_preact) ? (aux_is_preact == 2 ? 2 : 1) : 0};   // coarse grid N/2 = L
+  const K3Aux ax = {aux, Caux, L, (Caux > 0 && aux_is_preact) ? 1 : 0};              // coarse grid N/2 = L
   const K3Cand cd = {(const unsigned*)tau, (unsigned long long*)cand_keys, (unsigned*)cand_count, cap, nb};
   if (form == 0) form = DLPD_K3_DEFAULT_FORM;
-  // channels-last pre-activations are read by the role-split kernel only
-  if (ax.is_preact == 2 && !(form == 2 && dlpd_k3r_supported(L, HP, 1))) return DLPD_ERR_UNSUPPORTED;
   if (form == 2 && dlpd_k3r_supported(L, HP, 1) && (Caux == 0 || aux_is_preact))
     return dlpd_k3r_filter((const cplx*)wsB, V, CT, C, has_clash, nb, L, W1t, HP, b1, W2, b2, has_clip, clip, thr, ax, cd, st);
   switch (L) {
     case 32: return k3_filter_dispatch<64>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, ax, cd);
     case 40: return k3_filter_dispatch<80>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, ax, cd);
+#ifdef DLPD_TEST_VARIANTS
+    // the channel-owning formulation at N = 128 / 160: no default path reaches it (the role-split kernel covers every
+    // hidden width it has), it is the bit-exactness reference of the tests -- compiled into tests/variants only
     case 64: return k3_filter_dispatch<128>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, ax, cd);
     case 80: return k3_filter_dispatch<160>(HP, (const cplx*)wsB, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, ax, cd);
+#endif
     default: return DLPD_ERR_UNSUPPORTED;
   }
 }

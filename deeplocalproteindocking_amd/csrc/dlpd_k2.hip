@@ -738,7 +738,20 @@ int dlpd_k2_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb,
     case 32: return launch_k2<64, 1>(A, rec, out, CT, nb, rbs, 1.f, st, transposed);
     case 40: return launch_k2<80, 1>(A, rec, out, CT, nb, rbs, 1.f, st, transposed);
     case 64: return launch_k2<128, 1>(A, rec, out, CT, nb, rbs, 1.f, st, transposed);
+#ifdef DLPD_TEST_VARIANTS
     case 80: return launch_k2_quad<160, DLPD_K2Q_WAVES>(A, rec, out, CT, nb, rbs, st, transposed);
+#endif
     default: return DLPD_ERR_UNSUPPORTED;
   }
+}
+
+// Slabs that K1 stored transposed (dlpd_zfft_oriented, the per-channel K1 of ligands with fewer than 8 channels): every
+// compiled grid except N = 160, whose transposed reader is round 2's quad kernel -- kept as a TEST VARIANT
+// (-DDLPD_TEST_VARIANTS: tests/variants, never in libdlpd.so); the engine asks and visits box 80 in one orientation.
+int dlpd_k2_orientation_supported(int L) {
+#ifdef DLPD_TEST_VARIANTS
+  return (L == 32 || L == 40 || L == 64 || L == 80) ? 1 : 0;
+#else
+  return (L == 32 || L == 40 || L == 64) ? 1 : 0;
+#endif
 }

@@ -8,8 +8,6 @@
 // index (DockingModels.py:74-76): either the Caux clipped correlations of that resolution (W1t rows
 // C..C+Caux-1 are applied here), or -- is_preact -- the HP first-layer pre-activations k_filter_preact
 // computed from them once per COARSE voxel (bias included; the first layer is linear): 8x fewer multiply-adds.
-// is_preact == 2: the same HP values CHANNELS-LAST, (nb, Naux^3, HP) -- role-split kernel only (dlpd_k3r.hip); in its
-// MODE 2 (which produces the planes) the field names the OUTPUT layout.
 struct K3Aux {
   const float* p;   // (nb, Caux or HP, Naux^3), Naux = N/2
   int C, N, is_preact;

@@ -30,7 +30,14 @@
 // At N = 160, where the filter waves are the longer role (prologue = 48 global loads of coarse pre-activations per thread, 15 %
 // of their time): those planes staged in LDS one tile ahead by the transform waves' LDS-DMA (30 KB, waited for before the
 // tile's last hand-back barrier): bit-identical, 2.21 ms against 2.08 -- the extra wait in front of the barrier costs the
-// filter waves more than the shorter prologue saves.
+// filter waves more than the shorter prologue saves.  Round 4: the same planes CHANNELS-LAST (pre[b][x][y][z][HP]: twelve
+// 16-byte loads per thread instead of 48 4-byte ones at plane stride; git show 9fa2243): bit-identical, K3 1.97 against
+// 1.98 ms -- the 4-byte loads were coalesced 128-byte requests already -- and the coarse kernel that writes them 1.375
+// against 1.30 (16-byte stores at a 96-byte lane stride); removed.  The filter waves' first layer on the MATRIX pipe
+// (v_mfma_f32_4x4x1_16b_f32: each lane its own voxel times the four weights of its lane quad, one exact fmaf per
+// accumulator: bit-identical, registers as here; weight quads from an LDS table): K3 2.17 against 2.10 ms (real shapes),
+// 2.03 / 1.81 (48 ch x 64^3), 4.95 / 4.93 (48 ch x 80^3) -- the 4x4x1 form issues no faster than the vector FMAs of one
+// wave and serialises the two filter waves of a SIMD; with the weights from global memory 2.56 / 2.21 / 6.0; removed.
 #include <dlpd_platform.h>
 #include "dlpd_fft.h"
 #include "dlpd_internal.h"
@@ -62,9 +69,10 @@ template <int N> DLPD_D void init_twiddles_k3r(cplx* tw, int tid, int nthreads) 
 // WIDE: hidden widths 33..48 (the reference class default: multiplier 16 -> [32, 64] channels -> hidden 48,
 // ProteinRepresentationModels.py:24,35-36): 96 accumulators are two voxels x 48 hidden units, so the filter waves
 // take two voxels per thread and the tile shrinks to 8 rows where 16 rows would need 16 filter waves.
-#ifndef DLPD_K3R_WIDE_ABOVE
-#define DLPD_K3R_WIDE_ABOVE 32               // hidden widths above this take two voxels per filter thread
-#endif
+// Hidden widths above this take two voxels per filter thread (the WIDE configurations below).  Width 32 on four voxels
+// is 128 accumulators: at N = 128 that spills 9 registers and still beats the two-voxel blocks (K3 2.03 vs 2.56 ms at
+// 48 ch x 64^3); at N = 160 it spills 35 and loses (2.92 vs 2.38 ms on the real shapes) -- measured in round 4.
+template <int N> struct K3rWideAbove { static constexpr int value = (N == 160) ? 24 : 32; };
 template <int N, bool WIDE> struct K3rCfg;
 template <> struct K3rCfg<64, false> { static constexpr int F = 4, M = 4, TY = 16, RAWBUF = 2; };
 template <> struct K3rCfg<80, false> { static constexpr int F = 5, M = 5, TY = 16, RAWBUF = 2; };
@@ -182,12 +190,11 @@ template <int N> DLPD_D void k3r_second_pass(cplx* S, int rowoff, int t, const c
 //           if has_clash (mask = corr_C < thr); aux: HP first-layer pre-activation planes on the coarse grid (or none)
 //   MODE 2: out (nb, HP, N,N,N) = b1 + W1rows^T clamp(corr): the coarse resolution's half of the first layer
 //   W1t  (C, HP) transposed + zero padded, b1 (HP), W2 (HP);  G channels per group (<= F * CPW)
-//   PCL  the pre-activation planes (MODE 1: aux, read; MODE 2: out, written) are CHANNELS-LAST, (nb, Naux^3 | N^3, HP)
-template <int N, int HP, int MODE, bool PCL> __global__ void __launch_bounds__(64 * (K3rCfg<N, (HP > DLPD_K3R_WIDE_ABOVE)>::F + K3rCfg<N, (HP > DLPD_K3R_WIDE_ABOVE)>::M))
+template <int N, int HP, int MODE> __global__ void __launch_bounds__(64 * (K3rCfg<N, (HP > K3rWideAbove<N>::value)>::F + K3rCfg<N, (HP > K3rWideAbove<N>::value)>::M))
 k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int C, int has_clash, int G,
                   const float* __restrict__ W1t, const float* __restrict__ b1, const float* __restrict__ W2,
                   float b2, int has_clip, float clip, float thr, K3Aux aux, int ntiles, int tpb, K3Cand cd) {
-  typedef K3rCfg<N, (HP > DLPD_K3R_WIDE_ABOVE)> Cfg;
+  typedef K3rCfg<N, (HP > K3rWideAbove<N>::value)> Cfg;
   constexpr int F = Cfg::F, M = Cfg::M, TY = Cfg::TY, RAWBUF = Cfg::RAWBUF;
   constexpr int NZ = N / 2 + 1, RS = N + 8, NPAIR = TY / 2, NYT = N / TY;
   constexpr int CPW = 8 / NPAIR;               // channels per transform wave: its 8 pencils = CPW channels x NPAIR row pairs
@@ -308,26 +315,7 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
           // rows 2m, 2m+1 and columns z, z^1 of the fine grid share one coarse voxel
           const int Na = aux.N;
           const size_t cstride = (size_t)Na * Na * Na;
-          if constexpr (PCL) {
-            // channels-last planes pre[b][x][y][z][HP]: the HP values of a coarse voxel are one contiguous run
-            // (HP / 4 16-byte loads instead of HP 4-byte loads at plane stride)
-            const float* ab = aux.p + (((size_t)b * Na + (xo >> 1)) * Na * Na + (size_t)(y0 >> 1) * Na + (zz >> 1)) * HP;
-#pragma unroll
-            for (int e = 0; e < EPT; e++) {
-              const float* av = ab + (size_t)(m0 + e * MSTEP) * Na * HP;
-              if constexpr (HP % 4 == 0) {
-#pragma unroll
-                for (int q = 0; q < HP / 4; q++) {
-                  const float4 v = reinterpret_cast<const float4*>(av)[q];
-                  h[2 * e][4 * q] = v.x; h[2 * e][4 * q + 1] = v.y; h[2 * e][4 * q + 2] = v.z; h[2 * e][4 * q + 3] = v.w;
-                  h[2 * e + 1][4 * q] = v.x; h[2 * e + 1][4 * q + 1] = v.y; h[2 * e + 1][4 * q + 2] = v.z; h[2 * e + 1][4 * q + 3] = v.w;
-                }
-              } else {
-#pragma unroll
-                for (int j = 0; j < HP; j++) { h[2 * e][j] = av[j]; h[2 * e + 1][j] = av[j]; }
-              }
-            }
-          } else {
+          {
             const float* ab = aux.p + (size_t)b * HP * cstride + ((size_t)(xo >> 1) * Na + (y0 >> 1)) * Na + (zz >> 1);
 #pragma unroll
             for (int e = 0; e < EPT; e++)
@@ -368,39 +356,34 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
       DLPD_LDS_BARRIER();                      // B2: values held in registers, pencils free for the next group
       DLPD_STAMP(2);
       {
-        // first-layer weights are wave-uniform (scalar loads): the next piece's weights are requested before this
-        // piece's FMAs.  A piece is a channel's whole row up to hidden width 24; from 32 on it is HALF a row, so that the
-        // two buffers together take HP scalar registers instead of 2 HP (64 / 96 of the wave's ~100: they used to
-        // spill into vector registers, and those into scratch).  Same fmaf per accumulator and channel, same order.
-        constexpr int NH = HP >= 32 ? 2 : 1, HH = HP / NH;
-        float wcur[HH], wnxt[HH];
+        // first-layer weights are wave-uniform (scalar loads): channel g+1's row is requested before channel g's FMAs
+        // (round 4: the row in two halves for widths >= 32, HP scalar registers for the two buffers instead of 2 HP: the
+        // vector spills of <128, 32> / <160, 48> are the 128 / 96 accumulators themselves, 11 / 23 against 9 / 21 -- not kept)
+        float wcur[HP], wnxt[HP];
         if (gs > 0) {
 #pragma unroll
-          for (int j = 0; j < HH; j++) wcur[j] = W1t[(size_t)cbase * HP + j];
+          for (int j = 0; j < HP; j++) wcur[j] = W1t[(size_t)cbase * HP + j];
         }
 #pragma unroll
         for (int g = 0; g < GMAX; g++) {
           if (g < gs) {
+            const int gn1 = (g + 1 < gs ? g + 1 : g);
 #pragma unroll
-            for (int hf = 0; hf < NH; hf++) {
-              const int gn1 = (hf + 1 < NH) ? g : (g + 1 < gs ? g + 1 : g), hn1 = (hf + 1 < NH) ? hf + 1 : 0;
+            for (int j = 0; j < HP; j++) wnxt[j] = W1t[(size_t)(cbase + gn1) * HP + j];
+            DLPD_SCHED_FENCE();
 #pragma unroll
-              for (int j = 0; j < HH; j++) wnxt[j] = W1t[(size_t)(cbase + gn1) * HP + hn1 * HH + j];
-              DLPD_SCHED_FENCE();
+            for (int e = 0; e < EPT; e++) {
+              float v0 = vals[g][e].x, v1 = vals[g][e].y;
+              if (has_clip) { v0 = DLPD_CLAMP(v0, clip); v1 = DLPD_CLAMP(v1, clip); }
 #pragma unroll
-              for (int e = 0; e < EPT; e++) {
-                float v0 = vals[g][e].x, v1 = vals[g][e].y;
-                if (has_clip) { v0 = DLPD_CLAMP(v0, clip); v1 = DLPD_CLAMP(v1, clip); }
-#pragma unroll
-                for (int j = 0; j < HH; j++) {
-                  h[2 * e][hf * HH + j] = fmaf(wcur[j], v0, h[2 * e][hf * HH + j]);
-                  h[2 * e + 1][hf * HH + j] = fmaf(wcur[j], v1, h[2 * e + 1][hf * HH + j]);
-                }
+              for (int j = 0; j < HP; j++) {
+                h[2 * e][j] = fmaf(wcur[j], v0, h[2 * e][j]);
+                h[2 * e + 1][j] = fmaf(wcur[j], v1, h[2 * e + 1][j]);
               }
-              DLPD_SCHED_FENCE();
-#pragma unroll
-              for (int j = 0; j < HH; j++) wcur[j] = wnxt[j];
             }
+            DLPD_SCHED_FENCE();
+#pragma unroll
+            for (int j = 0; j < HP; j++) wcur[j] = wnxt[j];
           }
         }
       }
@@ -414,19 +397,7 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
             const int m = m0 + e * MSTEP;
 #pragma unroll
             for (int u = 0; u < 2; u++) {
-              if constexpr (PCL) {
-                // channels-last planes (see the MODE 1 prologue): one contiguous run of HP values per voxel
-                float* ov = out + ((((size_t)b * N + xo) * N + y0 + 2 * m + u) * N + zz) * HP;
-                if constexpr (HP % 4 == 0) {
-#pragma unroll
-                  for (int q = 0; q < HP / 4; q++)
-                    reinterpret_cast<float4*>(ov)[q] = make_float4(h[2 * e + u][4 * q], h[2 * e + u][4 * q + 1],
-                                                                   h[2 * e + u][4 * q + 2], h[2 * e + u][4 * q + 3]);
-                } else {
-#pragma unroll
-                  for (int j = 0; j < HP; j++) ov[j] = h[2 * e + u][j];
-                }
-              } else {
+              {
 #pragma unroll
                 for (int j = 0; j < HP; j++)
                   out[((((size_t)b * HP + j) * N + xo) * N + y0 + 2 * m + u) * N + zz] = h[2 * e + u][j];
@@ -474,19 +445,19 @@ static int k3r_group(int CT, int maxg, bool balanced) {
 #ifndef DLPD_K3R_TPB_DIV
 #define DLPD_K3R_TPB_DIV 1                   // tiles per block = (y-tiles of an x' plane) / DIV
 #endif
-template <int N, int HP, int MODE, bool PCL> static int launch_k3r(const cplx* Bw, float* out, int CT, int C, int has_clash, int nb,
+template <int N, int HP, int MODE> static int launch_k3r(const cplx* Bw, float* out, int CT, int C, int has_clash, int nb,
                                                          const float* W1t, const float* b1, const float* W2, float b2,
                                                          int has_clip, float clip, float thr, hipStream_t st, K3Aux aux,
                                                          K3Cand cd) {
-  typedef K3rCfg<N, (HP > DLPD_K3R_WIDE_ABOVE)> Cfg;
+  typedef K3rCfg<N, (HP > K3rWideAbove<N>::value)> Cfg;
   constexpr int RS = N + 8, NZ = N / 2 + 1, NPAIR = Cfg::TY / 2, CPW = 8 / NPAIR;
   constexpr int RAWC = ((NZ * NPAIR + 63) / 64) * 64;
   const size_t shmem = (size_t)(Cfg::F * 8 * RS + N) * sizeof(cplx) + (size_t)Cfg::RAWBUF * Cfg::F * CPW * RAWC * 16;
-  int rc = dlpd_set_max_dyn_shared((const void*)k_zifft_filter_rs<N, HP, MODE, PCL>, shmem);
+  int rc = dlpd_set_max_dyn_shared((const void*)k_zifft_filter_rs<N, HP, MODE>, shmem);
   if (rc) return rc;
   const int G = k3r_group(CT, Cfg::F * CPW, true);
   const int ntiles = (N / Cfg::TY) * N * nb, tpb = (N / Cfg::TY) / DLPD_K3R_TPB_DIV;
-  DLPD_LAUNCH((k_zifft_filter_rs<N, HP, MODE, PCL>), dim3((ntiles + tpb - 1) / tpb), dim3(64 * (Cfg::F + Cfg::M)), shmem, st, Bw,
+  DLPD_LAUNCH((k_zifft_filter_rs<N, HP, MODE>), dim3((ntiles + tpb - 1) / tpb), dim3(64 * (Cfg::F + Cfg::M)), shmem, st, Bw,
               out, CT, C, has_clash, G, W1t, b1, W2, b2, has_clip, clip, thr, aux, ntiles, tpb, cd);
   return dlpd_check_launch();
 }
@@ -499,17 +470,17 @@ int dlpd_k3r_supported(int L, int HP, int mode) {
   return 0;
 }
 
-template <int N, int MODE, bool PCL = false> static int k3r_dispatch(int HP, const cplx* Bw, float* out, int CT, int C, int has_clash, int nb,
+template <int N, int MODE> static int k3r_dispatch(int HP, const cplx* Bw, float* out, int CT, int C, int has_clash, int nb,
                                                    const float* W1t, const float* b1, const float* W2, float b2,
                                                    int has_clip, float clip, float thr, hipStream_t st, K3Aux aux, K3Cand cd) {
   switch (HP) {
-    case 2: return launch_k3r<N, 2, MODE, PCL>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
-    case 4: return launch_k3r<N, 4, MODE, PCL>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
-    case 8: return launch_k3r<N, 8, MODE, PCL>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
-    case 16: return launch_k3r<N, 16, MODE, PCL>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
-    case 24: return launch_k3r<N, 24, MODE, PCL>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
-    case 32: return launch_k3r<N, 32, MODE, PCL>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
-    case 48: return launch_k3r<N, 48, MODE, PCL>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 2: return launch_k3r<N, 2, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 4: return launch_k3r<N, 4, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 8: return launch_k3r<N, 8, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 16: return launch_k3r<N, 16, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 24: return launch_k3r<N, 24, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 32: return launch_k3r<N, 32, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 48: return launch_k3r<N, 48, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
     default: return DLPD_ERR_UNSUPPORTED;
   }
 }
@@ -520,25 +491,18 @@ int dlpd_k3r_filter(const cplx* Bw, float* V, int CT, int C, int has_clash, int 
                     hipStream_t st) {
   switch (L) {
     case 64: return k3r_dispatch<128, 1>(HP, Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
-    case 80:
-      if (aux.C > 0 && aux.is_preact == 2)
-        return k3r_dispatch<160, 1, true>(HP, Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
-      return k3r_dispatch<160, 1>(HP, Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 80: return k3r_dispatch<160, 1>(HP, Bw, V, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
     default: return DLPD_ERR_UNSUPPORTED;
   }
 }
 
 // wsB (nb, C, NZ, N, N) -> pre (nb, HP, N^3): z C2R fused with the (linear) first layer over these C channels
-// channels_last: pre (nb, N^3, HP) -- the layout the fine grid's role-split kernel reads with 16-byte loads
-// (K3Aux.is_preact == 2) -- instead of HP planes
 int dlpd_k3r_preact(const cplx* Bw, float* pre, int C, int nb, int L, const float* W1rows, int HP, const float* b1,
-                    int has_clip, float clip, int channels_last, hipStream_t st) {
-  const K3Aux ax = {nullptr, 0, 0, channels_last ? 2 : 0};
+                    int has_clip, float clip, hipStream_t st) {
+  const K3Aux ax = {nullptr, 0, 0, 0};
   const K3Cand cd = {nullptr, nullptr, nullptr, 0, 0};
   switch (L) {
-    case 40:
-      if (channels_last) return k3r_dispatch<80, 2, true>(HP, Bw, pre, C, C, 0, nb, W1rows, b1, b1, 0.f, has_clip, clip, 0.f, st, ax, cd);
-      return k3r_dispatch<80, 2>(HP, Bw, pre, C, C, 0, nb, W1rows, b1, b1, 0.f, has_clip, clip, 0.f, st, ax, cd);
+    case 40: return k3r_dispatch<80, 2>(HP, Bw, pre, C, C, 0, nb, W1rows, b1, b1, 0.f, has_clip, clip, 0.f, st, ax, cd);
     default: return DLPD_ERR_UNSUPPORTED;
   }
 }

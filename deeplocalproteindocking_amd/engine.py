@@ -125,7 +125,7 @@ class DockingEngine:
     def __init__(self, L, C, W1, b1, W2, b2, clip=5.0, threshold_clash=300.0, has_clash=True,
                  max_conf=1000, batch=8, device="cuda", lib=None, center=None, coarse_channels=0,
                  fine_unfused=None, channels_last=None, k3_form=0, coarse_center=None, extent=None,
-                 preact_channels_last=None, orient=True, quads=True, prefilter=True,
+                 orient=True, quads=True, prefilter=True,
                  rotation_scale=1.0, coarse_rotation_scale=None, rotation_axis_order="xyz", clip_mode="output",
                  rotation_transpose=False):
         """coarse_channels > 0: the reference's two-resolution layout -- C channels at L^3 plus
@@ -178,7 +178,7 @@ class DockingEngine:
         # channels-last gather (include/dlpd.h): one 16-byte load serves four channels of a corner, so the rotation
         # costs the same for every rotation; slab orientation and the quad layout are the per-channel kernel's
         # remedies and stay for ligands with few channels (and as diagnostic switches)
-        # Kernel choices are CONSTRUCTOR ARGUMENTS only (no environment switches): channels_last (default: ligands with
+        # Kernel choices are CONSTRUCTOR ARGUMENTS only (no switch is read from outside the call): channels_last (default: ligands with
         # >= 8 channels), orient / quads (the per-channel K1's launch variants), prefilter (top-K candidate lists from
         # K3).  They select equivalent kernels, never less work; ``switches()`` reports what is active.
         if channels_last is None:
@@ -186,7 +186,8 @@ class DockingEngine:
         self.use_cl = bool(channels_last)
         self.extent = int(extent) if extent and int(extent) < int(L) else 0
         self.extent1 = self.extent // 2
-        self.orient = bool(orient) and not self.use_cl
+        # (slab orientation needs K2's transposed reader: every compiled box except 80 in libdlpd.so)
+        self.orient = bool(orient) and not self.use_cl and bool(lib.call("dlpd_orientation_supported", int(L)))
         self.use_quads = bool(quads) and not self.use_cl and not self.extent
         if self.use_cl:
             self.ligcl = torch.empty(lib.call("dlpd_channels_last_floats", self.C, int(L)), dtype=f32, device=dev)
@@ -222,19 +223,8 @@ class DockingEngine:
         if self.fine_unfused:
             self.conv = torch.empty(nb, CT, N, N, N, dtype=f32, device=dev)
         if self.C1:
-            # first-layer pre-activations of the coarse channels on the coarse grid (dlpd_zifft_preact): HP planes (the
-            # default), or -- opt-in, where both role-split kernels exist -- channels-last (nb, N1^3, HP), which the fine
-            # grid's K3 reads with 16-byte loads (include/dlpd.h, dlpd_zifft_preact_cl); same values, same V.  Measured
-            # (round 4, real shapes): the fine K3 is unchanged (1.97 vs 1.98 ms), the coarse kernel's 16-byte-per-lane
-            # stores at a 96-byte lane stride cost +0.07 ms -> planes stay the default.
+            # first-layer pre-activations of the coarse channels on the coarse grid (dlpd_zifft_preact): HP planes
             self.pre = torch.empty(nb, self.HP, 2 * self.L1, 2 * self.L1, 2 * self.L1, dtype=f32, device=dev)
-            can_cl = bool(lib.call("dlpd_preact_channels_last_supported", self.L, self.HP))
-            if preact_channels_last and not can_cl:
-                raise RuntimeError("dlpd: channels-last pre-activations need the role-split K3 at box %d / hidden %d" % (L, self.HP))
-            self.preact_channels_last = bool(preact_channels_last)
-            self.preact_channels_last_supported = can_cl
-        else:
-            self.preact_channels_last = self.preact_channels_last_supported = False
         self.top = DeviceTopList(self.K, nb, dev, lib)
         # optional: callable(R (nb,3,3) f32 device) -> (nb,L,L,L) f32 device ligand forbidden volumes
         # re-projected from rotated ATOMS (Docker.py:221-224) instead of the rotated volume
@@ -260,18 +250,12 @@ class DockingEngine:
         from .Utils.Conventions import kernel_matrices
         return kernel_matrices(R, self.rot_scale1 if coarse else self.rot_scale, self.rot_axis_order, self.rot_transpose)
 
-    @property
-    def pre_cl(self):
-        """The coarse grid's pre-activations are channels-last for THIS launch (the role-split K3 reads them)."""
-        return self.preact_channels_last and self.k3_form != 1 and not self.fine_unfused
-
     def switches(self):
-        """Which of the equivalent kernel formulations this engine launches (recorded by bench.py)."""
+        """Which of the equivalent kernel formulations and which conventions this engine launches with (bench.py records it)."""
         return {"k1": "channels_last" if self.use_cl else "per_channel",
                 "k1_slab_orientation": bool(self.orient), "k1_quad_layout": bool(self.use_quads),
                 "k3_form": {0: "library default (role-split where compiled)", 1: "channel-owning", 2: "role-split"}[self.k3_form],
                 "k3_unfused": bool(self.fine_unfused), "topk_candidate_lists": bool(self.prefilter),
-                "preact_layout": (("channels_last" if self.pre_cl else "planes") if self.C1 else None),
                 "embedded_extent": self.extent or None,
                 "rotation": {"center": self.center, "scale": self.rot_scale, "axis_order": self.rot_axis_order,
                              "transpose": self.rot_transpose},
@@ -497,10 +481,6 @@ class DockingEngine:
     def _coarse_preact(self, nb, has_clip, clip, st):
         """Coarse grid, last stage: z-inverse + clip fused with the coarse half of the (linear) first layer
         (DockingModels.py:74-83): HP pre-activation planes on the coarse grid instead of C1 correlation volumes."""
-        if self.pre_cl:
-            self.lib.call("dlpd_zifft_preact_cl", _ptr(self.wsB1), _ptr(self.pre), nb, self.C1, self.L1,
-                          self.W1t.data_ptr() + self.C * self.HP * 4, _ptr(self.b1), self.HP, has_clip, clip, st)
-            return
         self.lib.call("dlpd_zifft_preact_form", _ptr(self.wsB1), _ptr(self.pre), nb, self.C1, self.L1,
                       self.W1t.data_ptr() + self.C * self.HP * 4, _ptr(self.b1), self.HP, has_clip, clip, self.k3_form, st)
 
@@ -528,7 +508,7 @@ class DockingEngine:
             tau, ck, cc, cap = (_ptr(self.top.tau), _ptr(cset["keys"]), _ptr(cset["count"]), cset["cap"]) if cset else (0, 0, 0, 0)
             call("dlpd_zifft_filter_form", _ptr(self.wsB), _ptr(V), nb, self.C, int(self.has_clash), L,
                  _ptr(self.W1t), _ptr(self.b1), _ptr(self.W2), self.b2, self.HP, has_clip, clip, self.threshold,
-                 aux, C1, (2 if self.pre_cl else 1) if C1 else 0, tau, ck, cc, cap, self.k3_form, st)
+                 aux, C1, int(C1 > 0), tau, ck, cc, cap, self.k3_form, st)
             self._cset_used = cset
             mark("k3_zifft_filter")
         return V[:nb]

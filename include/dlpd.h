@@ -29,6 +29,9 @@ int dlpd_version(void);
 const char* dlpd_source_hash(void);
 /* 1 if box size L has a compiled pipeline: L in {32, 40, 64, 80} (grids N = 2L = 64, 80, 128, 160) */
 int dlpd_grid_supported(int L);
+/* 1 if dlpd_xy_correlate_oriented(transposed = 1) exists for box L (slabs the per-channel K1 stored transposed): every
+ * compiled box except 80, whose transposed reader is a test variant (-DDLPD_TEST_VARIANTS), not part of libdlpd.so. */
+int dlpd_orientation_supported(int L);
 /* hidden width the filter kernel pads H to (2,4,8,16,24,32), -1 if H > 32 */
 int dlpd_hidden_pad(int H);
 /* Hidden width the FUSED pipeline (dlpd_zifft_filter*, dlpd_zifft_preact) pads H to on a fine grid of L^3 voxels
@@ -203,7 +206,10 @@ int dlpd_zifft_filter_cand(const void* wsB, float* V, int nb, int C, int has_cla
 /* dlpd_zifft_filter_cand with the kernel formulation named (same arithmetic, bit-identical V): form 0 = the
  * library's default, 1 = every wave owns a channel of the group and the transform / filter phases alternate behind
  * block barriers, 2 = role-split blocks -- dedicated transform waves (LDS-DMA, pack, z C2R) and filter waves (the
- * MLP of DockingModels.py:79-83 from registers) that overlap each other; falls back to 1 where 2 is not compiled. */
+ * MLP of DockingModels.py:79-83 from registers) that overlap each other; falls back to 1 where 2 is not compiled.
+ * libdlpd.so holds ONE formulation per box -- 1 at boxes 32 / 40, 2 at boxes 64 / 80; form 1 at boxes 64 / 80 (and raw
+ * aux channels there, aux_is_preact = 0) is DLPD_ERR_UNSUPPORTED unless the library was built with -DDLPD_TEST_VARIANTS
+ * (tests/variants: the bit-exactness reference of the tests). */
 int dlpd_zifft_filter_form(const void* wsB, float* V, int nb, int C, int has_clash, int L, const float* W1t,
                            const float* b1, const float* W2, float b2, int HP, int has_clip, float clip, float thr,
                            const float* aux, int Caux, int aux_is_preact, const void* tau, void* cand_keys,
@@ -219,15 +225,6 @@ int dlpd_zifft_preact(const void* wsB, float* pre, int nb, int C, int L, const f
 /* dlpd_zifft_preact with the kernel formulation named (see dlpd_zifft_filter_form). */
 int dlpd_zifft_preact_form(const void* wsB, float* pre, int nb, int C, int L, const float* W1rows, const float* b1,
                            int HP, int has_clip, float clip, int form, void* stream);
-
-/* dlpd_zifft_preact writing the same values CHANNELS-LAST, pre (nb, N^3, HP): the HP pre-activations of a coarse
- * voxel are one contiguous run, which the fine grid's role-split kernel -- dlpd_zifft_filter_form(aux = pre,
- * aux_is_preact = 2) -- fetches with HP / 4 16-byte loads instead of HP 4-byte loads at plane stride (same values,
- * bit-identical V).  Only where dlpd_preact_channels_last_supported(L_fine, HP) (both role-split kernels compiled);
- * L is this (coarse) resolution's box.  Replaces DockingModels.py:74-77 like dlpd_zifft_preact. */
-int dlpd_preact_channels_last_supported(int L_fine, int HP);
-int dlpd_zifft_preact_cl(const void* wsB, float* pre, int nb, int C, int L, const float* W1rows, const float* b1, int HP,
-                         int has_clip, float clip, void* stream);
 
 /* dlpd_zifft_real with the clamp restricted to channels [0, nclip). */
 int dlpd_zifft_real_part(const void* wsB, float* out, int nb, int CT, int nclip, int L, int has_clip, float clip,

@@ -13,7 +13,7 @@ MLP = ["prologue (preact / bias)", "B1 wait", "copy values + B2 wait", "multiply
 
 class A:
     workload = sys.argv[1] if len(sys.argv) > 1 else "config2"
-    channels = box = None
+    channels = box = hidden = None
     max_conf, batch, k3_form = 2000, 16, 2
 
 

@@ -27,7 +27,7 @@ def build(force=False):
         fcntl.flock(lock, fcntl.LOCK_EX)
         if force or not _fresh(deps):
             tmp = OUT + ".tmp.%d" % os.getpid()
-            cmd = ["g++", "-O2", "-g", "-std=c++17", "-shared", "-fPIC", "-fpermissive", "-w",
+            cmd = ["g++", "-O2", "-g", "-std=c++17", "-shared", "-fPIC", "-fpermissive", "-w", "-DDLPD_TEST_VARIANTS",
                    "-I", HERE, "-I", CSRC, "-o", tmp] + os.environ.get("DLPD_EMU_FLAGS", "").split()
             for s in srcs:
                 cmd += ["-x", "c++", s]

@@ -23,6 +23,15 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(scope="module")
+def variants():
+    """tests/variants/libdlpd_variants.so: the formulations libdlpd.so does not ship because no Docker path reaches them
+    (channel-owning K3 at N = 128 / 160, transposed-slab K2 at N = 160) -- the bit-exactness references."""
+    import __graft_entry__ as entry
+    from deeplocalproteindocking_amd._lib import DlpdLib
+    return DlpdLib(entry.build_test_variants())
+
+
 def _pair(L, C, seed=0, amp=0.1):
     g = torch.Generator().manual_seed(seed)
     rec = torch.randn(C, L, L, L, generator=g) * amp
@@ -617,7 +626,7 @@ def test_all_four_search_paths_match_oracle_at_baseline_config2_size(dev):
           "worst error %.2e of max|V|" % worst)
 
 
-def test_baseline_config5_shape_48ch_80cube_matches_oracle(dev):
+def test_baseline_config5_shape_48ch_80cube_matches_oracle(dev, variants):
     """BASELINE config 5's literal shape: 48 channels at 80^3, single resolution -> 160^3 (channels-last K1, the
     four-sub-problem K2 with 49 slabs per kz, fused K3 on 8-row tiles; the unfused z-inverse + k_filter_vec pair and
     the per-channel K1 with transposed slabs as variants), clip active, clash channel on; two rotations."""
@@ -647,7 +656,14 @@ def test_baseline_config5_shape_48ch_80cube_matches_oracle(dev):
             worst = max(worst, _assert_scores_match(eng2.score_batch(Rd).cpu()[0], Vo, norm, thr))
             del eng2
         else:                                                # the per-channel K1 with transposed slabs + quad layout
-            eng3 = DockingEngine(L, C, *W, clip=5.0, threshold_clash=thr, max_conf=100, batch=1, device=dev, channels_last=False)
+            # (K2's transposed-slab reader at N = 160 is a test variant: the product visits box 80 in one orientation)
+            eng3 = DockingEngine(L, C, *W, clip=5.0, threshold_clash=thr, max_conf=100, batch=1, device=dev, channels_last=False,
+                                 lib=variants)
+            assert eng3.orient
+            prod = DockingEngine(L, 4, torch.zeros(2, 4), torch.zeros(2), torch.zeros(1, 2), torch.zeros(1), max_conf=10, batch=1,
+                                 device=dev, channels_last=False)
+            assert not prod.orient and prod.use_quads       # libdlpd.so: no orientation at box 80
+            del prod
             eng3.set_receptor(rec, recf)
             eng3.set_ligand(lig, ligf)
             worst = max(worst, _assert_scores_match(eng3.score_batch(Rd, transposed=True, quads=True).cpu()[0], Vo, norm, thr))
@@ -727,15 +743,22 @@ def test_two_rank_nccl_search_equals_single_process(dev, tmp_path):
     assert res["sharded"] == res["single"] and len(res["single"]) == res["K"]
 
 
-def test_k3_role_split_equals_the_channel_owning_k3(dev):
+def test_k3_role_split_equals_the_channel_owning_k3(dev, variants):
     """k_zifft_filter_rs (dedicated transform / filter waves, the default) bit for bit against k_zifft_filter[_tiles]
     (every wave owns a channel) and against the oracle: 48 channels x 64^3 (13 groups of 4, the last one the clash
     channel alone), the reference's real shapes [16 @ 80^3, 32 @ 40^3] with the coarse pre-activation planes through
     both forms, and 48 channels x 80^3 (five groups of ten)."""
     from test_kernels_emu import _k3_both_formulations
-    _k3_both_formulations(None, dev, 64, 48, 24, 5.0, 5, nb=2)
-    _k3_both_formulations(None, dev, 80, 16, 24, 5.0, 6, C1=32, nb=2)
-    _k3_both_formulations(None, dev, 80, 48, 24, 5.0, 7)
+    _k3_both_formulations(variants, dev, 64, 48, 24, 5.0, 5, nb=2)
+    _k3_both_formulations(variants, dev, 80, 16, 24, 5.0, 6, C1=32, nb=2)
+    _k3_both_formulations(variants, dev, 80, 48, 24, 5.0, 7)
+    # the product library holds ONE formulation per box: the other one is refused, not silently replaced
+    from deeplocalproteindocking_amd.engine import DockingEngine
+    eng = DockingEngine(64, 2, torch.zeros(1, 2), torch.zeros(1), torch.zeros(1, 1), torch.zeros(1), max_conf=4, batch=1, device=dev, k3_form=1)
+    eng.set_receptor(torch.zeros(2, 64, 64, 64), torch.zeros(64, 64, 64))
+    eng.set_ligand(torch.zeros(2, 64, 64, 64), torch.zeros(64, 64, 64))
+    with pytest.raises(RuntimeError, match="UNSUPPORTED"):
+        eng.score_batch(torch.eye(3, device=dev).reshape(1, 3, 3).contiguous())
 
 
 def test_reference_class_default_hidden_width_48_is_fused(dev):

@@ -38,6 +38,21 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert built_lib.call("dlpd_topk_glist_bytes", 2000) == (2 + 4000) * 8
 
 
+def test_product_library_ships_one_formulation_per_box(built_lib):
+    """libdlpd.so holds only kernels a Docker path can reach: the channel-owning K3 at N = 128 / 160 and the
+    transposed-slab K2 at N = 160 are TEST VARIANTS (tests/variants/libdlpd_variants.so, -DDLPD_TEST_VARIANTS)."""
+    import subprocess
+    nm = subprocess.run(["nm", "-C", entry.LIB], capture_output=True, text=True).stdout
+    assert "k_zifft_filter_rs<128" in nm and "k_zifft_filter_rs<160" in nm and "k_xy_corr_q4<160>" in nm
+    assert "k_zifft_filter<64," in nm and "k_zifft_filter<80," in nm                      # boxes 32 / 40: the one formulation there
+    for absent in ("k_xy_corr_quad<", "k_zifft_filter<128, 24, 1>", "k_zifft_filter_tiles<160", "k_zifft_filter<160, 24, 2>",
+                   "k_zifft_filter<80, 24, 2>"):
+        assert absent not in nm, absent
+    assert built_lib.call("dlpd_orientation_supported", 64) == 1 and built_lib.call("dlpd_orientation_supported", 80) == 0
+    src = open(os.path.join(ROOT, "deeplocalproteindocking_amd", "engine.py")).read()
+    assert "environ" not in src and "getenv" not in src                              # kernel choices are constructor arguments only
+
+
 def test_product_path_fails_loudly_without_gpu_or_library(tmp_path):
     from deeplocalproteindocking_amd._lib import DlpdLib
     from deeplocalproteindocking_amd.engine import DockingEngine

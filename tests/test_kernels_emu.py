@@ -587,27 +587,14 @@ def _k3_both_formulations(lib, device, L, C, H, clip, seed, C1=0, nb=1):
     eng.set_ligand(lig, ligf, lig1)
     R = orc.euler_to_matrix([0.5, -2.1][:nb], [1.1, 0.3][:nb], [-0.4, 1.7][:nb])
     out = {}
-    can_cl = eng.preact_channels_last_supported  # both role-split kernels exist at this box (opt-in layout)
-    assert not eng.preact_channels_last
-    for form, cl in ((1, False), (2, False)) + (((2, True),) if can_cl else ()):
-        eng.k3_form, eng.preact_channels_last = form, cl
-        assert eng.pre_cl == cl
-        key = (form, cl)
-        out[key] = eng.score_batch(torch.from_numpy(R).float().to(device).contiguous()).cpu().clone()
+    for form in (1, 2):
+        eng.k3_form = form
+        out[form] = eng.score_batch(torch.from_numpy(R).float().to(device).contiguous()).cpu().clone()
         if C1:
-            pre = eng.pre[:nb].cpu().clone()
-            if cl:                               # (nb, N1^3, HP) -> HP planes
-                N1 = 2 * eng.L1
-                pre = pre.reshape(nb, N1, N1, N1, eng.HP).permute(0, 4, 1, 2, 3).contiguous()
-            out[key + ("pre",)] = pre
+            out[(form, "pre")] = eng.pre[:nb].cpu().clone()
     if C1:
-        assert torch.equal(out[(1, False, "pre")], out[(2, False, "pre")])
-    assert torch.equal(out[(1, False)], out[(2, False)])
-    if can_cl:
-        # channels-last pre-activation planes (dlpd_zifft_preact_cl -> aux_is_preact = 2): same values, same V, bit for bit
-        assert C1 and torch.equal(out[(2, True, "pre")], out[(2, False, "pre")])
-        assert torch.equal(out[(2, True)], out[(2, False)])
-    out[2] = out[(2, False)]
+        assert torch.equal(out[(1, "pre")], out[(2, "pre")])
+    assert torch.equal(out[1], out[2])
     for i in range(nb):
         Rb = torch.from_numpy(R[i:i + 1]).float()
         rr, ll = [rec[None]], [orc.rotate_volume(lig[None], Rb)]
@@ -626,16 +613,6 @@ def test_k3_role_split_equals_the_channel_owning_k3_emulated(emu):
     4 transform waves, the second partial), hidden width 20 (padded to 24), clip biting, one rotation."""
     assert emu.call("dlpd_hidden_pad", 20) == 24
     _k3_both_formulations(emu, "cpu", 64, 5, 20, 0.4, 77)
-
-
-def test_channels_last_preactivations_equal_the_planes_emulated(emu):
-    """[1 @ 80^3, 2 @ 40^3] -> 160^3 on the fibre emulator: the coarse grid's first-layer half written channels-last
-    (dlpd_zifft_preact_cl) and read by the fine grid's role-split K3 with 16-byte loads (aux_is_preact = 2) against
-    the HP planes of both formulations: bit-identical pre-activations and V; V against the oracle.  Hidden width 6
-    (padded to 8: two float4 per voxel)."""
-    assert emu.call("dlpd_preact_channels_last_supported", 80, 8) == 1
-    assert emu.call("dlpd_preact_channels_last_supported", 64, 8) == 0      # no role-split coarse kernel at box 32
-    _k3_both_formulations(emu, "cpu", 80, 1, 6, 0.4, 78, C1=2)
 
 
 def _fused_wide_hidden(lib, device, L, C, C1, H, nb, seed):
