@@ -213,6 +213,11 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
   float4* raw = reinterpret_cast<float4*>(tw + N);        // [RAWBUF][F][CPW][RAWC]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool is_fft = wave < F;
+  // (round 4: TEN half-size filter waves at N = 160 -- 15 waves, 128 registers, 3 spilled -- with the transform waves dealt
+  // one per SIMD, hardware waves {0, 1, 2, 3, 7}, since a workgroup's waves go to the SIMDs cyclically: K3 2.07-2.09 ms
+  // against 2.00-2.03 for 5 + 5 on the real shapes, 5.5 against 4.8 at 48 ch x 80^3; transform waves first: 2.07-2.20 / 5.4;
+  // bit-identical; not kept)
+  const int twave = wave, fwave = wave - F;
   const int t_beg = blockIdx.x * tpb, t_end = (t_beg + tpb < ntiles) ? t_beg + tpb : ntiles;
   if (t_beg >= t_end) return;
   init_twiddles_k3r<N>(tw, tid, 64 * (F + M));
@@ -221,12 +226,12 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
   // ---- transform role: this wave's channels of group `cb` of tile `t` -> raw staging buffer `buf`
   //      raw[k][m] <- Bw[b][cb + wave*CPW + j][k][xo][y0+2m .. +1]   (lane = NPAIR*(k % LPK) + m: LPK runs of NPAIR*16
   //      bytes per DMA instruction; k = N/2 is the last, short one)
-  float4* rawg = raw + wave * CPW * RAWC;
+  float4* rawg = raw + twave * CPW * RAWC;
   auto issue_channel = [&](int t, int cb, int buf) {
     const int ty0 = (t % NYT) * TY, txo = (t / NYT) % N, tb = t / (NYT * N);
 #pragma unroll
     for (int j = 0; j < CPW; j++) {
-      const int g = wave * CPW + j;
+      const int g = twave * CPW + j;
       if (g < G && cb + g < CT) {
         const cplx* src = Bw + (((size_t)tb * CT + cb + g) * NZ * N + txo) * N + ty0;
         // slot NPAIR*k + msl of the raw channel holds row pair msl ^ k3r_pair_swz(k) of bin k (see k3r_first_pass)
@@ -241,7 +246,7 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
   };
   const int tr = lane & 7, qr = lane >> 3;     // FFT: lane = 8*pencil + thread
   // ---- filter role: voxel ownership (rows y0 + 2m, y0 + 2m + 1, column zz)
-  const int tm = tid - 64 * F;
+  const int tm = 64 * fwave + lane;
   const int zz = is_fft ? 0 : tm % N, m0 = is_fft ? 0 : tm / N;
 
   if (is_fft) {
@@ -263,7 +268,7 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
     for (int step = 0; step < nsteps; step++) {
       const int gn = (CT - cbase) < G ? (CT - cbase) : G;
       const bool last_group = cbase + G >= CT;
-      const bool mine = wave * CPW < gn;
+      const bool mine = twave * CPW < gn;
       if (mine) {
         DLPD_WAIT_VMEM();                      // this wave's own DMA has landed
         DLPD_WAVE_SYNC();
@@ -281,12 +286,12 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
       // (a wave whose second channel lies beyond the group transforms stale staging data into pencils nobody reads)
       if (mine) {
         const int m = qr % NPAIR, j = qr / NPAIR;
-        k3r_first_pass<N, NPAIR>(S, (wave * 8 + qr) * RS, tr, m, rawg + rb * (F * CPW * RAWC) + j * RAWC);
+        k3r_first_pass<N, NPAIR>(S, (twave * 8 + qr) * RS, tr, m, rawg + rb * (F * CPW * RAWC) + j * RAWC);
         DLPD_WAVE_SYNC();                      // every lane's raw values are in registers: the staging buffer is free
       }
       DLPD_STAMP(1);
       if (RAWBUF == 1 && nt < t_end) issue_channel(nt, ncb, 0);
-      if (mine) k3r_second_pass<N>(S, (wave * 8 + qr) * RS, tr, tw);
+      if (mine) k3r_second_pass<N>(S, (twave * 8 + qr) * RS, tr, tw);
       DLPD_STAMP(2);
       if (RAWBUF == 2) rb ^= 1;
       DLPD_LDS_BARRIER();                      // B1
@@ -425,8 +430,8 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
     }
   }
 #ifdef DLPD_STAMPS
-  if (lane == 0 && (wave == 0 || wave == F)) {
-    const int o = wave == 0 ? 0 : 16;
+  if (lane == 0 && ((is_fft && twave == 0) || (!is_fft && fwave == 0))) {
+    const int o = is_fft ? 0 : 16;
     for (int i_ = 0; i_ < 8; i_++) atomicAdd(&dlpd_stamps_k3r[o + i_], st_sum[i_]);
     atomicAdd(&dlpd_stamps_k3r[o + 15], 1ull);
   }
