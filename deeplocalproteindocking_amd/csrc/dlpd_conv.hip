@@ -235,6 +235,209 @@ __global__ void __launch_bounds__(256) k_conv3d_pack(const float* __restrict__ w
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same convolution on the BF16 matrix cores with f32-grade results (round 4): every f32 value is split into three
+// bf16 terms, x = x_h + x_m + x_l (each the round-to-nearest bf16 of what the previous ones left: 3 x 8 significant
+// bits), and a product x w is summed from six bf16 x bf16 products -- hh, hm, mh, mm, hl, lh; the three dropped ones are
+// below 2^-24 |x w|, the size of f32's own rounding -- accumulated in f32 by v_mfma_f32_16x16x32_bf16, which runs at 16
+// x the rate of the f32-input form: 16 / 6 = 2.7 x the matrix throughput for results that differ from the exact-f32
+// kernel by a few 1e-7 relative (tests: <= 1e-5 against torch in float64).  Docker.dockE3's per-batch cost is two thirds
+// this convolution (Docker.py:166-167).
+//   M = 16 output channels, N = 16 z-consecutive voxels, K = 32 = 4 taps x 8 input channels per MFMA.
+//   block = (4 x 4 (x, y) patch, 16 z) of one volume, 16 / RW waves x RW rows; input channels in chunks of 8, staged
+//   through LDS CHANNELS-LAST and already split: Xs[split][voxel][8 ch] bf16 = 16 bytes per (split, voxel), so that a B
+//   fragment -- the 8 channels of one tap of one voxel -- is one ds_read_b128; lane (n, kg) of a tap group reads tap
+//   4 tg + kg at voxel n (per-lane tap offsets from a small LDS table).  A fragments (weights, split by
+//   dlpd_conv3d_split_pack) come straight from global memory -- 1 KB contiguous per wave and fragment, shared by all
+//   blocks, L2 / L1 resident -- one tap group ahead.  LDS: 61 KB (k = 5) / 31 KB (k = 3): two to four blocks per CU, whose
+//   staging and matrix phases overlap each other.
+// Measured (round 4, batch 16, the nine convolutions of E3MultiResRepr4x4(8) at box 80): 9.2 ms against 17.0-17.3 ms for
+// the exact-f32 kernel (86.5 for torch / MIOpen); rows per wave 1 / 2 / 4 / 8: 13.3 / 9.7 / 9.2 / 11.2 ms (a wave's A
+// fragments are re-read by every wave of the block: 4 rows halve that traffic, 8 rows leave two waves per block).  Also
+// built and NOT kept: B fragments one tap group ahead as well plus the next chunk's staging loads held in registers
+// across the matrix phase (166-210 registers, two waves per SIMD): 9.6-9.7 ms -- the k = 3 layers lose their four
+// resident blocks and the k = 5 layers do not change (2.85 against 2.78 ms): per matrix instruction the kernel needs
+// half an LDS fragment read and, at 16 output channels, an eighth of a global one -- matrix pipe, LDS and the vector
+// memory path each sit near half of their rate, and what would raise the arithmetic per fragment (more output-channel
+// tiles per wave) the 16-channel layers do not have.
+#ifndef DLPD_CONVS_RW
+#define DLPD_CONVS_RW 4
+#endif
+template <int KS> struct ConvSCfg {
+  static constexpr int TX = 4, TY = 4, ZT = 16, RW = DLPD_CONVS_RW, NW = TX * TY / RW, NT = 64 * NW, CK = 8;   // RW rows per wave
+  static constexpr int H = KS / 2;
+  static constexpr int XS = TX + KS - 1, YS = TY + KS - 1, ZS = ZT + KS - 1;
+  static constexpr int NVOX = XS * YS * ZS;
+  static constexpr int NTAP = KS * KS * KS, NTG = (NTAP + 3) / 4;
+  static constexpr size_t LDS_BYTES = (size_t)3 * NVOX * 16 + (size_t)NTG * 4 * sizeof(int);
+};
+
+// x = h + m + l in bf16 (bit patterns)
+DLPD_D void conv_split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+  h = dlpd_f2bf(x);
+  const float r1 = x - dlpd_bf2f(h);
+  m = dlpd_f2bf(r1);
+  const float r2 = r1 - dlpd_bf2f(m);
+  l = dlpd_f2bf(r2);
+}
+
+template <int KS, int COUT, int RELU, int STRIDE> __global__ void __launch_bounds__(ConvSCfg<KS>::NT)
+k_conv3d_bf16x3(const float* __restrict__ X, const float4* __restrict__ Wp, float* __restrict__ Y, int CIN, int D,
+                int cout_total, int co_base, int nzb) {
+  typedef ConvSCfg<KS> C;
+  constexpr int MT = COUT / 16, H = C::H, NTG = C::NTG, NVOX = C::NVOX, RW = C::RW, NT = C::NT;
+  DLPD_DYN_SHARED(float4, Xs);                                 // [3][NVOX] 16-byte cells
+  int* toff = reinterpret_cast<int*>(Xs + 3 * NVOX);           // [4 NTG] voxel offset of every tap (0 for the padding taps)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int x0 = blockIdx.x * C::TX, y0 = blockIdx.y * C::TY, b = blockIdx.z / nzb, z0 = (blockIdx.z % nzb) * C::ZT;
+  const size_t D3 = (size_t)D * D * D;
+  const float* Xb = X + (size_t)b * CIN * D3;
+  const int kg = lane >> 4, n = lane & 15;
+  for (int t = tid; t < 4 * NTG; t += NT) {
+    const int dz = t % KS, dy = (t / KS) % KS, dx = t / (KS * KS);
+    toff[t] = t < C::NTAP ? (dx * C::YS + dy) * C::ZS + dz : 0;
+  }
+  dlpd_acc4 acc[RW][MT];
+#pragma unroll
+  for (int r = 0; r < RW; r++)
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) acc[r][mt] = dlpd_acc4_zero();
+  int vbase[RW];
+  bool skip[RW];
+#pragma unroll
+  for (int r = 0; r < RW; r++) {
+    const int row = RW * wave + r;
+    vbase[r] = ((row / C::TY) * C::YS + (row % C::TY)) * C::ZS + n;
+    skip[r] = STRIDE == 2 && (((row / C::TY) | (row % C::TY)) & 1);      // stride 2: rows of odd x or y produce no output
+  }
+  const int nchunk = (CIN + C::CK - 1) / C::CK;
+  for (int ch = 0; ch < nchunk; ch++) {
+    __syncthreads();                                           // previous chunk consumed (first pass: toff written)
+    // ---- staging: one voxel (8 channels) per thread and step; split into the three bf16 planes
+    for (int v = tid; v < NVOX; v += NT) {
+      const int zz = v % C::ZS, yy = (v / C::ZS) % C::YS, xx = v / (C::ZS * C::YS);
+      const int gx = x0 + xx - H, gy = y0 + yy - H, gz = z0 + zz - H;
+      const bool ok = gx >= 0 && gx < D && gy >= 0 && gy < D && gz >= 0 && gz < D;
+      const float* src = Xb + ((size_t)(ok ? gx : 0) * D + (ok ? gy : 0)) * D + (ok ? gz : 0);
+      unsigned hh[8], mm[8], ll[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int ci = C::CK * ch + j;
+        const float x = (ok && ci < CIN) ? src[(size_t)ci * D3] : 0.f;
+        conv_split3(x, hh[j], mm[j], ll[j]);
+      }
+      float4 ph, pm, pl;
+      ph.x = __uint_as_float(hh[0] | (hh[1] << 16)); ph.y = __uint_as_float(hh[2] | (hh[3] << 16));
+      ph.z = __uint_as_float(hh[4] | (hh[5] << 16)); ph.w = __uint_as_float(hh[6] | (hh[7] << 16));
+      pm.x = __uint_as_float(mm[0] | (mm[1] << 16)); pm.y = __uint_as_float(mm[2] | (mm[3] << 16));
+      pm.z = __uint_as_float(mm[4] | (mm[5] << 16)); pm.w = __uint_as_float(mm[6] | (mm[7] << 16));
+      pl.x = __uint_as_float(ll[0] | (ll[1] << 16)); pl.y = __uint_as_float(ll[2] | (ll[3] << 16));
+      pl.z = __uint_as_float(ll[4] | (ll[5] << 16)); pl.w = __uint_as_float(ll[6] | (ll[7] << 16));
+      Xs[v] = ph;
+      Xs[NVOX + v] = pm;
+      Xs[2 * NVOX + v] = pl;
+    }
+    __syncthreads();
+    // ---- all tap groups of the chunk; A fragments one group ahead
+    const float4* wch = Wp + (size_t)ch * 3 * NTG * 4 * COUT + kg * COUT + n;
+    float4 a_cur[3][MT], a_nxt[3][MT];
+#pragma unroll
+    for (int sp = 0; sp < 3; sp++)
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++) a_cur[sp][mt] = wch[(size_t)(sp * NTG) * 4 * COUT + mt * 16];
+#pragma unroll 1
+    for (int tg = 0; tg < NTG; tg++) {
+      const int tgn = tg + 1 < NTG ? tg + 1 : tg;
+#pragma unroll
+      for (int sp = 0; sp < 3; sp++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) a_nxt[sp][mt] = wch[(size_t)(sp * NTG + tgn) * 4 * COUT + mt * 16];
+      const int off = toff[4 * tg + kg];
+      float4 bf[3][RW];
+#pragma unroll
+      for (int sp = 0; sp < 3; sp++)
+#pragma unroll
+        for (int r = 0; r < RW; r++) bf[sp][r] = Xs[sp * NVOX + vbase[r] + off];
+      DLPD_SCHED_FENCE();
+#pragma unroll
+      for (int r = 0; r < RW; r++) {
+        if (skip[r]) continue;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+          dlpd_acc4 c = acc[r][mt];
+          c = DLPD_MFMA_16x16x32_BF16(a_cur[2][mt], bf[0][r], c);      // w_l x_h   (small terms first)
+          c = DLPD_MFMA_16x16x32_BF16(a_cur[0][mt], bf[2][r], c);      // w_h x_l
+          c = DLPD_MFMA_16x16x32_BF16(a_cur[1][mt], bf[1][r], c);      // w_m x_m
+          c = DLPD_MFMA_16x16x32_BF16(a_cur[1][mt], bf[0][r], c);      // w_m x_h
+          c = DLPD_MFMA_16x16x32_BF16(a_cur[0][mt], bf[1][r], c);      // w_h x_m
+          c = DLPD_MFMA_16x16x32_BF16(a_cur[0][mt], bf[0][r], c);      // w_h x_h
+          acc[r][mt] = c;
+        }
+      }
+      DLPD_SCHED_FENCE();
+#pragma unroll
+      for (int sp = 0; sp < 3; sp++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) a_cur[sp][mt] = a_nxt[sp][mt];
+    }
+  }
+  // ---- epilogue: lane holds output channels 4 kg + j, voxel n (the C/D layout of every 16x16 form)
+  const int kq = kg;
+#pragma unroll
+  for (int r = 0; r < RW; r++) {
+    const int row = RW * wave + r, gx = x0 + row / C::TY, gy = y0 + row % C::TY, gz = z0 + n;
+    if (gx >= D || gy >= D || gz >= D) continue;
+    if (STRIDE == 2 && ((gx | gy | gz) & 1)) continue;
+    const int Do = (STRIDE == 2) ? (D - 1) / 2 + 1 : D;
+    const size_t Do3 = (size_t)Do * Do * Do;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float v = dlpd_acc4_get(acc[r][mt], j);
+        if (RELU) v = fmaxf(v, 0.f);
+        Y[((size_t)b * cout_total + co_base + mt * 16 + 4 * kq + j) * Do3 +
+          ((size_t)(gx / STRIDE) * Do + gy / STRIDE) * Do + gz / STRIDE] = v;
+      }
+  }
+}
+
+// wp[group][chunk][split][tap group][kg][co in group][8 ch] bf16: the A fragments in the order the kernel reads them
+__global__ void __launch_bounds__(256) k_conv3d_split_pack(const float* __restrict__ w, unsigned short* __restrict__ wp, int cin,
+                                                           int cout, int ks) {
+  const int ntap = ks * ks * ks, ntg = (ntap + 3) / 4, nch = (cin + 7) / 8;
+  const size_t per32 = (size_t)nch * 3 * ntg * 4 * 32 * 8;     // bf16 elements of a full group
+  const size_t total = (size_t)nch * 3 * ntg * 4 * cout * 8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i / per32), gw = conv_group_width(cout, g);
+    size_t r = i - (size_t)g * per32;
+    const int j = (int)(r % 8); r /= 8;
+    const int col = (int)(r % gw); r /= gw;
+    const int kg = (int)(r % 4); r /= 4;
+    const int tg = (int)(r % ntg); r /= ntg;
+    const int sp = (int)(r % 3); r /= 3;
+    const int ch = (int)r;
+    const int tap = 4 * tg + kg, ci = 8 * ch + j, co = 32 * g + col;
+    const float x = (tap < ntap && ci < cin) ? w[((size_t)co * cin + ci) * ntap + tap] : 0.f;
+    unsigned h, m, l;
+    conv_split3(x, h, m, l);
+    wp[i] = (unsigned short)(sp == 0 ? h : (sp == 1 ? m : l));
+  }
+}
+
+template <int KS, int COUT> static int launch_conv_split(const float* X, const float4* W, float* Y, int B, int CIN, int D,
+                                                         int relu, int stride, int cout_total, int co_base, hipStream_t st) {
+  typedef ConvSCfg<KS> C;
+  const int nzb = (D + C::ZT - 1) / C::ZT;
+  dim3 grid((D + C::TX - 1) / C::TX, (D + C::TY - 1) / C::TY, B * nzb), block(C::NT);
+#define DLPD_CS(R, S) { int rc = dlpd_set_max_dyn_shared((const void*)k_conv3d_bf16x3<KS, COUT, R, S>, C::LDS_BYTES); if (rc) return rc; \
+    DLPD_LAUNCH((k_conv3d_bf16x3<KS, COUT, R, S>), grid, block, C::LDS_BYTES, st, X, W, Y, CIN, D, cout_total, co_base, nzb); }
+  if (stride == 2) { if (relu) DLPD_CS(1, 2) else DLPD_CS(0, 2) }
+  else { if (relu) DLPD_CS(1, 1) else DLPD_CS(0, 1) }
+#undef DLPD_CS
+  return dlpd_check_launch();
+}
+
 // MaxPool3d(kernel 5, stride 2, padding 2) of the E3 plugin (ProteinRepresentationModels.py:101): out-of-range
 // taps do not take part (torch pads with -inf).  One thread per output voxel, z fastest; the 125 taps of
 // neighbouring outputs overlap, so the reads are served by L1/L2.
@@ -291,6 +494,38 @@ int dlpd_conv3d_pack(const float* w, float* wp, int cin, int cout, int ks, void*
 int dlpd_conv3d_supported(int cin, int cout, int ks, int D) {
   if (cin <= 0 || D <= 0 || D > 80) return 0;
   return ((ks == 3 || ks == 5) && cout >= 16 && cout % 16 == 0) ? 1 : 0;
+}
+
+size_t dlpd_conv3d_split_packed_bytes(int cin, int cout, int ks) {
+  return (size_t)((cin + 7) / 8) * 3 * ((ks * ks * ks + 3) / 4) * 4 * cout * 8 * sizeof(unsigned short);
+}
+
+int dlpd_conv3d_split_pack(const float* w, void* wp, int cin, int cout, int ks, void* stream) {
+  if (!w || !wp || cin <= 0 || cout <= 0 || ks <= 0) return DLPD_ERR_ARG;
+  const size_t total = dlpd_conv3d_split_packed_bytes(cin, cout, ks) / sizeof(unsigned short);
+  size_t nblk = (total + 255) / 256;
+  if (nblk > 65535) nblk = 65535;
+  DLPD_LAUNCH(k_conv3d_split_pack, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)wp, cin, cout, ks);
+  return dlpd_check_launch();
+}
+
+int dlpd_conv3d_split(const float* x, const void* wp, float* y, int B, int cin, int cout, int D, int ks, int relu, int stride,
+                      void* stream) {
+  if (!x || !wp || !y || B <= 0 || (stride != 1 && stride != 2)) return DLPD_ERR_ARG;
+  if (!dlpd_conv3d_supported(cin, cout, ks, D)) return DLPD_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t per32 = (size_t)((cin + 7) / 8) * 3 * ((ks * ks * ks + 3) / 4) * 4 * 32 * 8 * sizeof(unsigned short) / 16;   // float4 cells
+  for (int g = 0; 32 * g < cout; g++) {
+    const int gw = conv_group_width(cout, g), base = 32 * g;
+    const float4* wg = reinterpret_cast<const float4*>(wp) + per32 * g;
+    int rc = DLPD_ERR_UNSUPPORTED;
+    if (ks == 3 && gw == 16) rc = launch_conv_split<3, 16>(x, wg, y, B, cin, D, relu, stride, cout, base, st);
+    else if (ks == 3 && gw == 32) rc = launch_conv_split<3, 32>(x, wg, y, B, cin, D, relu, stride, cout, base, st);
+    else if (ks == 5 && gw == 16) rc = launch_conv_split<5, 16>(x, wg, y, B, cin, D, relu, stride, cout, base, st);
+    else if (ks == 5 && gw == 32) rc = launch_conv_split<5, 32>(x, wg, y, B, cin, D, relu, stride, cout, base, st);
+    if (rc) return rc;
+  }
+  return DLPD_OK;
 }
 
 int dlpd_conv3d_strided(const float* x, const float* wp, float* y, int B, int cin, int cout, int D, int ks, int relu,

@@ -148,3 +148,14 @@ __device__ __forceinline__ dlpd_acc4 dlpd_acc4_zero() { dlpd_acc4 z = {0.f, 0.f,
 __device__ __forceinline__ float dlpd_acc4_get(dlpd_acc4 v, int j) { return v[j]; }
 __device__ __forceinline__ dlpd_acc4 dlpd_acc4_make(float a, float b, float c, float d) { dlpd_acc4 z = {a, b, c, d}; return z; }
 #define DLPD_MFMA_16x16x4(a, b, acc) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (acc), 0, 0, 0)
+// bf16-input matrix core: D(16x16) += A(16x32) * B(32x16), f32 accumulate.  A fragment is 8 consecutive k values
+// (16 bytes, passed as a float4): lane l holds A[l&15][8*(l>>4) + j] and B[8*(l>>4) + j][l&15], j = 0..7; D as 16x16x4.
+typedef __bf16 dlpd_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ dlpd_acc4 dlpd_mfma_16x16x32_bf16(float4 a, float4 b, dlpd_acc4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dlpd_bf16x8, a), __builtin_bit_cast(dlpd_bf16x8, b), acc, 0, 0, 0);
+}
+#define DLPD_MFMA_16x16x32_BF16(a, b, acc) dlpd_mfma_16x16x32_bf16((a), (b), (acc))
+// f32 -> bf16 bit pattern (round to nearest even: v_cvt_pk_bf16_f32) and back
+__device__ __forceinline__ unsigned dlpd_f2bf(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
+__device__ __forceinline__ float dlpd_bf2f(unsigned h) { return __uint_as_float(h << 16); }
+

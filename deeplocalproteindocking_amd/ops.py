@@ -161,10 +161,16 @@ def conv3d_supported(weight, D, lib=None):
     return bool(cubic and (lib or get_lib()).call("dlpd_conv3d_supported", int(cin), int(cout), int(ks), int(D)))
 
 
-def conv3d(x, weight, relu=False, lib=None, stride=1):
+CONV_PRECISION = "split_bf16"      # default arithmetic of conv3d: "split_bf16" (3 x bf16 terms, six products: f32-grade) | "f32"
+
+
+def conv3d(x, weight, relu=False, lib=None, stride=1, precision=None):
     """[relu] Conv3d(x, weight, padding=k//2, stride=1|2, bias=None) of the representation plugins
-    (ProteinRepresentationModels.py:38-61,85-114) on the f32 matrix cores (inference only: no autograd).
-    x (B, cin, D, D, D) float32; weight (cout, cin, k, k, k)."""
+    (ProteinRepresentationModels.py:38-61,85-114) on the matrix cores (inference only: no autograd).
+    x (B, cin, D, D, D) float32; weight (cout, cin, k, k, k).
+    precision: "f32" = exact f32 products on the f32-input matrix instruction; "split_bf16" = every value as three
+    bf16 terms, six bf16 products per f32 product, f32 accumulation (equal to the f32 form to a few 1e-7 relative,
+    2-3x faster); None = ``ops.CONV_PRECISION``."""
     lib = lib or get_lib()
     x = x.contiguous()
     if x.dtype != torch.float32 or x.dim() != 5 or not (x.shape[2] == x.shape[3] == x.shape[4]):
@@ -174,30 +180,38 @@ def conv3d(x, weight, relu=False, lib=None, stride=1):
     cout, ks = w.shape[0], w.shape[2]
     if w.shape[1] != cin:
         raise RuntimeError("dlpd: conv3d channel mismatch %d vs %d" % (w.shape[1], cin))
-    wp = _packed_weights(weight, w, lib, x.device)
+    precision = precision or CONV_PRECISION
+    if precision not in ("f32", "split_bf16"):
+        raise RuntimeError("dlpd: conv3d precision %r" % (precision,))
+    split = precision == "split_bf16"
+    wp = _packed_weights(weight, w, lib, x.device, split)
     if stride not in (1, 2):
         raise RuntimeError("dlpd: conv3d stride %r not supported (1 or 2)" % (stride,))
     Do = (D - 1) // stride + 1
     y = torch.empty(B, cout, Do, Do, Do, dtype=torch.float32, device=x.device)
-    lib.call("dlpd_conv3d_strided", _ptr(x), _ptr(wp), _ptr(y), B, cin, cout, D, ks, int(bool(relu)), int(stride),
-             _stream(x.device))
+    lib.call("dlpd_conv3d_split" if split else "dlpd_conv3d_strided", _ptr(x), _ptr(wp), _ptr(y), B, cin, cout, D, ks,
+             int(bool(relu)), int(stride), _stream(x.device))
     return y
 
 
 _PACKED = {}
 
 
-def _packed_weights(weight, w, lib, device):
+def _packed_weights(weight, w, lib, device, split=False):
     """dlpd_conv3d_pack; cached per (parameter, version) for nn.Parameters -- inference weights do not
     change between batches.  Other tensors (e.g. kernels composed on the fly) are packed per call: their
     storage may be recycled with new contents under the same address."""
     cacheable = isinstance(weight, torch.nn.Parameter)
-    key = (id(weight), weight.data_ptr(), weight._version, tuple(weight.shape), str(device), id(lib))
+    key = (id(weight), weight.data_ptr(), weight._version, tuple(weight.shape), str(device), id(lib), bool(split))
     if cacheable and key in _PACKED:
         return _PACKED[key]
     cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
-    wp = torch.empty(lib.call("dlpd_conv3d_packed_floats", cin, cout, ks), dtype=torch.float32, device=device)
-    lib.call("dlpd_conv3d_pack", _ptr(w), _ptr(wp), cin, cout, ks, _stream(device))
+    if split:
+        wp = torch.empty(lib.call("dlpd_conv3d_split_packed_bytes", cin, cout, ks), dtype=torch.uint8, device=device)
+        lib.call("dlpd_conv3d_split_pack", _ptr(w), _ptr(wp), cin, cout, ks, _stream(device))
+    else:
+        wp = torch.empty(lib.call("dlpd_conv3d_packed_floats", cin, cout, ks), dtype=torch.float32, device=device)
+        lib.call("dlpd_conv3d_pack", _ptr(w), _ptr(wp), cin, cout, ks, _stream(device))
     if cacheable:
         if len(_PACKED) > 64:
             _PACKED.clear()

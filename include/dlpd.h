@@ -245,6 +245,17 @@ int dlpd_conv3d(const float* x, const float* wp, float* y, int B, int cin, int c
 int dlpd_conv3d_strided(const float* x, const float* wp, float* y, int B, int cin, int cout, int D, int ks, int relu,
                         int stride, void* stream);
 
+/* The same convolution on the BF16 matrix cores with f32-grade results: inputs and weights are split into three bf16
+ * terms each and every product is summed from six bf16 products in f32 (the three dropped ones are below f32's own
+ * rounding): 16 / 6 = 2.7 x the matrix throughput of the exact-f32 form, results equal to it to a few 1e-7 relative.
+ * Weights are passed packed AND split: wp = dlpd_conv3d_split_pack(w (cout, cin, ks^3)), dlpd_conv3d_split_packed_bytes()
+ * bytes.  Same supported shapes as dlpd_conv3d (dlpd_conv3d_supported); stride 1 or 2.  Replaces the same reference
+ * lines (ProteinRepresentationModels.py:85-114, Docker.py:166-167). */
+size_t dlpd_conv3d_split_packed_bytes(int cin, int cout, int ks);
+int dlpd_conv3d_split_pack(const float* w, void* wp, int cin, int cout, int ks, void* stream);
+int dlpd_conv3d_split(const float* x, const void* wp, float* y, int B, int cin, int cout, int D, int ks, int relu,
+                      int stride, void* stream);
+
 /* MaxPool3d(kernel 5, stride 2, padding 2) of the E3 plugin (ProteinRepresentationModels.py:101):
  * x (nvol, D^3) -> y (nvol, Do^3), Do = (D - 1) / 2 + 1. */
 int dlpd_maxpool3d_5s2(const float* x, float* y, int nvol, int D, void* stream);

@@ -62,6 +62,7 @@ struct State {
   int live, bar_arrived;
   int wave_live[16], wave_arrived[16];
   uint64_t wave_buf[16][64];
+  unsigned char wave_wide[16][64][32];
   unsigned char* dyn_smem;
   std::function<void()> body;
 };
@@ -261,3 +262,33 @@ static inline dlpd_acc4 dlpd_emu_mfma_16x16x4(float a, float b, dlpd_acc4 acc) {
   return acc;
 }
 #define DLPD_MFMA_16x16x4(a, b, acc) dlpd_emu_mfma_16x16x4((a), (b), (acc))
+// bf16 MFMA 16x16x32 as a wave collective: lane l holds A[l&15][8*(l>>4) + j] / B[8*(l>>4) + j][l&15] (8 bf16 = 16 bytes each);
+// exact products, summed in double and rounded once (the hardware's internal order is not specified; tests use tolerances)
+static inline unsigned dlpd_f2bf(float x) {
+  unsigned u; memcpy(&u, &x, 4);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+static inline float dlpd_bf2f(unsigned h) { unsigned u = h << 16; float f; memcpy(&f, &u, 4); return f; }
+static inline dlpd_acc4 dlpd_emu_mfma_16x16x32_bf16(float4 a, float4 b, dlpd_acc4 acc) {
+  emu::State& s = emu::S();
+  const int w = s.cur / 64, l = s.cur % 64;
+  memcpy(&s.wave_wide[w][l][0], &a, 16);
+  memcpy(&s.wave_wide[w][l][16], &b, 16);
+  emu::wave_sync();
+  for (int j = 0; j < 4; j++) {
+    const int row = 4 * (l >> 4) + j, col = l & 15;
+    double sum = acc.v[j];
+    for (int k = 0; k < 32; k++) {
+      unsigned short ha, hb;
+      memcpy(&ha, &s.wave_wide[w][row + 16 * (k >> 3)][2 * (k & 7)], 2);
+      memcpy(&hb, &s.wave_wide[w][col + 16 * (k >> 3)][16 + 2 * (k & 7)], 2);
+      sum += (double)dlpd_bf2f(ha) * (double)dlpd_bf2f(hb);
+    }
+    acc.v[j] = (float)sum;
+  }
+  emu::wave_sync();
+  return acc;
+}
+#define DLPD_MFMA_16x16x32_BF16(a, b, acc) dlpd_emu_mfma_16x16x32_bf16((a), (b), (acc))
+

@@ -425,11 +425,14 @@ def test_conv3d_matches_torch_at_plugin_shapes(dev, cin, cout, ks, D):
     g = torch.Generator().manual_seed(100 + cin + D)
     x = torch.randn(2, cin, D, D, D, generator=g).to(dev)
     w = (torch.randn(cout, cin, ks, ks, ks, generator=g) * 0.05).to(dev)
-    for relu in (False, True):
-        got = ops.conv3d(x, w, relu=relu)
-        want = torch.nn.functional.conv3d(x.cpu(), w.cpu(), padding=ks // 2)
-        want = torch.relu(want) if relu else want
-        assert (got.cpu() - want).abs().max() <= 1e-5 * want.abs().max()
+    want0 = torch.nn.functional.conv3d(x.cpu().double(), w.cpu().double(), padding=ks // 2)
+    for precision in ("f32", "split_bf16"):          # exact f32 products / three bf16 terms and six products per product
+        for relu in (False, True):
+            got = ops.conv3d(x, w, relu=relu, precision=precision)
+            want = torch.relu(want0) if relu else want0
+            err = float((got.cpu().double() - want).abs().max() / want.abs().max())
+            assert err <= 1e-5, (precision, relu, err)
+    assert ops.CONV_PRECISION == "split_bf16"         # what the plugins run by default
 
 
 def test_conv3d_stride2_and_se3_plugin_never_touch_torch_convolutions(dev, monkeypatch):
@@ -441,9 +444,10 @@ def test_conv3d_stride2_and_se3_plugin_never_touch_torch_convolutions(dev, monke
     g = torch.Generator().manual_seed(7)
     x = torch.randn(2, 16, 80, 80, 80, generator=g).to(dev)
     w = (torch.randn(32, 16, 5, 5, 5, generator=g) * 0.05).to(dev)
-    got = ops.conv3d(x, w, stride=2)
     want = torch.nn.functional.conv3d(x.cpu(), w.cpu(), padding=2, stride=2)
-    assert got.shape == (2, 32, 40, 40, 40) and (got.cpu() - want).abs().max() <= 1e-5 * want.abs().max()
+    for precision in ("f32", "split_bf16"):
+        got = ops.conv3d(x, w, stride=2, precision=precision)
+        assert got.shape == (2, 32, 40, 40, 40) and (got.cpu() - want).abs().max() <= 1e-5 * want.abs().max(), precision
     torch.manual_seed(3)
     model = SE3MultiResReprScalar(multiplier=8).eval()
     vol = torch.rand(1, 11, 80, 80, 80, generator=g)

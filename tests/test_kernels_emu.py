@@ -333,32 +333,54 @@ def test_fused_two_resolution_pipeline(emu, unfused):
     assert ((V[0] - Vo).abs()[sure]).max() <= 1e-4 * Vo.abs().max()
 
 
+@pytest.mark.parametrize("precision", ["f32", "split_bf16"])
 @pytest.mark.parametrize("cin,cout,ks,D,relu", [(11, 16, 5, 6, True), (16, 32, 3, 9, False), (8, 32, 3, 17, True), (5, 48, 3, 5, False)])
-def test_conv3d_mfma_kernel_matches_torch(emu, cin, cout, ks, D, relu):
-    """The representation plugin's Conv3d (+ReLU) on the emulated f32 matrix core: channel counts that
-    are not multiples of 4 (zero-padded chunk), box sizes that are not multiples of the 4 x 4 patch or
-    of the 16-voxel z tile, both kernel sizes."""
+def test_conv3d_mfma_kernel_matches_torch(emu, cin, cout, ks, D, relu, precision):
+    """The representation plugin's Conv3d (+ReLU) on the emulated matrix cores, both arithmetic forms -- exact f32
+    products (16x16x4 f32) and three bf16 terms per value with six bf16 products per f32 product (16x16x32 bf16) --:
+    channel counts that are not multiples of the chunk (zero-padded), box sizes that are not multiples of the 4 x 4
+    patch or of the 16-voxel z tile, both kernel sizes, tap counts that are not multiples of the 4-tap group."""
     from deeplocalproteindocking_amd import ops
     g = torch.Generator().manual_seed(5 + cin)
     x = torch.randn(1, cin, D, D, D, generator=g)
     w = torch.randn(cout, cin, ks, ks, ks, generator=g) * 0.1
     assert ops.conv3d_supported(w, D, emu)
-    y = ops.conv3d(x, w, relu=relu, lib=emu)
-    want = torch.nn.functional.conv3d(x, w, padding=ks // 2)
+    y = ops.conv3d(x, w, relu=relu, lib=emu, precision=precision)
+    want = torch.nn.functional.conv3d(x.double(), w.double(), padding=ks // 2)
     want = torch.relu(want) if relu else want
-    assert (y - want).abs().max() <= 2e-5 * want.abs().max()
+    assert (y.double() - want).abs().max() <= 1e-5 * want.abs().max()
 
 
+@pytest.mark.parametrize("precision", ["f32", "split_bf16"])
 @pytest.mark.parametrize("cin,cout,ks,D", [(8, 32, 5, 8), (5, 16, 3, 9), (8, 16, 5, 7)])
-def test_conv3d_stride2_matches_torch(emu, cin, cout, ks, D):
+def test_conv3d_stride2_matches_torch(emu, cin, cout, ks, D, precision):
     """The stride-2 layer of SE3MultiResReprScalar (ProteinRepresentationModels.py:51): even and odd box sizes."""
     from deeplocalproteindocking_amd import ops
     g = torch.Generator().manual_seed(50 + cin)
     x = torch.randn(2, cin, D, D, D, generator=g)
     w = torch.randn(cout, cin, ks, ks, ks, generator=g) * 0.1
-    y = ops.conv3d(x, w, lib=emu, stride=2)
-    want = torch.nn.functional.conv3d(x, w, padding=ks // 2, stride=2)
-    assert y.shape == want.shape and (y - want).abs().max() <= 2e-5 * want.abs().max()
+    y = ops.conv3d(x, w, lib=emu, stride=2, precision=precision)
+    want = torch.nn.functional.conv3d(x.double(), w.double(), padding=ks // 2, stride=2)
+    assert y.shape == want.shape and (y.double() - want).abs().max() <= 1e-5 * want.abs().max()
+
+
+def test_three_bf16_terms_carry_a_float(emu):
+    """The split the bf16 convolution rests on: x = h + m + l with each term a bf16 reproduces a float to 2^-24 relative
+    (checked on the host with the same rounding rule the kernels use: round to nearest even on the upper 16 bits)."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.cat([torch.randn(20000, generator=g) * 10.0 ** torch.randint(-6, 6, (20000,), generator=g).float(),
+                   torch.tensor([0.0, 1.0, -1.0, 3.0e38, 1e-30, 0.1, 255.99998])])
+
+    def bf(v):
+        u = v.view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+        u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16 << 16
+        return (u & 0xFFFFFFFF).to(torch.int64).to(torch.int32).view(torch.float32) if False else \
+            torch.from_numpy((u.numpy() & 0xFFFFFFFF).astype("uint32").view("float32").copy())
+    h = bf(x)
+    m = bf(x - h)
+    l = bf(x - h - m)
+    err = ((h.double() + m.double() + l.double()) - x.double()).abs()
+    assert (err <= 2.0 ** -24 * x.double().abs() + 1e-45).all()
 
 
 def test_plugins_refuse_a_silent_torch_convolution(emu, monkeypatch):
