@@ -742,7 +742,8 @@ def e3_measurement(dev, nb, nsteps=6):
                            % (repr_.get_num_outputs(), 160, 110),
                "rotations_per_launch": nb, "ms_projection": ms_proj, "ms_representation": ms_repr, "ms_engine": ms_eng,
                "ms_per_launch": ms_all, "rot_per_s": nb / (ms_all * 1e-3), "value": nb / (ms_all * 1e-3) * (2.0 * L) ** 3,
-               "unit": "pose scores/s", "ligand_atoms": natoms, "path": "fused engine on the batch's own volumes"}
+               "unit": "pose scores/s", "ligand_atoms": natoms, "path": "fused engine on the batch's own volumes",
+               "conv_precision": __import__("deeplocalproteindocking_amd.ops", fromlist=["CONV_PRECISION"]).CONV_PRECISION}
         dk.release_engine()
         del eng
         torch.cuda.empty_cache()
