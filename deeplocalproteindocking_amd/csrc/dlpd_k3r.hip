@@ -216,7 +216,12 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
   // (round 4: TEN half-size filter waves at N = 160 -- 15 waves, 128 registers, 3 spilled -- with the transform waves dealt
   // one per SIMD, hardware waves {0, 1, 2, 3, 7}, since a workgroup's waves go to the SIMDs cyclically: K3 2.07-2.09 ms
   // against 2.00-2.03 for 5 + 5 on the real shapes, 5.5 against 4.8 at 48 ch x 80^3; transform waves first: 2.07-2.20 / 5.4;
-  // bit-identical; not kept)
+  // bit-identical; not kept.  Also round 4: FOUR transform + FOUR filter waves at N = 160 -- one wave of each role per SIMD,
+  // 256 registers per thread, a filter thread owning five voxels (two row pairs and half of a third: the tile's 1,280
+  // voxels over 256 threads; 212 registers, no spill), 8 channels per group -- K3 2.03-2.08 against 2.00-2.02 ms on the
+  // real shapes, 4.86-4.95 against 4.59-4.66 at 48 ch x 80^3, bit-identical: balancing the SIMDs buys nothing when each
+  // holds only two waves to hide the other's LDS round trips.  Every block shape tried at N = 160 (5 + 5, 5 + 10 in two
+  // role maps, 4 + 4) lands within 4 % of 2.0 ms on the real shapes.)
   const int twave = wave, fwave = wave - F;
   const int t_beg = blockIdx.x * tpb, t_end = (t_beg + tpb < ntiles) ? t_beg + tpb : ntiles;
   if (t_beg >= t_end) return;
