@@ -666,6 +666,7 @@ class Docker:
                 top = DeviceTopList(self.max_conf, nbatch, dev, self._library())
                 top.reset()
                 receptor_forbidden = receptor.sum(dim=1).unsqueeze(dim=1).contiguous()
+            ebuf = None
             for beg in range(0, len(ids), nbatch):
                 bid = ids[beg:beg + nbatch]
                 nb = len(bid)
@@ -677,8 +678,15 @@ class Docker:
                 if eng is not None:
                     vols = (ligand_volumes[0], ligand.sum(dim=1), ligand_volumes[1] if eng.C1 else None)
                     if Lc:
-                        vols = (self._embed(vols[0], Lc), self._embed(vols[1], Lc),
-                                self._embed(vols[2], Lc // 2) if eng.C1 else None)
+                        # the batch's volumes into the corner of buffers that were zeroed ONCE (not three allocations and
+                        # zero fills per batch); they stay alive with this call
+                        if ebuf is None:
+                            ebuf = [torch.zeros((nbatch,) + tuple(v.shape[1:-3]) + (le, le, le), dtype=torch.float32, device=dev)
+                                    if v is not None else None for v, le in zip(vols, (Lc, Lc, Lc // 2))]
+                        for buf, v in zip(ebuf, vols):
+                            if v is not None:
+                                buf[:nb][..., :v.shape[-3], :v.shape[-2], :v.shape[-1]] = v
+                        vols = tuple(None if buf is None else buf[:nb] for buf in ebuf)
                     eng.step(None, bid_dev, volumes=vols)
                     continue
                 ligand_forbidden = ligand.sum(dim=1).unsqueeze(dim=1).contiguous()

@@ -155,7 +155,11 @@ class IsotropicConv3d(Module):
         shells = torch.stack([torch.exp(-0.5 * ((r - k) / sigma) ** 2) for k in range(nr)])
         shells = shells * (r <= size // 2 + 0.5)                      # spherical support
         self.register_buffer("shells", shells / shells.flatten(1).norm(dim=1)[:, None, None, None])
-        self.register_buffer("dense", None)        # se3cnn's dense kernel once load_dense_kernel(exact=True) has run
+        # se3cnn's dense kernel once load_dense_kernel(exact=True) has run.  A NON-persistent attribute, kept out of the
+        # state dict on purpose: checkpoints stay loadable into a freshly constructed model (a strict load would reject
+        # an unexpected 'dense' key), the shell coefficients in ``weight`` always hold the kernel's projection, and a later
+        # load_state_dict -- new shell coefficients -- drops the dense kernel instead of being silently ignored.
+        self.dense = None
         self.weight = nn.Parameter(torch.empty(cout, cin, nr))
         # He-style scale for inputs that vary slowly across the 5^3 window (atom densities are smooth
         # and non-negative): the gain that matters is the kernel SUM, not its norm; without this the
@@ -165,8 +169,15 @@ class IsotropicConv3d(Module):
 
     def kernel(self):
         if self.dense is not None:                 # se3cnn's own kernel, handed over as it is (load_dense_kernel)
+            if self.dense.device != self.weight.device:
+                self.dense = self.dense.to(self.weight.device)
             return self.dense
         return torch.einsum("oik,kxyz->oixyz", self.weight, self.shells)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        self.dense = None                          # reloaded shell coefficients replace a handed-over dense kernel
+        state_dict.pop(prefix + "dense", None)     # (checkpoints written while 'dense' was a registered buffer)
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def load_dense_kernel(self, dense_kernel, exact=True):
         """The dense (cout, cin, size, size, size) kernel se3cnn evaluates for this layer.  exact: it is used AS IS from now

@@ -199,6 +199,10 @@ class DockingEngine:
             # The top-K takes the gathered grid; K3's candidate lists carry indices of the large grid and are not used.
             e = self.extent
             self.window = torch.tensor(list(range(0, e + 1)) + list(range(2 * int(L) - (e - 1), 2 * int(L))), dtype=torch.long, device=dev)
+            # ... as ONE flat gather index over the (2L)^3 volume (the three per-axis index_selects it replaces made
+            # three passes over the score volume per batch)
+            w, Nn = self.window, 2 * int(L)
+            self.window_flat = ((w[:, None, None] * Nn + w[None, :, None]) * Nn + w[None, None, :]).reshape(-1).contiguous()
             self.prefilter = False
         if self.use_quads:
             self.ligq = torch.empty(lib.call("dlpd_quads_floats", CT, int(L)), dtype=f32, device=dev)
@@ -527,8 +531,7 @@ class DockingEngine:
 
     def gather_window(self, V, nb):
         """(nb, N^3) scores of this engine's grid -> (nb, (2 extent)^3): the reference's grid of the embedded box."""
-        w, N = self.window, self.N
-        return V.reshape(nb, N, N, N).index_select(1, w).index_select(2, w).index_select(3, w).contiguous()
+        return V.reshape(nb, -1).index_select(1, self.window_flat)
 
     def merge_batch(self, rot_ids, nb):
         """Docker.py:100-105 on the device-resident list.  rot_ids int32 (nb,) ascending."""

@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 12 --warmup 2 --cpu_rotations 0 --no_real_shapes --sustained_s 0 $@"
+ARGS="--steps 12 --warmup 2 --cpu_rotations 0 --no_real_shapes --sustained_s 0 --strong_s 0 --gather_rotations 0 $@"
 echo "python3 bench.py $ARGS" > $OUT/command.txt
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py $ARGS > $OUT/stats.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ROOT/bench.py $ARGS > $OUT/fetch.log 2>&1

@@ -451,6 +451,15 @@ def test_se3_representation_takes_the_reference_checkpoint_as_dense_kernels():
         m.load_dense_kernels({k: v for k, v in kernels.items() if k != "sequence_res1.6"})
     with pytest.raises(Exception, match="shape mismatch"):
         m.load_dense_kernels(dict(kernels, **{"sequence_res0.0": torch.zeros(2, 11, 3, 3, 3)}))
+    # the handed-over dense kernels are not part of the state dict: a checkpoint of this model loads into a fresh one
+    # (strict), and reloading shell coefficients drops the dense kernels instead of being ignored
+    sd = m.state_dict()
+    assert not any(k.endswith("dense") for k in sd)
+    fresh = SE3MultiResReprScalar(multiplier=1)
+    fresh.load_state_dict(sd)
+    m.load_state_dict(fresh.state_dict())
+    with torch.no_grad():
+        assert torch.allclose(m(x)[0], fresh(x)[0], atol=1e-6) and not torch.allclose(m(x)[0], y, atol=1e-3)
     # radial kernels survive the projection mode too (exact=False re-parametrises on the shells)
     src = SE3MultiResReprScalar(multiplier=1)
     radial = {k: getattr(src, k.split(".")[0])[int(k.split(".")[1])].kernel().detach() for k in src.dense_kernel_contract()}
