@@ -330,8 +330,10 @@ def sharded_search(eng, R_all, ids_global, rank, world, K, dist, dev):
     import torch
     from deeplocalproteindocking_amd.Docker.Docker import all_gather_top_entries
     mine = np.sort(np.asarray(ids_global)[rank::world])
+    on_gpu = torch.device(dev).type == "cuda"               # (the CPU tests run this function on the emulated kernels + gloo)
     eng.reset_top()
-    torch.cuda.synchronize()
+    if on_gpu:
+        torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
@@ -341,7 +343,8 @@ def sharded_search(eng, R_all, ids_global, rank, world, K, dist, dev):
     if world > 1:
         ent = all_gather_top_entries(ent, K, world, None, dev)
         dist.barrier()
-    torch.cuda.synchronize()
+    if on_gpu:
+        torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)

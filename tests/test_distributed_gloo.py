@@ -94,6 +94,56 @@ def test_rank_with_empty_shard_still_joins_the_gather():
     assert len(single[0]) == 30 and {t[0] for t in single[0]} == {0}
 
 
+def _run_bench_gather(rank, world, port, out):
+    """bench.py's `gather_check` / `strong` leg (bench.sharded_search + bench.list_sha256) on the emulated kernels."""
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(1)
+    import bench
+    from emu_lib import emu_lib
+    from deeplocalproteindocking_amd.engine import DockingEngine
+    if world > 1:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    L, rec, lig, recf, ligf, filt, R = _inputs()
+    K = 25
+    eng = DockingEngine(L, 4, *filt.parameters_tuple(), clip=5.0, threshold_clash=4000.0, max_conf=K, batch=2, device="cpu",
+                        lib=emu_lib())
+    eng.set_receptor(rec[0], recf)
+    eng.set_ligand(lig[0], ligf)
+    R_all = torch.from_numpy(R)
+    ids = np.array([4, 0, 3, 1, 2])[:5]                       # a visiting order that is not the index order
+    ent, dt = bench.sharded_search(eng, R_all, ids, rank, world, K, dist if world > 1 else None, torch.device("cpu"))
+    out[rank] = (bench.list_sha256(ent), len(ent[0]), sorted(set(int(r) for r in ent[0])))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_bench_gather_check_hash_does_not_depend_on_the_world_size():
+    """What the driver's N = 1 and N = 8 bench lines are compared by: `gather_check.list_sha256` -- the same subset of
+    rotations sharded r::W, one all-gather, the deterministic merge -- must be one value for every W (here 1, 2, 3; three
+    ranks share five rotations 2 / 2 / 1)."""
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    results = {}
+    for world, base in ((2, 33100), (3, 34200)):
+        out = mgr.dict()
+        port = base + (os.getpid() % 900)
+        procs = [ctx.Process(target=_run_bench_gather, args=(r, world, port, out)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(900)
+            assert p.exitcode == 0
+        assert len({out[r][0] for r in range(world)}) == 1    # every rank holds the same merged list
+        results[world] = out[0]
+    single = {}
+    _run_bench_gather(0, 1, 0, single)
+    assert single[0][1] == 25 and len(single[0][2]) > 1
+    assert results[2] == single[0] and results[3] == single[0]
+
+
 def test_bench_spawns_its_own_ranks_when_started_as_plain_python():
     """The driver runs `python bench.py --gpus N` for its scaling sweep: the process must start the N ranks itself
     (child torch.distributed.run, 127.0.0.1 rendezvous, free port), relay rank 0's single JSON line and its exit
