@@ -221,7 +221,11 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
   // voxels over 256 threads; 212 registers, no spill), 8 channels per group -- K3 2.03-2.08 against 2.00-2.02 ms on the
   // real shapes, 4.86-4.95 against 4.59-4.66 at 48 ch x 80^3, bit-identical: balancing the SIMDs buys nothing when each
   // holds only two waves to hide the other's LDS round trips.  Every block shape tried at N = 160 (5 + 5, 5 + 10 in two
-  // role maps, 4 + 4) lands within 4 % of 2.0 ms on the real shapes.)
+  // role maps, 4 + 4) lands within 4 % of 2.0 ms on the real shapes.  So does TWO PENCIL BUFFERS (4 transform + 5 filter
+  // waves, 8 channels per group, 136 KB: the transform waves write group s + 1 while the filter waves copy group s, one
+  // barrier per group instead of two, the transform waves up to a group ahead): 2.14 against 2.115 ms, 5.01 against 4.88 at
+  // 48 ch x 80^3, bit-identical -- the filter waves' wait at "pencils ready" (22 % in the stamps) is not what a decoupled
+  // producer removes.)
   const int twave = wave, fwave = wave - F;
   const int t_beg = blockIdx.x * tpb, t_end = (t_beg + tpb < ntiles) ? t_beg + tpb : ntiles;
   if (t_beg >= t_end) return;
