@@ -60,6 +60,9 @@ template <int N> DLPD_D void init_twiddles_k3r(cplx* tw, int tid, int nthreads) 
 #ifndef DLPD_K3R_M160
 #define DLPD_K3R_M160 5
 #endif
+#ifndef DLPD_K3R_TY160
+#define DLPD_K3R_TY160 8
+#endif
 #ifndef DLPD_K3R_RAWBUF128
 #define DLPD_K3R_RAWBUF128 1
 #endif
@@ -77,7 +80,7 @@ template <int N, bool WIDE> struct K3rCfg;
 template <> struct K3rCfg<64, false> { static constexpr int F = 4, M = 4, TY = 16, RAWBUF = 2; };
 template <> struct K3rCfg<80, false> { static constexpr int F = 5, M = 5, TY = 16, RAWBUF = 2; };
 template <> struct K3rCfg<128, false> { static constexpr int F = DLPD_K3R_F128, M = 8, TY = 16, RAWBUF = DLPD_K3R_RAWBUF128; };
-template <> struct K3rCfg<160, false> { static constexpr int F = 5, M = DLPD_K3R_M160, TY = 8, RAWBUF = 1; };
+template <> struct K3rCfg<160, false> { static constexpr int F = 5, M = DLPD_K3R_M160, TY = DLPD_K3R_TY160, RAWBUF = 1; };
 template <> struct K3rCfg<80, true> { static constexpr int F = 5, M = 10, TY = 16, RAWBUF = 1; };
 template <> struct K3rCfg<128, true> { static constexpr int F = 4, M = 8, TY = 8, RAWBUF = 1; };
 template <> struct K3rCfg<160, true> { static constexpr int F = 5, M = 10, TY = 8, RAWBUF = 1; };
@@ -256,7 +259,7 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
   const int tr = lane & 7, qr = lane >> 3;     // FFT: lane = 8*pencil + thread
   // ---- filter role: voxel ownership (rows y0 + 2m, y0 + 2m + 1, column zz)
   const int tm = 64 * fwave + lane;
-  const int zz = is_fft ? 0 : tm % N, m0 = is_fft ? 0 : tm / N;
+  const int zz_ = is_fft ? 0 : tm % N, m0_ = is_fft ? 0 : tm / N;
 
   if (is_fft) {
     if (DLPD_K3R_FFT_PRIO) DLPD_SET_PRIO(DLPD_K3R_FFT_PRIO);
@@ -320,6 +323,12 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
       const int y0 = (t % NYT) * TY, xo = (t / NYT) % N, b = t / (NYT * N);
       const int gn = (CT - cbase) < G ? (CT - cbase) : G;
       const bool last_group = cbase + G >= CT;
+      // the lane's voxel coordinates re-enter every step as opaque values: what is derived from them (LDS offsets, global
+      // offsets) is then recomputed where it is used -- a few vector instructions -- instead of being hoisted out of the
+      // step loop and, at the 128 registers of the 15-wave blocks, spilled (35 spilled registers without this at width 24)
+      int zz = zz_, m0 = m0_;
+      DLPD_OPAQUE_V(zz);
+      DLPD_OPAQUE_V(m0);
       if (cbase == 0) {
         // first group of a tile: hidden pre-activations
         if (MODE == 1 && cd.keys && !cand_tau && tm == 0) cd.count[cd.nb + b] = 1u;
@@ -327,19 +336,23 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
         for (int e = 0; e < EPT * 2; e++) nrm[e] = 0.f;
         if (MODE == 1 && aux.C > 0) {
           // rows 2m, 2m+1 and columns z, z^1 of the fine grid share one coarse voxel
+          // (wave-uniform 64-bit plane bases + one 32-bit lane offset per row pair: scalar address arithmetic, so that
+          // no per-plane vector addresses are kept -- or spilled -- across the step loop)
           const int Na = aux.N;
-          const size_t cstride = (size_t)Na * Na * Na;
-          {
-            const float* ab = aux.p + (size_t)b * HP * cstride + ((size_t)(xo >> 1) * Na + (y0 >> 1)) * Na + (zz >> 1);
+          size_t cstride = (size_t)Na * Na * Na;
+          DLPD_OPAQUE_S(cstride);                // (its 24 multiples are not worth 48 scalar registers across the loop either)
+          const float* ub = aux.p + (size_t)b * HP * cstride + ((size_t)(xo >> 1) * Na + (y0 >> 1)) * Na;
+          unsigned lo[EPT];
 #pragma unroll
-            for (int e = 0; e < EPT; e++)
+          for (int e = 0; e < EPT; e++) lo[e] = (unsigned)((m0 + e * MSTEP) * Na + (zz >> 1));
 #pragma unroll
-              for (int j = 0; j < HP; j++) {
-                const float v = ab[(size_t)j * cstride + (size_t)(m0 + e * MSTEP) * Na];
-                h[2 * e][j] = v;
-                h[2 * e + 1][j] = v;
-              }
-          }
+          for (int e = 0; e < EPT; e++)
+#pragma unroll
+            for (int j = 0; j < HP; j++) {
+              const float v = (ub + (size_t)j * cstride)[lo[e]];
+              h[2 * e][j] = v;
+              h[2 * e + 1][j] = v;
+            }
         } else {
 #pragma unroll
           for (int e = 0; e < EPT * 2; e++)
@@ -414,7 +427,7 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
               {
 #pragma unroll
                 for (int j = 0; j < HP; j++)
-                  out[((((size_t)b * HP + j) * N + xo) * N + y0 + 2 * m + u) * N + zz] = h[2 * e + u][j];
+                  (out + ((((size_t)b * HP + j) * N + xo) * N + y0) * N)[(unsigned)((2 * m + u) * N + zz)] = h[2 * e + u][j];
               }
             }
           }
@@ -428,7 +441,7 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
 #pragma unroll
               for (int j = 0; j < HP; j++) acc = fmaf(W2[j], fmaxf(h[2 * e + u][j], 0.f), acc);
               if (has_clash) acc = acc * ((nrm[2 * e + u] < thr) ? 1.0f : 0.0f);
-              out[(((size_t)b * N + xo) * N + y0 + 2 * m + u) * N + zz] = acc;
+              (out + (((size_t)b * N + xo) * N + y0) * N)[(unsigned)((2 * m + u) * N + zz)] = acc;
               if (cd.keys && cand_tau) k3_emit(cd, cand_tau, b, (unsigned)((xo * N + y0 + 2 * m + u) * N + zz), acc);
             }
           }

@@ -65,6 +65,10 @@ __device__ __forceinline__ float2 dlpd_load_stream_c(const float2* p) {
 #define DLPD_CLAMP(v, c) __builtin_amdgcn_fmed3f((v), -(c), (c))
 // keeps the compiler from moving instructions across this point (software-pipelined loops)
 #define DLPD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// value barriers for the optimiser: x leaves as "some vector / scalar register value" -- nothing computed from it is
+// loop-invariant or shared with code before this point (no instruction is emitted)
+#define DLPD_OPAQUE_V(x) asm volatile("" : "+v"(x))
+#define DLPD_OPAQUE_S(x) asm volatile("" : "+s"(x))
 // make a lane-dependent int opaque to the optimiser at this point: stops loop-invariant code motion
 // from hoisting dozens of swizzled LDS offsets out of the pencil-set loops (they are cheap to
 // recompute and expensive to keep in VGPRs)
