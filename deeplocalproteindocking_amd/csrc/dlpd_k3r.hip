@@ -58,10 +58,13 @@ template <int N> DLPD_D void init_twiddles_k3r(cplx* tw, int tid, int nthreads) 
 #define DLPD_K3R_F128 4
 #endif
 #ifndef DLPD_K3R_M160
-#define DLPD_K3R_M160 5
+#define DLPD_K3R_M160 10
 #endif
 #ifndef DLPD_K3R_TY160
-#define DLPD_K3R_TY160 8
+#define DLPD_K3R_TY160 16
+#endif
+#ifndef DLPD_K3R_PBUF160
+#define DLPD_K3R_PBUF160 2
 #endif
 #ifndef DLPD_K3R_RAWBUF128
 #define DLPD_K3R_RAWBUF128 1
@@ -77,13 +80,13 @@ template <int N> DLPD_D void init_twiddles_k3r(cplx* tw, int tid, int nthreads) 
 // 48 ch x 64^3); at N = 160 it spills 35 and loses (2.92 vs 2.38 ms on the real shapes) -- measured in round 4.
 template <int N> struct K3rWideAbove { static constexpr int value = (N == 160) ? 24 : 32; };
 template <int N, bool WIDE> struct K3rCfg;
-template <> struct K3rCfg<64, false> { static constexpr int F = 4, M = 4, TY = 16, RAWBUF = 2; };
-template <> struct K3rCfg<80, false> { static constexpr int F = 5, M = 5, TY = 16, RAWBUF = 2; };
-template <> struct K3rCfg<128, false> { static constexpr int F = DLPD_K3R_F128, M = 8, TY = 16, RAWBUF = DLPD_K3R_RAWBUF128; };
-template <> struct K3rCfg<160, false> { static constexpr int F = 5, M = DLPD_K3R_M160, TY = DLPD_K3R_TY160, RAWBUF = 1; };
-template <> struct K3rCfg<80, true> { static constexpr int F = 5, M = 10, TY = 16, RAWBUF = 1; };
-template <> struct K3rCfg<128, true> { static constexpr int F = 4, M = 8, TY = 8, RAWBUF = 1; };
-template <> struct K3rCfg<160, true> { static constexpr int F = 5, M = 10, TY = 8, RAWBUF = 1; };
+template <> struct K3rCfg<64, false> { static constexpr int F = 4, M = 4, TY = 16, RAWBUF = 2, PBUF = 1; };
+template <> struct K3rCfg<80, false> { static constexpr int F = 5, M = 5, TY = 16, RAWBUF = 2, PBUF = 1; };
+template <> struct K3rCfg<128, false> { static constexpr int F = DLPD_K3R_F128, M = 8, TY = 16, RAWBUF = DLPD_K3R_RAWBUF128, PBUF = 1; };
+template <> struct K3rCfg<160, false> { static constexpr int F = 5, M = DLPD_K3R_M160, TY = DLPD_K3R_TY160, RAWBUF = 1, PBUF = DLPD_K3R_PBUF160; };
+template <> struct K3rCfg<80, true> { static constexpr int F = 5, M = 10, TY = 16, RAWBUF = 1, PBUF = 1; };
+template <> struct K3rCfg<128, true> { static constexpr int F = 4, M = 8, TY = 8, RAWBUF = 1, PBUF = 1; };
+template <> struct K3rCfg<160, true> { static constexpr int F = 5, M = 10, TY = 8, RAWBUF = 1, PBUF = 1; };
 
 #ifdef DLPD_STAMPS
 __device__ unsigned long long dlpd_stamps_k3r[32];
@@ -207,12 +210,16 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
   constexpr int NTM = 64 * M;                  // filter threads
   constexpr int EPT = (NPAIR * N) / NTM;       // complex values (voxel pairs: rows 2m, 2m+1) per filter thread and channel
   constexpr int MSTEP = NTM / N;               // pair stride between a thread's values
-  constexpr int RAWC = ((NZ * NPAIR + 63) / 64) * 64;    // float4 slots per raw channel (whole waves)
+  constexpr int PBUF = Cfg::PBUF;              // pencil buffers (2: see "TWO PENCIL BUFFERS" below)
+  constexpr int PSZ = F * 8 * RS;              // complex elements per pencil buffer
+  // float4 slots per raw channel: whole waves, or -- where two pencil buffers leave no room -- exactly the channel, the last
+  // DMA instruction then running on NPAIR lanes only
+  constexpr int RAWC = (PBUF == 2) ? NZ * NPAIR : ((NZ * NPAIR + 63) / 64) * 64;
   static_assert(NPAIR == 8 || NPAIR == 4, "one transform wave = 8 pencils x 8 threads");
   static_assert(EPT >= 1 && EPT * NTM == NPAIR * N && NTM % N == 0, "the filter waves tile the voxels exactly");
   static_assert(NZ * NPAIR == NFULL * 64 + NPAIR, "raw channel = NFULL full DMA instructions + one short one");
   DLPD_DYN_SHARED(cplx, S);
-  cplx* tw = S + F * 8 * RS;
+  cplx* tw = S + PBUF * PSZ;
   float4* raw = reinterpret_cast<float4*>(tw + N);        // [RAWBUF][F][CPW][RAWC]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool is_fft = wave < F;
@@ -252,7 +259,7 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
 #pragma unroll
         for (int it = 0; it < NFULL; it++) DLPD_GLDS16(lane_src + (size_t)it * LPK * N * N, rj + it * 64);
         const int mt = lane % NPAIR;                        // tail lanes re-read valid elements
-        DLPD_GLDS16(src + (size_t)(N / 2) * N * N + 2 * mt, rj + NFULL * 64);
+        if (PBUF == 1 || lane < NPAIR) DLPD_GLDS16(src + (size_t)(N / 2) * N * N + 2 * mt, rj + NFULL * 64);
       }
     }
   };
@@ -276,6 +283,7 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
   if (is_fft) {
     // ================= transform waves: raw -> pencils of group (t, cbase) =================
     int t = t_beg, cbase = 0, rb = 0;
+    cplx* P = S;                               // this step's pencil buffer
 #pragma unroll 1
     for (int step = 0; step < nsteps; step++) {
       const int gn = (CT - cbase) < G ? (CT - cbase) : G;
@@ -298,17 +306,22 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
       // (a wave whose second channel lies beyond the group transforms stale staging data into pencils nobody reads)
       if (mine) {
         const int m = qr % NPAIR, j = qr / NPAIR;
-        k3r_first_pass<N, NPAIR>(S, (twave * 8 + qr) * RS, tr, m, rawg + rb * (F * CPW * RAWC) + j * RAWC);
+        k3r_first_pass<N, NPAIR>(P, (twave * 8 + qr) * RS, tr, m, rawg + rb * (F * CPW * RAWC) + j * RAWC);
         DLPD_WAVE_SYNC();                      // every lane's raw values are in registers: the staging buffer is free
       }
       DLPD_STAMP(1);
       if (RAWBUF == 1 && nt < t_end) issue_channel(nt, ncb, 0);
-      if (mine) k3r_second_pass<N>(S, (twave * 8 + qr) * RS, tr, tw);
+      if (mine) k3r_second_pass<N>(P, (twave * 8 + qr) * RS, tr, tw);
       DLPD_STAMP(2);
       if (RAWBUF == 2) rb ^= 1;
       DLPD_LDS_BARRIER();                      // B1
       DLPD_STAMP(3);
-      DLPD_LDS_BARRIER();                      // B2
+      if (PBUF == 2) {
+        // the other buffer: the filter waves finished reading it before they arrived at this barrier
+        P = (P == S) ? S + PSZ : S;
+      } else {
+        DLPD_LDS_BARRIER();                    // B2
+      }
       DLPD_STAMP(4);
       if (last_group) { cbase = 0; t++; } else cbase += G;
     }
@@ -316,7 +329,8 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
     // ================= filter waves =================
     float nrm[EPT * 2];
     float h[EPT * 2][HP];
-    cplx vals[GMAX][EPT];
+    cplx vals[PBUF == 2 ? 1 : GMAX][EPT];
+    const cplx* P = S;
     int t = t_beg, cbase = 0;
 #pragma unroll 1
     for (int step = 0; step < nsteps; step++) {
@@ -365,24 +379,67 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
       DLPD_STAMP(1);
       // score channels of this group; the clash channel (index C, always last) is peeled off
       const int gs = (cbase + gn <= C) ? gn : (C - cbase > 0 ? C - cbase : 0);
+      if (PBUF == 1) {
 #pragma unroll
-      for (int g = 0; g < GMAX; g++)
-        if (g < gs) {
+        for (int g = 0; g < GMAX; g++)
+          if (g < gs) {
 #pragma unroll
-          for (int e = 0; e < EPT; e++) vals[g][e] = S[(g * NPAIR + m0 + e * MSTEP) * RS + pencil_out_pos<N>(zz)];
-        }
+            for (int e = 0; e < EPT; e++) vals[g][e] = S[(g * NPAIR + m0 + e * MSTEP) * RS + pencil_out_pos<N>(zz)];
+          }
+      }
       if (MODE == 1 && has_clash && cbase + gn > C) {
         const int g = C - cbase;
 #pragma unroll
         for (int e = 0; e < EPT; e++) {
-          const cplx v = S[(g * NPAIR + m0 + e * MSTEP) * RS + pencil_out_pos<N>(zz)];
+          const cplx v = P[(g * NPAIR + m0 + e * MSTEP) * RS + pencil_out_pos<N>(zz)];
           nrm[2 * e] = v.x;
           nrm[2 * e + 1] = v.y;
         }
       }
-      DLPD_LDS_BARRIER();                      // B2: values held in registers, pencils free for the next group
+      if (PBUF == 1) DLPD_LDS_BARRIER();       // B2: values held in registers, pencils free for the next group
       DLPD_STAMP(2);
-      {
+      if (PBUF == 2) {
+        // TWO PENCIL BUFFERS: the values are read where they are used -- this buffer stays untouched until these waves
+        // arrive at the next step's barrier (the transform waves work on the other one) -- so no copy phase, no second
+        // barrier and no values held in registers (20 of them at 5 channels per group); channel g + 1's values and weights
+        // are requested before channel g's multiply-adds
+        const cplx* pv = P + (m0 * RS + pencil_out_pos<N>(zz));
+        float wcur[HP], wnxt[HP];
+        cplx vcur[EPT], vnxt[EPT];
+        if (gs > 0) {
+#pragma unroll
+          for (int j = 0; j < HP; j++) wcur[j] = W1t[(size_t)cbase * HP + j];
+#pragma unroll
+          for (int e = 0; e < EPT; e++) vcur[e] = pv[e * MSTEP * RS];
+        }
+#pragma unroll
+        for (int g = 0; g < GMAX; g++) {
+          if (g < gs) {
+            const int gn1 = (g + 1 < gs ? g + 1 : g);
+#pragma unroll
+            for (int j = 0; j < HP; j++) wnxt[j] = W1t[(size_t)(cbase + gn1) * HP + j];
+#pragma unroll
+            for (int e = 0; e < EPT; e++) vnxt[e] = pv[(gn1 * NPAIR + e * MSTEP) * RS];
+            DLPD_SCHED_FENCE();
+#pragma unroll
+            for (int e = 0; e < EPT; e++) {
+              float v0 = vcur[e].x, v1 = vcur[e].y;
+              if (has_clip) { v0 = DLPD_CLAMP(v0, clip); v1 = DLPD_CLAMP(v1, clip); }
+#pragma unroll
+              for (int j = 0; j < HP; j++) {
+                h[2 * e][j] = fmaf(wcur[j], v0, h[2 * e][j]);
+                h[2 * e + 1][j] = fmaf(wcur[j], v1, h[2 * e + 1][j]);
+              }
+            }
+            DLPD_SCHED_FENCE();
+#pragma unroll
+            for (int j = 0; j < HP; j++) wcur[j] = wnxt[j];
+#pragma unroll
+            for (int e = 0; e < EPT; e++) vcur[e] = vnxt[e];
+          }
+        }
+        P = (P == S) ? S + PSZ : S;
+      } else {
         // first-layer weights are wave-uniform (scalar loads): channel g+1's row is requested before channel g's FMAs
         // (round 4: the row in two halves for widths >= 32, HP scalar registers for the two buffers instead of 2 HP: the
         // vector spills of <128, 32> / <160, 48> are the 128 / 96 accumulators themselves, 11 / 23 against 9 / 21 -- not kept)
@@ -478,8 +535,8 @@ template <int N, int HP, int MODE> static int launch_k3r(const cplx* Bw, float* 
                                                          K3Cand cd) {
   typedef K3rCfg<N, (HP > K3rWideAbove<N>::value)> Cfg;
   constexpr int RS = N + 8, NZ = N / 2 + 1, NPAIR = Cfg::TY / 2, CPW = 8 / NPAIR;
-  constexpr int RAWC = ((NZ * NPAIR + 63) / 64) * 64;
-  const size_t shmem = (size_t)(Cfg::F * 8 * RS + N) * sizeof(cplx) + (size_t)Cfg::RAWBUF * Cfg::F * CPW * RAWC * 16;
+  constexpr int RAWC = (Cfg::PBUF == 2) ? NZ * NPAIR : ((NZ * NPAIR + 63) / 64) * 64;
+  const size_t shmem = (size_t)(Cfg::PBUF * Cfg::F * 8 * RS + N) * sizeof(cplx) + (size_t)Cfg::RAWBUF * Cfg::F * CPW * RAWC * 16;
   int rc = dlpd_set_max_dyn_shared((const void*)k_zifft_filter_rs<N, HP, MODE>, shmem);
   if (rc) return rc;
   const int G = k3r_group(CT, Cfg::F * CPW, true);
