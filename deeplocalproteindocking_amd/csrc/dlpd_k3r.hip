@@ -246,7 +246,7 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
   //      raw[k][m] <- Bw[b][cb + wave*CPW + j][k][xo][y0+2m .. +1]   (lane = NPAIR*(k % LPK) + m: LPK runs of NPAIR*16
   //      bytes per DMA instruction; k = N/2 is the last, short one)
   float4* rawg = raw + twave * CPW * RAWC;
-  auto issue_channel = [&](int t, int cb, int buf) {
+  auto issue_channel = [&](int t, int cb, int buf, int lane) {
     const int ty0 = (t % NYT) * TY, txo = (t / NYT) % N, tb = t / (NYT * N);
 #pragma unroll
     for (int j = 0; j < CPW; j++) {
@@ -263,14 +263,13 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
       }
     }
   };
-  const int tr = lane & 7, qr = lane >> 3;     // FFT: lane = 8*pencil + thread
   // ---- filter role: voxel ownership (rows y0 + 2m, y0 + 2m + 1, column zz)
   const int tm = 64 * fwave + lane;
   const int zz_ = is_fft ? 0 : tm % N, m0_ = is_fft ? 0 : tm / N;
 
   if (is_fft) {
     if (DLPD_K3R_FFT_PRIO) DLPD_SET_PRIO(DLPD_K3R_FFT_PRIO);
-    issue_channel(t_beg, 0, 0);
+    issue_channel(t_beg, 0, 0, lane);
   }
   DLPD_LDS_BARRIER();                          // twiddle table visible
   DLPD_STAMP_DECL;
@@ -289,6 +288,11 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
       const int gn = (CT - cbase) < G ? (CT - cbase) : G;
       const bool last_group = cbase + G >= CT;
       const bool mine = twave * CPW < gn;
+      // (the lane index re-enters every step as an opaque value, as the voxel coordinates of the filter waves do: the
+      // addresses derived from it are recomputed per step instead of being kept -- at 128 registers: spilled -- across it)
+      int ln = lane;
+      if (F + M > 12) DLPD_OPAQUE_V(ln);
+      const int tr = ln & 7, qr = ln >> 3;     // FFT: lane = 8*pencil + thread
       if (mine) {
         DLPD_WAIT_VMEM();                      // this wave's own DMA has landed
         DLPD_WAVE_SYNC();
@@ -296,7 +300,7 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
       DLPD_STAMP(0);
       // the next group of this tile, or the first group of the next tile
       const int nt = last_group ? t + 1 : t, ncb = last_group ? 0 : cbase + G;
-      if (RAWBUF == 2 && nt < t_end) issue_channel(nt, ncb, rb ^ 1);
+      if (RAWBUF == 2 && nt < t_end) issue_channel(nt, ncb, rb ^ 1, ln);
       // FIRST PASS STRAIGHT FROM THE RAW SPECTRA.  A pencil holds two real rows as one complex sequence,
       // Z[k] = A[k] + i B[k], Z[N-k] = conj(A[k]) + i conj(B[k]) (k <= N/2; A, B the Hermitian half-spectra of rows
       // 2m, 2m+1).  Thread t of the first pass (radix R1 = N/8, butterfly t) needs Z[t + 8r], r < R1: the first half
@@ -310,7 +314,7 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
         DLPD_WAVE_SYNC();                      // every lane's raw values are in registers: the staging buffer is free
       }
       DLPD_STAMP(1);
-      if (RAWBUF == 1 && nt < t_end) issue_channel(nt, ncb, 0);
+      if (RAWBUF == 1 && nt < t_end) issue_channel(nt, ncb, 0, ln);
       if (mine) k3r_second_pass<N>(P, (twave * 8 + qr) * RS, tr, tw);
       DLPD_STAMP(2);
       if (RAWBUF == 2) rb ^= 1;
@@ -509,7 +513,8 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
     }
   }
 #ifdef DLPD_STAMPS
-  if (lane == 0 && ((is_fft && twave == 0) || (!is_fft && fwave == 0))) {
+  // (-DDLPD_STAMPS=<w>: transform wave w % F and filter wave w % M report)
+  if (lane == 0 && ((is_fft && twave == (DLPD_STAMPS) % F) || (!is_fft && fwave == (DLPD_STAMPS) % M))) {
     const int o = is_fft ? 0 : 16;
     for (int i_ = 0; i_ < 8; i_++) atomicAdd(&dlpd_stamps_k3r[o + i_], st_sum[i_]);
     atomicAdd(&dlpd_stamps_k3r[o + 15], 1ull);
