@@ -63,6 +63,9 @@ template <int N> DLPD_D void init_twiddles_k3r(cplx* tw, int tid, int nthreads) 
 #ifndef DLPD_K3R_TY160
 #define DLPD_K3R_TY160 16
 #endif
+#ifndef DLPD_K3R_PBUF128
+#define DLPD_K3R_PBUF128 1
+#endif
 #ifndef DLPD_K3R_PBUF160
 #define DLPD_K3R_PBUF160 2
 #endif
@@ -82,7 +85,7 @@ template <int N> struct K3rWideAbove { static constexpr int value = (N == 160) ?
 template <int N, bool WIDE> struct K3rCfg;
 template <> struct K3rCfg<64, false> { static constexpr int F = 4, M = 4, TY = 16, RAWBUF = 2, PBUF = 1; };
 template <> struct K3rCfg<80, false> { static constexpr int F = 5, M = 5, TY = 16, RAWBUF = 2, PBUF = 1; };
-template <> struct K3rCfg<128, false> { static constexpr int F = DLPD_K3R_F128, M = 8, TY = 16, RAWBUF = DLPD_K3R_RAWBUF128, PBUF = 1; };
+template <> struct K3rCfg<128, false> { static constexpr int F = DLPD_K3R_F128, M = 8, TY = 16, RAWBUF = DLPD_K3R_RAWBUF128, PBUF = DLPD_K3R_PBUF128; };
 template <> struct K3rCfg<160, false> { static constexpr int F = 5, M = DLPD_K3R_M160, TY = DLPD_K3R_TY160, RAWBUF = 1, PBUF = DLPD_K3R_PBUF160; };
 template <> struct K3rCfg<80, true> { static constexpr int F = 5, M = 10, TY = 16, RAWBUF = 1, PBUF = 1; };
 template <> struct K3rCfg<128, true> { static constexpr int F = 4, M = 8, TY = 8, RAWBUF = 1, PBUF = 1; };
