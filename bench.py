@@ -82,6 +82,8 @@ def parse_args():
                     help="untimed extra `gather_check`: the first n rotations of the visiting sequence, sharded r::W, one "
                          "all-gather + merge; the list hash must not depend on the world size (0: skip)")
     ap.add_argument("--no_extras", action="store_true", help="skip the c48l80 and e3 extra objects of the default line")
+    ap.add_argument("--natural_receptor", action="store_true",
+                    help="A/B switch: K2 of boxes 80 / 40 reads the receptor spectrum in its natural layout (not the packed copy)")
     ap.add_argument("--k3_form", type=int, default=0, choices=(0, 1, 2),
                     help="kernel formulation of the fused K3 (include/dlpd.h, dlpd_zifft_filter_form): 0 = library default")
     ap.add_argument("--dry_run", action="store_true",
@@ -283,7 +285,8 @@ def build_workload(name, args, dev):
         W = (torch.randn(H, Ct, generator=g) * (2.0 / (H + Ct)) ** 0.5, torch.zeros(H), torch.randn(1, H, generator=g) * (2.0 / (H + 1)) ** 0.5,
              torch.zeros(1))
     eng = DockingEngine(L, C, *W, clip=5.0, threshold_clash=thr, has_clash=True, max_conf=args.max_conf,
-                        batch=args.batch, device=dev, coarse_channels=C1, k3_form=args.k3_form)
+                        batch=args.batch, device=dev, coarse_channels=C1, k3_form=args.k3_form,
+                        packed_receptor=not getattr(args, "natural_receptor", False))
     eng.set_receptor(rec[0], recf, rec[1] if C1 else None)
     eng.set_ligand(lig[0], ligf, lig[1] if C1 else None)
     return eng, dict(C=C, L=L, C1=C1, angle=angle, desc=desc, rec=rec, lig=lig, recf=recf, ligf=ligf, W=W, thr=thr)

@@ -33,6 +33,9 @@ SIGNATURES = {
     "dlpd_project_atoms_ext": (_i, [_p, _p, _p, _p, _f, _f, _f, _p, _i, _i, _i, _i, _f, _i, _f, _i, _f, _f, _p]),
     "dlpd_rfft3d_padded": (_i, [_p, _p, _p, _i, _i, _f, _p]),
     "dlpd_xy_correlate": (_i, [_p, _p, _p, _i, _i, _i, _ll, _p]),
+    "dlpd_receptor_packed_floats": (_ll, [_i, _i]),
+    "dlpd_receptor_pack": (_i, [_p, _p, _i, _i, _p]),
+    "dlpd_xy_correlate_packed": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "dlpd_quads_floats": (ctypes.c_size_t, [_i, _i]),
     "dlpd_make_quads": (_i, [_p, _p, _i, _i, _p]),
     "dlpd_zfft_quads": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),

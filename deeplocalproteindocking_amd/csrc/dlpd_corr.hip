@@ -1285,6 +1285,9 @@ int dlpd_k2_forward(const cplx* A, cplx* out, int CT, int nb, int L, float scale
 int dlpd_k2_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, int L, long long rbs, hipStream_t st,
                       int transposed = 0);
 int dlpd_k2_orientation_supported(int L);
+long long dlpd_k2_packed_receptor_floats(int CT, int L);
+int dlpd_k2_pack_receptor(const cplx* rec, void* packed, int CT, int L, hipStream_t st);
+int dlpd_k2_correlate_packed(const cplx* A, const cplx* packed, cplx* out, int CT, int nb, int L, hipStream_t st);
 
 // channels per group.  One channel per wave (16-row tiles, N <= 128): as many as there are channel-owning waves -- 49
 // channels on 8 waves are six full groups and one with the clash channel alone, 1 % faster than seven groups of seven,
@@ -1516,6 +1519,17 @@ int dlpd_xy_correlate_oriented(const void* wsA, const void* rec, void* wsB, int 
 int dlpd_xy_correlate(const void* wsA, const void* rec, void* wsB, int nb, int CT, int L, long long rec_bstride,
                       void* stream) {
   return dlpd_xy_correlate_oriented(wsA, rec, wsB, nb, CT, L, rec_bstride, 0, stream);
+}
+
+// One receptor for the whole batch, re-ordered once (dlpd_receptor_pack) into the order K2 reads it: boxes 80 and 40
+long long dlpd_receptor_packed_floats(int CT, int L) { return dlpd_k2_packed_receptor_floats(CT, L); }
+int dlpd_receptor_pack(const void* rec, void* packed, int CT, int L, void* stream) {
+  if (!rec || !packed || CT <= 0) return DLPD_ERR_ARG;
+  return dlpd_k2_pack_receptor((const cplx*)rec, packed, CT, L, (hipStream_t)stream);
+}
+int dlpd_xy_correlate_packed(const void* wsA, const void* rec_packed, void* wsB, int nb, int CT, int L, void* stream) {
+  if (!wsA || !rec_packed || !wsB || nb <= 0 || CT <= 0) return DLPD_ERR_ARG;
+  return dlpd_k2_correlate_packed((const cplx*)wsA, (const cplx*)rec_packed, (cplx*)wsB, CT, nb, L, (hipStream_t)stream);
 }
 
 // wsB -> real correlation volumes out (nb, CT, N^3), optional clamp

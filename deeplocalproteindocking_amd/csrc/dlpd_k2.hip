@@ -722,7 +722,8 @@ int dlpd_k2_forward(const cplx* A, cplx* out, int CT, int nb, int L, float scale
 
 // N = 160 with 4-lane pencils and affine LDS addressing: dlpd_k2q.hip (untransposed slabs)
 int dlpd_k2q_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, int L, long long rbs, int nsplit_override,
-                       hipStream_t st);
+                       hipStream_t st, int packed);
+int dlpd_k2q_pack_receptor(const cplx* rec, void* packed, int CT, int L, hipStream_t st);
 #ifndef DLPD_K2_Q4
 #define DLPD_K2_Q4 1
 #endif
@@ -733,7 +734,7 @@ int dlpd_k2q_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb
 int dlpd_k2_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, int L, long long rbs, hipStream_t st,
                       int transposed) {
   if (((DLPD_K2_Q4 && L == 80) || (DLPD_K2_S4 && L == 40)) && !transposed)
-    return dlpd_k2q_correlate(A, rec, out, CT, nb, L, rbs, k2_nsplit_override(), st);
+    return dlpd_k2q_correlate(A, rec, out, CT, nb, L, rbs, k2_nsplit_override(), st, 0);
   switch (L) {
     case 32: return launch_k2<64, 1>(A, rec, out, CT, nb, rbs, 1.f, st, transposed);
     case 40: return launch_k2<80, 1>(A, rec, out, CT, nb, rbs, 1.f, st, transposed);
@@ -743,6 +744,21 @@ int dlpd_k2_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb,
 #endif
     default: return DLPD_ERR_UNSUPPORTED;
   }
+}
+
+// The receptor spectrum re-ordered for the grids whose K2 re-reads it for every rotation (the 4-lane-pencil kernels of
+// dlpd_k2q.hip; the N = 64 / 128 kernels hold their receptor values in registers across the batch and take the natural layout)
+long long dlpd_k2_packed_receptor_floats(int CT, int L) {
+  if (!((DLPD_K2_Q4 && L == 80) || (DLPD_K2_S4 && L == 40)) || CT <= 0) return 0;
+  return (long long)CT * (L + 1) * (2 * L) * (2 * L) * 2;
+}
+int dlpd_k2_pack_receptor(const cplx* rec, void* packed, int CT, int L, hipStream_t st) {
+  if (!dlpd_k2_packed_receptor_floats(CT, L)) return DLPD_ERR_UNSUPPORTED;
+  return dlpd_k2q_pack_receptor(rec, packed, CT, L, st);
+}
+int dlpd_k2_correlate_packed(const cplx* A, const cplx* packed, cplx* out, int CT, int nb, int L, hipStream_t st) {
+  if (!dlpd_k2_packed_receptor_floats(CT, L)) return DLPD_ERR_UNSUPPORTED;
+  return dlpd_k2q_correlate(A, packed, out, CT, nb, L, 0, k2_nsplit_override(), st, 1);
 }
 
 // Slabs that K1 stored transposed (dlpd_zfft_oriented, the per-channel K1 of ligands with fewer than 8 channels): every

@@ -178,7 +178,9 @@ template <int ES> struct Q4 {
 //   rec  (CT, NZ, N, N) complex [kz][kx][ky], times 1/N^3; rec_bstride: element stride between batch entries (0: shared)
 //   out  (nb, CT, NZ, N, N) complex [kz][x'][y'] = IFFT2( rec * conj(FFT2(pad(A))) )   (unnormalised inverse)
 //   grid NZ*CT*nsplit (XCD-aware decode as in k_xy_corr), block 640 threads, persistent over its part of the batch
-template <int N> __global__ void __launch_bounds__(640)
+//   PACKED: rec is the receptor spectrum re-ordered by k_pack_rec_q4 (below) -- every wave's 20 values per lane as twenty
+//   contiguous half-kilobytes per (slab, p) -- instead of the natural [kz][kx][ky]
+template <int N, bool PACKED> __global__ void __launch_bounds__(640)
 k_xy_corr_q4(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __restrict__ out,
              int CT, int nb, int nsplit, long long rec_bstride) {
   constexpr int L = N / 2, H = N / 2, NZ = N / 2 + 1;
@@ -263,12 +265,23 @@ k_xy_corr_q4(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __r
       // (DLPD_K2Q_RV_LATE: requested behind the first column pass instead -- 40 registers less under the radix-20 butterfly)
       cplx rv[5][4];
       auto fetch_rec = [&]() {
-        const cplx* rb = rec + (size_t)b * rec_bstride + (((size_t)c * NZ + kz) * N + p) * N + (2 * ccol + cq) +
-                         (size_t)(2 * N) * t;
+        if constexpr (PACKED) {
+          // natural layout: lane (t, column 2 ccol + cq) reads rows 2 (t + 4 i + 20 r) + p -- eight lanes share a 64-byte
+          // run, every instruction touches eight half lines (measured: the loads cost 0.45 of K2's 2.40 ms at the real
+          // shapes); packed: 512 contiguous bytes per instruction
+          const cplx* rp = rec + ((((size_t)c * NZ + kz) * 2 + p) * W + DLPD_UNIFORM(wave)) * 1280;
 #pragma unroll
-        for (int i = 0; i < 5; i++)
+          for (int i = 0; i < 5; i++)
 #pragma unroll
-          for (int r = 0; r < 4; r++) rv[i][r] = rb[(unsigned)(2 * N * (4 * i + 20 * r))];
+            for (int r = 0; r < 4; r++) rv[i][r] = rp[(unsigned)((4 * i + r) * 64 + lane)];
+        } else {
+          const cplx* rb = rec + (size_t)b * rec_bstride + (((size_t)c * NZ + kz) * N + p) * N + (2 * ccol + cq) +
+                           (size_t)(2 * N) * t;
+#pragma unroll
+          for (int i = 0; i < 5; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) rv[i][r] = rb[(unsigned)(2 * N * (4 * i + 20 * r))];
+        }
       };
       if (!DLPD_K2Q_RV_LATE) fetch_rec();
       DLPD_LDS_BARRIER();                              // all rows y-transformed
@@ -375,7 +388,15 @@ k_xy_corr_q4(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __r
 // column passes overwrite them), owns 16 columns of the column phase, and rows 16w..16w+15 of the inverse y transform,
 // which it also copies out; two block barriers per slab.
 // ------------------------------------------------------------------------------------------------------------------
-template <int N> __global__ void __launch_bounds__(320)
+// column of lane group `pidx` of wave `wave` in the column phase of k_xy_corr_s4 (shared with the receptor packing)
+DLPD_HD int k2s4_column(int wave, int pidx) {
+  // pairs of 4-column blocks 16 eight-byte columns apart (mod 32) share a 32-lane read group; the last wave's
+  // blocks 16..19 have no such partner (a 2-way conflict on an eighth of its loads)
+  const int pr = 2 * wave + (pidx >> 3);
+  const int blk = (pr < 8) ? ((pr & 3) + 8 * (pr >> 2) + 4 * ((pidx >> 2) & 1)) : (16 + 2 * (pr - 8) + ((pidx >> 2) & 1));
+  return 4 * blk + (pidx & 3);
+}
+template <int N, bool PACKED> __global__ void __launch_bounds__(320)
 k_xy_corr_s4(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __restrict__ out,
              int CT, int nb, int nsplit, long long rec_bstride) {
   constexpr int L = N / 2, NZ = N / 2 + 1, RS = N + 4, HR = N + 4;
@@ -401,11 +422,7 @@ k_xy_corr_s4(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __r
   const int fbase = ((pidx >> 3) * L + 8 * wave + (pidx & 7)) * RS;
   // inverse rows: 16w .. 16w + 15
   const int ibase = (16 * wave + pidx) * RS;
-  // columns: pairs of 4-column blocks 16 eight-byte columns apart (mod 32) share a 32-lane read group; the last wave's
-  // blocks 16..19 have no such partner (a 2-way conflict on an eighth of its loads)
-  const int pr = 2 * wave + (pidx >> 3);
-  const int blk = (pr < 8) ? ((pr & 3) + 8 * (pr >> 2) + 4 * ((pidx >> 2) & 1)) : (16 + 2 * (pr - 8) + ((pidx >> 2) & 1));
-  const int ccol = 4 * blk + (pidx & 3);
+  const int ccol = k2s4_column(wave, pidx);
   const int cbase = ccol;
   const typename Q4<1>::Rot rot_r = Q4<1>::rot_of(t);
   const typename Q4<RS>::Rot rot_c = Q4<RS>::rot_of(t);
@@ -437,7 +454,14 @@ k_xy_corr_s4(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __r
       Q4<1>::store_nat(S, fbase, t, u);
     }
     cplx rv[5][4];
-    {
+    if constexpr (PACKED) {
+      // (natural layout: four lanes share a 32-byte run)
+      const cplx* rp = rec + (((size_t)c * NZ + kz) * W + DLPD_UNIFORM(wave)) * 1280;
+#pragma unroll
+      for (int i = 0; i < 5; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) rv[i][r] = rp[(unsigned)((4 * i + r) * 64 + lane)];
+    } else {
       const cplx* rb = rec + (size_t)b * rec_bstride + ((size_t)c * NZ + kz) * N * N + ccol + (size_t)N * t;
 #pragma unroll
       for (int i = 0; i < 5; i++)
@@ -501,25 +525,66 @@ k_xy_corr_s4(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __r
 
 int dlpd_k2q_supported(int L) { return (L == 80 || L == 40) ? 1 : 0; }
 
-int dlpd_k2q_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, int L, long long rbs, int nsplit_override,
-                       hipStream_t st) {
-  int nsplit = nb >= 8 ? 2 : 1;
-  if (nsplit_override > 0) nsplit = nsplit_override;
+// The receptor spectrum in the order the column phases read it: complex number
+//   N = 160:  (((slab * 2 + p) * 10 + wave) * 20 + k) * 64 + lane  =  rec[slab][2 m + p][2 ccol + cq],
+//   N =  80:  ((slab * 5 + wave) * 20 + k) * 64 + lane             =  rec[slab][m][ccol]
+// with k = 4 i + r, m = t + 4 i + 20 r and (t, ccol, cq) the lane's pencil thread and column as in the kernels above: a
+// wave's load number k is 512 contiguous bytes.  Same size as the natural layout; written once per receptor.
+template <int N> __global__ void __launch_bounds__(256) k_pack_rec_k2q(const cplx* __restrict__ rec, cplx* __restrict__ packed,
+                                                                      long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = (int)(idx % 64), k = (int)((idx / 64) % 20);
+  const int t = lane & 3, pidx = lane >> 2;
+  const int m = t + 4 * (k / 4) + 20 * (k % 4);
+  if constexpr (N == 160) {
+    const int wave = (int)((idx / 1280) % 10), p = (int)((idx / 12800) % 2);
+    const long long slab = idx / 25600;
+    const int cq = (pidx >> 2) & 1, ccol = 4 * (2 * wave + (pidx >> 3)) + (pidx & 3);
+    packed[idx] = rec[(slab * N + (2 * m + p)) * N + 2 * ccol + cq];
+  } else {
+    const int wave = (int)((idx / 1280) % 5);
+    const long long slab = idx / 6400;
+    packed[idx] = rec[(slab * N + m) * N + k2s4_column(wave, pidx)];
+  }
+}
+
+int dlpd_k2q_pack_receptor(const cplx* rec, void* packed, int CT, int L, hipStream_t st) {
+  if (L != 80 && L != 40) return DLPD_ERR_UNSUPPORTED;
+  const int N = 2 * L, NZ = N / 2 + 1;
+  const long long total = (long long)CT * NZ * N * N;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (L == 80) DLPD_LAUNCH((k_pack_rec_k2q<160>), grid, dim3(256), 0, st, rec, (cplx*)packed, total);
+  else DLPD_LAUNCH((k_pack_rec_k2q<80>), grid, dim3(256), 0, st, rec, (cplx*)packed, total);
+  return dlpd_check_launch();
+}
+
+template <bool PACKED> static int k2q_launch(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, int L, long long rbs,
+                                             int nsplit, hipStream_t st) {
   if (L == 40) {
     constexpr int N = 80, NZ = N / 2 + 1, RS = N + 4;
     const size_t shmem = (size_t)(RS * RS + N) * sizeof(cplx);
-    int rc = dlpd_set_max_dyn_shared((const void*)k_xy_corr_s4<N>, shmem);
+    int rc = dlpd_set_max_dyn_shared((const void*)k_xy_corr_s4<N, PACKED>, shmem);
     if (rc) return rc;
     const int slabs8 = ((NZ * CT + 7) / 8) * 8;
-    DLPD_LAUNCH((k_xy_corr_s4<N>), dim3(slabs8 * nsplit), dim3(320), shmem, st, A, rec, out, CT, nb, nsplit, rbs);
+    DLPD_LAUNCH((k_xy_corr_s4<N, PACKED>), dim3(slabs8 * nsplit), dim3(320), shmem, st, A, rec, out, CT, nb, nsplit, rbs);
     return dlpd_check_launch();
   }
   if (L != 80) return DLPD_ERR_UNSUPPORTED;
   constexpr int N = 160, NZ = N / 2 + 1, H = N / 2, RS = H + 4;
   const size_t shmem = (size_t)(2 * RS * RS + N + H) * sizeof(cplx) + (size_t)(5 - DLPD_K2Q_H0_REGS) * 2 * 640 * sizeof(float4);
-  int rc = dlpd_set_max_dyn_shared((const void*)k_xy_corr_q4<N>, shmem);
+  int rc = dlpd_set_max_dyn_shared((const void*)k_xy_corr_q4<N, PACKED>, shmem);
   if (rc) return rc;
   const int slabs8 = ((NZ * CT + 7) / 8) * 8;
-  DLPD_LAUNCH((k_xy_corr_q4<N>), dim3(slabs8 * nsplit), dim3(640), shmem, st, A, rec, out, CT, nb, nsplit, rbs);
+  DLPD_LAUNCH((k_xy_corr_q4<N, PACKED>), dim3(slabs8 * nsplit), dim3(640), shmem, st, A, rec, out, CT, nb, nsplit, rbs);
   return dlpd_check_launch();
+}
+
+// packed: rec is dlpd_k2q_pack_receptor's output (one receptor shared by the batch)
+int dlpd_k2q_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, int L, long long rbs, int nsplit_override,
+                       hipStream_t st, int packed) {
+  int nsplit = nb >= 8 ? 2 : 1;
+  if (nsplit_override > 0) nsplit = nsplit_override;
+  if (packed) return rbs ? DLPD_ERR_ARG : k2q_launch<true>(A, rec, out, CT, nb, L, 0, nsplit, st);
+  return k2q_launch<false>(A, rec, out, CT, nb, L, rbs, nsplit, st);
 }

@@ -68,6 +68,8 @@ __device__ __forceinline__ float2 dlpd_load_stream_c(const float2* p) {
 // value barriers for the optimiser: x leaves as "some vector / scalar register value" -- nothing computed from it is
 // loop-invariant or shared with code before this point (no instruction is emitted)
 #define DLPD_OPAQUE_V(x) asm volatile("" : "+v"(x))
+// a wave-uniform integer as a SCALAR register value (addresses built from it use scalar arithmetic)
+#define DLPD_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #define DLPD_OPAQUE_S(x) asm volatile("" : "+s"(x))
 // make a lane-dependent int opaque to the optimiser at this point: stops loop-invariant code motion
 // from hoisting dozens of swizzled LDS offsets out of the pencil-set loops (they are cheap to

@@ -125,7 +125,7 @@ class DockingEngine:
     def __init__(self, L, C, W1, b1, W2, b2, clip=5.0, threshold_clash=300.0, has_clash=True,
                  max_conf=1000, batch=8, device="cuda", lib=None, center=None, coarse_channels=0,
                  fine_unfused=None, channels_last=None, k3_form=0, coarse_center=None, extent=None,
-                 orient=True, quads=True, prefilter=True,
+                 orient=True, quads=True, prefilter=True, packed_receptor=True,
                  rotation_scale=1.0, coarse_rotation_scale=None, rotation_axis_order="xyz", clip_mode="output",
                  rotation_transpose=False):
         """coarse_channels > 0: the reference's two-resolution layout -- C channels at L^3 plus
@@ -172,6 +172,11 @@ class DockingEngine:
         nb, CT, NZ, N = self.batch, self.CT, self.NZ, self.N
         self.lig = torch.zeros(CT, L, L, L, dtype=f32, device=dev)
         self.recF = torch.zeros(CT, NZ, N, N, 2, dtype=f32, device=dev)
+        # boxes whose K2 re-reads the receptor spectrum for every rotation (80, 40) take a copy in the order its column
+        # phase consumes it (include/dlpd.h: dlpd_receptor_pack); written by set_receptor, read by untransposed launches
+        npk = lib.call("dlpd_receptor_packed_floats", CT, int(L)) if packed_receptor else 0
+        self.recP = torch.zeros(npk, dtype=f32, device=dev) if npk else None
+        self.recP1 = None
         self.wsA = torch.empty(nb * CT * NZ * L * L * 2, dtype=f32, device=dev)
         self.wsB = torch.empty(nb * CT * NZ * N * N * 2, dtype=f32, device=dev)
         self.V = torch.empty(nb, N, N, N, dtype=f32, device=dev)
@@ -215,6 +220,8 @@ class DockingEngine:
             self.center1 = float(L1) / 2.0 if coarse_center is None else float(coarse_center)
             self.lig1 = torch.zeros(C1, L1, L1, L1, dtype=f32, device=dev)
             self.recF1 = torch.zeros(C1, NZ1, N1, N1, 2, dtype=f32, device=dev)
+            npk1 = lib.call("dlpd_receptor_packed_floats", C1, L1) if packed_receptor else 0
+            self.recP1 = torch.zeros(npk1, dtype=f32, device=dev) if npk1 else None
             self.wsA1 = torch.empty(nb * C1 * NZ1 * L1 * L1 * 2, dtype=f32, device=dev)
             self.wsB1 = torch.empty(nb * C1 * NZ1 * N1 * N1 * 2, dtype=f32, device=dev)
             if self.use_quads:
@@ -260,6 +267,7 @@ class DockingEngine:
                 "k1_slab_orientation": bool(self.orient), "k1_quad_layout": bool(self.use_quads),
                 "k3_form": {0: "library default (role-split where compiled)", 1: "channel-owning", 2: "role-split"}[self.k3_form],
                 "k3_unfused": bool(self.fine_unfused), "topk_candidate_lists": bool(self.prefilter),
+                "k2_packed_receptor": {"fine": self.recP is not None, "coarse": self.recP1 is not None},
                 "embedded_extent": self.extent or None,
                 "rotation": {"center": self.center, "scale": self.rot_scale, "axis_order": self.rot_axis_order,
                              "transpose": self.rot_transpose},
@@ -301,6 +309,8 @@ class DockingEngine:
                 r1 = r1.clamp(-self._in_clip, self._in_clip)
             self.lib.call("dlpd_rfft3d_padded", _ptr(r1), _ptr(self.recF1), _ptr(self.wsA1), self.C1, L1,
                           1.0 / float(2 * L1) ** 3, _stream(self.device))
+            if self.recP1 is not None:
+                self.lib.call("dlpd_receptor_pack", _ptr(self.recF1), _ptr(self.recP1), self.C1, L1, _stream(self.device))
         rec = torch.zeros(CT, L, L, L, dtype=torch.float32, device=self.device)
         rec[: self.C] = torch.as_tensor(rec_volumes, dtype=torch.float32).reshape(self.C, L, L, L).to(self.device)
         if self._in_clip is not None:
@@ -310,6 +320,17 @@ class DockingEngine:
         scale = 1.0 / float(N) ** 3
         self.lib.call("dlpd_rfft3d_padded", _ptr(rec), _ptr(self.recF), _ptr(self.wsA), CT, L, scale,
                       _stream(self.device))
+        if self.recP is not None:
+            self.lib.call("dlpd_receptor_pack", _ptr(self.recF), _ptr(self.recP), CT, L, _stream(self.device))
+
+    def _k2(self, coarse, nb, tr, st):
+        """Stage K2 of the fine or the coarse grid on what K1 left in its wsA; tr: the slab orientation K1 used."""
+        wsA, rec, recP, wsB, CT, L = ((self.wsA1, self.recF1, self.recP1, self.wsB1, self.C1, self.L1) if coarse else
+                                      (self.wsA, self.recF, self.recP, self.wsB, self.CT, self.L))
+        if recP is not None and not tr:
+            self.lib.call("dlpd_xy_correlate_packed", _ptr(wsA), _ptr(recP), _ptr(wsB), nb, CT, L, st)
+        else:
+            self.lib.call("dlpd_xy_correlate_oriented", _ptr(wsA), _ptr(rec), _ptr(wsB), nb, CT, L, 0, tr, st)
 
     def set_ligand(self, lig_volumes, lig_forbidden=None, lig_coarse=None):
         L = self.L
@@ -392,8 +413,7 @@ class DockingEngine:
             else:
                 call("dlpd_zfft_oriented_ext", _ptr(self.lig1), _ptr(R1), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1, 0, 1,
                      self.center1, tr, self.extent1, st)
-            call("dlpd_xy_correlate_oriented", _ptr(self.wsA1), _ptr(self.recF1), _ptr(self.wsB1), nb, self.C1, L1, 0,
-                 tr, st)
+            self._k2(True, nb, tr, st)
             self._coarse_preact(nb, has_clip, clip, st)
             mark("coarse")
         if provider is not None:
@@ -442,7 +462,7 @@ class DockingEngine:
             L1 = self.L1
             vc = f32c(vc).reshape(nb, self.C1, L1, L1, L1)
             call("dlpd_zfft", _ptr(vc), 0, _ptr(self.wsA1), nb, self.C1, L1, self.C1 * L1 ** 3, 0, 0.0, st)
-            call("dlpd_xy_correlate", _ptr(self.wsA1), _ptr(self.recF1), _ptr(self.wsB1), nb, self.C1, L1, 0, st)
+            self._k2(True, nb, 0, st)
             self._coarse_preact(nb, has_clip, clip, st)
             mark("coarse")
         vl = f32c(vl).reshape(nb, self.C, L, L, L)
@@ -493,8 +513,7 @@ class DockingEngine:
         orientation K1 used."""
         has_clip, clip = self._out_clip
         call, st, L = self.lib.call, _stream(self.device), self.L
-        call("dlpd_xy_correlate_oriented", _ptr(self.wsA), _ptr(self.recF), _ptr(self.wsB), nb, self.CT, L, 0,
-             tr, st)
+        self._k2(False, nb, tr, st)
         mark("k2_xy_corr")
         aux, C1, N1 = (_ptr(self.pre), self.C1, 2 * self.L1) if self.C1 else (0, 0, 0)
         if self.fine_unfused:

@@ -129,6 +129,16 @@ int dlpd_rfft3d_padded(const float* vol, void* spec, void* wsA, int nvol, int L,
 int dlpd_xy_correlate(const void* wsA, const void* rec, void* wsB, int nb, int CT, int L,
                       long long rec_bstride, void* stream);
 
+/* The same stage for ONE receptor shared by the whole batch (the search: Docker.py:213-232 scores every rotation of the
+ * ligand against the same receptor) on the boxes whose K2 re-reads the receptor spectrum for every rotation (80 and 40:
+ * their slab does not stay in registers): dlpd_receptor_pack re-orders the spectrum ONCE into the order K2's column
+ * phase consumes it (contiguous kilobytes per instruction instead of 64- / 32-byte runs), dlpd_xy_correlate_packed reads
+ * that copy.  Same arithmetic, same results bit for bit.  dlpd_receptor_packed_floats: floats of the packed copy (as
+ * many as the spectrum), 0 for boxes that take the natural layout only. */
+long long dlpd_receptor_packed_floats(int CT, int L);
+int dlpd_receptor_pack(const void* rec, void* packed, int CT, int L, void* stream);
+int dlpd_xy_correlate_packed(const void* wsA, const void* rec_packed, void* wsB, int nb, int CT, int L, void* stream);
+
 /* VolumeConvolution (Docker.py:32,225; DockingModels.py:48,71) for ANY box size -- `box_size` is a free constructor
  * argument of the reference's Docker (Docker.py:18,22-24,31): out (nvol, N^3)[t mod N] = sum_r v1[r + t] v2[r], N = 2L,
  * optional clamp to +-clip.  Direct O(n N) transforms, no radix plan: the slow path for boxes without a compiled

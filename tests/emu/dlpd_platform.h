@@ -231,6 +231,7 @@ static inline float2 dlpd_load_stream_c(const float2* p) { return *p; }
 #define DLPD_CLAMP(v, c) fminf(fmaxf((v), -(c)), (c))
 #define DLPD_SCHED_FENCE() ((void)0)
 #define DLPD_OPAQUE_V(x) ((void)0)
+#define DLPD_UNIFORM(x) (x)
 #define DLPD_OPAQUE_S(x) ((void)0)
 #define DLPD_OPAQUE(x) ((void)(x))
 #define DLPD_SET_PRIO(n) ((void)0)

@@ -819,3 +819,31 @@ def test_four_degree_rotation_set_head_and_tail_match_the_oracle(dev):
     assert max(abs(a[4] - b[4]) for a, b in zip(got, want)) <= band
     assert sum(a[:4] == b[:4] for a, b in zip(got, want)) >= int(0.97 * K)
     assert any(g[0] >= nrot - 32 for g in got) and any(g[0] < 32 for g in got)
+
+def test_packed_receptor_is_invisible_in_k2(dev):
+    """K2 of boxes 80 and 40 on the receptor spectrum in the natural layout and in the packed order of its column phase
+    (dlpd_receptor_pack / dlpd_xy_correlate_packed, what the engine launches): the correlation spectra bit for bit, at the
+    real shapes' channel counts and batch; and an engine with the packed copies switched off returns the same scores."""
+    from test_kernels_emu import _packed_receptor_equals_natural
+    from deeplocalproteindocking_amd._lib import get_lib
+    from deeplocalproteindocking_amd.engine import DockingEngine
+    lib = get_lib()
+    _packed_receptor_equals_natural(lib, dev, 80, 17, 16)
+    _packed_receptor_equals_natural(lib, dev, 40, 32, 16)
+    L, C, C1, H = 80, 4, 6, 8
+    g = torch.Generator().manual_seed(12)
+    rec, lig = torch.randn(C, L, L, L, generator=g) * 0.05, torch.randn(C, L, L, L, generator=g) * 0.05
+    rec1, lig1 = torch.randn(C1, 40, 40, 40, generator=g) * 0.1, torch.randn(C1, 40, 40, 40, generator=g) * 0.1
+    recf, ligf = torch.rand(L, L, L, generator=g), torch.rand(L, L, L, generator=g)
+    W1, b1 = torch.randn(H, C + C1, generator=g) * 0.4, torch.randn(H, generator=g) * 0.1
+    W2, b2 = torch.randn(1, H, generator=g), torch.randn(1, generator=g)
+    R = torch.from_numpy(orc.euler_to_matrix([0.5, -2.1], [1.1, 0.3], [-0.4, 1.7])).float().to(dev).contiguous()
+    out = []
+    for packed in (True, False):
+        eng = DockingEngine(L, C, W1, b1, W2, b2, clip=0.6, threshold_clash=0.125 * L ** 3, max_conf=10, batch=2, device=dev,
+                            coarse_channels=C1, packed_receptor=packed)
+        assert eng.switches()["k2_packed_receptor"] == {"fine": packed, "coarse": packed}
+        eng.set_receptor(rec, recf, rec1)
+        eng.set_ligand(lig, ligf, lig1)
+        out.append(eng.score_batch(R).clone())
+    assert torch.equal(out[0], out[1])

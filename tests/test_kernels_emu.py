@@ -717,3 +717,42 @@ def _search_with_and_without_candidate_lists(lib, device, L, C, K, nrot, batch, 
 
 def test_topk_candidate_lists_from_k3_equal_the_full_select_emulated(emu, monkeypatch):
     _search_with_and_without_candidate_lists(emu, "cpu", 32, 3, 25, 7, 2, monkeypatch)
+
+def _packed_receptor_equals_natural(lib, device, L, CT, nb, seed=3):
+    """K2 of the boxes that re-read the receptor spectrum for every rotation (80, 40), fed the spectrum in the natural layout
+    and in the order its column phase consumes it (include/dlpd.h: dlpd_receptor_pack, dlpd_xy_correlate_packed): the same
+    arithmetic on the same values, so the correlation spectra must agree bit for bit."""
+    N, NZ = 2 * L, L + 1
+    g = torch.Generator().manual_seed(seed)
+    wsA = torch.randn(nb, CT, NZ, L, L, 2, generator=g).to(device)
+    rec = torch.randn(CT, NZ, N, N, 2, generator=g).to(device)
+    n = lib.call("dlpd_receptor_packed_floats", CT, L)
+    assert n == rec.numel()
+    packed = torch.zeros(n, dtype=torch.float32, device=device)
+    B0 = torch.zeros(nb, CT, NZ, N, N, 2, device=device)
+    B1 = torch.zeros_like(B0)
+    st = 0 if device == "cpu" else torch.cuda.current_stream().cuda_stream
+    lib.call("dlpd_xy_correlate", _ptr(wsA), _ptr(rec), _ptr(B0), nb, CT, L, 0, st)
+    lib.call("dlpd_receptor_pack", _ptr(rec), _ptr(packed), CT, L, st)
+    lib.call("dlpd_xy_correlate_packed", _ptr(wsA), _ptr(packed), _ptr(B1), nb, CT, L, st)
+    if device != "cpu":
+        torch.cuda.synchronize()
+    assert sorted(packed.tolist()) == sorted(rec.flatten().tolist()) if rec.numel() < 2_000_000 else True
+    assert float(B0.abs().max()) > 0
+    assert torch.equal(B0, B1)
+
+
+@pytest.mark.parametrize("L,CT,nb", [(40, 2, 2), (80, 1, 1)])
+def test_packed_receptor_is_invisible_in_k2_emulated(emu, L, CT, nb):
+    _packed_receptor_equals_natural(emu, "cpu", L, CT, nb)
+
+
+def test_packed_receptor_exists_only_where_k2_rereads_it(emu):
+    """Boxes 32 / 64 hold their receptor values in registers across the batch: no packed form, and asking for one fails."""
+    for L in (32, 64):
+        assert emu.call("dlpd_receptor_packed_floats", 4, L) == 0
+        x = torch.zeros(16)
+        with pytest.raises(RuntimeError):
+            emu.call("dlpd_xy_correlate_packed", _ptr(x), _ptr(x), _ptr(x), 1, 1, L, 0)
+    assert emu.call("dlpd_receptor_packed_floats", 3, 40) == 3 * 41 * 80 * 80 * 2
+    assert emu.call("dlpd_receptor_packed_floats", 3, 80) == 3 * 81 * 160 * 160 * 2
