@@ -775,11 +775,12 @@ def pmc_traffic(workload, C, L, nb, kernel):
     return None, None
 
 
-# FETCH_SIZE calibration (MI355X_MICROARCH.md, HBM section): gfx950 tallies a 128-byte read request at 64 bytes -> x 2;
-# K3 at N = 160 reads its spectra in 64-byte runs (8-row tiles), tallied at face value
-FETCH_SCALE = {("k3_zifft_filter", 160): 1.0}
+# FETCH_SIZE calibration (MI355X_MICROARCH.md, HBM section): gfx950 tallies a 128-byte read request at 64 bytes -> x 2.
+# (Until round 4 K3 at N = 160 read its spectra in 64-byte runs -- 8-row tiles --, which are tallied at face value: an
+# entry {("k3_zifft_filter", 160): 1.0} here; its 16-row tiles read whole lines like every other kernel.)
+FETCH_SCALE = {}
 STAGE_KERNELS = {"k1_rotate_zfft": ("k_rotate_zfft_cl<%d>", "k_rotate_zfft<%d>"),
-                 "k2_xy_corr": ("k_xy_corr<%d, 1>", "k_xy_corr_q4<%d>", "k_xy_corr_quad<%d,"),
+                 "k2_xy_corr": ("k_xy_corr<%d, 1>", "k_xy_corr_q4<%d,", "k_xy_corr_quad<%d,"),
                  "k3_zifft_filter": ("k_zifft_filter_rs<%d,",)}
 
 

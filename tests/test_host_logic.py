@@ -43,7 +43,7 @@ def test_product_library_ships_one_formulation_per_box(built_lib):
     transposed-slab K2 at N = 160 are TEST VARIANTS (tests/variants/libdlpd_variants.so, -DDLPD_TEST_VARIANTS)."""
     import subprocess
     nm = subprocess.run(["nm", "-C", entry.LIB], capture_output=True, text=True).stdout
-    assert "k_zifft_filter_rs<128" in nm and "k_zifft_filter_rs<160" in nm and "k_xy_corr_q4<160>" in nm
+    assert "k_zifft_filter_rs<128" in nm and "k_zifft_filter_rs<160" in nm and "k_xy_corr_q4<160, true>" in nm and "k_xy_corr_s4<80, true>" in nm
     assert "k_zifft_filter<64," in nm and "k_zifft_filter<80," in nm                      # boxes 32 / 40: the one formulation there
     for absent in ("k_xy_corr_quad<", "k_zifft_filter<128, 24, 1>", "k_zifft_filter_tiles<160", "k_zifft_filter<160, 24, 2>",
                    "k_zifft_filter<80, 24, 2>"):
