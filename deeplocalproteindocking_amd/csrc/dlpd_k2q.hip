@@ -26,15 +26,20 @@
 //     block barriers -- two per sub-problem pair instead of five.
 //   The last forward x pass (radix 4, outputs kx = j + 20 r) hands its registers to the first inverse x pass (radix 4
 //   over exactly those inputs); H_0 waits in registers (40 VGPRs) for H_1 and the output slab is written once.
+// Round 4, measured and not kept (git show f67fb5a): the radix-4 stage of every 80-point transform ACROSS the four lanes of
+// its quad (two DPP exchange-and-add stages, lane 3 turning its difference by -+i in between; frequency k1 + 20 kb on the
+// lane with kb = bit-reversed t, stored in blocks of 21), which makes a transform one read and one write of its pencil and
+// the whole column phase -- butterfly, quad stage, receptor product, quad stage back, butterfly -- a register affair: LDS
+// operations per sub-problem pair 390 -> 239, vector instructions 1,448 -> 2,001 (a DPP move per component and stage, the
+// lane-3 turn as two selects, 299 hazard no-ops), bit-identical to the oracle's tolerance on emulator and GPU -- and K2
+// 2.20 against 2.05-2.09 ms at the real shapes, 6.40 against 6.03 at 48 ch x 80^3.  The kernel's time follows the SUM of its
+// vector and LDS work (about 62 % / 38 %); trading the cheaper for the dearer loses.
 #include <dlpd_platform.h>
 #include "dlpd_fft.h"
 #include "dlpd_internal.h"
 
 #ifndef DLPD_K2Q_RV_LATE
 #define DLPD_K2Q_RV_LATE 1
-#endif
-#ifndef DLPD_K2Q_XLANE
-#define DLPD_K2Q_XLANE 1                     // the radix-4 stage of every 80-point transform across the lanes of its quad (DPP)
 #endif
 #ifndef DLPD_K2Q_H0_REGS
 #define DLPD_K2Q_H0_REGS 3                   // pairs of H_0 kept in registers (of 5); the rest waits in LDS
@@ -154,71 +159,6 @@ template <int ES> struct Q4 {
 #pragma unroll
     for (int r = 0; r < 20; r++) lds_st(p0 + 4 * r * ES, v[r]);
   }
-  // ---- THE RADIX-4 STAGE ACROSS THE FOUR LANES OF A PENCIL (round 4; DPP quad permutes, no LDS) ----
-  // 80 = 20 x 4 with n = t + 4 r, k = k1 + 20 k2:  X[k1 + 20 k2] = sum_t w4^(t k2) [ w80^(t k1) DFT20_r(x[t + 4 r])[k1] ].
-  // Thread t holds x[t + 4 r]; after its radix-20 butterfly and the twiddle, the 4-point transform over t runs ACROSS the
-  // quad: two exchange-and-add stages (partner t ^ 2, then t ^ 1; lane 3 turns its difference by -i in between), which
-  // leave X[k1 + 20 kb] on the lane with kb = bit-reversed t.  The inverse runs the stages the other way round.  A whole
-  // transform is then one read and one write of the pencil -- the in-place two-pass form above reads and writes it twice.
-  struct Quad { float s_hi, s_odd; bool l3; int kb; };
-  DLPD_D static Quad quad_of(int t) {
-    Quad q;
-    q.s_hi = (t & 2) ? -1.f : 1.f;
-    q.s_odd = (t & 1) ? -1.f : 1.f;
-    q.l3 = (t == 3);
-    q.kb = ((t & 1) << 1) | (t >> 1);
-    return q;
-  }
-  DLPD_D static cplx xq1(cplx v) { return c_make(DLPD_QUAD_XOR1(v.x), DLPD_QUAD_XOR1(v.y)); }
-  DLPD_D static cplx xq2(cplx v) { return c_make(DLPD_QUAD_XOR2(v.x), DLPD_QUAD_XOR2(v.y)); }
-  // v[k1] = w80^(t k1) DFT20(...)[k1] on lane t  ->  v[k1] = X[k1 + 20 kb];  twq: this lane's twiddles w80^(t k1)
-  DLPD_D static void fwd_across(cplx (&v)[20], const Quad& q, const cplx* twq) {
-#pragma unroll
-    for (int k1 = 0; k1 < 20; k1++) {
-      const cplx z = k1 ? c_mul(v[k1], lds_ld(twq + k1)) : v[0];
-      cplx a = c_axpy(xq2(z), q.s_hi, z);              // t < 2: z_t + z_(t+2);  t >= 2: z_(t-2) - z_t
-      if (q.l3) a = c_make(a.y, -a.x);                 // lane 3: -i (z_1 - z_3)
-      v[k1] = c_axpy(xq1(a), q.s_odd, a);
-    }
-  }
-  // v[k1] = X[k1 + 20 kb]  ->  v[k1] = conj(w80^(t k1)) sum_k2 (+i)^(t k2) X[k1 + 20 k2] on lane t (DFT20 inverse still to do)
-  DLPD_D static void inv_across(cplx (&v)[20], const Quad& q, const cplx* twq) {
-#pragma unroll
-    for (int k1 = 0; k1 < 20; k1++) {
-      const cplx x = v[k1];
-      cplx a = c_axpy(xq1(x), q.s_odd, x);
-      if (q.l3) a = c_make(-a.y, a.x);                 // lane 3: +i (X_1 - X_3)
-      const cplx w = c_axpy(xq2(a), q.s_hi, a);
-      v[k1] = k1 ? c_mulc(w, lds_ld(twq + k1)) : w;
-    }
-  }
-  // whole transforms: pencil element e at S[base + e * ES] in natural order on the x side; on the X side frequency
-  // k1 + 20 kb sits at k1 + 21 kb ("blocks of 21": the four lanes of a quad and the four pencils of a 16-lane store group
-  // then cover 16 distinct 8-byte columns)
-  DLPD_D static void forward_x(cplx* S, int base, int t, const Quad& q, const cplx* twq) {
-    cplx v[20];
-    const cplx* p0 = S + base + t * ES;
-#pragma unroll
-    for (int r = 0; r < 20; r++) v[r] = lds_ld(p0 + 4 * r * ES);
-    SmallDft<20, -1>::run(v);
-    fwd_across(v, q, twq);
-    DLPD_WAVE_SYNC();
-    cplx* p1 = S + base + 21 * q.kb * ES;
-#pragma unroll
-    for (int k1 = 0; k1 < 20; k1++) lds_st(p1 + k1 * ES, v[k1]);
-  }
-  DLPD_D static void inverse_x(cplx* S, int base, int t, const Quad& q, const cplx* twq) {
-    cplx v[20];
-    const cplx* p1 = S + base + 21 * q.kb * ES;
-#pragma unroll
-    for (int k1 = 0; k1 < 20; k1++) v[k1] = lds_ld(p1 + k1 * ES);
-    inv_across(v, q, twq);
-    SmallDft<20, +1>::run(v);
-    DLPD_WAVE_SYNC();
-    cplx* p0 = S + base + t * ES;
-#pragma unroll
-    for (int r = 0; r < 20; r++) lds_st(p0 + 4 * r * ES, v[r]);
-  }
   // whole transforms, in place
   DLPD_D static void forward(cplx* S, int base, int t, const cplx* tw80) {
     fwd_a(S, base, t);
@@ -268,30 +208,19 @@ k_xy_corr_q4(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __r
   const int kz = slab % NZ, c = slab / NZ;
   const int b_beg = (int)(((long long)nb * part) / nsplit), b_end = (int)(((long long)nb * (part + 1)) / nsplit);
   if (b_beg >= b_end) return;
-  constexpr bool XL = DLPD_K2Q_XLANE != 0;
   cplx* tw = S + 2 * SUB;                              // exp(-2 pi i k / N)
   cplx* twh = tw + N;                                  // exp(-2 pi i k / H)
-  cplx* twq = twh + H;                                 // XL: [t][k1] = exp(-2 pi i t k1 / H), the quad stage's twiddles
   init_twiddles_k2q<N>(tw, tid, NT);
   init_twiddles_k2q<H>(twh, tid, NT);
-  if (XL && tid < 80) {
-    double sn, cs;
-    sincospi(-2.0 * (double)((tid / 20) * (tid % 20)) / (double)H, &sn, &cs);
-    twq[tid] = c_make((float)cs, (float)sn);
-  }
 
   const int t = lane & 3, pidx = lane >> 2;            // thread of the pencil, pencil of the set
   // row set: rows 8w..8w+7 of sub-slab 0 (lanes 0-31) and of sub-slab 1 (lanes 32-63)
   const int rbase = (pidx >> 3) * SUB + (8 * wave + (pidx & 7)) * RS;
   // column set: 4-column blocks 2w (lanes 0-31) and 2w+1 (lanes 32-63), each of sub-slab 0 (first 16 lanes) and 1
-  // (XL: frequency ky of the rows sits at ky + ky / 20, the "blocks of 21" the y transform leaves)
   const int cq = (pidx >> 2) & 1, ccol = 4 * (2 * wave + (pidx >> 3)) + (pidx & 3);
-  const int cbase = cq * SUB + (XL ? ccol + ccol / 20 : ccol);
+  const int cbase = cq * SUB + ccol;
   const typename Q4<1>::Rot rot_r = Q4<1>::rot_of(t);
   const typename Q4<RS>::Rot rot_c = Q4<RS>::rot_of(t);
-  const typename Q4<1>::Quad qd = Q4<1>::quad_of(t);
-  const typename Q4<RS>::Quad qdc = Q4<RS>::quad_of(t);
-  const cplx* twq_t = twq + 20 * t;
 
   // this wave's 8 rows of a rotation's A slab (8 L contiguous complex): lane = 8 * row + piece reads float4 number
   // piece + 8 k of its row -- eight 128-byte lines per instruction and no division anywhere (staging and combination
@@ -308,7 +237,7 @@ k_xy_corr_q4(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __r
   // sub-slabs leave free (with all 40 registers held the column phase of p = 1 spills)
   constexpr int NPR = DLPD_K2Q_H0_REGS;
   float4 h0[NPR > 0 ? NPR : 1][2];
-  float4* park = reinterpret_cast<float4*>(twh + H + (XL ? 80 : 0)) + tid;     // [(k - NPR) * 2 + j][NT]
+  float4* park = reinterpret_cast<float4*>(twh + H) + tid;     // [(k - NPR) * 2 + j][NT]
   fetch_A(b_beg);
   DLPD_LDS_BARRIER();                                  // twiddle tables visible
   DLPD_STAMP_DECL;
@@ -338,8 +267,7 @@ k_xy_corr_q4(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __r
       DLPD_WAVE_SYNC();
       DLPD_STAMP(0);
       // ---- forward along y: the wave's own rows of both sub-slabs
-      if (XL) Q4<1>::forward_x(S, rbase, t, qd, twq_t);
-      else Q4<1>::forward(S, rbase, t, twh);
+      Q4<1>::forward(S, rbase, t, twh);
       DLPD_STAMP(1);
       // receptor values of this wave's column set: rec[2 m + p][2 n + q] for m = t + 4 i + 20 r, in flight over the barrier
       // (DLPD_K2Q_RV_LATE: requested behind the first column pass instead -- 40 registers less under the radix-20 butterfly)
@@ -349,7 +277,6 @@ k_xy_corr_q4(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __r
           // natural layout: lane (t, column 2 ccol + cq) reads rows 2 (t + 4 i + 20 r) + p -- eight lanes share a 64-byte
           // run, every instruction touches eight half lines (measured: the loads cost 0.45 of K2's 2.40 ms at the real
           // shapes); packed: 512 contiguous bytes per instruction
-          // (XL: value k of a lane is kx = k + 20 kb, otherwise kx = t + 4 i + 20 r for k = 4 i + r -- k_pack_rec_k2q)
           const cplx* rp = rec + ((((size_t)c * NZ + kz) * 2 + p) * W + DLPD_UNIFORM(wave)) * 1280;
 #pragma unroll
           for (int i = 0; i < 5; i++)
@@ -357,35 +284,17 @@ k_xy_corr_q4(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __r
             for (int r = 0; r < 4; r++) rv[i][r] = rp[(unsigned)((4 * i + r) * 64 + lane)];
         } else {
           const cplx* rb = rec + (size_t)b * rec_bstride + (((size_t)c * NZ + kz) * N + p) * N + (2 * ccol + cq) +
-                           (size_t)(2 * N) * (XL ? 20 * qd.kb : t);
+                           (size_t)(2 * N) * t;
 #pragma unroll
           for (int i = 0; i < 5; i++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) rv[i][r] = rb[(unsigned)(2 * N * (XL ? 4 * i + r : 4 * i + 20 * r))];
+            for (int r = 0; r < 4; r++) rv[i][r] = rb[(unsigned)(2 * N * (4 * i + 20 * r))];
         }
       };
       if (!DLPD_K2Q_RV_LATE) fetch_rec();
       DLPD_LDS_BARRIER();                              // all rows y-transformed
       DLPD_STAMP(2);
       // ---- columns: forward x, receptor multiply, inverse x
-      if constexpr (XL) {
-        // one read and one write of the column: radix-20 butterfly, quad stage, receptor product, quad stage back,
-        // radix-20 butterfly -- the receptor values requested behind the first butterfly, released before the second
-        cplx v[20];
-        cplx* p0 = S + cbase + t * RS;
-#pragma unroll
-        for (int r = 0; r < 20; r++) v[r] = lds_ld(p0 + 4 * r * RS);
-        SmallDft<20, -1>::run(v);
-        fetch_rec();
-        Q4<RS>::fwd_across(v, qdc, twq_t);
-#pragma unroll
-        for (int k1 = 0; k1 < 20; k1++) v[k1] = c_mulc(rv[k1 / 4][k1 % 4], v[k1]);
-        Q4<RS>::inv_across(v, qdc, twq_t);
-        SmallDft<20, +1>::run(v);
-        DLPD_WAVE_SYNC();
-#pragma unroll
-        for (int r = 0; r < 20; r++) lds_st(p0 + 4 * r * RS, v[r]);
-      } else {
       {
         Q4<RS>::fwd_a(S, cbase, t);
         if (DLPD_K2Q_RV_LATE) fetch_rec();
@@ -425,14 +334,12 @@ k_xy_corr_q4(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __r
         DLPD_WAVE_SYNC();
         Q4<RS>::store_a(S, cbase, t, v);
       }
-      }
       DLPD_STAMP(3);
       DLPD_LDS_BARRIER();                              // all columns done
       DLPD_STAMP(4);
       if (p == 1 && b + 1 < b_end) fetch_A(b + 1);     // next rotation's rows, in flight over the rest of this slab
       // ---- inverse along y: own rows -> G_p0, G_p1
-      if (XL) Q4<1>::inverse_x(S, rbase, t, qd, twq_t);
-      else Q4<1>::inverse(S, rbase, t, rot_r, twh);
+      Q4<1>::inverse(S, rbase, t, rot_r, twh);
       DLPD_WAVE_SYNC();
       DLPD_STAMP(5);
       // ---- H_p[u][v + H r] = G_p0[u][v] + (-1)^r conj(w^v) G_p1[u][v];  out[u + H s][y'] = H_0 + (-1)^s conj(w^u) H_1
@@ -637,9 +544,8 @@ template <int N> __global__ void __launch_bounds__(256) k_pack_rec_k2q(const cpl
   if (idx >= total) return;
   const int lane = (int)(idx % 64), k = (int)((idx / 64) % 20);
   const int t = lane & 3, pidx = lane >> 2;
-  int m = t + 4 * (k / 4) + 20 * (k % 4);
+  const int m = t + 4 * (k / 4) + 20 * (k % 4);
   if constexpr (N == 160) {
-    if (DLPD_K2Q_XLANE) m = k + 20 * (((t & 1) << 1) | (t >> 1));
     const int wave = (int)((idx / 1280) % 10), p = (int)((idx / 12800) % 2);
     const long long slab = idx / 25600;
     const int cq = (pidx >> 2) & 1, ccol = 4 * (2 * wave + (pidx >> 3)) + (pidx & 3);
@@ -674,8 +580,7 @@ template <bool PACKED> static int k2q_launch(const cplx* A, const cplx* rec, cpl
   }
   if (L != 80) return DLPD_ERR_UNSUPPORTED;
   constexpr int N = 160, NZ = N / 2 + 1, H = N / 2, RS = H + 4;
-  const size_t shmem = (size_t)(2 * RS * RS + N + H + (DLPD_K2Q_XLANE ? 80 : 0)) * sizeof(cplx) +
-                       (size_t)(5 - DLPD_K2Q_H0_REGS) * 2 * 640 * sizeof(float4);
+  const size_t shmem = (size_t)(2 * RS * RS + N + H) * sizeof(cplx) + (size_t)(5 - DLPD_K2Q_H0_REGS) * 2 * 640 * sizeof(float4);
   int rc = dlpd_set_max_dyn_shared((const void*)k_xy_corr_q4<N, PACKED>, shmem);
   if (rc) return rc;
   const int slabs8 = ((NZ * CT + 7) / 8) * 8;

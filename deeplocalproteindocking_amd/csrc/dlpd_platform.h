@@ -68,15 +68,6 @@ __device__ __forceinline__ float2 dlpd_load_stream_c(const float2* p) {
 // value barriers for the optimiser: x leaves as "some vector / scalar register value" -- nothing computed from it is
 // loop-invariant or shared with code before this point (no instruction is emitted)
 #define DLPD_OPAQUE_V(x) asm volatile("" : "+v"(x))
-// the value of the lane whose index differs in bit 0 / bit 1 (DPP quad_perm [1,0,3,2] / [2,3,0,1]): no LDS involved
-__device__ __forceinline__ float dlpd_quad_xor1(float x) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float dlpd_quad_xor2(float x) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
-}
-#define DLPD_QUAD_XOR1(x) dlpd_quad_xor1(x)
-#define DLPD_QUAD_XOR2(x) dlpd_quad_xor2(x)
 // a wave-uniform integer as a SCALAR register value (addresses built from it use scalar arithmetic)
 #define DLPD_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #define DLPD_OPAQUE_S(x) asm volatile("" : "+s"(x))

@@ -232,8 +232,6 @@ static inline float2 dlpd_load_stream_c(const float2* p) { return *p; }
 #define DLPD_SCHED_FENCE() ((void)0)
 #define DLPD_OPAQUE_V(x) ((void)0)
 #define DLPD_UNIFORM(x) (x)
-#define DLPD_QUAD_XOR1(x) __shfl_xor((x), 1)
-#define DLPD_QUAD_XOR2(x) __shfl_xor((x), 2)
 #define DLPD_OPAQUE_S(x) ((void)0)
 #define DLPD_OPAQUE(x) ((void)(x))
 #define DLPD_SET_PRIO(n) ((void)0)
