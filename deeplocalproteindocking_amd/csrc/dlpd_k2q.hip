@@ -31,7 +31,7 @@
 // lane with kb = bit-reversed t, stored in blocks of 21), which makes a transform one read and one write of its pencil and
 // the whole column phase -- butterfly, quad stage, receptor product, quad stage back, butterfly -- a register affair: LDS
 // operations per sub-problem pair 390 -> 239, vector instructions 1,448 -> 2,001 (a DPP move per component and stage, the
-// lane-3 turn as two selects, 299 hazard no-ops), bit-identical to the oracle's tolerance on emulator and GPU -- and K2
+// lane-3 turn as two selects, 299 hazard no-ops), inside the parity tolerance on emulator and GPU -- and K2
 // 2.20 against 2.05-2.09 ms at the real shapes, 6.40 against 6.03 at 48 ch x 80^3.  The kernel's time follows the SUM of its
 // vector and LDS work (about 62 % / 38 %); trading the cheaper for the dearer loses.
 #include <dlpd_platform.h>
