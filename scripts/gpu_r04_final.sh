@@ -1,10 +1,10 @@
 #!/bin/bash
 # Round-4 evidence run (one gpurun call): the whole GPU suite, the driver's bench line, rocprofv3 stats + PMC passes of the
 # timed command at config 2 / the real shapes / 48 ch x 80^3, the convolution benchmark under rocprofv3, the complete 6- and
-# 4-degree searches and the config-4-shaped end-to-end soak.  Outputs under gpurun_out/r04_z/ (copied to profiles/r04_zz_*).
+# 4-degree searches and the config-4-shaped end-to-end soak.  Outputs under gpurun_out/r04_zz/ (copied to profiles/r04_zz_*).
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT
-OUT=$ROOT/gpurun_out/r04_zzz
+OUT=$ROOT/gpurun_out/r04_zz
 mkdir -p $OUT
 timeout 2400 python -m pytest tests -q -m gpu > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
 timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 300 $OUT/bench_default.err
