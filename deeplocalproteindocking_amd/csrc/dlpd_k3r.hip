@@ -244,6 +244,8 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
   if (t_beg >= t_end) return;
   init_twiddles_k3r<N>(tw, tid, 64 * (F + M));
   const unsigned cand_tau = (MODE == 1 && cd.keys) ? *cd.tau : 0u;
+  // no clip = a clamp to +-infinity, which returns its argument: one v_med3 per value instead of a v_med3 and a select
+  const float clampv = has_clip ? clip : __builtin_inff();
 
   // ---- transform role: this wave's channels of group `cb` of tile `t` -> raw staging buffer `buf`
   //      raw[k][m] <- Bw[b][cb + wave*CPW + j][k][xo][y0+2m .. +1]   (lane = NPAIR*(k % LPK) + m: LPK runs of NPAIR*16
@@ -431,7 +433,8 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
 #pragma unroll
             for (int e = 0; e < EPT; e++) {
               float v0 = vcur[e].x, v1 = vcur[e].y;
-              if (has_clip) { v0 = DLPD_CLAMP(v0, clip); v1 = DLPD_CLAMP(v1, clip); }
+              v0 = DLPD_CLAMP(v0, clampv);
+              v1 = DLPD_CLAMP(v1, clampv);
 #pragma unroll
               for (int j = 0; j < HP; j++) {
                 h[2 * e][j] = fmaf(wcur[j], v0, h[2 * e][j]);
@@ -465,7 +468,8 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
 #pragma unroll
             for (int e = 0; e < EPT; e++) {
               float v0 = vals[g][e].x, v1 = vals[g][e].y;
-              if (has_clip) { v0 = DLPD_CLAMP(v0, clip); v1 = DLPD_CLAMP(v1, clip); }
+              v0 = DLPD_CLAMP(v0, clampv);
+              v1 = DLPD_CLAMP(v1, clampv);
 #pragma unroll
               for (int j = 0; j < HP; j++) {
                 h[2 * e][j] = fmaf(wcur[j], v0, h[2 * e][j]);
