@@ -52,8 +52,10 @@ template <int N> DLPD_D void init_twiddles_k3r(cplx* tw, int tid, int nthreads) 
 }
 
 // F transform waves, M filter waves, TY rows per tile (16: a transform wave owns one channel = 8 two-row pencils;
-// 8: two channels of 4 pencils), RAWBUF raw staging buffers per transform wave (2: the next group's DMA is issued
-// before this group is packed)
+// 8: two channels of 4 pencils -- 64-byte DMA runs: only where two voxels per filter thread leave no room for 16 rows),
+// RAWBUF raw staging buffers per transform wave (2: the next group's DMA is issued before this group is packed), PBUF
+// pencil buffers (2: the filter waves read their values straight from the pencils while the transform waves fill the
+// other buffer -- "TWO PENCIL BUFFERS" in the kernel)
 #ifndef DLPD_K3R_F128
 #define DLPD_K3R_F128 4
 #endif
@@ -226,7 +228,17 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
   float4* raw = reinterpret_cast<float4*>(tw + N);        // [RAWBUF][F][CPW][RAWC]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool is_fft = wave < F;
-  // (round 4: TEN half-size filter waves at N = 160 -- 15 waves, 128 registers, 3 spilled -- with the transform waves dealt
+  // N = 160, ROUND 4.  What bounded this kernel was the SHAPE of its reads: 8-row tiles fetch the spectra in 64-byte runs
+  // (one (channel, kz) line of a tile), which HBM serves at 3.6 TB/s where 128-byte runs get 6.4-6.9 (scripts/micro/
+  // dma_gather.hip); a build with neither transforms nor multiply-adds took 1.92 of the kernel's 2.04 ms.  Hence 16-row
+  // tiles: five transform waves x one channel, TEN filter waves x four voxels, 15 waves at 128 registers -- 1.75 ms -- and
+  // two pencil buffers (PBUF, below) -- 1.47-1.55 ms.  The experiments of the following paragraph were all measured UNDER
+  // the 64-byte bound: their "no gain" says nothing about the kernel as it is now.  Measured on the new kernel and not kept:
+  // transform waves at s_setprio 1 / 3 (1.65-1.68 against 1.51-1.54 on that box), the younger filter waves raised (1.60
+  // against 1.51), touches of the next tile's pre-activation planes by the transform waves (one LDS-DMA per line into a junk
+  // kilobyte: 1.68 with the non-temporal hint, 1.507 against 1.51-1.55 without).  The same two buffers at N = 128: 2.04
+  // against 1.87 ms (that kernel is vector-issue bound; PBUF stays a per-box choice).
+  // (first half of round 4: TEN half-size filter waves at N = 160 on 8-row tiles -- 15 waves, 128 registers, 3 spilled -- with the transform waves dealt
   // one per SIMD, hardware waves {0, 1, 2, 3, 7}, since a workgroup's waves go to the SIMDs cyclically: K3 2.07-2.09 ms
   // against 2.00-2.03 for 5 + 5 on the real shapes, 5.5 against 4.8 at 48 ch x 80^3; transform waves first: 2.07-2.20 / 5.4;
   // bit-identical; not kept.  Also round 4: FOUR transform + FOUR filter waves at N = 160 -- one wave of each role per SIMD,
