@@ -291,13 +291,26 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
 //    blocks alike -- the kernel is not waiting for a free block slot, and the second set of passes and barriers costs.
 //  * 16 rows x 16 channels = 128 pencils per block (64-byte gathers AND 128-byte pieces; 145 KB, one block per CU, 1024
 //    threads): 0.77-0.80 ms against 0.76-0.77.
-template <int N> struct K1ClCfg { static constexpr int YG = (N == 128) ? 16 : 8, CC = 128 / YG; };
-template <int N> __global__ void __launch_bounds__(64 * FftPlan<N>::T)
+//  * round 4, N = 160 (one 89 KB block per CU): 32 pencils per block -- 44 KB, three blocks per CU -- as 8 rows x 8 channels
+//    0.686 ms (32-byte gathers), as 4 rows x 16 channels 1.67 ms (32-byte OUTPUT runs: 2.7 x), 16 rows x 8 channels
+//    re-measured 0.675, against 0.61 for 8 x 16; 48 ch x 80^3: 1.93 / 3.65 / 2.12 against 1.71.  Occupancy is not what this
+//    kernel lacks; the run lengths of its gathers and stores are what it pays for.
+#ifndef DLPD_K1_YG160
+#define DLPD_K1_YG160 8
+#endif
+#ifndef DLPD_K1_CC160
+#define DLPD_K1_CC160 16
+#endif
+template <int N> struct K1ClCfg {
+  static constexpr int YG = (N == 128) ? 16 : (N == 160 ? DLPD_K1_YG160 : 8), CC = (N == 160) ? DLPD_K1_CC160 : 128 / YG;
+  static constexpr int NP = CC * (YG / 2);             // two-row pencils per block
+};
+template <int N> __global__ void __launch_bounds__(K1ClCfg<N>::NP * FftPlan<N>::T)
 k_rotate_zfft_cl(const float4* __restrict__ cl, const float* __restrict__ R, cplx* __restrict__ A,
                  int C, int Cq, int nb, float c0, int CT_out, int c_base, int ext) {
-  constexpr int L = N / 2, NZ = N / 2 + 1, NP = 64, CC = K1ClCfg<N>::CC, YG = K1ClCfg<N>::YG, NPR = YG / 2;
+  constexpr int L = N / 2, NZ = N / 2 + 1, NP = K1ClCfg<N>::NP, CC = K1ClCfg<N>::CC, YG = K1ClCfg<N>::YG, NPR = YG / 2;
   constexpr int LPV = CC / 4, SKEW = 16 / LPV;         // lanes per voxel; bank skew (complex) between channel quads
-  static_assert(CC * NPR == NP && L % YG == 0, "64 pencils per block");
+  static_assert(CC * NPR == NP && L % YG == 0 && (NP * FftPlan<N>::T) % 64 == 0, "whole waves of pencils per block");
   constexpr int RS = N + 13;
   constexpr int T = FftPlan<N>::T, R1 = FftPlan<N>::R1, R2 = FftPlan<N>::R2;
   constexpr int NT = NP * T;
@@ -425,12 +438,12 @@ template <int N> static int launch_k1_cl(const float4* cl, const float* R, cplx*
                                          int CT_out, int c_base, int ext = 0) {
   constexpr int L = N / 2, RS = N + 13;
   const int Cq = ((C + DLPD_K1CL_CC - 1) / DLPD_K1CL_CC) * (DLPD_K1CL_CC / 4);
-  const size_t shmem = (size_t)(64 * RS + N) * sizeof(cplx);
+  const size_t shmem = (size_t)(K1ClCfg<N>::NP * RS + N) * sizeof(cplx);
   int rc = dlpd_set_max_dyn_shared((const void*)k_rotate_zfft_cl<N>, shmem);
   if (rc) return rc;
   const int per = (L / K1ClCfg<N>::YG) * (Cq / (K1ClCfg<N>::CC / 4));
   const int gper = (nb * L + 7) / 8;
-  dim3 grid((unsigned)(8 * gper * per)), block(64 * FftPlan<N>::T);
+  dim3 grid((unsigned)(8 * gper * per)), block(K1ClCfg<N>::NP * FftPlan<N>::T);
   DLPD_LAUNCH((k_rotate_zfft_cl<N>), grid, block, shmem, st, cl, R, A, C, Cq, nb, c0, CT_out, c_base, (ext > 0 && ext < L) ? ext : L);
   return dlpd_check_launch();
 }
