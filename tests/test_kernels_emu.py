@@ -646,6 +646,14 @@ def test_k3_role_split_equals_the_channel_owning_k3_emulated(emu):
     _k3_both_formulations(emu, "cpu", 64, 5, 20, 0.4, 77)
 
 
+def test_k3_two_pencil_buffers_at_box_80_emulated(emu):
+    """The N = 160 formulation (16-row tiles, five transform + ten filter waves, TWO pencil buffers read in place, raw staging
+    of exactly one channel per wave with its last DMA instruction on eight lanes): 6 score channels + clash = 7 channels = two
+    groups (4 + 3: the fifth transform wave idles, the clash channel closes the second group), hidden width 20 (padded to 24),
+    clip biting -- bit for bit against the channel-owning K3 (a test variant) and within tolerance of the oracle."""
+    _k3_both_formulations(emu, "cpu", 80, 6, 20, 0.4, 5)
+
+
 def _fused_wide_hidden(lib, device, L, C, C1, H, nb, seed):
     """Hidden widths 33..48 on the fused pipeline (role-split K3, two voxels per thread): V against the oracle."""
     g = torch.Generator().manual_seed(seed)
