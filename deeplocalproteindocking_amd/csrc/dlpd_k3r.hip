@@ -68,6 +68,9 @@ template <int N> DLPD_D void init_twiddles_k3r(cplx* tw, int tid, int nthreads) 
 #ifndef DLPD_K3R_PBUF160W
 #define DLPD_K3R_PBUF160W 2
 #endif
+#ifndef DLPD_K3R_PBUF128W
+#define DLPD_K3R_PBUF128W 2
+#endif
 #ifndef DLPD_K3R_PBUF128
 #define DLPD_K3R_PBUF128 1
 #endif
@@ -83,7 +86,8 @@ template <int N> DLPD_D void init_twiddles_k3r(cplx* tw, int tid, int nthreads) 
 // WIDE: hidden widths 33..48 (the reference class default: multiplier 16 -> [32, 64] channels -> hidden 48,
 // ProteinRepresentationModels.py:24,35-36): 96 accumulators are two voxels x 48 hidden units, so the filter waves
 // take two voxels per thread and the tile shrinks to 8 rows where 16 rows would need 16 filter waves.
-// (round 4: the WIDE configuration at N = 160 runs two pencil buffers as well -- K3 3.40 -> 3.05 ms at width 48 on the real
+// (round 4: the WIDE configurations run two pencil buffers as well -- N = 128, 48 channels, width 48: K3 3.86-3.94 -> 3.81-3.83 ms;
+// N = 160: K3 3.40 -> 3.05 ms at width 48 on the real
 // shapes' channels, no spill left; 2.19 / 2.20 at width 32 --, on 8-row tiles still: 16 rows x 160 voxels x 48 accumulators are
 // 480 KB of the CU's 512 KB of registers)
 // Hidden widths above this take two voxels per filter thread (the WIDE configurations below).  Width 32 on four voxels
@@ -96,7 +100,7 @@ template <> struct K3rCfg<80, false> { static constexpr int F = 5, M = 5, TY = 1
 template <> struct K3rCfg<128, false> { static constexpr int F = DLPD_K3R_F128, M = 8, TY = 16, RAWBUF = DLPD_K3R_RAWBUF128, PBUF = DLPD_K3R_PBUF128; };
 template <> struct K3rCfg<160, false> { static constexpr int F = 5, M = DLPD_K3R_M160, TY = DLPD_K3R_TY160, RAWBUF = 1, PBUF = DLPD_K3R_PBUF160; };
 template <> struct K3rCfg<80, true> { static constexpr int F = 5, M = 10, TY = 16, RAWBUF = 1, PBUF = 1; };
-template <> struct K3rCfg<128, true> { static constexpr int F = 4, M = 8, TY = 8, RAWBUF = 1, PBUF = 1; };
+template <> struct K3rCfg<128, true> { static constexpr int F = 4, M = 8, TY = 8, RAWBUF = 1, PBUF = DLPD_K3R_PBUF128W; };
 template <> struct K3rCfg<160, true> { static constexpr int F = 5, M = 10, TY = 8, RAWBUF = 1, PBUF = DLPD_K3R_PBUF160W; };
 
 #ifdef DLPD_STAMPS
