@@ -24,6 +24,14 @@ __device__ __forceinline__ void dlpd_glds16(const void* g, void* l) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(la), "v"(g) : "memory", "m0");
 }
 #define DLPD_GLDS16(g, l) dlpd_glds16((const void*)(g), (void*)(l))
+// the same from a wave-uniform base (scalar register pair) + a 32-bit byte offset per lane: the per-instruction address is
+// scalar arithmetic, no 64-bit vector add
+__device__ __forceinline__ void dlpd_glds16_so(const void* base, unsigned voff, void* l) {
+  const unsigned la =
+      __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)l);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(la), "v"(voff), "s"(base) : "memory", "m0");
+}
+#define DLPD_GLDS16_SO(base, voff, l) dlpd_glds16_so((const void*)(base), (unsigned)(voff), (void*)(l))
 // barrier that orders LDS traffic only (leaves global loads / LDS-DMA in flight)
 #define DLPD_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define DLPD_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")

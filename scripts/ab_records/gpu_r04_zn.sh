@@ -1,0 +1,9 @@
+#!/bin/bash
+# round 4, call zn: K3's raw-spectrum DMA addressed from a scalar base + one 32-bit lane offset (default) against 64-bit vector
+# addresses (k3vaddr, built from the previous source)
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+cd $ROOT
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -m gpu -k "k3_role or real or two_res or hidden or fused or pipeline" 2>&1 | tail -1
+for wl in config2 real c48l80; do
+  bash scripts/gpu_ab_now.sh r04_zn_$wl 40 --workload $wl --no_pmc --gather_rotations 0 --strong_s 0 -- default k3vaddr
+done
