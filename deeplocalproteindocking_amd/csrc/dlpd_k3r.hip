@@ -361,7 +361,7 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
     // ================= filter waves =================
     float nrm[EPT * 2];
     float h[EPT * 2][HP];
-    cplx vals[PBUF == 2 ? 1 : GMAX][EPT];
+    cplx vals[PBUF == 2 ? 1 : GMAX][EPT] = {};
     const cplx* P = S;
     int t = t_beg, cbase = 0;
 #pragma unroll 1
@@ -428,7 +428,17 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
           nrm[2 * e + 1] = v.y;
         }
       }
-      if (PBUF == 1) DLPD_LDS_BARRIER();       // B2: values held in registers, pencils free for the next group
+      if (PBUF == 1) {
+        DLPD_LDS_BARRIER();                    // B2: values held in registers, pencils free for the next group
+        // (the barrier's own wait is inline assembly the compiler does not see: consumed here, the copied values are not
+        // "pending" when the channel blocks start -- see "THE FIRST CHANNEL'S OPERANDS ARE CONSUMED HERE" below)
+        // (unconditionally: a consumption under `g < gs` leaves the value pending on the other path of the join)
+#pragma unroll
+        for (int g = 0; g < GMAX; g++) {
+#pragma unroll
+          for (int e = 0; e < EPT; e++) { DLPD_SINK_V(vals[g][e].x); DLPD_SINK_V(vals[g][e].y); }
+        }
+      }
       DLPD_STAMP(2);
       if (PBUF == 2) {
         // TWO PENCIL BUFFERS: the values are read where they are used -- this buffer stays untouched until these waves
@@ -443,6 +453,15 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
           for (int j = 0; j < HP; j++) wcur[j] = W1t[(size_t)cbase * HP + j];
 #pragma unroll
           for (int e = 0; e < EPT; e++) vcur[e] = pv[e * MSTEP * RS];
+          // THE FIRST CHANNEL'S OPERANDS ARE CONSUMED HERE (empty asm): scalar loads return out of order, so any wait on
+          // them is a wait for all of them; left pending into the channel blocks, the first row forces a full wait behind
+          // EVERY block's requests for the next channel -- the multiply-adds of channel g then start only when channel
+          // g + 1's operands have arrived (seen in the ISA: s_load, ds_read, s_waitcnt lgkmcnt(0), 48 packed FMAs).  With
+          // nothing pending on entry the compiler waits where the hand-over needs it: behind the multiply-adds.
+#pragma unroll
+          for (int j = 0; j < HP; j++) DLPD_SINK_S(wcur[j]);
+#pragma unroll
+          for (int e = 0; e < EPT; e++) { DLPD_SINK_V(vcur[e].x); DLPD_SINK_V(vcur[e].y); }
         }
 #pragma unroll
         for (int g = 0; g < GMAX; g++) {
@@ -480,6 +499,8 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
         if (gs > 0) {
 #pragma unroll
           for (int j = 0; j < HP; j++) wcur[j] = W1t[(size_t)cbase * HP + j];
+#pragma unroll
+          for (int j = 0; j < HP; j++) DLPD_SINK_S(wcur[j]);      // (see "THE FIRST CHANNEL'S OPERANDS ARE CONSUMED HERE")
         }
 #pragma unroll
         for (int g = 0; g < GMAX; g++) {

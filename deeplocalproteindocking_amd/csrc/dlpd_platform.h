@@ -78,6 +78,9 @@ __device__ __forceinline__ float2 dlpd_load_stream_c(const float2* p) {
 #define DLPD_OPAQUE_V(x) asm volatile("" : "+v"(x))
 // a wave-uniform integer as a SCALAR register value (addresses built from it use scalar arithmetic)
 #define DLPD_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+// uses of a scalar / vector register value that emit nothing (the compiler must have the value at this point)
+#define DLPD_SINK_S(x) asm volatile("" ::"s"(x))
+#define DLPD_SINK_V(x) asm volatile("" ::"v"(x))
 #define DLPD_OPAQUE_S(x) asm volatile("" : "+s"(x))
 // make a lane-dependent int opaque to the optimiser at this point: stops loop-invariant code motion
 // from hoisting dozens of swizzled LDS offsets out of the pencil-set loops (they are cheap to

@@ -233,6 +233,9 @@ static inline float2 dlpd_load_stream_c(const float2* p) { return *p; }
 #define DLPD_SCHED_FENCE() ((void)0)
 #define DLPD_OPAQUE_V(x) ((void)0)
 #define DLPD_UNIFORM(x) (x)
+// uses of a scalar / vector register value that emit nothing (the compiler must have the value at this point)
+#define DLPD_SINK_S(x) ((void)(x))
+#define DLPD_SINK_V(x) ((void)(x))
 #define DLPD_OPAQUE_S(x) ((void)0)
 #define DLPD_OPAQUE(x) ((void)(x))
 #define DLPD_SET_PRIO(n) ((void)0)
