@@ -283,11 +283,11 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
         const cplx* src = Bw + (((size_t)tb * CT + cb + DLPD_UNIFORM(g)) * NZ * N + txo) * N + ty0;
         // slot NPAIR*k + msl of the raw channel holds row pair msl ^ k3r_pair_swz(k) of bin k (see k3r_first_pass)
         const unsigned lane_off = (unsigned)(((lane / NPAIR) * N * N + 2 * ((lane % NPAIR) ^ k3r_pair_swz<NPAIR>(lane / NPAIR))) * sizeof(cplx));
-        float4* rj = rawg + buf * (F * CPW * RAWC) + j * RAWC;
+        const dlpd_lds_t rj = DLPD_LDS_ADDR(rawg + buf * (F * CPW * RAWC) + j * RAWC);      // LDS address, taken once
 #pragma unroll
-        for (int it = 0; it < NFULL; it++) DLPD_GLDS16_SO(src + (size_t)it * LPK * N * N, lane_off, rj + it * 64);
+        for (int it = 0; it < NFULL; it++) DLPD_GLDS16_SOA(src + (size_t)it * LPK * N * N, lane_off, rj + it * 1024);
         const int mt = lane % NPAIR;                        // tail lanes re-read valid elements
-        if (PBUF == 1 || lane < NPAIR) DLPD_GLDS16_SO(src + (size_t)(N / 2) * N * N, 2 * mt * sizeof(cplx), rj + NFULL * 64);
+        if (PBUF == 1 || lane < NPAIR) DLPD_GLDS16_SOA(src + (size_t)(N / 2) * N * N, 2 * mt * sizeof(cplx), rj + NFULL * 1024);
       }
     }
   };

@@ -32,6 +32,17 @@ __device__ __forceinline__ void dlpd_glds16_so(const void* base, unsigned voff, 
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(la), "v"(voff), "s"(base) : "memory", "m0");
 }
 #define DLPD_GLDS16_SO(base, voff, l) dlpd_glds16_so((const void*)(base), (unsigned)(voff), (void*)(l))
+// ... and the LDS destination as a 32-bit LDS address taken ONCE (the cast of a generic pointer costs a 64-bit add, two
+// readfirstlanes, a null check and a select per use): dlpd_lds_t a = DLPD_LDS_ADDR(p); DLPD_GLDS16_SOA(base, voff, a + bytes)
+typedef unsigned dlpd_lds_t;
+__device__ __forceinline__ dlpd_lds_t dlpd_lds_addr(void* l) {
+  return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)l);
+}
+__device__ __forceinline__ void dlpd_glds16_soa(const void* base, unsigned voff, dlpd_lds_t la) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(la), "v"(voff), "s"(base) : "memory", "m0");
+}
+#define DLPD_LDS_ADDR(p) dlpd_lds_addr((void*)(p))
+#define DLPD_GLDS16_SOA(base, voff, la) dlpd_glds16_soa((const void*)(base), (unsigned)(voff), (la))
 // barrier that orders LDS traffic only (leaves global loads / LDS-DMA in flight)
 #define DLPD_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define DLPD_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")

@@ -218,6 +218,9 @@ static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
 #define DLPD_GLDS16(g, l) memcpy(reinterpret_cast<char*>(l) + 16 * (emu::S().cur % 64), (const void*)(g), 16)
 #define DLPD_GLDS16_SO(base, voff, l) DLPD_GLDS16(reinterpret_cast<const char*>(base) + (voff), l)
+typedef char* dlpd_lds_t;
+#define DLPD_LDS_ADDR(p) reinterpret_cast<char*>(p)
+#define DLPD_GLDS16_SOA(base, voff, la) DLPD_GLDS16(reinterpret_cast<const char*>(base) + (voff), (la))
 #define DLPD_LDS_BARRIER() emu::barrier()
 #define DLPD_WAIT_VMEM() ((void)0)
 #define DLPD_WAVE_SYNC() emu::wave_sync()
