@@ -348,6 +348,30 @@ template <int N, int R, int NS, int DIR, int T, int NNZ = N, int ADJ = 0> struct
       }
     }
   }
+  // the same with this thread's twiddles handed in (twr[i][r - 1] = tw[k_i r]: they do not change between calls, so a caller
+  // that loops can keep them in registers -- fetch_twiddles -- instead of re-reading the LDS table every time)
+  DLPD_D void fetch_twiddles(int t, const cplx* tw, cplx (&twr)[PER][R - 1]) const {
+    static_assert(NS > 1 && NNZ == N, "second or later pass of an unpruned plan");
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+      const int k = (bf(i, t) % NS) * (N / (NS * R));
+#pragma unroll
+      for (int r = 1; r < R; r++) twr[i][r - 1] = active(i, t) ? tw[k * r] : c_make(1.f, 0.f);
+    }
+  }
+  template <class Addr> DLPD_D void load_twr(const cplx* S, const Addr& ad, int t, const cplx (&twr)[PER][R - 1]) {
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+      const int j = bf(i, t);
+      if (active(i, t)) {
+#pragma unroll
+        for (int r = 0; r < R; r++) v[i][r] = lds_ld(S + ad(j + r * NBF));
+#pragma unroll
+        for (int r = 1; r < R; r++) v[i][r] = DIR < 0 ? c_mul(v[i][r], twr[i][r - 1]) : c_mulc(v[i][r], twr[i][r - 1]);
+        SmallDft<R, DIR>::run(v[i]);
+      }
+    }
+  }
   DLPD_HD int out_index(int i, int r, int t) const {
     const int j = bf(i, t);
     return (j / NS) * NS * R + (j % NS) + r * NS;

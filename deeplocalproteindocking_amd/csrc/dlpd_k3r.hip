@@ -68,6 +68,9 @@ template <int N> DLPD_D void init_twiddles_k3r(cplx* tw, int tid, int nthreads) 
 #ifndef DLPD_K3R_PBUF160W
 #define DLPD_K3R_PBUF160W 2
 #endif
+#ifndef DLPD_K3R_TWREG128
+#define DLPD_K3R_TWREG128 1
+#endif
 #ifndef DLPD_K3R_PBUF128W
 #define DLPD_K3R_PBUF128W 2
 #endif
@@ -172,10 +175,22 @@ template <int N, int NPAIR> DLPD_D void k3r_first_pass(cplx* S, int rowoff, int 
   k3r_first_pass_store<N>(S, rowoff, t, ps);
 }
 
-template <int N> DLPD_D void k3r_second_pass(cplx* S, int rowoff, int t, const cplx* tw) {
+// second pass of the transform waves.  K3rTwReg<N>: the pass' twiddles (14 complex values per thread at N = 128) stay in the
+// transform waves' registers for the whole kernel instead of being read from the LDS table in every step -- the block's register
+// allocation is set by the filter waves' accumulators, the transform waves have room
+template <int N> struct K3rTwReg { static constexpr bool value = (N == 128) && (DLPD_K3R_TWREG128 != 0); };
+template <int N> struct K3rSecond { typedef FftPassW<N, 8, N / 8, +1, 8> Pass; };
+template <int N> DLPD_D void k3r_second_pass(cplx* S, int rowoff, int t, const cplx* tw,
+                                             const cplx (&twr)[K3rSecond<N>::Pass::PER][7]) {
   constexpr int R1 = N / 8;
   DLPD_WAVE_SYNC();
-  if constexpr (N == 160) {
+  if constexpr (K3rTwReg<N>::value) {
+    const RowAddr<0> ad = {rowoff};
+    typename K3rSecond<N>::Pass ps;
+    ps.load_twr(S, ad, t, twr);
+    DLPD_WAVE_SYNC();
+    ps.store(S, ad, t);
+  } else if constexpr (N == 160) {
     cplx* P = S + rowoff;
     FftPassW<N, 8, 20, +1, 8> ps;                    // 20 butterflies of radix 8: three rounds, the last half full
 #pragma unroll
@@ -311,6 +326,11 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
     // ================= transform waves: raw -> pencils of group (t, cbase) =================
     int t = t_beg, cbase = 0, rb = 0;
     cplx* P = S;                               // this step's pencil buffer
+    cplx twr[K3rSecond<N>::Pass::PER][7];      // (K3rTwReg: the second pass' twiddles, fetched once)
+    if constexpr (K3rTwReg<N>::value) {
+      typename K3rSecond<N>::Pass ps0;
+      ps0.fetch_twiddles(lane & 7, tw, twr);
+    }
 #pragma unroll 1
     for (int step = 0; step < nsteps; step++) {
       const int gn = (CT - cbase) < G ? (CT - cbase) : G;
@@ -343,7 +363,7 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
       }
       DLPD_STAMP(1);
       if (RAWBUF == 1 && nt < t_end) issue_channel(nt, ncb, 0, ln);
-      if (mine) k3r_second_pass<N>(P, (twave * 8 + qr) * RS, tr, tw);
+      if (mine) k3r_second_pass<N>(P, (twave * 8 + qr) * RS, tr, tw, twr);
       DLPD_STAMP(2);
       if (RAWBUF == 2) rb ^= 1;
       DLPD_LDS_BARRIER();                      // B1
