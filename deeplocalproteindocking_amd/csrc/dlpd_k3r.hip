@@ -279,6 +279,8 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
   const int twave = wave, fwave = wave - F;
   const int t_beg = blockIdx.x * tpb, t_end = (t_beg + tpb < ntiles) ? t_beg + tpb : ntiles;
   if (t_beg >= t_end) return;
+  // a block's tiles lie in ONE x' plane (tpb divides the NYT tiles of a plane): plane, x' and rotation are decoded once
+  const int plane = t_beg / NYT, plane_x = plane % N, plane_b = plane / N;
   init_twiddles_k3r<N>(tw, tid, 64 * (F + M));
   const unsigned cand_tau = (MODE == 1 && cd.keys) ? *cd.tau : 0u;
   // no clip = a clamp to +-infinity, which returns its argument: one v_med3 per value instead of a v_med3 and a select
@@ -289,7 +291,7 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
   //      bytes per DMA instruction; k = N/2 is the last, short one)
   float4* rawg = raw + twave * CPW * RAWC;
   auto issue_channel = [&](int t, int cb, int buf, int lane) {
-    const int ty0 = (t % NYT) * TY, txo = (t / NYT) % N, tb = t / (NYT * N);
+    const int ty0 = (t - plane * NYT) * TY, txo = plane_x, tb = plane_b;
 #pragma unroll
     for (int j = 0; j < CPW; j++) {
       const int g = twave * CPW + j;
@@ -386,7 +388,7 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
     int t = t_beg, cbase = 0;
 #pragma unroll 1
     for (int step = 0; step < nsteps; step++) {
-      const int y0 = (t % NYT) * TY, xo = (t / NYT) % N, b = t / (NYT * N);
+      const int y0 = (t - plane * NYT) * TY, xo = plane_x, b = plane_b;
       const int gn = (CT - cbase) < G ? (CT - cbase) : G;
       const bool last_group = cbase + G >= CT;
       // the lane's voxel coordinates re-enter every step as opaque values: what is derived from them (LDS offsets, global
