@@ -177,7 +177,8 @@ template <int N, int NPAIR> DLPD_D void k3r_first_pass(cplx* S, int rowoff, int 
 
 // second pass of the transform waves.  K3rTwReg<N>: the pass' twiddles (14 complex values per thread at N = 128) stay in the
 // transform waves' registers for the whole kernel instead of being read from the LDS table in every step -- the block's register
-// allocation is set by the filter waves' accumulators, the transform waves have room
+// allocation is set by the filter waves' accumulators, the transform waves have room (K3<128> 1.78 -> 1.74 ms; at N = 160 the
+// 21 values per thread do not fit next to the radix-20 pass under the 128 registers of 15 waves: 4 spilled, not enabled)
 template <int N> struct K3rTwReg { static constexpr bool value = (N == 128) && (DLPD_K3R_TWREG128 != 0); };
 template <int N> struct K3rSecond { typedef FftPassW<N, 8, N / 8, +1, 8> Pass; };
 template <int N> DLPD_D void k3r_second_pass(cplx* S, int rowoff, int t, const cplx* tw,
