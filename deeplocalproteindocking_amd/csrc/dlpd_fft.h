@@ -359,6 +359,24 @@ template <int N, int R, int NS, int DIR, int T, int NNZ = N, int ADJ = 0> struct
       for (int r = 1; r < R; r++) twr[i][r - 1] = active(i, t) ? tw[k * r] : c_make(1.f, 0.f);
     }
   }
+  // ... in two halves, so that a caller can put other work behind the LDS reads while they are in flight
+  template <class Addr> DLPD_D void load_only(const cplx* S, const Addr& ad, int t) {
+#pragma unroll
+    for (int i = 0; i < PER; i++)
+      if (active(i, t)) {
+#pragma unroll
+        for (int r = 0; r < R; r++) v[i][r] = lds_ld(S + ad(bf(i, t) + r * NBF));
+      }
+  }
+  DLPD_D void run_twr(int t, const cplx (&twr)[PER][R - 1]) {
+#pragma unroll
+    for (int i = 0; i < PER; i++)
+      if (active(i, t)) {
+#pragma unroll
+        for (int r = 1; r < R; r++) v[i][r] = DIR < 0 ? c_mul(v[i][r], twr[i][r - 1]) : c_mulc(v[i][r], twr[i][r - 1]);
+        SmallDft<R, DIR>::run(v[i]);
+      }
+  }
   template <class Addr> DLPD_D void load_twr(const cplx* S, const Addr& ad, int t, const cplx (&twr)[PER][R - 1]) {
 #pragma unroll
     for (int i = 0; i < PER; i++) {

@@ -68,6 +68,9 @@ template <int N> DLPD_D void init_twiddles_k3r(cplx* tw, int tid, int nthreads) 
 #ifndef DLPD_K3R_PBUF160W
 #define DLPD_K3R_PBUF160W 2
 #endif
+#ifndef DLPD_K3R_DMA_BEHIND_LOADS
+#define DLPD_K3R_DMA_BEHIND_LOADS 1
+#endif
 #ifndef DLPD_K3R_TWREG128
 #define DLPD_K3R_TWREG128 1
 #endif
@@ -365,8 +368,23 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
         DLPD_WAVE_SYNC();                      // every lane's raw values are in registers: the staging buffer is free
       }
       DLPD_STAMP(1);
-      if (RAWBUF == 1 && nt < t_end) issue_channel(nt, ncb, 0, ln);
-      if (mine) k3r_second_pass<N>(P, (twave * 8 + qr) * RS, tr, tw, twr);
+      if constexpr (K3rTwReg<N>::value && DLPD_K3R_DMA_BEHIND_LOADS) {
+        // the second pass' 16 LDS reads first, the next group's DMA (scalar address arithmetic, nine to eleven instructions)
+        // behind them while they are in flight, then twiddles, butterflies and stores
+        const RowAddr<0> ad = {(twave * 8 + qr) * RS};
+        typename K3rSecond<N>::Pass ps;
+        DLPD_WAVE_SYNC();
+        if (mine) ps.load_only(P, ad, tr);
+        if (RAWBUF == 1 && nt < t_end) issue_channel(nt, ncb, 0, ln);
+        if (mine) {
+          ps.run_twr(tr, twr);
+          DLPD_WAVE_SYNC();
+          ps.store(P, ad, tr);
+        }
+      } else {
+        if (RAWBUF == 1 && nt < t_end) issue_channel(nt, ncb, 0, ln);
+        if (mine) k3r_second_pass<N>(P, (twave * 8 + qr) * RS, tr, tw, twr);
+      }
       DLPD_STAMP(2);
       if (RAWBUF == 2) rb ^= 1;
       DLPD_LDS_BARRIER();                      // B1
