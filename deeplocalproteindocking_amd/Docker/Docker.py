@@ -71,9 +71,15 @@ class _FixedRotations(object):
         self.source = "explicit"
 
 
-def random_rotation(generator=None):
+def random_rotation(generator=None, seed=None):
     """Uniform random rotation (1,3,3) float64 -- stand-in for TPL getRandomRotation(1)
-    (Docker.py:44); the TPL RNG stream cannot be matched (source absent)."""
+    (Docker.py:44); the TPL RNG stream cannot be matched (source absent).
+    Without ``generator`` the numbers come from a generator of their own -- seeded with ``seed`` or, for ``None``, from
+    the operating system's entropy -- so that the rotation neither repeats from run to run (torch's global generator
+    starts from a fixed default seed) nor depends on what else has drawn from the process-global stream."""
+    if generator is None:
+        generator = torch.Generator()
+        generator.manual_seed(int(seed)) if seed is not None else generator.seed()
     u = torch.rand(3, generator=generator, dtype=torch.float64).numpy()
     phi, psi = 2 * np.pi * u[0] - np.pi, 2 * np.pi * u[2] - np.pi
     theta = np.arccos(1.0 - 2.0 * u[1])
@@ -119,7 +125,7 @@ class Docker:
     def __init__(self, docking_model, angle_inc=15.0, box_size=80, resolution=1.25, max_conf=1000,
                  randomize_rot=False, rotations=None, device="cuda", coords_backend=None,
                  rank=0, world_size=1, process_group=None, lib=None, launch_batch=None, rotation_center=None,
-                 conventions=None):
+                 conventions=None, rotation_seed=None):
         self.docking_model = docking_model
         self.log = None
 
@@ -133,14 +139,20 @@ class Docker:
         self.box_center = torch.zeros(1, 3, dtype=torch.double, device='cpu')
         self.box_center.fill_(self.box_length / 2.0)
 
-        self.randomize_rot = randomize_rot
-        if self.randomize_rot:
-            self.randR = random_rotation()
-            print("Adding random rotation to the receptor:", self.randR)
-
         self.device = torch.device(device)
         self.coords_backend = coords_backend
         self.rank, self.world_size, self.process_group = int(rank), int(world_size), process_group
+
+        # Docker.py:42-45.  Rotation-sharded over ranks, every rank must score the SAME rotated receptor: rank 0's
+        # matrix is broadcast (here when the process group already exists, else at the start of the first dock* call);
+        # rotation_seed makes it reproducible (None: a fresh one per Docker, as "random" says).
+        self.randomize_rot = randomize_rot
+        self._randR_shared = self.world_size <= 1
+        if self.randomize_rot:
+            self.randR = random_rotation(seed=rotation_seed)
+            self._share_random_rotation(required=False)
+            if self.rank == 0 or not self._randR_shared:
+                print("Adding random rotation to the receptor:", self.randR)
         self._lib = lib
         self.launch_batch = int(launch_batch or os.environ.get("DLPD_LAUNCH_BATCH", LAUNCH_BATCH))
         # Pivot of the trilinear VOLUME rotation in voxel-index units (build-defined: TorchProteinLibrary's
@@ -163,6 +175,26 @@ class Docker:
         self.top_list = []
         self.engine = None
         atexit.register(self.cleanup)
+
+    def _share_random_rotation(self, required=True):
+        """world_size > 1: replace this rank's ``randR`` by rank 0's (one broadcast of nine doubles, once per Docker).
+        Without it the ranks would score differently rotated receptors and merge them into one silently wrong list."""
+        if not self.randomize_rot or self._randR_shared:
+            return
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            if required:
+                raise Exception("Docker(world_size=%d, randomize_rot=True) needs an initialised torch.distributed "
+                                "process group to share the random rotation" % self.world_size)
+            return
+        group = self.process_group
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        buf = self.randR.to(dtype=torch.float64).reshape(9).clone()
+        if dist.get_backend(group) == "nccl":
+            buf = buf.to(self.device)
+        dist.broadcast(buf, src=src, group=group)
+        self.randR = buf.cpu().reshape(1, 3, 3)
+        self._randR_shared = True
 
     # ------------------------------------------------------------------ the reference's operator objects
     # Docker.py:29-40 creates TorchProteinLibrary operators as attributes; nothing outside the class reads them, but
@@ -312,6 +344,7 @@ class Docker:
         on it.  model_batch: rotations per call of a model that has to be CALLED (generic path)."""
         model = self.docking_model
         model.eval() if hasattr(model, "eval") else None
+        self._share_random_rotation()           # (write_conformations undoes randR: the same matrix on every rank)
         rec = [torch.as_tensor(v, dtype=torch.float32) for v in receptor_volumes]
         lig = [torch.as_tensor(v, dtype=torch.float32) for v in ligand_volumes]
         rec = [v.reshape((-1,) + tuple(v.shape[-3:])) for v in rec]
@@ -593,6 +626,7 @@ class Docker:
         be = self._need_backend()
         self.top_list = []
         self.docking_model.eval()
+        self._share_random_rotation()
         rcoords, rnat, roff, rT, rnatoms = self.load_batch([ureceptor], bbox_center=False)
         lcoords, lnat, loff, lT, lnatoms = self.load_batch([uligand], bbox_center=False)
         if self.randomize_rot:
@@ -625,6 +659,7 @@ class Docker:
         model = self.docking_model
         model.eval()
         dev = self.device
+        self._share_random_rotation()
         rcoords, rnat, roff, rT, rnatoms = self.load_batch([ureceptor], bbox_center=False)
         lcoords, lnat, loff, lT, lnatoms = self.load_batch([uligand], bbox_center=False)
         if self.randomize_rot:

@@ -301,3 +301,117 @@ def test_bench_eight_rank_launch_plumbing():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0]) == {"dry_run": True, "n_gpus": 8, "steps": 4, "warmup": 1}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the reference's production call (local_test.py:55: randomize_rot=True) on a rotation-sharded search
+# ---------------------------------------------------------------------------------------------------------------
+def _run_random_rot(rank, world, port, out, tmp, method="dockSE3", late_group=False, randR=None):
+    """One rank of Docker(randomize_rot=True).dockSE3 / dockE3 from PDB files on the emulated kernels.  Every rank has
+    its OWN RNG state (global seed and rotation_seed differ per rank), as any rank-dependent seeding would give it; rank
+    0 alone opens the .dat.  late_group: the process group is created AFTER the Docker (the matrix is then shared at the
+    start of dock*).  randR: force this matrix (the single-process comparison run)."""
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(1)
+    from emu_lib import emu_lib
+    from oracle import docking_oracle as orc
+    from test_atoms import _assert_scores_are_informative, _tiny_model, _typed
+    from deeplocalproteindocking_amd.Docker import Docker
+    from deeplocalproteindocking_amd.Docker.Docker import random_rotation
+    from deeplocalproteindocking_amd.Utils.FullAtom import CoordsBackend
+    import pathlib
+    tmp = pathlib.Path(tmp)
+    init = lambda: dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    if world > 1 and not late_group:
+        init()
+    L, res, K = 32, 1.25, 40
+    frec, _, _, _ = _typed(tmp, 14, seed=5)
+    flig, _, _, _ = _typed(tmp, 9, seed=6)
+    model = _tiny_model()
+    # five neighbouring rotations: their best scores are close, so the merged list draws on both shards
+    R = orc.euler_to_matrix(0.3 + 0.03 * np.arange(5), 1.1 - 0.02 * np.arange(5), -2.0 + 0.025 * np.arange(5))
+    torch.manual_seed(1000 + 17 * rank)                            # rank-dependent global RNG state
+    lib = emu_lib()
+    dk = Docker(model, box_size=L, resolution=res, max_conf=K, rotations=R, device="cpu", lib=lib,
+                coords_backend=CoordsBackend(lib=lib), randomize_rot=True, rotation_seed=500 + rank,
+                rank=rank, world_size=world)
+    own = random_rotation(seed=500 + rank)
+    if world > 1 and late_group:
+        assert torch.equal(dk.randR, own)                          # nothing to share it through yet
+        init()
+    if randR is not None:
+        dk.randR = torch.as_tensor(randR, dtype=torch.float64).reshape(1, 3, 3)
+    log = str(tmp / ("%s_w%d.dat" % (method, world)))
+    if rank == 0:
+        assert dk.new_log(log)
+    with torch.no_grad():
+        getattr(dk, method)(frec, flig, batch_size=2)
+    dk.cleanup()
+    _assert_scores_are_informative(dk.top_list)
+    out[rank] = {"top": list(dk.top_list), "randR": dk.randR.reshape(9).tolist(), "own": own.reshape(9).tolist(),
+                 "dat": open(log, "rb").read() if rank == 0 else None}
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _random_rot_case(tmp_path, method, late_group, base_port):
+    d2, d1 = tmp_path / "w2", tmp_path / "w1"
+    d2.mkdir(), d1.mkdir()
+    out, procs = _spawn(_run_random_rot, 2, base_port + (os.getpid() % 1500), str(d2), method, late_group)
+    _join(procs)
+    r0, r1 = out[0], out[1]
+    assert r0["own"] != r1["own"]                                  # the ranks drew different matrices ...
+    assert r0["randR"] == r0["own"] and r1["randR"] == r0["own"]   # ... and both ended with rank 0's
+    assert r0["top"] == r1["top"] and len(r0["top"]) == 40
+    assert len({t[0] % 2 for t in r0["top"]}) == 2                 # entries from both shards
+    single = {}
+    _run_random_rot(0, 1, 0, single, str(d1), method, False, r0["randR"])
+    assert single[0]["top"] == r0["top"]
+    assert single[0]["dat"] == r0["dat"] and len(r0["dat"].splitlines()) == 40
+    # a rank-1-only matrix would have given another list: the receptor really is rotated by randR
+    other = {}
+    d3 = tmp_path / "w1b"
+    d3.mkdir()
+    _run_random_rot(0, 1, 0, other, str(d3), method, False, r1["own"])
+    assert other[0]["top"] != r0["top"]
+
+
+def test_two_rank_dockSE3_with_random_receptor_rotation_equals_single_process(tmp_path):
+    """local_test.py:55 constructs Docker(randomize_rot=True); Docker.py:44,193-197 rotates the receptor's atoms by that
+    matrix.  Rotation-sharded, every rank must use rank 0's: the merged list and the .dat bytes equal a single-process
+    run given the same matrix, although each rank's generator would have drawn another."""
+    _random_rot_case(tmp_path, "dockSE3", False, 38400)
+
+
+def test_two_rank_dockE3_with_random_receptor_rotation_and_a_late_process_group(tmp_path):
+    """The same for dockE3 (Docker.py:135-182), with the process group created after the Docker: the matrix is then
+    shared at the start of the dock call."""
+    _random_rot_case(tmp_path, "dockE3", True, 40100)
+
+
+def test_sharded_docker_without_a_process_group_refuses_to_dock_with_a_private_rotation(tmp_path):
+    from emu_lib import emu_lib
+    from test_atoms import _tiny_model, _typed
+    from deeplocalproteindocking_amd.Docker import Docker
+    import pytest
+    frec, _, _, _ = _typed(tmp_path, 6, seed=5)
+    dk = Docker(_tiny_model(), box_size=32, max_conf=5, rotations=np.eye(3)[None],
+                device="cpu", lib=emu_lib(), randomize_rot=True, rank=1, world_size=2)
+    with pytest.raises(Exception, match="process group"):
+        dk.dockSE3(frec, frec, batch_size=2)
+
+
+def test_random_rotation_is_fresh_per_docker_and_reproducible_with_a_seed():
+    from deeplocalproteindocking_amd.Docker.Docker import random_rotation
+    a, b = random_rotation(), random_rotation()
+    assert not torch.equal(a, b)
+    assert torch.equal(random_rotation(seed=4), random_rotation(seed=4))
+    state = torch.get_rng_state()
+    random_rotation()
+    assert torch.equal(torch.get_rng_state(), state)               # the process-global stream is left alone
+    for r in (a, b):
+        m = r[0].numpy()
+        assert np.abs(m @ m.T - np.eye(3)).max() < 1e-12 and abs(np.linalg.det(m) - 1) < 1e-12

@@ -747,6 +747,58 @@ def test_two_rank_nccl_search_equals_single_process(dev, tmp_path):
     assert res["sharded"] == res["single"] and len(res["single"]) == res["K"]
 
 
+def _bench_line(extra, timeout=1500):
+    """`python bench.py ...` as the driver starts it (plain python, no torch.distributed environment) -> its JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    return json.loads(lines[0])
+
+
+def test_bench_multi_rank_leg_runs_the_hip_pipeline_with_two_ranks_on_this_gpu(dev):
+    """The code the driver's scaling sweep runs -- bench.py's world > 1 branches: process-group initialisation, the timed
+    region ending in the all-gather + merge, the max-over-ranks reduction, `gather_check`, `strong` -- executed with the
+    HIP kernels by TWO ranks on the one GPU of this box (gloo transport; RCCL wants one device per rank).  The merged
+    list of the gather check must equal the single-process one (same sha256), and the line must carry the contract."""
+    common = ["--steps", "4", "--warmup", "2", "--cpu_rotations", "0", "--no_real_shapes", "--sustained_s", "0",
+              "--gather_rotations", "256"]
+    two = _bench_line(["--gpus", "2", "--backend", "gloo", "--same_device", "--strong_s", "2"] + common)
+    one = _bench_line(["--gpus", "1", "--strong_s", "0"] + common)
+    assert two["n_gpus"] == 2 and two["steps"] == 4 and two["warmup"] == 2 and two["scaling"] == "weak"
+    assert two["config"]["world_size_seen_by_the_collective"] == 2 and two["config"]["collective_backend"] == "gloo"
+    assert two["gather_check"]["world_size_seen"] == 2 and one["gather_check"]["world_size_seen"] == 1
+    assert two["gather_check"]["list_entries"] == 2000
+    assert two["gather_check"]["list_sha256"] == one["gather_check"]["list_sha256"]
+    assert two["strong"]["world_size"] == 2 and two["strong"]["rotations"] >= 16 and two["strong"]["list_entries"] == 2000
+    assert two["value"] > 0 and two["roofline"]["frac"] > 0 and two["top_entries"] == 2000
+    # weak scaling on ONE device: the two ranks share it, so the aggregate stays near the single-rank rate
+    assert 0.5 < two["value"] / one["value"] < 1.6
+    for line in (one, two):
+        assert set(line["setup"]) >= {"host_inputs_s", "device_setup_s"}
+        assert abs(line["setup"]["host_inputs_s"] + line["setup"]["device_setup_s"] - line["per_rank_setup_s"]) < 0.5
+
+
+def test_bench_refuses_same_device_with_rccl(dev):
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = dict({k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")},
+               WORLD_SIZE="2", RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29655")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--same_device"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "--same_device needs --backend gloo" in (r.stdout + r.stderr)
+
+
 def test_k3_role_split_equals_the_channel_owning_k3(dev, variants):
     """k_zifft_filter_rs (dedicated transform / filter waves, the default) bit for bit against k_zifft_filter[_tiles]
     (every wave owns a channel) and against the oracle: 48 channels x 64^3 (13 groups of 4, the last one the clash
