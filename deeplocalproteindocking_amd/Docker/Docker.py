@@ -121,6 +121,37 @@ def all_gather_top_entries(entries, K, world_size, process_group=None, device="c
 LAUNCH_BATCH = 16      # rotations per launch of the fused pipeline
 
 
+class PreparedPair(object):
+    """Everything ``dockSE3`` / ``dockE3`` do for a target BEFORE the rotation loop (Docker.py:184-209 / :135-161): the
+    two PDB files parsed, typed and centred, the receptor projected and represented, its spectrum in an engine, the
+    ligand's volumes (SE3) and its atoms on the device.  ``Docker.prepare`` builds one -- on a stream and a host thread
+    of its own if the caller wants the next target prepared while the current one is searched (local_test.py sweep) --
+    and the dock call consumes it.  ``ready`` orders the consumer's stream after the producer's."""
+
+    def __init__(self, group, ureceptor, uligand, slot):
+        self.group, self.ureceptor, self.uligand, self.slot = group, ureceptor, uligand, slot
+        self.receptor = self.receptor_volumes = self.receptor_forbidden = self.ligand_volumes = None
+        self.ligand_atoms = None           # (coords, num_atoms_of_type, offsets) on the device, origin-centred
+        self.engine = None                 # fused engine with receptor (and, SE3, ligand) already set; None: other paths
+        self.ready = None                  # torch.cuda.Event recorded on the producer's stream
+        self.seconds = 0.0                 # host time of the preparation
+
+    def wait(self, device):
+        """The caller's current stream waits for the preparation; tensors made on the producer's stream are marked as
+        used here so that the caching allocator does not hand their memory out while this stream still reads it."""
+        if self.ready is None or device.type != "cuda":
+            return
+        cur = torch.cuda.current_stream(device)
+        cur.wait_event(self.ready)
+        for t in self.tensors():
+            t.record_stream(cur)
+
+    def tensors(self):
+        out = [self.receptor, self.receptor_forbidden] + list(self.receptor_volumes or []) + list(self.ligand_volumes or []) + \
+            list(self.ligand_atoms or [])
+        return [t for t in out if torch.is_tensor(t) and t.is_cuda]
+
+
 class Docker:
     def __init__(self, docking_model, angle_inc=15.0, box_size=80, resolution=1.25, max_conf=1000,
                  randomize_rot=False, rotations=None, device="cuda", coords_backend=None,
@@ -174,6 +205,7 @@ class Docker:
         self._top = None            # DeviceTopList behind update_top()
         self.top_list = []
         self.engine = None
+        self._engine_pool = {}      # slot -> (key, engine): slot 1 exists only while targets are prepared ahead (prepare)
         atexit.register(self.cleanup)
 
     def _share_random_rotation(self, required=True):
@@ -244,13 +276,19 @@ class Docker:
         that already holds more than one non-blank line counts as finished -- no log is opened and False is
         returned so the caller skips the target; anything else is (re)started from scratch."""
         self.cleanup()
-        if not rewrite and os.path.exists(log_file_name):
-            with open(log_file_name) as existing:
-                filled = sum(1 for line in existing if line.split())
-            if filled > 1:
-                return False
+        if not rewrite and self.log_is_complete(log_file_name):
+            return False
         self.log = open(log_file_name, "w")
         return True
+
+    @staticmethod
+    def log_is_complete(log_file_name):
+        """The test of the resume rule alone (Docker.py:66-76), without opening anything: does the file exist and hold
+        more than one non-blank line?  (A sweep uses it to decide which target to prepare ahead.)"""
+        if not os.path.exists(log_file_name):
+            return False
+        with open(log_file_name) as existing:
+            return sum(1 for line in existing if line.split()) > 1
 
     def cleanup(self):
         """Close the current log, if any (also registered with atexit, Docker.py:46,81-84)."""
@@ -321,8 +359,9 @@ class Docker:
     def release_engine(self):
         """Drop the cached fused engine and its device workspaces (several GB at box 80: wsB for 16 rotations,
         double-buffered score volumes).  The next ``dock*`` call builds a new one."""
-        if self.engine is not None:
-            self.engine.finish()
+        for _, eng in self._engine_pool.values():
+            eng.finish()
+        self._engine_pool = {}
         self.engine, self._engine_key = None, None
         self._top = None
 
@@ -332,7 +371,7 @@ class Docker:
         return np.arange(self.rank, nrot, self.world_size, dtype=np.int64)
 
     def dock_volumes(self, receptor_volumes, ligand_volumes, receptor_forbidden=None, ligand_forbidden=None,
-                     batch_size=None, rot_indices=None, write=True, clash_provider=None, model_batch=None):
+                     batch_size=None, rot_indices=None, write=True, clash_provider=None, model_batch=None, prepared=None):
         """Search all rotations for one pair given its representation volumes.
 
         receptor_volumes / ligand_volumes: lists of (1,C_i,L_i,L_i,L_i) (or (C_i,L_i,..)) tensors
@@ -356,7 +395,9 @@ class Docker:
         R_all = self.rot.R
         ids = self.shard(R_all.shape[0]) if rot_indices is None else np.asarray(rot_indices, dtype=np.int64)
         params = fused_filter_parameters(model)
-        eng = self._make_engine(rec, receptor_forbidden, nb, params)
+        # prepared: a PreparedPair whose engine already holds this receptor's spectrum and this ligand (Docker.prepare)
+        pre_eng = prepared.engine if prepared is not None else None
+        eng = pre_eng if pre_eng is not None else self._make_engine(rec, receptor_forbidden, nb, params)
         entries = None
         if eng is None and self.embed_uncompiled_boxes and not self._library().call("dlpd_grid_supported", int(L)):
             entries = self._dock_volumes_embedded(rec, lig, receptor_forbidden, ligand_forbidden, nb, ids,
@@ -369,8 +410,9 @@ class Docker:
             pass
         elif eng is not None:
             two_res = eng.C1 > 0
-            eng.set_ligand(lig[0], ligand_forbidden if ligand_forbidden is not None else torch.zeros(L, L, L),
-                           lig[1] if two_res else None)
+            if pre_eng is None:
+                eng.set_ligand(lig[0], ligand_forbidden if ligand_forbidden is not None else torch.zeros(L, L, L),
+                               lig[1] if two_res else None)
             eng.clash_provider = clash_provider
             eng.reset_top()
             eng.search(R_all[ids], rot_ids=ids)
@@ -388,7 +430,7 @@ class Docker:
             self.write_conformations()
         return self.top_list
 
-    def _make_engine(self, rec, receptor_forbidden, batch_size, params, inner_box=None):
+    def _make_engine(self, rec, receptor_forbidden, batch_size, params, inner_box=None, slot=0):
         """DockingEngine for one receptor (one resolution, or the reference's [C0 @ L, C1 @ L/2] pair);
         None when the fused pipeline has no kernel for the shape (other grids or resolution layouts,
         hidden width above 32) or the model's scoring is not the MLP it fuses: the stand-alone-op paths
@@ -417,7 +459,8 @@ class Docker:
         key = (int(L), int(C), int(C1), has_clash, HP, int(self.max_conf),
                int(batch_size), str(self.device), self.rotation_pivot(Lp), Lp, cv.scale(Lp), cv.rotation_axis_order, cv.clip_mode,
                cv.rotation_transpose)
-        eng = self.engine if getattr(self, "_engine_key", None) == key else None
+        pooled = self._engine_pool.get(slot)
+        eng = pooled[1] if pooled is not None and pooled[0] == key else None
         if eng is None:
             eng = DockingEngine(L, C, W1.cpu(), b1.cpu(), W2.cpu(), b2.cpu(), clip=getattr(model, "clip", 5.0),
                                 threshold_clash=model.threshold_clash, has_clash=has_clash, max_conf=self.max_conf,
@@ -426,12 +469,14 @@ class Docker:
                                 extent=(Lp if Lp < L else None), rotation_scale=cv.scale(Lp),
                                 coarse_rotation_scale=cv.scale(Lp // 2), rotation_axis_order=cv.rotation_axis_order,
                                 clip_mode=cv.clip_mode, rotation_transpose=cv.rotation_transpose)
-            self.engine, self._engine_key = eng, key
+            self._engine_pool[slot] = (key, eng)
         else:
             eng.finish()
             eng.set_filter(W1.cpu(), b1.cpu(), W2.cpu(), b2.cpu())
             eng.clip, eng.threshold = getattr(model, "clip", 5.0), float(model.threshold_clash)
         eng.set_receptor(rec[0], receptor_forbidden, rec[1] if two_res else None)
+        if slot == 0:
+            self.engine, self._engine_key = eng, key
         return eng
 
     @staticmethod
@@ -617,42 +662,93 @@ class Docker:
         coords = be.translate(coords, translation, num_atoms)
         return coords, num_atoms_of_type, offsets, translation, num_atoms
 
-    def dockSE3(self, ureceptor, uligand, batch_size):
+    def prepare(self, ureceptor, uligand, group="SE3", slot=0, stream=None):
+        """The rotation-independent part of ``dockSE3`` / ``dockE3`` for one target (Docker.py:184-209 / :135-161) ->
+        ``PreparedPair``.  With ``stream`` (a torch.cuda.Stream) all its device work is enqueued there and ``slot`` names
+        the engine it fills (0 / 1), so that a sweep over targets (local_test.py:57-75) can prepare target n + 1 --
+        from a host thread of its own -- while target n is being searched in the other engine.  No collective is issued
+        here (the random receptor rotation is shared by ``dock*`` / the constructor, on the caller's thread)."""
+        import contextlib
+        import time
+        t0 = time.perf_counter()
+        if group not in ("SE3", "E3"):
+            raise Exception("Unknown equivariance group", group)
+        be = self._need_backend()
+        model = self.docking_model
+        model.eval()
+        dev, L, res = self.device, self.box_size, self.resolution
+        p = PreparedPair(group, ureceptor, uligand, slot)
+        on_stream = stream is not None and dev.type == "cuda"
+        with (torch.cuda.stream(stream) if on_stream else contextlib.nullcontext()), torch.no_grad():
+            rcoords, rnat, roff, rT, rnatoms = self.load_batch([ureceptor], bbox_center=False)
+            lcoords, lnat, loff, lT, lnatoms = self.load_batch([uligand], bbox_center=False)
+            if self.randomize_rot:
+                rcoords = be.rotate(rcoords, self.randR, rnatoms)
+            rcoords = be.translate(rcoords, self.box_center, rnatoms)
+            p.receptor = be.project(rcoords, rnat, roff, L, res, dev)
+            p.receptor_volumes = model.representation(p.receptor)
+            p.receptor_forbidden = p.receptor.sum(dim=1)[0]
+            p.ligand_atoms = be.to_device(lcoords, lnat, loff, dev)             # origin-centred ligand atoms
+            if group == "SE3":
+                lcoords_trans = be.translate(lcoords, self.box_center, lnatoms)
+                ligand = be.project(lcoords_trans, lnat, loff, L, res, dev)
+                p.ligand_volumes = model.representation(ligand)
+            # the fused engine of a compiled box: receptor spectrum (+ ligand layouts) now, not at the start of the search
+            rec = [v.reshape((-1,) + tuple(v.shape[-3:])) for v in p.receptor_volumes]
+            params = fused_filter_parameters(model)
+            if params is not None and rec[0].shape[-1] == L:
+                eng = self._make_engine(rec, p.receptor_forbidden, self.launch_batch, params, slot=slot)
+                if eng is not None and group == "SE3":
+                    lig = [v.reshape((-1,) + tuple(v.shape[-3:])) for v in p.ligand_volumes]
+                    # (the clash channel comes from re-projected atoms: the stored forbidden volume is never read)
+                    eng.set_ligand(lig[0], torch.zeros(L, L, L), lig[1] if eng.C1 > 0 else None)
+                p.engine = eng
+            if on_stream:
+                p.ready = torch.cuda.Event()
+                p.ready.record(stream)
+        p.seconds = time.perf_counter() - t0
+        return p
+
+    def _prepared_for(self, prepared, ureceptor, uligand, group):
+        if prepared is None:
+            return self.prepare(ureceptor, uligand, group)
+        if (prepared.group, prepared.ureceptor, prepared.uligand) != (group, ureceptor, uligand):
+            raise Exception("Prepared pair does not belong to this call", prepared.group, prepared.ureceptor, prepared.uligand)
+        prepared.wait(self.device)
+        return prepared
+
+    def dockSE3(self, ureceptor, uligand, batch_size, prepared=None):
         """Docker.py:184-238: representations computed once, ligand volumes rotated on the GPU, and
         the ligand forbidden volume re-projected from the rotated ATOMS every batch (Docker.py:221-224)
         -- by one kernel that rotates on the fly, without the reference's per-batch host round trip.
         ``batch_size`` (2 in local_test.py:71) only sizes the calls of a model that has to be called
-        (generic path); the fused pipeline always launches ``self.launch_batch`` rotations."""
+        (generic path); the fused pipeline always launches ``self.launch_batch`` rotations.
+        prepared: the ``PreparedPair`` of this target if ``prepare`` already ran (a sweep preparing targets ahead)."""
         be = self._need_backend()
         self.top_list = []
         self.docking_model.eval()
         self._share_random_rotation()
-        rcoords, rnat, roff, rT, rnatoms = self.load_batch([ureceptor], bbox_center=False)
-        lcoords, lnat, loff, lT, lnatoms = self.load_batch([uligand], bbox_center=False)
-        if self.randomize_rot:
-            rcoords = be.rotate(rcoords, self.randR, rnatoms)
-        rcoords = be.translate(rcoords, self.box_center, rnatoms)
-        lcoords_trans = be.translate(lcoords, self.box_center, lnatoms)
+        p = self._prepared_for(prepared, ureceptor, uligand, "SE3")
         L, res, dev = self.box_size, self.resolution, self.device
         with torch.no_grad():
-            receptor = be.project(rcoords, rnat, roff, L, res, dev)
-            receptor_volumes = self.docking_model.representation(receptor)
-            receptor_forbidden = receptor.sum(dim=1)[0]
-            ligand = be.project(lcoords_trans, lnat, loff, L, res, dev)
-            ligand_volumes = self.docking_model.representation(ligand)
-            lc, ln, lo = be.to_device(lcoords, lnat, loff, dev)          # origin-centred ligand atoms
+            lc, ln, lo = p.ligand_atoms
 
             def provider(Rb):   # rotate about the origin, translate to the box centre, project, sum types
                 return be.project(lc, ln, lo, L, res, dev, R=Rb, shift=self.box_center, sum_types=True)
 
-            self.dock_volumes(receptor_volumes, ligand_volumes, receptor_forbidden, None, batch_size=None,
-                              clash_provider=provider, model_batch=batch_size)
+            self.dock_volumes(p.receptor_volumes, p.ligand_volumes, p.receptor_forbidden, None, batch_size=None,
+                              clash_provider=provider, model_batch=batch_size, prepared=p)
 
-    def dockE3(self, ureceptor, uligand, batch_size):
+    E3_OVERLAP = True       # dockE3: projection + representation of batch i + 1 on a stream of their own beside the engine
+
+    def dockE3(self, ureceptor, uligand, batch_size, prepared=None):
         """Docker.py:135-182: the ligand is rotated in coordinate space and re-projected and
         re-represented every batch (the plugin's cost), then scored by the same kernels: the fused
         engine takes the batch's volumes as they are (no volume rotation); the stand-alone ops, or a
-        call of the model itself, where the engine has no layout for the model (see dock_volumes)."""
+        call of the model itself, where the engine has no layout for the model (see dock_volumes).
+        On the fused engine the two halves of a batch use different units -- the plugin's convolutions the matrix
+        cores, the engine vector units, LDS and HBM -- so batch i + 1 is projected and represented on a second stream
+        while the engine scores batch i (``E3_OVERLAP``; the list does not depend on it)."""
         be = self._need_backend()
         from deeplocalproteindocking_amd.ops import VolumeConvolution, filter_volumes
         self.top_list = []
@@ -660,20 +756,15 @@ class Docker:
         model.eval()
         dev = self.device
         self._share_random_rotation()
-        rcoords, rnat, roff, rT, rnatoms = self.load_batch([ureceptor], bbox_center=False)
-        lcoords, lnat, loff, lT, lnatoms = self.load_batch([uligand], bbox_center=False)
-        if self.randomize_rot:
-            rcoords = be.rotate(rcoords, self.randR, rnatoms)
-        rcoords = be.translate(rcoords, self.box_center, rnatoms)
+        p = self._prepared_for(prepared, ureceptor, uligand, "E3")
         ids = self.shard(self.rot.R.shape[0])
         L = self.box_size
         with torch.no_grad():
-            receptor = be.project(rcoords, rnat, roff, L, self.resolution, dev)
-            receptor_volumes = model.representation(receptor)
-            lc, ln, lo = be.to_device(lcoords, lnat, loff, dev)
+            receptor, receptor_volumes = p.receptor, p.receptor_volumes
+            lc, ln, lo = p.ligand_atoms
             rec = [v.reshape((-1,) + tuple(v.shape[-3:])) for v in receptor_volumes]
             params = fused_filter_parameters(model)
-            eng = self._make_engine(rec, receptor.sum(dim=1)[0], self.launch_batch, params)
+            eng = p.engine
             Lc = None
             if eng is None and params is not None and self.embed_uncompiled_boxes and \
                     not self._library().call("dlpd_grid_supported", int(L)):
@@ -690,6 +781,7 @@ class Docker:
             nbatch = self.launch_batch if self.path != "call" else int(batch_size)
             if eng is not None:
                 eng.reset_top()
+                self.engine = eng
             else:
                 emb = self.embed_uncompiled_boxes
                 conv_noclip = VolumeConvolution(lib=self._lib, embed=emb)
@@ -701,29 +793,21 @@ class Docker:
                 top = DeviceTopList(self.max_conf, nbatch, dev, self._library())
                 top.reset()
                 receptor_forbidden = receptor.sum(dim=1).unsqueeze(dim=1).contiguous()
-            ebuf = None
-            for beg in range(0, len(ids), nbatch):
-                bid = ids[beg:beg + nbatch]
-                nb = len(bid)
+
+            def represent(bid):
+                """rotate + translate + project in one kernel (Docker.py:163-165), then the plugin (Docker.py:166-167)"""
                 Rb = self.rot.R[bid].to(device=dev, dtype=torch.float32).contiguous()
-                # rotate + translate + project in one kernel (Docker.py:163-165)
                 ligand = be.project(lc, ln, lo, L, self.resolution, dev, R=Rb, shift=self.box_center)
-                ligand_volumes = model.representation(ligand)
+                return ligand, model.representation(ligand)
+
+            batches = [ids[beg:beg + nbatch] for beg in range(0, len(ids), nbatch)]
+            if eng is not None:
+                self._dockE3_fused(eng, batches, represent, Lc, nbatch)
+                batches = []
+            for bid in batches:
+                nb = len(bid)
+                ligand, ligand_volumes = represent(bid)
                 bid_dev = torch.as_tensor(bid, dtype=torch.int32).to(dev)
-                if eng is not None:
-                    vols = (ligand_volumes[0], ligand.sum(dim=1), ligand_volumes[1] if eng.C1 else None)
-                    if Lc:
-                        # the batch's volumes into the corner of buffers that were zeroed ONCE (not three allocations and
-                        # zero fills per batch); they stay alive with this call
-                        if ebuf is None:
-                            ebuf = [torch.zeros((nbatch,) + tuple(v.shape[1:-3]) + (le, le, le), dtype=torch.float32, device=dev)
-                                    if v is not None else None for v, le in zip(vols, (Lc, Lc, Lc // 2))]
-                        for buf, v in zip(ebuf, vols):
-                            if v is not None:
-                                buf[:nb][..., :v.shape[-3], :v.shape[-2], :v.shape[-1]] = v
-                        vols = tuple(None if buf is None else buf[:nb] for buf in ebuf)
-                    eng.step(None, bid_dev, volumes=vols)
-                    continue
                 ligand_forbidden = ligand.sum(dim=1).unsqueeze(dim=1).contiguous()
                 norm = conv_noclip(receptor_forbidden.expand(nb, -1, -1, -1, -1).contiguous(), ligand_forbidden)
                 norm = norm.squeeze(1).contiguous()
@@ -741,3 +825,64 @@ class Docker:
         entries = self._gather(eng.top_entries() if eng is not None else top.entries())
         self.top_list = DeviceTopList.to_top_list(entries, 2 * self.box_size)
         self.write_conformations()
+
+    def _dockE3_fused(self, eng, batches, represent, Lc, nbatch):
+        """The batch loop of dockE3 on the fused engine.  On a GPU the plugin's half of batch i + 1 (projection,
+        representation, the type sum for the clash channel) is enqueued on ``self._e3_stream`` BEFORE the engine's half
+        of batch i on the caller's stream, so the two run side by side; events order each hand-over, and the volumes --
+        allocated on the plugin's stream -- are marked as used by the engine's stream for the caching allocator."""
+        dev = self.device
+        overlap = self.E3_OVERLAP and dev.type == "cuda" and len(batches) > 1
+        ebuf = {}
+
+        def volumes_of(ligand, ligand_volumes, nb, slot):
+            vols = (ligand_volumes[0], ligand.sum(dim=1), ligand_volumes[1] if eng.C1 else None)
+            if Lc:
+                # the batch's volumes into the corner of buffers that were zeroed ONCE (not three allocations and zero
+                # fills per batch); two sets when the plugin runs ahead of the engine
+                if slot not in ebuf:
+                    ebuf[slot] = [torch.zeros((nbatch,) + tuple(v.shape[1:-3]) + (le, le, le), dtype=torch.float32, device=dev)
+                                  if v is not None else None for v, le in zip(vols, (Lc, Lc, Lc // 2))]
+                for buf, v in zip(ebuf[slot], vols):
+                    if v is not None:
+                        buf[:nb][..., :v.shape[-3], :v.shape[-2], :v.shape[-1]] = v
+                vols = tuple(None if buf is None else buf[:nb] for buf in ebuf[slot])
+            return vols
+
+        if not overlap:
+            for bid in batches:
+                ligand, ligand_volumes = represent(bid)
+                bid_dev = torch.as_tensor(bid, dtype=torch.int32).to(dev)
+                eng.step(None, bid_dev, volumes=volumes_of(ligand, ligand_volumes, len(bid), 0))
+            return
+        if getattr(self, "_e3_stream", None) is None:
+            self._e3_stream = torch.cuda.Stream(device=dev)
+        side, main = self._e3_stream, torch.cuda.current_stream(dev)
+        side.wait_stream(main)                              # receptor side, engine reset: all issued on the caller's stream
+        consumed = [None, None]                             # per buffer slot: the engine has read the volumes of that slot
+
+        def produce(i):
+            with torch.cuda.stream(side):
+                if consumed[i & 1] is not None:
+                    side.wait_event(consumed[i & 1])        # (embedded boxes: the slot's corner buffers are free again)
+                ligand, ligand_volumes = represent(batches[i])
+                vols = volumes_of(ligand, ligand_volumes, len(batches[i]), i & 1)
+                bid_dev = torch.as_tensor(batches[i], dtype=torch.int32).to(dev)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            return vols, bid_dev, ev
+
+        nxt = produce(0)
+        for i in range(len(batches)):
+            vols, bid_dev, ev = nxt
+            if i + 1 < len(batches):
+                nxt = produce(i + 1)                        # enqueued ahead of the engine's half of batch i
+            main.wait_event(ev)
+            for t in vols + (bid_dev,):
+                if t is not None:
+                    t.record_stream(main)
+            eng.step(None, bid_dev, volumes=vols)
+            done = torch.cuda.Event()
+            done.record(main)
+            consumed[i & 1] = done
+        main.wait_stream(side)

@@ -415,3 +415,102 @@ def test_random_rotation_is_fresh_per_docker_and_reproducible_with_a_seed():
     for r in (a, b):
         m = r[0].numpy()
         assert np.abs(m @ m.T - np.eye(3)).max() < 1e-12 and abs(np.linalg.det(m) - 1) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the rank-aware benchmark sweep (local_test.py:57-75 on W ranks; BASELINE config 5)
+# ---------------------------------------------------------------------------------------------------------------
+def _sweep_targets(root, write=False):
+    """three synthetic targets (receptor / ligand PDB files) in ``root``; written by the test, only named by the ranks"""
+    import pathlib
+    from test_atoms import _typed
+    root = pathlib.Path(root)
+    out = []
+    for k, (nrec, nlig) in enumerate(((14, 9), (11, 8), (9, 12))):
+        if write:
+            root.mkdir(exist_ok=True)
+            _typed(root, nrec, seed=30 + 2 * k), _typed(root, nlig, seed=31 + 2 * k)
+        out.append(("T%d" % k, str(root / ("p%d.pdb" % (30 + 2 * k))), str(root / ("p%d.pdb" % (31 + 2 * k)))))
+    return out
+
+
+def _run_sweep(rank, world, port, out, root, test_dir, rewrite, prefetch, group="SE3"):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(1)
+    from emu_lib import emu_lib
+    from oracle import docking_oracle as orc
+    from test_atoms import _tiny_model
+    from deeplocalproteindocking_amd.Docker import Docker
+    from deeplocalproteindocking_amd.Utils.FullAtom import CoordsBackend
+    from deeplocalproteindocking_amd import local_test
+    if world > 1:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    targets = _sweep_targets(root)
+    R = orc.euler_to_matrix(0.3 + 0.03 * np.arange(5), 1.1 - 0.02 * np.arange(5), -2.0 + 0.025 * np.arange(5))
+    torch.manual_seed(2000 + rank)
+    lib = emu_lib()
+    dk = Docker(_tiny_model(), box_size=32, resolution=1.25, max_conf=40, rotations=R, device="cpu", lib=lib,
+                coords_backend=CoordsBackend(lib=lib), randomize_rot=True, rotation_seed=900 + rank, rank=rank, world_size=world)
+    said = []
+    rep = local_test.sweep(dk, targets, test_dir, group=group, rewrite=rewrite, batch_size=2, prefetch=prefetch,
+                           say=lambda *a: said.append(" ".join(str(x) for x in a)))
+    assert dk.log is None                                          # closed by the sweep
+    out[rank] = {"rep": rep, "said": said, "randR": dk.randR.reshape(9).tolist()}
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _dat_files(test_dir):
+    return {f: open(os.path.join(test_dir, f), "rb").read() for f in sorted(os.listdir(test_dir))}
+
+
+def test_two_rank_benchmark_sweep_equals_the_single_process_sweep(tmp_path):
+    """local_test.py's target loop on two ranks: every target's rotations sharded, rank 0 alone writes, the next
+    target prepared on a second host thread while the current one is searched.  The .dat files must equal the
+    single-process sweep's byte for byte; with -rewrite 0 finished targets are skipped BY BOTH RANKS (rank 0's decision
+    is broadcast) and an unfinished one is redone."""
+    root, d2, d1 = str(tmp_path / "pdb"), str(tmp_path / "w2"), str(tmp_path / "w1")
+    os.makedirs(d2), os.makedirs(d1)
+    _sweep_targets(root, write=True)
+    out, procs = _spawn(_run_sweep, 2, 41800 + (os.getpid() % 1500), root, d2, True, True)
+    _join(procs)
+    r0, r1 = out[0]["rep"], out[1]["rep"]
+    assert out[0]["randR"] == out[1]["randR"]
+    assert r0["processed"] == r1["processed"] == 3 and r0["skipped"] == 0 and r0["world_size"] == 2
+    assert r0["targets_per_s"] > 0 and r0["prepared_ahead"]
+    assert [t["target"] for t in r0["targets"]] == ["T0", "T1", "T2"]
+    assert [t["prepared_ahead"] for t in r0["targets"]] == [False, True, True]
+    assert all(t["poses"] == 40 and t["path"] == "fused" for t in r0["targets"])
+    assert out[0]["said"] == ["Processing T0", "Processing T1", "Processing T2"] == out[1]["said"]
+    # single process, no preparation ahead, the same random rotation (rotation_seed of rank 0)
+    single = {}
+    _run_sweep(0, 1, 0, single, root, d1, True, False)
+    assert single[0]["randR"] == out[0]["randR"] and not single[0]["rep"]["prepared_ahead"]
+    files2, files1 = _dat_files(d2), _dat_files(d1)
+    assert sorted(files2) == ["T0.dat", "T1.dat", "T2.dat"] and files2 == files1
+    assert all(len(b.splitlines()) == 40 for b in files2.values()) and len(set(files2.values())) == 3
+    # resume: T1 is cut down to one line (an interrupted run), T0 and T2 are complete
+    with open(os.path.join(d2, "T1.dat"), "wb") as f:
+        f.write(files2["T1.dat"].splitlines(True)[0])
+    out, procs = _spawn(_run_sweep, 2, 43400 + (os.getpid() % 1500), root, d2, False, True)
+    _join(procs)
+    for r in (0, 1):
+        assert out[r]["said"] == ["Skipping T0", "Processing T1", "Skipping T2"]
+        assert out[r]["rep"]["processed"] == 1 and out[r]["rep"]["skipped"] == 2
+    assert _dat_files(d2) == files1
+
+
+def test_benchmark_sweep_E3_prepared_ahead_equals_unprepared(tmp_path):
+    """The same loop through dockE3, single rank: targets prepared ahead (receptor side in the second engine) give the
+    files of the plain loop."""
+    root, da, db = str(tmp_path / "pdb"), str(tmp_path / "a"), str(tmp_path / "b")
+    os.makedirs(da), os.makedirs(db)
+    _sweep_targets(root, write=True)
+    a, b = {}, {}
+    _run_sweep(0, 1, 0, a, root, da, True, True, "E3")
+    _run_sweep(0, 1, 0, b, root, db, True, False, "E3")
+    assert [t["prepared_ahead"] for t in a[0]["rep"]["targets"]] == [False, True, True]
+    assert _dat_files(da) == _dat_files(db) and len(_dat_files(da)) == 3

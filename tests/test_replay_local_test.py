@@ -150,3 +150,66 @@ def test_synthetic_benchmark_directory_is_what_the_loader_reads(tmp_path):
     items = list(get_benchmark_stream(bench, struct_folder="Matched", subset="Table.csv", debug=False))
     assert [i[0][0] for i in items] == ["1SYN", "2SYN"]
     assert all(os.path.exists(i[k][0]) for i in items for k in (1, 2, 3, 4, 5)) and int(items[0][6][0]) == 1
+
+
+def _sweep(root, log_name, nproc, extra_args=(), extra_env=None, port=29671):
+    """deeplocalproteindocking_amd/local_test.py (the rank-aware driver) in fresh processes -> (report, stdout)."""
+    env = dict(os.environ)
+    env.update({"DLPD_DATA_DIR": os.path.join(root, "data"), "DLPD_MODELS_DIR": os.path.join(root, "models"),
+                "DLPD_LOG_DIR": os.path.join(root, log_name), "DLPD_ALLOW_GENERATED_ROTATIONS": "1",
+                "PYTHONDONTWRITEBYTECODE": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "DLPD_LAUNCH_BATCH"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    os.makedirs(os.path.join(env["DLPD_LOG_DIR"], "LocalDebugSE3"), exist_ok=True)
+    script = os.path.join(ROOT, "deeplocalproteindocking_amd", "local_test.py")
+    launch = [sys.executable, script] if nproc == 1 else \
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+         "127.0.0.1", "--master-port", str(port), script, "-backend", "gloo", "-same_device", "1"]
+    cmd = launch + ["-angle_inc", "20", "-seed", "7", "-init_weights", "1", "-report", "1", "-threshold_clash", "40.0",
+                    "-start", "0", "-end", "3"] + list(extra_args)
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    rep = [l for l in out.stdout.splitlines() if l.startswith("SWEEP ")]
+    assert len(rep) == 1
+    return json.loads(rep[0][len("SWEEP "):]), out.stdout
+
+
+@pytest.mark.gpu
+def test_rank_aware_sweep_two_ranks_on_this_gpu_equals_one_rank(tmp_path):
+    """BASELINE config 5's driver on hardware, as far as a one-GPU box goes: local_test.py's target loop over a
+    three-target synthetic benchmark by TWO ranks (both on this GPU, gloo transport), rotations of every target sharded,
+    rank 0 writing, the next target prepared on a second stream and host thread -- against the single-rank sweep
+    without preparation ahead: the same .dat bytes; then the resume rule across ranks."""
+    import __graft_entry__ as entry
+    entry.build()
+    root = str(tmp_path)
+    make_benchmark(root, targets=(("1SYN", 150, 90, 21), ("2SYN", 120, 100, 41), ("3SYN", 100, 60, 61)))
+    two, stdout2 = _sweep(root, "logW2", 2, ["-rewrite", "1"])
+    one, _ = _sweep(root, "logW1", 1, ["-rewrite", "1", "-prefetch", "0"])
+    assert two["world_size"] == 2 and two["processed"] == 3 and two["prepared_ahead"] and not one["prepared_ahead"]
+    assert [t["prepared_ahead"] for t in two["targets"]] == [False, True, True]
+    assert all(t["path"] == "fused" and t["poses"] == 2000 and t["rotations"] == 1854 for t in two["targets"])
+    assert [t["randR"] for t in two["targets"]] == [t["randR"] for t in one["targets"]]      # -seed 7 on both
+    for name in ("1SYN", "2SYN", "3SYN"):
+        a = open(os.path.join(two["test_dir"], name + ".dat"), "rb").read()
+        b = open(os.path.join(one["test_dir"], name + ".dat"), "rb").read()
+        assert a == b and len(a.splitlines()) == 2000
+    print("sweep: %.2f targets/s on two ranks sharing the GPU (prepared ahead), %.2f on one rank (not prepared ahead); "
+          "waited for a prepared target: %s s" % (two["targets_per_s"], one["targets_per_s"],
+                                                  [round(t["waited_for_preparation_s"], 3) for t in two["targets"]]))
+    # resume (local_test.py:65 with -rewrite 0): an interrupted 2SYN is redone, the others are skipped by both ranks
+    dat = os.path.join(two["test_dir"], "2SYN.dat")
+    whole = open(dat, "rb").read()
+    with open(dat, "wb") as f:
+        f.write(whole.splitlines(True)[0])
+    again, stdout = _sweep(root, "logW2", 2, ["-rewrite", "0"], port=29673)
+    assert again["processed"] == 1 and again["skipped"] == 2 and [t["target"] for t in again["targets"]] == ["2SYN"]
+    assert "Skipping 1SYN" in stdout and "Processing 2SYN" in stdout and "Skipping 3SYN" in stdout
+    assert open(dat, "rb").read() == whole
+    # one rank, targets prepared ahead: the same files again (the second engine and the side stream on one process)
+    pre, _ = _sweep(root, "logW1p", 1, ["-rewrite", "1", "-prefetch", "1"])
+    for name in ("1SYN", "2SYN", "3SYN"):
+        assert open(os.path.join(pre["test_dir"], name + ".dat"), "rb").read() == \
+            open(os.path.join(one["test_dir"], name + ".dat"), "rb").read()
+    print("sweep, one rank: %.2f targets/s prepared ahead vs %.2f" % (pre["targets_per_s"], one["targets_per_s"]))
