@@ -18,6 +18,10 @@ recorded below is the reference's real code:
   G6  scripts/Results/Benchmark/DockerParser.py   DockerParser.parse_output (on G4's text)
       src/Dataset/SplitComplexBenchmark.py        read_pdb_list, read_dataset_list (synthetic tables)
                                                                   -> g6_consumers.npz
+  G7  src/Models/ProteinRepresentationModels.py   E3MultiResRepr4x4 (plain torch; se3cnn mocked): seeded state_dict,
+                                      a seeded (1, 11, 12^3) input and both outputs, multiplier 1 and 8
+      src/local_train.py                          select_model, E3 branch (``.cuda()`` made a no-op: no GPU here)
+                                                                  -> g7_e3_plugin.npz
 Only data (inputs + expected outputs) is written; no reference source is copied.
 """
 import hashlib
@@ -234,6 +238,50 @@ def main():
         g6["pdb_list_json"] = np.frombuffer(json.dumps(rel(t1)).encode(), dtype=np.uint8)
         g6["dataset_list_json"] = np.frombuffer(json.dumps(rel(t2)).encode(), dtype=np.uint8)
     np.savez_compressed(os.path.join(HERE, "g6_consumers.npz"), **g6)
+
+    # ---------------- G7: the E3 representation plugin + select_model ----------------
+    PR = importlib.import_module("src.Models.ProteinRepresentationModels")
+    g7 = {}
+    for m in (1, 8):
+        torch.manual_seed(700 + m)
+        net = PR.E3MultiResRepr4x4(multiplier=m).eval()
+        g = torch.Generator().manual_seed(710 + m)
+        x = torch.relu(torch.randn(1, 11, 12, 12, 12, generator=g)) * 0.5          # density-like: non-negative
+        with torch.no_grad():
+            v1, v2 = net(x)
+        sd = net.state_dict()
+        g7["m%d_keys" % m] = np.frombuffer(json.dumps(list(sd.keys())).encode(), dtype=np.uint8)
+        for k, v in sd.items():
+            g7["m%d_sd_%s" % (m, k)] = v.numpy()
+        g7["m%d_input" % m] = x.numpy()
+        g7["m%d_out0" % m], g7["m%d_out1" % m] = v1.numpy(), v2.numpy()
+        g7["m%d_num_outputs" % m] = np.array(net.get_num_outputs(), dtype=np.int64)
+    # select_model (local_train.py:19-43): which classes, which multiplier, how the filter is sized; error behaviour
+    for name in ("Training", "Dataset"):
+        sys.modules[name] = MagicMock()
+    sys.modules["Models"] = importlib.import_module("src.Models")
+    sys.modules["src"].MODELS_DIR = "/nonexistent"
+    LT = importlib.import_module("src.local_train")
+    real_cuda = torch.nn.Module.cuda
+    torch.nn.Module.cuda = lambda self, device=None: self
+    try:
+        args = types.SimpleNamespace(group="E3", model="E3MultiResRepr4x4", filter="SimpleFilter")
+        pm, cf = LT.select_model(args)
+        sel = {"repr_class": type(pm).__name__, "filter_class": type(cf).__name__, "num_outputs": pm.get_num_outputs(),
+               "repr_shapes": {k: list(v.shape) for k, v in pm.state_dict().items()},
+               "filter_shapes": {k: list(v.shape) for k, v in cf.state_dict().items()}, "errors": {}}
+        for tag, bad in (("group", dict(group="XX", model="E3MultiResRepr4x4", filter="SimpleFilter")),
+                         ("model", dict(group="E3", model="Nope", filter="SimpleFilter")),
+                         ("filter", dict(group="E3", model="E3MultiResRepr4x4", filter="Nope"))):
+            try:
+                LT.select_model(types.SimpleNamespace(**bad))
+                sel["errors"][tag] = None
+            except Exception as exc:
+                sel["errors"][tag] = [type(exc).__name__] + [str(a) for a in exc.args]
+    finally:
+        torch.nn.Module.cuda = real_cuda
+    g7["select_model_json"] = np.frombuffer(json.dumps(sel, sort_keys=True).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "g7_e3_plugin.npz"), **g7)
 
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

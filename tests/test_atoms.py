@@ -769,3 +769,29 @@ def test_dockE3_reference_configuration_on_gpu(tmp_path):
         dk2.dockE3(frec, flig, batch_size=2)
     assert dk2.path == "embedded" and dk2.engine_box == 80
     assert _check_lists_band(dk2.top_list, want2, scale2, K) <= 2
+
+
+@pytest.mark.gpu
+def test_e3_plugin_on_the_hip_convolutions_reproduces_the_reference_class(golden):
+    """Fixture G7 on hardware: the reference's E3MultiResRepr4x4 weights and input (multiplier 8: 16 / 32 channels, every
+    layer on dlpd_conv3d / dlpd_maxpool3d_5s2) reproduce the reference's outputs to 1e-5 of the largest output value,
+    in the default split-bf16 arithmetic and in exact f32."""
+    import __graft_entry__ as entry
+    entry.build()
+    from test_host_logic import _g7_net
+    from deeplocalproteindocking_amd import ops
+    g = golden("g7_e3_plugin.npz")
+    dev = torch.device("cuda:0")
+    net = _g7_net(g, 8).to(dev)
+    x = torch.from_numpy(g["m8_input"]).to(dev)
+    saved = ops.CONV_PRECISION
+    try:
+        for precision in ("split_bf16", "f32"):
+            ops.CONV_PRECISION = precision
+            with torch.no_grad():
+                v = net(x)
+            for got, want in zip(v, (g["m8_out0"], g["m8_out1"])):
+                err = np.abs(got.cpu().numpy() - want).max() / np.abs(want).max()
+                assert err <= 1e-5, (precision, err)
+    finally:
+        ops.CONV_PRECISION = saved

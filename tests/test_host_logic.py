@@ -260,3 +260,71 @@ def test_bench_reads_the_dominant_kernels_traffic_from_a_counter_pass(tmp_path, 
     assert traffic == (2.0 * 1000.0 + 3000.0) * 1024.0 and "measured in this run" in src
     assert "raw FETCH_SIZE 1024000 bytes x 2" in src and "raw WRITE_SIZE 3072000 bytes" in src      # auditable
     assert bench.live_pmc_traffic(args, "topk_select", 128) == (None, None)
+
+
+def _g7_net(g, m):
+    """The build's E3MultiResRepr4x4 holding the reference class's seeded weights (fixture G7), strictly loaded."""
+    import json
+    from deeplocalproteindocking_amd.Models import E3MultiResRepr4x4
+    keys = json.loads(bytes(g["m%d_keys" % m]).decode())
+    net = E3MultiResRepr4x4(multiplier=m).eval()
+    assert list(net.state_dict().keys()) == keys                  # the reference's module tree, key for key
+    net.load_state_dict({k: torch.from_numpy(g["m%d_sd_%s" % (m, k)]) for k in keys}, strict=True)
+    return net
+
+
+def test_e3_plugin_reproduces_the_reference_class(golden):
+    """Fixture G7: the reference's own E3MultiResRepr4x4 (ProteinRepresentationModels.py:78-128, plain torch, imported
+    with se3cnn mocked) with seeded weights on a seeded (1, 11, 12^3) input.  The build's class loads that state dict
+    with strict=True and reproduces both outputs to 2e-6 of the largest output value (the bias-free stack shrinks the
+    signal to 1e-2 / 1e-3, so the tolerance is relative; torch's own CPU kernels differ by up to 4e-7 with the thread
+    count)."""
+    g = golden("g7_e3_plugin.npz")
+    for m in (1, 8):
+        net = _g7_net(g, m)
+        assert net.get_num_outputs() == g["m%d_num_outputs" % m].tolist() == [2 * m, 4 * m]
+        with torch.no_grad():
+            v = net(torch.from_numpy(g["m%d_input" % m]))
+        for got, want in zip(v, (g["m%d_out0" % m], g["m%d_out1" % m])):
+            assert tuple(got.shape) == want.shape
+            assert np.abs(got.numpy() - want).max() <= 2e-6 * np.abs(want).max()
+            assert np.abs(want).max() > 1e-4                       # (not a comparison of zeros)
+
+
+def test_e3_plugin_on_the_emulated_hip_convolutions_reproduces_the_reference_class(golden, emu):
+    """The same fixture through ops.conv3d / ops.maxpool3d_5s2 (the kernels' sources, emulated): 16 / 32 channels."""
+    g = golden("g7_e3_plugin.npz")
+    net = _g7_net(g, 8)
+    net.hip_lib = emu
+    with torch.no_grad():
+        v = net(torch.from_numpy(g["m8_input"]))
+    for got, want in zip(v, (g["m8_out0"], g["m8_out1"])):
+        assert np.abs(got.numpy() - want).max() <= 1e-5 * np.abs(want).max()
+
+
+def test_select_model_follows_the_reference(golden, monkeypatch):
+    """Fixture G7, second half: what the reference's select_model (local_train.py:19-43) returns for the E3 branch --
+    classes, multiplier, filter sizing -- and how it fails for unknown names (Exception with the reference's args)."""
+    import json
+    import os
+    import sys
+    import types
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "deeplocalproteindocking_amd")
+    monkeypatch.syspath_prepend(pkg)
+    monkeypatch.setattr(torch.nn.Module, "cuda", lambda self, device=None: self)     # no GPU in this test
+    import local_train
+    want = json.loads(bytes(golden("g7_e3_plugin.npz")["select_model_json"]).decode())
+    pm, cf = local_train.select_model(types.SimpleNamespace(group="E3", model="E3MultiResRepr4x4", filter="SimpleFilter"))
+    assert (type(pm).__name__, type(cf).__name__) == (want["repr_class"], want["filter_class"])
+    assert pm.get_num_outputs() == want["num_outputs"]
+    assert {k: list(v.shape) for k, v in pm.state_dict().items()} == want["repr_shapes"]
+    assert {k: list(v.shape) for k, v in cf.state_dict().items()} == want["filter_shapes"]
+    for tag, bad in (("group", dict(group="XX", model="E3MultiResRepr4x4", filter="SimpleFilter")),
+                     ("model", dict(group="E3", model="Nope", filter="SimpleFilter")),
+                     ("filter", dict(group="E3", model="E3MultiResRepr4x4", filter="Nope"))):
+        try:
+            local_train.select_model(types.SimpleNamespace(**bad))
+            got = None
+        except Exception as exc:
+            got = [type(exc).__name__] + [str(a) for a in exc.args]
+        assert got == want["errors"][tag], (tag, got, want["errors"][tag])
