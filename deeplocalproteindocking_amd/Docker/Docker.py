@@ -195,7 +195,8 @@ class Docker:
         # density splat -- next to the pivot.  ``rotation_center`` given explicitly wins over the file's.
         if isinstance(conventions, str):
             conventions = VolumeConventions.load(conventions)
-        self.conventions = conventions if conventions is not None else VolumeConventions()
+        # (a copy: the rotation_center setter below must not reach into an object the caller shares between Dockers)
+        self.conventions = conventions.copy() if conventions is not None else VolumeConventions()
         if rotation_center is not None:
             self.conventions = VolumeConventions.from_dict(dict(self.conventions.to_dict(), rotation_center=rotation_center))
         self._ops_cache = {}
@@ -456,6 +457,8 @@ class Docker:
         # crop of the rotation are the small box's
         Lp = int(inner_box or L)
         cv = self.conventions
+        if cv.clip_mode == "input" and Lp < L:
+            return None          # clamped INPUTS are not combined with embedded boxes: the stand-alone ops take the pair
         key = (int(L), int(C), int(C1), has_clash, HP, int(self.max_conf),
                int(batch_size), str(self.device), self.rotation_pivot(Lp), Lp, cv.scale(Lp), cv.rotation_axis_order, cv.clip_mode,
                cv.rotation_transpose)

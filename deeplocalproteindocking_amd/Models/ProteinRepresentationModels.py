@@ -169,14 +169,20 @@ class IsotropicConv3d(Module):
 
     def kernel(self):
         if self.dense is not None:                 # se3cnn's own kernel, handed over as it is (load_dense_kernel)
-            if self.dense.device != self.weight.device:
-                self.dense = self.dense.to(self.weight.device)
+            if self.dense.device != self.weight.device or self.dense.dtype != self.weight.dtype:
+                self.dense = self.dense.to(device=self.weight.device, dtype=self.weight.dtype)   # follows .to() / .half()
             return self.dense
         return torch.einsum("oik,kxyz->oixyz", self.weight, self.shells)
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
-        self.dense = None                          # reloaded shell coefficients replace a handed-over dense kernel
-        state_dict.pop(prefix + "dense", None)     # (checkpoints written while 'dense' was a registered buffer)
+        # reloaded shell coefficients replace a handed-over dense kernel -- loudly: the layer goes back to the shell
+        # PROJECTION of whatever is loaded, which is not se3cnn's kernel (non-zero residual)
+        stale = state_dict.pop(prefix + "dense", None)   # (checkpoints written while 'dense' was a registered buffer)
+        if self.dense is not None or stale is not None:
+            warnings.warn("dlpd: %sweight loaded from a state dict: the exact dense kernel of this layer (load_dense_kernel) is "
+                          "dropped and the layer uses its radial-shell projection again -- call load_dense_kernels after load()"
+                          % prefix)
+        self.dense = None
         return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def load_dense_kernel(self, dense_kernel, exact=True):

@@ -9,8 +9,8 @@ maintainer who HAS a TorchProteinLibrary build plugs in what ``scripts/calibrate
     conv = VolumeConventions.load("tpl_conventions.json")      # written by scripts/calibrate_tpl.py
     Docker(model, ..., conventions=conv)
 
-    rotation_center      pivot of the trilinear volume rotation: None = index L/2; "grid_sample" = (L-1)/2; a number =
-                         that index on the fine grid (scaled to coarser grids)
+    rotation_center      pivot of the trilinear volume rotation: None = index L/2; "grid_sample" = (L-1)/2; "L/2-1" = one
+                         voxel below the centre; a number = that index on the fine grid (scaled to coarser grids)
     rotation_scale       stretch of the sample offset: None / 1.0; "(L-1)/L" or "L/(L-1)" (grid_sample's normalised
                          coordinates generated with one align_corners convention and sampled with the other); a number
     rotation_axis_order  "xyz": axis 0 of the rotation matrix <-> first spatial index; "zyx": <-> last
@@ -52,9 +52,11 @@ def rotation_pivot(center, L, fine_L=None):
     if center is None:
         return float(L) / 2.0
     if isinstance(center, str):
-        if center != "grid_sample":
-            raise Exception("Unknown rotation_center", center)
-        return (float(L) - 1.0) / 2.0
+        if center == "grid_sample":
+            return (float(L) - 1.0) / 2.0
+        if center == "L/2-1":
+            return float(L) / 2.0 - 1.0
+        raise Exception("Unknown rotation_center", center)
     return float(center) * float(L) / float(fine_L or L)
 
 
@@ -105,9 +107,19 @@ class VolumeConventions(object):
                 "rotation_axis_order": self.rotation_axis_order, "rotation_transpose": self.rotation_transpose,
                 "clip_mode": self.clip_mode, "splat": dict(self.splat), "atom_types": dict(self.atom_types)}
 
+    KEYS = ("rotation_center", "rotation_scale", "rotation_axis_order", "rotation_transpose", "clip_mode", "splat", "atom_types")
+
+    def copy(self):
+        return VolumeConventions.from_dict(self.to_dict())
+
     @classmethod
     def from_dict(cls, d):
+        """A key this class cannot represent is an ERROR, never dropped: a calibration that found something else in the
+        library (e.g. correlation arguments in the opposite roles) must not silently run with the defaults."""
         d = d.get("conventions", d)
+        unknown = sorted(set(d) - set(cls.KEYS))
+        if unknown:
+            raise Exception("Unknown convention keys", unknown)
         return cls(rotation_center=d.get("rotation_center"), rotation_scale=d.get("rotation_scale"),
                    rotation_axis_order=d.get("rotation_axis_order", "xyz"), clip_mode=d.get("clip_mode", "output"),
                    splat=d.get("splat"), rotation_transpose=d.get("rotation_transpose", False), atom_types=d.get("atom_types"))

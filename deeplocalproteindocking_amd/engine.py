@@ -127,7 +127,7 @@ class DockingEngine:
                  fine_unfused=None, channels_last=None, k3_form=0, coarse_center=None, extent=None,
                  orient=True, quads=True, prefilter=True, packed_receptor=True,
                  rotation_scale=1.0, coarse_rotation_scale=None, rotation_axis_order="xyz", clip_mode="output",
-                 rotation_transpose=False):
+                 rotation_transpose=False, keep_receptor_spectrum=False):
         """coarse_channels > 0: the reference's two-resolution layout -- C channels at L^3 plus
         ``coarse_channels`` at (L/2)^3 (ProteinRepresentationModels.py:72-76); W1 is (H, C+coarse).
         extent < L: the volumes are extent^3 boxes in the corner of the L^3 ones (a box size without a compiled plan
@@ -148,8 +148,10 @@ class DockingEngine:
         self.CT = self.C + (1 if self.has_clash else 0)
         self.center = float(L) / 2.0 if center is None else float(center)
         # Conventions of the volume rotation and of VolumeConvolution(clip) that TorchProteinLibrary may define
-        # differently (Utils/Conventions.py): scale + axis order are folded into the 3x3 maps K1 samples with (the clash
-        # provider keeps the true rotations: atoms are rotated geometrically); clip_mode "input" clamps the receptor once
+        # differently (Utils/Conventions.py): scale + axis order are folded into the 3x3 maps K1 samples with.  The clash
+        # channel follows where it comes from: re-projected ATOMS (clash_provider, the reference's own path,
+        # Docker.py:221-224) are rotated geometrically by the TRUE R; a stored forbidden VOLUME (dock_volumes without a
+        # provider -- the synthetic configs) is a volume like the others and turns with the mapped matrix; clip_mode "input" clamps the receptor once
         # and every rotated ligand batch before its transform (through the volumes path: exact, one extra round trip of
         # the rotated volumes -- the price of a convention nobody has confirmed), "none" drops the clamp.
         self.rot_scale = float(rotation_scale)
@@ -191,11 +193,19 @@ class DockingEngine:
         self.use_cl = bool(channels_last)
         self.extent = int(extent) if extent and int(extent) < int(L) else 0
         self.extent1 = self.extent // 2
+        if self.extent and self.clip_mode == "input":
+            raise RuntimeError("dlpd: clip_mode 'input' is not combined with embedded boxes (use a compiled box size)")
         # (slab orientation needs K2's transposed reader: every compiled box except 80 in libdlpd.so)
         self.orient = bool(orient) and not self.use_cl and bool(lib.call("dlpd_orientation_supported", int(L)))
         self.use_quads = bool(quads) and not self.use_cl and not self.extent
         if self.use_cl:
             self.ligcl = torch.empty(lib.call("dlpd_channels_last_floats", self.C, int(L)), dtype=f32, device=dev)
+        # With the channels-last K1 every launch is untransposed and goes through the staged path, so where K2 reads the
+        # PACKED receptor copy (boxes 80 / 40) the natural-layout spectrum is dead once it has been packed: it becomes a
+        # temporary of set_receptor instead of a second resident copy (282 MB at 17 channels, 813 MB at 49, box 80).
+        self._spectrum_is_temporary = bool(self.use_cl and not keep_receptor_spectrum)
+        if self._spectrum_is_temporary and self.recP is not None:
+            self.recF = None
         self.prefilter = bool(prefilter)
         self.window = None
         if self.extent:
@@ -222,6 +232,8 @@ class DockingEngine:
             self.recF1 = torch.zeros(C1, NZ1, N1, N1, 2, dtype=f32, device=dev)
             npk1 = lib.call("dlpd_receptor_packed_floats", C1, L1) if packed_receptor else 0
             self.recP1 = torch.zeros(npk1, dtype=f32, device=dev) if npk1 else None
+            if self._spectrum_is_temporary and self.recP1 is not None:
+                self.recF1 = None
             self.wsA1 = torch.empty(nb * C1 * NZ1 * L1 * L1 * 2, dtype=f32, device=dev)
             self.wsB1 = torch.empty(nb * C1 * NZ1 * N1 * N1 * 2, dtype=f32, device=dev)
             if self.use_quads:
@@ -307,10 +319,12 @@ class DockingEngine:
             r1 = torch.as_tensor(rec_coarse, dtype=torch.float32).reshape(self.C1, L1, L1, L1).to(self.device).contiguous()
             if self._in_clip is not None:
                 r1 = r1.clamp(-self._in_clip, self._in_clip)
-            self.lib.call("dlpd_rfft3d_padded", _ptr(r1), _ptr(self.recF1), _ptr(self.wsA1), self.C1, L1,
+            recF1 = self.recF1 if self.recF1 is not None else \
+                torch.empty(self.C1, L1 + 1, 2 * L1, 2 * L1, 2, dtype=torch.float32, device=self.device)
+            self.lib.call("dlpd_rfft3d_padded", _ptr(r1), _ptr(recF1), _ptr(self.wsA1), self.C1, L1,
                           1.0 / float(2 * L1) ** 3, _stream(self.device))
             if self.recP1 is not None:
-                self.lib.call("dlpd_receptor_pack", _ptr(self.recF1), _ptr(self.recP1), self.C1, L1, _stream(self.device))
+                self.lib.call("dlpd_receptor_pack", _ptr(recF1), _ptr(self.recP1), self.C1, L1, _stream(self.device))
         rec = torch.zeros(CT, L, L, L, dtype=torch.float32, device=self.device)
         rec[: self.C] = torch.as_tensor(rec_volumes, dtype=torch.float32).reshape(self.C, L, L, L).to(self.device)
         if self._in_clip is not None:
@@ -318,10 +332,12 @@ class DockingEngine:
         if self.has_clash:
             rec[self.C] = torch.as_tensor(rec_forbidden, dtype=torch.float32).reshape(L, L, L).to(self.device)
         scale = 1.0 / float(N) ** 3
-        self.lib.call("dlpd_rfft3d_padded", _ptr(rec), _ptr(self.recF), _ptr(self.wsA), CT, L, scale,
+        recF = self.recF if self.recF is not None else \
+            torch.empty(CT, self.NZ, N, N, 2, dtype=torch.float32, device=self.device)
+        self.lib.call("dlpd_rfft3d_padded", _ptr(rec), _ptr(recF), _ptr(self.wsA), CT, L, scale,
                       _stream(self.device))
         if self.recP is not None:
-            self.lib.call("dlpd_receptor_pack", _ptr(self.recF), _ptr(self.recP), CT, L, _stream(self.device))
+            self.lib.call("dlpd_receptor_pack", _ptr(recF), _ptr(self.recP), CT, L, _stream(self.device))
 
     def _k2(self, coarse, nb, tr, st):
         """Stage K2 of the fine or the coarse grid on what K1 left in its wsA; tr: the slab orientation K1 used."""
@@ -498,8 +514,6 @@ class DockingEngine:
             vc = torch.empty(nb, self.C1, L1, L1, L1, dtype=f32, device=self.device)
             call("dlpd_rotate_trilinear", _ptr(self.lig1), _ptr(Rk1), _ptr(vc), nb, self.C1, L1, 0,
                  self.center1, st)
-        if self.extent:
-            raise RuntimeError("dlpd: clip_mode 'input' is not combined with embedded boxes (use a compiled box size)")
         return self._score_volumes((vl, vf, vc), mark, out, cset)
 
     def _coarse_preact(self, nb, has_clip, clip, st):

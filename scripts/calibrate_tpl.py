@@ -157,12 +157,9 @@ def calibrate_rotation(tpl, torch, device):
     conv = None
     if best is not None:
         cn, sn, ax, tr = best
-        conv = {"rotation_center": {"L/2": None, "grid_sample": "grid_sample"}.get(cn, cn),
+        # every candidate pivot is a rule of Utils/Conventions.rotation_pivot ("L/2" is its default, None)
+        conv = {"rotation_center": None if cn == "L/2" else cn,
                 "rotation_scale": None if sn == "1" else sn, "rotation_axis_order": ax, "rotation_transpose": bool(tr)}
-        if cn == "L/2-1":
-            conv["rotation_center"] = None
-            report.append("  pivot L/2 - 1 is not expressible as a rule of Utils/Conventions.py: pass rotation_center = box_size / 2 - 1")
-            conv["rotation_center_note"] = "L/2-1"
     return conv, report, probes, [("%s|%s|%s|%s" % k, v) for k, v in ranked[:6]]
 
 
@@ -186,9 +183,11 @@ def calibrate_convolution(tpl, torch, device):
     if mode is not None and arg is not None:
         conv = {"clip_mode": mode}
         if swapped:
-            report.append("  NOTE: the library correlates with its two arguments in the OPPOSITE roles to MultiplyVolumes.py:13-47; "
-                          "the product follows MultiplyVolumes (pinned by the reference's own code)")
-            conv["correlation_arguments_swapped"] = True
+            # not representable in Utils/Conventions.py (the product follows MultiplyVolumes.py:13-47, which the reference's own
+            # code pins): report it as NOT identified rather than writing a file that would run with unswapped arguments
+            report.append("  the library correlates with its two arguments in the OPPOSITE roles to MultiplyVolumes.py:13-47: "
+                          "this build has no such convention -> VolumeConvolution NOT identified")
+            conv = None
     return conv, report, probe, [(str(k), v) for k, v in ranked]
 
 

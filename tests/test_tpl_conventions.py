@@ -42,7 +42,7 @@ def make_stand_in(name, center, scale_rule, axis_order, transpose, clip_mode, sp
     class VolumeRotationS(object):
         def __call__(self, volume, R):
             L = volume.shape[-1]
-            c = {"L/2": L / 2.0, "grid_sample": (L - 1) / 2.0}[center]
+            c = {"L/2": L / 2.0, "grid_sample": (L - 1) / 2.0, "L/2-1": L / 2.0 - 1.0}[center]
             return orc.rotate_volume(volume.cpu(), R.cpu(), center=c, scale=orc.rotation_scale(scale_rule, L),
                                      axis_order=axis_order, transpose=transpose, dtype=torch.float64).float()
 
@@ -128,6 +128,44 @@ def test_calibration_of_the_build_defaults_and_an_unidentifiable_library(tmp_pat
     assert _load_script().main(["--module", "dlpd_fake_tpl_odd", "--out", out2, "--device", "cpu"]) == 1
     d = json.load(open(out2))
     assert not d["all_identified"] and not d["evidence"]["rotation"]["identified"] and d["evidence"]["convolution"]["identified"]
+
+
+def test_calibration_never_writes_a_file_that_runs_with_the_wrong_conventions(tmp_path, emu):
+    """Two things a library could do that used to be written as free text beside DEFAULT values:
+    (i) a pivot one voxel below the centre -- now a rule of its own ("L/2-1"), written and honoured;
+    (ii) correlation arguments in the opposite roles -- no such convention exists in this build (MultiplyVolumes.py:13-47
+    pins the roles), so the operator is reported as NOT identified (exit code 1) and nothing about it is written.
+    A conventions file with a key the class does not know is refused, not read with the key dropped."""
+    splat = {"sigma": 1.0, "window": 2, "voxel_offset": 0.0, "norm": 1.0}
+    make_stand_in("dlpd_fake_tpl_low", "L/2-1", None, "xyz", False, "output", splat, {})
+    out = str(tmp_path / "low.json")
+    assert _load_script().main(["--module", "dlpd_fake_tpl_low", "--out", out, "--device", "cpu"]) == 0
+    d = json.load(open(out))
+    assert d["conventions"]["rotation_center"] == "L/2-1" and set(d["conventions"]) <= set(VolumeConventions.KEYS)
+    conv = VolumeConventions.load(out)
+    assert conv.pivot(80) == 39.0 and conv.pivot(40, 80) == 19.0
+    assert max(replay_fixture(out, emu, "cpu").values()) < 2e-5          # the product kernels reproduce that library
+    pkg = make_stand_in("dlpd_fake_tpl_swapped", "L/2", None, "xyz", False, "output", splat, {})
+    plain = pkg.Volume.VolumeConvolution
+
+    class Swapped(plain):
+        def __call__(self, v1, v2):
+            return plain.__call__(self, v2, v1)
+    pkg.Volume.VolumeConvolution = Swapped
+    out2 = str(tmp_path / "swapped.json")
+    assert _load_script().main(["--module", "dlpd_fake_tpl_swapped", "--out", out2, "--device", "cpu"]) == 1
+    d2 = json.load(open(out2))
+    assert not d2["all_identified"] and not d2["evidence"]["convolution"]["identified"]
+    assert "clip_mode" not in d2["conventions"] and set(d2["conventions"]) <= set(VolumeConventions.KEYS)
+    with pytest.raises(Exception, match="Unknown convention keys"):
+        VolumeConventions.from_dict({"clip_mode": "output", "correlation_arguments_swapped": True})
+
+
+def test_docker_keeps_its_own_copy_of_the_conventions(emu):
+    shared = VolumeConventions()
+    dk = Docker(None, box_size=32, rotations=np.eye(3)[None], device="cpu", lib=emu, conventions=shared)
+    dk.rotation_center = "grid_sample"
+    assert shared.rotation_center is None and dk.rotation_pivot(32) == 15.5
 
 
 def replay_fixture(path, lib, device):
