@@ -90,6 +90,8 @@ def parse_args():
                     help="collective backend of the multi-rank run: nccl (= RCCL over xGMI, one GPU per rank) or gloo")
     ap.add_argument("--same_device", action="store_true",
                     help="every rank on cuda:0 (needs --backend gloo): the multi-rank code path with the HIP kernels on a one-GPU box")
+    ap.add_argument("--k1_form", type=int, default=0, choices=(0, 1, 2),
+                    help="kernel formulation of the channels-last K1 (include/dlpd.h, dlpd_zfft_channels_last_form): 0 = library default")
     ap.add_argument("--dry_run", action="store_true",
                     help="launch plumbing only (gloo, no GPU): every rank joins the group, rank 0 prints a JSON line")
     return ap.parse_args()
@@ -291,7 +293,7 @@ def build_workload(name, args, dev):
              torch.zeros(1))
     host_inputs_s = time.perf_counter() - t_host
     eng = DockingEngine(L, C, *W, clip=5.0, threshold_clash=thr, has_clash=True, max_conf=args.max_conf,
-                        batch=args.batch, device=dev, coarse_channels=C1, k3_form=args.k3_form,
+                        batch=args.batch, device=dev, coarse_channels=C1, k3_form=args.k3_form, k1_form=getattr(args, "k1_form", 0),
                         packed_receptor=not getattr(args, "natural_receptor", False))
     eng.set_receptor(rec[0], recf, rec[1] if C1 else None)
     eng.set_ligand(lig[0], ligf, lig[1] if C1 else None)
@@ -801,7 +803,7 @@ def pmc_traffic(workload, C, L, nb, kernel):
 # (Until round 4 K3 at N = 160 read its spectra in 64-byte runs -- 8-row tiles --, which are tallied at face value: an
 # entry {("k3_zifft_filter", 160): 1.0} here; its 16-row tiles read whole lines like every other kernel.)
 FETCH_SCALE = {}
-STAGE_KERNELS = {"k1_rotate_zfft": ("k_rotate_zfft_cl<%d>", "k_rotate_zfft<%d>"),
+STAGE_KERNELS = {"k1_rotate_zfft": ("k_rotate_zfft_cl<%d>", "k_rotate_zfft_cl_rs<%d>", "k_rotate_zfft<%d>"),
                  "k2_xy_corr": ("k_xy_corr<%d, 1>", "k_xy_corr_q4<%d,", "k_xy_corr_quad<%d,"),
                  "k3_zifft_filter": ("k_zifft_filter_rs<%d,",)}
 
@@ -836,7 +838,7 @@ def live_pmc_traffic(args, stage, N):
     pats = tuple(p % N for p in pats)
     child = [sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--cpu_rotations", "0", "--no_real_shapes",
              "--sustained_s", "0", "--strong_s", "0", "--gather_rotations", "0", "--workload", args.workload,
-             "--batch", str(args.batch), "--max_conf", str(args.max_conf), "--k3_form", str(args.k3_form)]
+             "--batch", str(args.batch), "--max_conf", str(args.max_conf), "--k3_form", str(args.k3_form), "--k1_form", str(args.k1_form)]
     for flag, val in (("--channels", args.channels), ("--box", args.box), ("--angle_inc", args.angle_inc), ("--hidden", args.hidden)):
         if val is not None:
             child += [flag, str(val)]

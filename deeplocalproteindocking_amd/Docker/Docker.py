@@ -75,9 +75,12 @@ def random_rotation(generator=None, seed=None):
     """Uniform random rotation (1,3,3) float64 -- stand-in for TPL getRandomRotation(1)
     (Docker.py:44); the TPL RNG stream cannot be matched (source absent).
     Without ``generator`` the numbers come from a generator of their own -- seeded with ``seed`` or, for ``None``, from
-    the operating system's entropy -- so that the rotation neither repeats from run to run (torch's global generator
-    starts from a fixed default seed) nor depends on what else has drawn from the process-global stream."""
+    the environment variable DLPD_ROTATION_SEED or, for ``None`` and no such variable, from the operating system's
+    entropy -- so that the rotation neither repeats from run to run (torch's global generator starts from a fixed default
+    seed) nor depends on what else has drawn from the process-global stream."""
     if generator is None:
+        if seed is None and os.environ.get("DLPD_ROTATION_SEED", "") != "":
+            seed = int(os.environ["DLPD_ROTATION_SEED"])   # an UNCHANGED caller (local_test.py passes no such keyword)
         generator = torch.Generator()
         generator.manual_seed(int(seed)) if seed is not None else generator.seed()
     u = torch.rand(3, generator=generator, dtype=torch.float64).numpy()

@@ -45,6 +45,7 @@ SIGNATURES = {
     "dlpd_zfft_oriented": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _ll, _i, _f, _i, _p]),
     "dlpd_zfft_oriented_ext": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _ll, _i, _f, _i, _i, _p]),
     "dlpd_zfft_channels_last_ext": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "dlpd_zfft_channels_last_form": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
     "dlpd_xy_correlate_oriented": (_i, [_p, _p, _p, _i, _i, _i, _ll, _i, _p]),
     "dlpd_score_rotations_oriented": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _f, _i, _i, _f, _f,
                                            _p, _p, _p, _i, _p]),

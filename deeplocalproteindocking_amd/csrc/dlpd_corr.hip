@@ -18,6 +18,7 @@
 #include <dlpd_platform.h>
 #include "dlpd_fft.h"
 #include "dlpd_internal.h"
+#include "dlpd_k1.h"
 #include "dlpd_k3.h"
 
 #define DLPD_K1_UNROLL 2                 // samples per thread whose gathers are issued together (2..16 measured equal: not latency-bound)
@@ -277,34 +278,6 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
 //   rows, which puts the 8-byte stores of a voxel's lanes (channel quads 4 YG/2 pencils apart: same bank otherwise)
 //   on disjoint banks.
 // ------------------------------------------------------------------------------------------
-#define DLPD_K1CL_CC 16                   // channel padding of the channels-last copy
-// rows x channels per block (64 two-row pencils either way).  8 x 16: 64-byte gathers, 64-byte output pieces;
-// 16 x 8: 32-byte gathers, full 128-byte output lines.  Measured: N = 128 (48 channels) 0.83 / 0.75 ms,
-// N = 160 (16 channels) 0.61 / 0.66 ms.  32 x 4 (16-byte gathers, 256-byte pieces), round 3: 1.24 ms at N = 128.
-// Also measured in round 3 (all bit-identical or equal to rounding, none kept):
-//  * a lane fetching TWO adjacent channel quads of a corner itself (position, weights and offsets computed once per voxel
-//    instead of once per lane: a third fewer vector instructions): 1.56 ms at N = 128, 0.66 against 0.60 at N = 160 (four
-//    quads per lane 0.90) -- what the gather costs is the number of (lane, instruction) line requests, and two lanes
-//    reading 32 adjacent bytes in ONE instruction are one request where one lane reading them in two instructions is two;
-//  * the z transform as two half-length transforms (Z[2j] = FFT_L(z), Z[2j+1] = FFT_L(z w_N^n); samples kept in registers,
-//    34 KB of LDS and 63 registers: four blocks per CU instead of two): 0.90-0.93 ms against 0.77 with 2, 3 or 4 resident
-//    blocks alike -- the kernel is not waiting for a free block slot, and the second set of passes and barriers costs.
-//  * 16 rows x 16 channels = 128 pencils per block (64-byte gathers AND 128-byte pieces; 145 KB, one block per CU, 1024
-//    threads): 0.77-0.80 ms against 0.76-0.77.
-//  * round 4, N = 160 (one 89 KB block per CU): 32 pencils per block -- 44 KB, three blocks per CU -- as 8 rows x 8 channels
-//    0.686 ms (32-byte gathers), as 4 rows x 16 channels 1.67 ms (32-byte OUTPUT runs: 2.7 x), 16 rows x 8 channels
-//    re-measured 0.675, against 0.61 for 8 x 16; 48 ch x 80^3: 1.93 / 3.65 / 2.12 against 1.71.  Occupancy is not what this
-//    kernel lacks; the run lengths of its gathers and stores are what it pays for.
-#ifndef DLPD_K1_YG160
-#define DLPD_K1_YG160 8
-#endif
-#ifndef DLPD_K1_CC160
-#define DLPD_K1_CC160 16
-#endif
-template <int N> struct K1ClCfg {
-  static constexpr int YG = (N == 128) ? 16 : (N == 160 ? DLPD_K1_YG160 : 8), CC = (N == 160) ? DLPD_K1_CC160 : 128 / YG;
-  static constexpr int NP = CC * (YG / 2);             // two-row pencils per block
-};
 template <int N> __global__ void __launch_bounds__(K1ClCfg<N>::NP * FftPlan<N>::T)
 k_rotate_zfft_cl(const float4* __restrict__ cl, const float* __restrict__ R, cplx* __restrict__ A,
                  int C, int Cq, int nb, float c0, int CT_out, int c_base, int ext) {
@@ -326,57 +299,12 @@ k_rotate_zfft_cl(const float4* __restrict__ cl, const float* __restrict__ R, cpl
   const int b = g / L, x = g % L;
   init_twiddles<N>(tw, tid, NT);
   {
-    const float* r = R + (size_t)b * 9;
-    const float r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6], r7 = r[7], r8 = r[8];
-    const float dx = x - c0;
-    const int hi = L - 1;
+    const K1ClRot rot = k1cl_load_rotation(R + (size_t)b * 9);
     for (int task = tid; task < NPR * L * LPV; task += NT) {
       const int q = task % LPV, z = (task / LPV) % L, m = (task / LPV) / L;
       const float4* src = cl + chunk * (CC / 4) + q;
-      const float dz = z - c0;
       float4 acc[2];
-#pragma unroll
-      for (int u = 0; u < 2; u++) {
-        // outside the embedded box (ext < L) the sample is cropped: all eight weights zero (no branch: the loads of both
-        // rows stay batched; a branch here cost 0.06 ms at N = 128)
-        const bool live = max(x, max(yg * YG + 2 * m + u, z)) < ext;
-        const float dy = (yg * YG + 2 * m + u) - c0;
-        const float px = c0 + (r0 * dx + r3 * dy + r6 * dz);
-        const float py = c0 + (r1 * dx + r4 * dy + r7 * dz);
-        const float pz = c0 + (r2 * dx + r5 * dy + r8 * dz);
-        const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
-        const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
-        const float ax = px - fx, ay = py - fy, az = pz - fz;
-        const bool x0 = live & (ix >= 0) & (ix <= hi), x1 = live & (ix + 1 >= 0) & (ix + 1 <= hi);
-        const bool y0 = (iy >= 0) & (iy <= hi), y1 = (iy + 1 >= 0) & (iy + 1 <= hi);
-        const bool z0 = (iz >= 0) & (iz <= hi), z1 = (iz + 1 >= 0) & (iz + 1 <= hi);
-        const float wx0 = x0 ? 1.f - ax : 0.f, wx1 = x1 ? ax : 0.f;
-        const float wy0 = y0 ? 1.f - ay : 0.f, wy1 = y1 ? ay : 0.f;
-        const float wz0 = z0 ? 1.f - az : 0.f, wz1 = z1 ? az : 0.f;
-        const int cx0 = min(max(ix, 0), hi), cx1 = min(max(ix + 1, 0), hi);
-        const int cy0 = min(max(iy, 0), hi), cy1 = min(max(iy + 1, 0), hi);
-        const int cz0 = min(max(iz, 0), hi), cz1 = min(max(iz + 1, 0), hi);
-        const float4 v000 = src[(size_t)((cx0 * L + cy0) * L + cz0) * Cq], v001 = src[(size_t)((cx0 * L + cy0) * L + cz1) * Cq];
-        const float4 v010 = src[(size_t)((cx0 * L + cy1) * L + cz0) * Cq], v011 = src[(size_t)((cx0 * L + cy1) * L + cz1) * Cq];
-        const float4 v100 = src[(size_t)((cx1 * L + cy0) * L + cz0) * Cq], v101 = src[(size_t)((cx1 * L + cy0) * L + cz1) * Cq];
-        const float4 v110 = src[(size_t)((cx1 * L + cy1) * L + cz0) * Cq], v111 = src[(size_t)((cx1 * L + cy1) * L + cz1) * Cq];
-        const float w000 = wx0 * wy0 * wz0, w001 = wx0 * wy0 * wz1, w010 = wx0 * wy1 * wz0, w011 = wx0 * wy1 * wz1;
-        const float w100 = wx1 * wy0 * wz0, w101 = wx1 * wy0 * wz1, w110 = wx1 * wy1 * wz0, w111 = wx1 * wy1 * wz1;
-#define DLPD_TRI(f)                                                                                               \
-  {                                                                                                               \
-    float a = v000.f * w000;                                                                                      \
-    a += v001.f * w001;                                                                                           \
-    a += v010.f * w010;                                                                                           \
-    a += v011.f * w011;                                                                                           \
-    a += v100.f * w100;                                                                                           \
-    a += v101.f * w101;                                                                                           \
-    a += v110.f * w110;                                                                                           \
-    a += v111.f * w111;                                                                                           \
-    acc[u].f = a;                                                                                                 \
-  }
-        DLPD_TRI(x) DLPD_TRI(y) DLPD_TRI(z) DLPD_TRI(w)
-#undef DLPD_TRI
-      }
+      k1cl_sample_rows(src, Cq, L, ext, c0, rot, x, yg * YG + 2 * m, z, acc);
       // rows 2m (real part) and 2m+1 (imaginary part) of the four channels' pencils
       cplx* P = S + ((4 * q) * NPR + m) * RS + SKEW * q + z;
       P[0] = c_make(acc[0].x, acc[1].x);
@@ -1480,12 +1408,19 @@ int dlpd_make_channels_last(const float* vol, float* cl, int C, int L, void* str
 }
 
 // rotation + z FFT of the C score channels of ONE ligand shared by all rotations, gathered from its channels-last copy
-int dlpd_zfft_channels_last_ext(const float* cl, const float* R, void* wsA, int nb, int C, int CT_out, int c_base, int L,
-                                float center, int extent, void* stream) {
+#ifndef DLPD_K1_DEFAULT_FORM
+#define DLPD_K1_DEFAULT_FORM 1               // 1: every wave gathers, transforms and stores (this file), 2: role-split (dlpd_k1r.hip)
+#endif
+
+int dlpd_zfft_channels_last_form(const float* cl, const float* R, void* wsA, int nb, int C, int CT_out, int c_base, int L,
+                                 float center, int extent, int form, void* stream) {
   if (!cl || !R || !wsA || nb <= 0 || C <= 0 || c_base < 0 || c_base + C > CT_out || extent < 0 || extent > L) return DLPD_ERR_ARG;
+  if (form < 0 || form > 2) return DLPD_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   cplx* A = (cplx*)wsA;
   const float4* c4 = (const float4*)cl;
+  if (form == 0) form = (L == 64 || L == 80) ? DLPD_K1_DEFAULT_FORM : 1;
+  if (form == 2) return dlpd_k1_role_split(c4, R, A, C, nb, center, st, CT_out, c_base, extent, L);
   switch (L) {
     case 32: return launch_k1_cl<64>(c4, R, A, C, nb, center, st, CT_out, c_base, extent);
     case 40: return launch_k1_cl<80>(c4, R, A, C, nb, center, st, CT_out, c_base, extent);
@@ -1493,6 +1428,11 @@ int dlpd_zfft_channels_last_ext(const float* cl, const float* R, void* wsA, int 
     case 80: return launch_k1_cl<160>(c4, R, A, C, nb, center, st, CT_out, c_base, extent);
     default: return DLPD_ERR_UNSUPPORTED;
   }
+}
+
+int dlpd_zfft_channels_last_ext(const float* cl, const float* R, void* wsA, int nb, int C, int CT_out, int c_base, int L,
+                                float center, int extent, void* stream) {
+  return dlpd_zfft_channels_last_form(cl, R, wsA, nb, C, CT_out, c_base, L, center, extent, 0, stream);
 }
 
 int dlpd_zfft_channels_last(const float* cl, const float* R, void* wsA, int nb, int C, int CT_out, int c_base, int L,

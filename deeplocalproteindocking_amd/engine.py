@@ -127,7 +127,7 @@ class DockingEngine:
                  fine_unfused=None, channels_last=None, k3_form=0, coarse_center=None, extent=None,
                  orient=True, quads=True, prefilter=True, packed_receptor=True,
                  rotation_scale=1.0, coarse_rotation_scale=None, rotation_axis_order="xyz", clip_mode="output",
-                 rotation_transpose=False, keep_receptor_spectrum=False):
+                 rotation_transpose=False, keep_receptor_spectrum=False, k1_form=0):
         """coarse_channels > 0: the reference's two-resolution layout -- C channels at L^3 plus
         ``coarse_channels`` at (L/2)^3 (ProteinRepresentationModels.py:72-76); W1 is (H, C+coarse).
         extent < L: the volumes are extent^3 boxes in the corner of the L^3 ones (a box size without a compiled plan
@@ -169,6 +169,9 @@ class DockingEngine:
         f32 = torch.float32
         self.C1 = int(coarse_channels)
         self.k3_form = int(k3_form)
+        # kernel formulation of the channels-last K1 (include/dlpd.h, dlpd_zfft_channels_last_form): 0 = the library's
+        # default, 1 = every wave gathers / transforms / stores in turn, 2 = role-split (boxes 64 and 80); same bits
+        self.k1_form = int(k1_form)
         self.fine_unfused = bool(fine_unfused)
         self.set_filter(W1, b1, W2, b2)
         nb, CT, NZ, N = self.batch, self.CT, self.NZ, self.N
@@ -273,10 +276,15 @@ class DockingEngine:
         from .Utils.Conventions import kernel_matrices
         return kernel_matrices(R, self.rot_scale1 if coarse else self.rot_scale, self.rot_axis_order, self.rot_transpose)
 
+    def _k1_form_at(self, L):
+        """The requested K1 formulation where the library holds both (boxes 64, 80); its only one elsewhere."""
+        return self.k1_form if int(L) in (64, 80) else 0
+
     def switches(self):
         """Which of the equivalent kernel formulations and which conventions this engine launches with (bench.py records it)."""
         return {"k1": "channels_last" if self.use_cl else "per_channel",
                 "k1_slab_orientation": bool(self.orient), "k1_quad_layout": bool(self.use_quads),
+                "k1_form": {0: "library default", 1: "phased", 2: "role-split"}[self.k1_form],
                 "k3_form": {0: "library default (role-split where compiled)", 1: "channel-owning", 2: "role-split"}[self.k3_form],
                 "k3_unfused": bool(self.fine_unfused), "topk_candidate_lists": bool(self.prefilter),
                 "k2_packed_receptor": {"fine": self.recP is not None, "coarse": self.recP1 is not None},
@@ -421,8 +429,8 @@ class DockingEngine:
             # coarse resolution first: rotate + correlate + clip -> real volumes the fine filter reads
             L1 = self.L1
             if self.use_cl:
-                call("dlpd_zfft_channels_last_ext", _ptr(self.ligcl1), _ptr(R1), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1,
-                     self.center1, self.extent1, st)
+                call("dlpd_zfft_channels_last_form", _ptr(self.ligcl1), _ptr(R1), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1,
+                     self.center1, self.extent1, self._k1_form_at(L1), st)
             elif use_quads:
                 call("dlpd_zfft_quads", _ptr(self.ligq1), _ptr(R1), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1,
                      self.center1, tr, st)
@@ -436,8 +444,8 @@ class DockingEngine:
             # clash channel from re-projected rotated ATOMS (Docker.py:221-224), scores from rotated volumes
             forb = provider(R_true).reshape(nb, L, L, L).contiguous()
             if self.use_cl:
-                call("dlpd_zfft_channels_last_ext", _ptr(self.ligcl), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0, L,
-                     self.center, self.extent, st)
+                call("dlpd_zfft_channels_last_form", _ptr(self.ligcl), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0, L,
+                     self.center, self.extent, self._k1_form_at(L), st)
             elif use_quads:
                 call("dlpd_zfft_quads", _ptr(self.ligq), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0, L,
                      self.center, tr, st)
@@ -447,8 +455,8 @@ class DockingEngine:
             call("dlpd_zfft_oriented", _ptr(forb), 0, _ptr(self.wsA), nb, 1, self.CT, self.C, L, L ** 3, 0, 0.0,
                  tr, st)                      # same orientation as the score channels
         elif self.use_cl:
-            call("dlpd_zfft_channels_last_ext", _ptr(self.ligcl), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0, L,
-                 self.center, self.extent, st)
+            call("dlpd_zfft_channels_last_form", _ptr(self.ligcl), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0, L,
+                 self.center, self.extent, self._k1_form_at(L), st)
             if self.has_clash:                # the ligand's forbidden volume: one channel, per-channel kernel
                 call("dlpd_zfft_oriented_ext", self.lig.data_ptr() + self.C * L ** 3 * 4, _ptr(R), _ptr(self.wsA), nb, 1,
                      self.CT, self.C, L, 0, 1, self.center, 0, self.extent, st)

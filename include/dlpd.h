@@ -102,6 +102,12 @@ int dlpd_zfft_oriented_ext(const float* vol, const float* R, void* wsA, int nb, 
                            long long vol_bstride, int do_rotate, float center, int transposed, int extent, void* stream);
 int dlpd_zfft_channels_last_ext(const float* cl, const float* R, void* wsA, int nb, int C, int CT_out, int c_base, int L,
                                 float center, int extent, void* stream);
+/* ... with the kernel formulation named: 0 = the library's default, 1 = every wave gathers, transforms and stores in turn
+ * (k_rotate_zfft_cl), 2 = gather waves and transform / store waves with fixed roles, one block per CU walking a range of
+ * work items (k_rotate_zfft_cl_rs; boxes 64 and 80 only, DLPD_ERR_UNSUPPORTED elsewhere).  Same samples, same butterflies:
+ * the spectra are bit-identical. */
+int dlpd_zfft_channels_last_form(const float* cl, const float* R, void* wsA, int nb, int C, int CT_out, int c_base, int L,
+                                 float center, int extent, int form, void* stream);
 
 /* CoordsRotate + CoordsTranslate + TypedCoords2Volume (+ channel sum) of src/Docker/Docker.py:204,
  * 208,221-224 in one kernel: p' = R_b p + shift, density exp(-|r - p'|^2 / 2) on the 5^3 voxels

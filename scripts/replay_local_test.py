@@ -75,6 +75,7 @@ def main():
     torch.cuda.set_device(0)
     if args.seed is not None:
         torch.manual_seed(args.seed)
+        os.environ["DLPD_ROTATION_SEED"] = str(args.seed)     # Docker draws the receptor rotation from a generator of its own
 
     stream_test = get_benchmark_stream(data_dir, struct_folder="Matched", subset=subset_name, debug=False)
     protein_model, conformations_filter = select_model(args)

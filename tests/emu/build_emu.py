@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.abspath(os.path.join(HERE, "..", "..", "deeplocalproteindocking_amd", "csrc"))
 OUT = os.path.join(HERE, "libdlpd_emu.so")
-SRCS = ["dlpd_corr.hip", "dlpd_k2.hip", "dlpd_k2q.hip", "dlpd_k3r.hip", "dlpd_topk.hip", "dlpd_generic.hip", "dlpd_atoms.hip", "dlpd_conv.hip", "dlpd_version.hip"]
+SRCS = ["dlpd_corr.hip", "dlpd_k2.hip", "dlpd_k2q.hip", "dlpd_k3r.hip", "dlpd_k1r.hip", "dlpd_topk.hip", "dlpd_generic.hip", "dlpd_atoms.hip", "dlpd_conv.hip", "dlpd_version.hip"]
 
 
 def _fresh(deps):
@@ -17,7 +17,7 @@ def _fresh(deps):
 def build(force=False):
     import fcntl
     srcs = [os.path.join(CSRC, s) for s in SRCS]
-    deps = srcs + [os.path.join(CSRC, h) for h in ("dlpd_fft.h", "dlpd_internal.h", "dlpd_k3.h")] + \
+    deps = srcs + [os.path.join(CSRC, h) for h in ("dlpd_fft.h", "dlpd_internal.h", "dlpd_k1.h", "dlpd_k3.h")] + \
         [os.path.join(HERE, "dlpd_platform.h")]
     if not force and _fresh(deps):
         return OUT

@@ -799,6 +799,32 @@ def test_bench_refuses_same_device_with_rccl(dev):
     assert r.returncode != 0 and "--same_device needs --backend gloo" in (r.stdout + r.stderr)
 
 
+def test_k1_role_split_equals_the_phased_k1(dev):
+    """k_rotate_zfft_cl_rs (gather waves + transform / store waves, one block per CU over a range of work items) bit for
+    bit against k_rotate_zfft_cl on the hardware, at the sizes of the BASELINE configs: 48 channels x 64^3 and the
+    reference's 16 channels x 80^3 with 16 rotations per launch, 48 x 80^3, a partly filled chunk and an embedded box."""
+    from test_kernels_emu import _k1_both_formulations
+    from deeplocalproteindocking_amd._lib import get_lib
+    lib = get_lib()
+    _k1_both_formulations(lib, dev, 64, 48, 16)
+    _k1_both_formulations(lib, dev, 80, 16, 16)
+    _k1_both_formulations(lib, dev, 80, 48, 5)
+    _k1_both_formulations(lib, dev, 64, 9, 3)
+    _k1_both_formulations(lib, dev, 80, 20, 2, extent=50)
+    # ... and through the engine: the scores of a batch do not depend on the formulation
+    rec, lig, recf, ligf, W1, b1, W2, b2 = _pair(64, 48)
+    from deeplocalproteindocking_amd.engine import DockingEngine
+    R = torch.from_numpy(_rots(4)).float().to(dev).contiguous()
+    Vs = []
+    for form in (1, 2):
+        eng = DockingEngine(64, 48, W1, b1, W2, b2, clip=5.0, threshold_clash=4000.0, max_conf=50, batch=4, device=dev, k1_form=form)
+        eng.set_receptor(rec, recf)
+        eng.set_ligand(lig, ligf)
+        assert eng.switches()["k1_form"] == {1: "phased", 2: "role-split"}[form]
+        Vs.append(eng.score_batch(R).clone())
+    assert torch.equal(Vs[0], Vs[1])
+
+
 def test_k3_role_split_equals_the_channel_owning_k3(dev, variants):
     """k_zifft_filter_rs (dedicated transform / filter waves, the default) bit for bit against k_zifft_filter[_tiles]
     (every wave owns a channel) and against the oracle: 48 channels x 64^3 (13 groups of 4, the last one the clash

@@ -222,6 +222,40 @@ def test_channels_last_rotation_equals_the_per_channel_kernel(emu, L, C):
     assert torch.equal(got, want)
 
 
+def _k1_both_formulations(lib, device, L, C, nb, extent=0, seed=13):
+    """K1 of the channels-last path through both kernel formulations (include/dlpd.h, dlpd_zfft_channels_last_form):
+    1 = every wave gathers, transforms and stores in turn; 2 = gather waves + transform / store waves (one block per CU
+    walking a range of work items).  Same samples, same butterflies: the spectra must be the same BITS."""
+    g = torch.Generator().manual_seed(seed)
+    NZ, CT = L + 1, C + 1
+    vol = torch.randn(C, L, L, L, generator=g).to(device)
+    ang = np.random.RandomState(seed).uniform(-np.pi, np.pi, size=(nb, 3))
+    R = torch.from_numpy(orc.euler_to_matrix(ang[:, 0], np.abs(ang[:, 1]), ang[:, 2])).float().contiguous().to(device)
+    st = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0
+    cl = torch.empty(lib.call("dlpd_channels_last_floats", C, L), device=device)
+    lib.call("dlpd_make_channels_last", _ptr(vol), _ptr(cl), C, L, st)
+    outs = []
+    for form in (1, 2):
+        out = torch.full((nb * CT * NZ * L * L * 2,), 7.0, device=device)       # (channel C of the workspace stays untouched)
+        lib.call("dlpd_zfft_channels_last_form", _ptr(cl), _ptr(R), _ptr(out), nb, C, CT, 0, L, L / 2.0 if not extent else extent / 2.0,
+                 extent, form, st)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    v = outs[1].view(nb, CT, NZ, L, L, 2)
+    assert bool((v[:, C] == 7.0).all()) and float(v[:, :C].abs().max()) > 1.0 and not bool((v[:, :C] == 7.0).any())
+    return outs[1]
+
+
+@pytest.mark.parametrize("L,C,nb,extent", [(64, 9, 1, 0), (80, 16, 1, 0), (80, 20, 1, 50)])
+def test_k1_role_split_equals_the_phased_k1(emu, L, C, nb, extent):
+    """Boxes 64 (two input buffers, one barrier per work item) and 80 (one input buffer, two barriers; the radix-16 x 10
+    plan run on 8 lanes per pencil), channel counts that leave a partly filled last chunk, an embedded box (crop)."""
+    _k1_both_formulations(emu, "cpu", L, C, nb, extent)
+    if L == 64:
+        with pytest.raises(RuntimeError, match="UNSUPPORTED"):                  # no role-split kernel for the small boxes
+            emu.call("dlpd_zfft_channels_last_form", 1, 1, 1, 1, 4, 5, 0, 32, 16.0, 0, 2, 0)
+
+
 @pytest.mark.parametrize("L,nvol", [(32, 2), (64, 1)])
 def test_volume_convolution_stages_match_oracle_and_definition(emu, L, nvol):
     """rfft3d_padded + zfft + xy_correlate + zifft_real == VolumeConvolution; spot-checked against
