@@ -19,6 +19,8 @@ _sz = ctypes.c_size_t
 SIGNATURES = {
     "dlpd_version": (_i, []),
     "dlpd_source_hash": (ctypes.c_char_p, []),
+    "dlpd_debug_poison_lds": (_i, [_i]),
+    "dlpd_debug_poison_selfcheck": (_i, [_p, _p]),
     "dlpd_grid_supported": (_i, [_i]),
     "dlpd_orientation_supported": (_i, [_i]),
     "dlpd_hidden_pad": (_i, [_i]),
@@ -110,7 +112,7 @@ class DlpdLib:
     def call(self, name, *args):
         rc = getattr(self, "_" + name)(*args)
         if SIGNATURES[name][0] is _i and name not in ("dlpd_version", "dlpd_grid_supported", "dlpd_conv3d_supported", "dlpd_orientation_supported",
-                                                      "dlpd_hidden_pad", "dlpd_fused_hidden_pad", "dlpd_generic_box_supported") and rc != 0:
+                                                      "dlpd_hidden_pad", "dlpd_fused_hidden_pad", "dlpd_generic_box_supported", "dlpd_debug_poison_selfcheck") and rc != 0:
             raise RuntimeError("dlpd: %s failed: %s" % (name, ERRORS.get(rc, rc)))
         return rc
 

@@ -13,8 +13,14 @@
 // caller's own runtime use (e.g. torch's event queries): clear it before each launch, latch a
 // failure of any launch of the current entry point, report + reset in dlpd_check_launch().
 static inline int& dlpd_launch_failed() { static thread_local int f = 0; return f; }
+// TEST HOOK (dlpd_version.hip, dlpd_debug_poison_lds): when switched on, every launch is preceded by a kernel that fills the
+// LDS of every CU with NaNs, so a kernel whose result depends on LDS it never wrote stops being "right by accident" (the
+// left-over of its own previous block) and fails the same way on every run.  Off: one load and one branch per launch.
+extern "C" int dlpd_debug_poison_state(void);
+void dlpd_debug_poison_now(hipStream_t st);
 #define DLPD_LAUNCH(kern, grid, block, shmem, stream, ...)              \
   do {                                                                  \
+    if (dlpd_debug_poison_state()) dlpd_debug_poison_now(stream);       \
     (void)hipGetLastError();                                            \
     DLPD_LAUNCH_RAW(kern, grid, block, shmem, stream, __VA_ARGS__);     \
     const hipError_t e_ = hipGetLastError();                            \

@@ -19,10 +19,24 @@
 // the other input buffer while item i is transformed and stored; INBUF = 1 (N = 160: 53 KB + 86 KB, a second input buffer
 // does not fit): two per item -- the gather of item i + 1 starts as soon as the first pass of item i has its inputs in
 // registers.
+//
+// MEASURED (round 5, one MI355X, bench.py --k1_form 1 / 2, twice each): 48 ch x 64^3 K1 1.14 against 0.82-0.85 ms,
+// the reference's real shapes 0.645 against 0.60-0.61, 48 ch x 80^3 1.91 against 1.91.  In-kernel stamps (48 x 64^3): a
+// gather wave spends 62 % gathering and 37 % waiting at the item barrier; a transform / store wave 13 % taking its inputs,
+// 76 % in stores + second pass + untangle + global stores, 10 % waiting -- the transform / store waves are the longer role,
+// and most of their time is waiting for vector-memory issue behind the gather's loads: both roles go through the same
+// address unit, which the split cannot duplicate.  NOT the default; kept as a TEST VARIANT (-DDLPD_TEST_VARIANTS:
+// tests/variants/libdlpd_variants.so and the emulated library) because it is the bit-exactness cross-check of K1.
 #include <dlpd_platform.h>
 #include "dlpd_fft.h"
 #include "dlpd_internal.h"
 #include "dlpd_k1.h"
+
+#ifndef DLPD_TEST_VARIANTS
+int dlpd_k1_role_split(const float4*, const float*, cplx*, int, int, float, hipStream_t, int, int, int, int) {
+  return DLPD_ERR_UNSUPPORTED;               // the product library ships one K1 formulation (k_rotate_zfft_cl)
+}
+#else
 
 template <int N> struct K1RsCfg {
   static constexpr int L = N / 2, NZ = N / 2 + 1;
@@ -277,3 +291,4 @@ int dlpd_k1_role_split(const float4* cl, const float* R, cplx* A, int C, int nb,
     default: return DLPD_ERR_UNSUPPORTED;
   }
 }
+#endif  // DLPD_TEST_VARIANTS

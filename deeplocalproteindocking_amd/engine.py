@@ -437,7 +437,12 @@ class DockingEngine:
             else:
                 call("dlpd_zfft_oriented_ext", _ptr(self.lig1), _ptr(R1), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1, 0, 1,
                      self.center1, tr, self.extent1, st)
+            sub = getattr(mark, "sub_stages", False)     # (diagnostic callers: a mark after every kernel of the coarse stage)
+            if sub:
+                mark("coarse_k1")
             self._k2(True, nb, tr, st)
+            if sub:
+                mark("coarse_k2")
             self._coarse_preact(nb, has_clip, clip, st)
             mark("coarse")
         if provider is not None:

@@ -15,9 +15,9 @@ or plain ``python deeplocalproteindocking_amd/local_test.py ...`` for one GPU.  
   * only rank 0 opens, truncates and writes the ``.dat`` files; its ``new_log`` decision (the resume rule of
     Docker.py:63-79) is broadcast, so all ranks skip or process the same targets;
   * the next target is PREPARED while the current one is searched: PDB parsing, typing, projection, representation
-    and the receptor spectrum (``Docker.prepare``) run on a host thread and a stream of their own, into the second of
-    two engines -- the per-target serial term (about 0.3-0.5 s at box 80, against 2.9 s of search per target at eight
-    ranks on the 6-degree set) disappears behind the search;
+    and the receptor spectrum (``Docker.prepare``) run on a host thread of their own, into the second of two engines --
+    the host part of the per-target serial term disappears behind the search (its kernels stay in stream order with the
+    search's: see ``sweep``);
   * ``-report 1`` prints one JSON line (rank 0): per-target seconds, rotations/s, and ``targets_per_s`` of the sweep.
 
 ``sweep()`` only needs an object with the ``Docker`` interface and is what the tests drive (two gloo ranks on the
@@ -52,7 +52,7 @@ def _broadcast_flags(docker, flags, n):
     return [bool(v) for v in buf.cpu().tolist()]
 
 
-def sweep(docker, targets, test_dir, group="SE3", rewrite=False, batch_size=2, prefetch=True, say=print):
+def sweep(docker, targets, test_dir, group="SE3", rewrite=False, batch_size=2, prefetch=True, say=print, prepare_stream=False):
     """Dock every target of ``targets`` = [(pdb_name, receptor_path, ligand_path), ...] into ``test_dir/<pdb_name>.dat``
     (local_test.py:57-75), on all ranks of ``docker``'s process group.  -> report dict (the same on every rank except
     for the timings, which are the rank's own)."""
@@ -70,9 +70,15 @@ def sweep(docker, targets, test_dir, group="SE3", rewrite=False, batch_size=2, p
     if prefetch and n_targets > 1:
         from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dlpd-prepare")
-        stream = torch.cuda.Stream(device=dev) if on_gpu else None
+        # The preparing thread enqueues its device work on the CALLER'S stream (stream = None), in order with the search's
+        # launches: what overlaps with the search is the host side (PDB parsing, typing, launch overhead), which is the
+        # larger part.  A stream of its own (prepare_stream=True) also overlaps the projection / representation kernels --
+        # and was measured to change the last bits of a few scores in about 5 % of the sweeps: the plugin's bf16 x 3
+        # convolution, co-resident on a CU with the coarse grid's K1 (k_rotate_zfft_cl<80>), perturbs that kernel's
+        # pencils 48-63 (EXPERIMENTS.md, round 5; scripts/search_race_probe.py reproduces it) -- within the 1e-4 parity
+        # band, but not the byte-identical .dat files this driver promises.
+        stream = torch.cuda.Stream(device=dev) if (on_gpu and prepare_stream) else None
     pending = {}                                      # target index -> Future of its PreparedPair
-
     def prepare_in_background(j, slot):
         def work():
             if on_gpu:

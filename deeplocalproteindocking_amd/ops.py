@@ -213,6 +213,10 @@ def _packed_weights(weight, w, lib, device, split=False):
         wp = torch.empty(lib.call("dlpd_conv3d_packed_floats", cin, cout, ks), dtype=torch.float32, device=device)
         lib.call("dlpd_conv3d_pack", _ptr(w), _ptr(wp), cin, cout, ks, _stream(device))
     if cacheable:
+        if device.type == "cuda":
+            # the packed copy outlives this call and may next be used from ANOTHER stream (a sweep prepares the next target
+            # on a stream of its own, Docker.prepare): it must be complete before it is published -- once per weight
+            torch.cuda.current_stream(device).synchronize()
         if len(_PACKED) > 64:
             _PACKED.clear()
         _PACKED[key] = wp

@@ -24,6 +24,13 @@ extern "C" {
 #define DLPD_ERR_LAUNCH 3
 
 int dlpd_version(void);
+/* TEST HOOK, no reference counterpart: on = 1 makes every kernel launch of this library be preceded by a kernel that fills
+ * the LDS of every CU with NaNs (a result that depends on LDS the kernel never wrote then fails on every run instead of
+ * once in a while beside another stream); 0 switches it off.  Never on in a timed or production run. */
+int dlpd_debug_poison_lds(int on);
+/* ... and its self-check: poison, then a kernel that writes nothing to its LDS counts the poisoned words it finds -> per mille
+ * (0 .. 1000), -1 on a launch error.  counter8: 8 bytes of device memory. */
+int dlpd_debug_poison_selfcheck(void* counter8, void* stream);
 /* sha256 (64 hex digits) of the sources, headers and flags this library was built from; the build
  * script refuses a library whose hash differs from the sources next to it */
 const char* dlpd_source_hash(void);

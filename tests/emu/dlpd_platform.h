@@ -46,6 +46,8 @@ static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
 #define hipMemcpyDeviceToDevice 0
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memmove(d, s, n); return 0; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+#define hipMemcpyDeviceToHost 2
 
 namespace emu {
 struct Fiber {

@@ -799,13 +799,13 @@ def test_bench_refuses_same_device_with_rccl(dev):
     assert r.returncode != 0 and "--same_device needs --backend gloo" in (r.stdout + r.stderr)
 
 
-def test_k1_role_split_equals_the_phased_k1(dev):
+def test_k1_role_split_equals_the_phased_k1(dev, variants):
     """k_rotate_zfft_cl_rs (gather waves + transform / store waves, one block per CU over a range of work items) bit for
     bit against k_rotate_zfft_cl on the hardware, at the sizes of the BASELINE configs: 48 channels x 64^3 and the
     reference's 16 channels x 80^3 with 16 rotations per launch, 48 x 80^3, a partly filled chunk and an embedded box."""
     from test_kernels_emu import _k1_both_formulations
     from deeplocalproteindocking_amd._lib import get_lib
-    lib = get_lib()
+    lib = variants                   # (the role-split K1 is a test variant: measured slower, kept as the cross-check)
     _k1_both_formulations(lib, dev, 64, 48, 16)
     _k1_both_formulations(lib, dev, 80, 16, 16)
     _k1_both_formulations(lib, dev, 80, 48, 5)
@@ -817,12 +817,154 @@ def test_k1_role_split_equals_the_phased_k1(dev):
     R = torch.from_numpy(_rots(4)).float().to(dev).contiguous()
     Vs = []
     for form in (1, 2):
-        eng = DockingEngine(64, 48, W1, b1, W2, b2, clip=5.0, threshold_clash=4000.0, max_conf=50, batch=4, device=dev, k1_form=form)
+        eng = DockingEngine(64, 48, W1, b1, W2, b2, clip=5.0, threshold_clash=4000.0, max_conf=50, batch=4, device=dev, k1_form=form,
+                            lib=variants)
         eng.set_receptor(rec, recf)
         eng.set_ligand(lig, ligf)
         assert eng.switches()["k1_form"] == {1: "phased", 2: "role-split"}[form]
         Vs.append(eng.score_batch(R).clone())
     assert torch.equal(Vs[0], Vs[1])
+    # the product library holds the phased K1 only: the other formulation is refused, not silently replaced
+    with pytest.raises(RuntimeError, match="UNSUPPORTED"):
+        get_lib().call("dlpd_zfft_channels_last_form", 1, 1, 1, 1, 4, 5, 0, 64, 32.0, 0, 2, 0)
+
+
+def test_no_kernel_writes_outside_its_output_buffers(dev, tmp_path):
+    """Every device buffer the host code hands to a kernel as an output (engine workspaces, score volumes, candidate
+    lists, top-K buffers, projection and convolution outputs, channels-last / packed copies) sits between two 1 MB guard
+    bands here (tests/guard_alloc.py); after whole searches -- dockSE3 and dockE3 from PDB files at box 80 with the
+    reference's layer plans, a 48-channel 64^3 engine, an embedded box -- no guard byte may have changed.  (A store past the
+    end of a buffer is invisible on one stream and a timing-dependent corruption once a second stream has live data there.)"""
+    from guard_alloc import GuardedAllocations
+    from synth_pdb import write_protein_like_pdb
+    from deeplocalproteindocking_amd.Docker import Docker
+    from deeplocalproteindocking_amd.engine import DockingEngine
+    from deeplocalproteindocking_amd.Models import E3MultiResRepr4x4, GlobalDockingModel, SE3MultiResReprScalar, SimpleFilter
+    rec_pdb, lig_pdb = str(tmp_path / "rec.pdb"), str(tmp_path / "lig.pdb")
+    write_protein_like_pdb(rec_pdb, 150, 21)
+    write_protein_like_pdb(lig_pdb, 90, 22)
+    R = _rots(40, seed=5)
+    problems = []
+    for plugin, method in ((SE3MultiResReprScalar, "dockSE3"), (E3MultiResRepr4x4, "dockE3")):
+        for seed in range(11, 60):                 # a randomly initialised filter whose scores go NEGATIVE on this pair (an
+            torch.manual_seed(seed)                # all-positive one leaves nothing but masked zeros in every list)
+            repr_ = plugin(multiplier=8)
+            model = GlobalDockingModel(repr_, SimpleFilter(repr_.get_num_outputs()), threshold_clash=40.0).to(dev)
+            with torch.no_grad():
+                probe = Docker(model, box_size=80, resolution=1.25, max_conf=50, rotations=R[:2], device=dev, randomize_rot=True,
+                               rotation_seed=3)
+                getattr(probe, method)(rec_pdb, lig_pdb, batch_size=2)
+            best = probe.top_list[0][4]
+            probe.release_engine()
+            del probe
+            if best < -0.05:
+                break
+        lists = []
+        # ... and no result may depend on what an ``empty`` buffer held before its first kernel: NaN bytes, zeros, 0xA5
+        for empty_byte in (0xA5, 0xFF, 0x00):
+            with GuardedAllocations(empty_byte=empty_byte) as g, torch.no_grad():
+                dk = Docker(model, box_size=80, resolution=1.25, max_conf=2000, rotations=R, device=dev, randomize_rot=True, rotation_seed=3)
+                getattr(dk, method)(rec_pdb, lig_pdb, batch_size=2)
+                assert dk.path == "fused" and len(dk.top_list) == 2000 and len(g.items) > 30
+                problems += ["%s: %s" % (method, b) for b in g.check()]
+                lists.append(list(dk.top_list))
+                dk.release_engine()
+            del dk
+            torch.cuda.empty_cache()
+        assert min(t[4] for t in lists[0]) < 0 and all(t[4] == t[4] for t in lists[1])
+        if not (lists[0] == lists[1] == lists[2]):
+            problems.append("%s: the ranked list depends on the initial content of an uninitialised buffer (%d / %d of 2000 entries differ)"
+                            % (method, sum(a != b for a, b in zip(lists[0], lists[1])), sum(a != b for a, b in zip(lists[0], lists[2]))))
+    # the synthetic configuration of the metric (48 ch x 64^3, stored forbidden volume) and an embedded box (50 inside 64)
+    rec, lig, recf, ligf, W1, b1, W2, b2 = _pair(64, 48)
+    with GuardedAllocations() as g:
+        eng = DockingEngine(64, 48, W1, b1, W2, b2, clip=5.0, threshold_clash=4000.0, max_conf=2000, batch=16, device=dev)
+        eng.set_receptor(rec, recf)
+        eng.set_ligand(lig, ligf)
+        eng.reset_top()
+        eng.search(torch.from_numpy(_rots(48, seed=6)))
+        assert len(eng.top_entries()[0]) == 2000
+        problems += ["engine 48 x 64^3: %s" % b for b in g.check()]
+    del eng
+    torch.cuda.empty_cache()
+    from deeplocalproteindocking_amd.Models import SyntheticRepr
+    rec, lig, recf, ligf = _pair(50, 4)[:4]
+    torch.manual_seed(6)
+    model = GlobalDockingModel(SyntheticRepr((4,)), SimpleFilter([4]), threshold_clash=4000.0).to(dev)
+    with GuardedAllocations() as g:
+        dk = Docker(model, box_size=50, max_conf=100, rotations=_rots(20, seed=7), device=dev)
+        dk.dock_volumes([rec], [lig], recf, ligf, write=False)
+        assert dk.path == "embedded"
+        problems += ["embedded box 50: %s" % b for b in g.check()]
+    assert not problems, "\n".join(problems)
+
+
+def test_no_result_depends_on_lds_a_kernel_never_wrote(dev, tmp_path):
+    """dlpd_debug_poison_lds(1): a kernel that fills the LDS of every CU with NaNs runs before EVERY launch of the library.
+    A kernel that reads LDS it did not write itself normally sees the left-over of its own previous block -- stable
+    from run to run, small enough to hide inside the 1e-4 tolerance against the oracle, and different as soon as another
+    stream's kernels share the CUs (a sweep preparing the next target).  With the poison such a read turns every score
+    into a NaN; here the ranked lists of whole searches must be the same entries with and without it."""
+    from synth_pdb import write_protein_like_pdb
+    from deeplocalproteindocking_amd._lib import get_lib
+    from deeplocalproteindocking_amd.Docker import Docker
+    from deeplocalproteindocking_amd.engine import DockingEngine
+    from deeplocalproteindocking_amd.Models import E3MultiResRepr4x4, GlobalDockingModel, SE3MultiResReprScalar, SimpleFilter
+    lib = get_lib()
+    # the hook itself: a kernel launched behind the poison finds (nearly) every LDS word it did not write poisoned
+    counter = torch.zeros(1, dtype=torch.int64, device=dev)
+    seen = lib.call("dlpd_debug_poison_selfcheck", counter.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    assert seen >= 900, seen
+    rec_pdb, lig_pdb = str(tmp_path / "rec.pdb"), str(tmp_path / "lig.pdb")
+    write_protein_like_pdb(rec_pdb, 150, 21)
+    write_protein_like_pdb(lig_pdb, 90, 22)
+    R = _rots(40, seed=5)
+
+    def both(run):
+        out = []
+        try:
+            for on in (0, 1, 0):
+                lib.call("dlpd_debug_poison_lds", on)
+                out.append(run())
+                torch.cuda.synchronize()
+        finally:
+            lib.call("dlpd_debug_poison_lds", 0)
+        return out
+
+    problems = []
+    for plugin, method, seed in ((SE3MultiResReprScalar, "dockSE3", 7), (E3MultiResRepr4x4, "dockE3", 79)):
+        torch.manual_seed(seed)
+        repr_ = plugin(multiplier=8)
+        model = GlobalDockingModel(repr_, SimpleFilter(repr_.get_num_outputs()), threshold_clash=40.0).to(dev)
+
+        def run():
+            with torch.no_grad():
+                dk = Docker(model, box_size=80, resolution=1.25, max_conf=2000, rotations=R, device=dev, randomize_rot=True, rotation_seed=3)
+                getattr(dk, method)(rec_pdb, lig_pdb, batch_size=2)
+            top = list(dk.top_list)
+            dk.release_engine()
+            return top
+        a, b, c = both(run)
+        assert a == c and len(a) == 2000
+        if a != b:
+            nan = sum(1 for t in b if t[4] != t[4])
+            problems.append("%s at box 80: %d of 2000 entries differ under the poison (%d NaN scores)" % (method, sum(x != y for x, y in zip(a, b)), nan))
+    for L, C in ((64, 48), (32, 4), (40, 8)):
+        rec, lig, recf, ligf, W1, b1, W2, b2 = _pair(L, C)
+
+        def run():
+            eng = DockingEngine(L, C, W1, b1, W2, b2, clip=5.0, threshold_clash=0.12 * L ** 3, max_conf=500, batch=16, device=dev)
+            eng.set_receptor(rec, recf)
+            eng.set_ligand(lig, ligf)
+            eng.reset_top()
+            eng.search(torch.from_numpy(_rots(32, seed=6)))
+            ent = eng.top_entries()
+            return [tuple(np.asarray(x).tolist()) for x in ent]
+        a, b, c = both(run)
+        assert a == c
+        if a != b:
+            problems.append("engine %d ch x %d^3: the list differs under the poison" % (C, L))
+    assert not problems, "\n".join(problems)
 
 
 def test_k3_role_split_equals_the_channel_owning_k3(dev, variants):

@@ -45,7 +45,7 @@ def test_product_library_ships_one_formulation_per_box(built_lib):
     nm = subprocess.run(["nm", "-C", entry.LIB], capture_output=True, text=True).stdout
     assert "k_zifft_filter_rs<128" in nm and "k_zifft_filter_rs<160" in nm and "k_xy_corr_q4<160, true>" in nm and "k_xy_corr_s4<80, true>" in nm
     assert "k_zifft_filter<64," in nm and "k_zifft_filter<80," in nm                      # boxes 32 / 40: the one formulation there
-    for absent in ("k_xy_corr_quad<", "k_zifft_filter<128, 24, 1>", "k_zifft_filter_tiles<160", "k_zifft_filter<160, 24, 2>",
+    for absent in ("k_rotate_zfft_cl_rs<", "k_xy_corr_quad<", "k_zifft_filter<128, 24, 1>", "k_zifft_filter_tiles<160", "k_zifft_filter<160, 24, 2>",
                    "k_zifft_filter<80, 24, 2>"):
         assert absent not in nm, absent
     assert built_lib.call("dlpd_orientation_supported", 64) == 1 and built_lib.call("dlpd_orientation_supported", 80) == 0
@@ -328,3 +328,32 @@ def test_select_model_follows_the_reference(golden, monkeypatch):
         except Exception as exc:
             got = [type(exc).__name__] + [str(a) for a in exc.args]
         assert got == want["errors"][tag], (tag, got, want["errors"][tag])
+
+
+def test_engine_gating_on_the_product_dispatch_tables():
+    """The emulated library of the other CPU tests is built WITH the test-variant kernels (it must hold both sides of
+    every bit-identity test), so it answers dlpd_orientation_supported(80) = 1 and accepts every K3 formulation.  Here
+    the same sources are compiled as libdlpd.so compiles them (no -DDLPD_TEST_VARIANTS): the engine must find box 80
+    without a transposed-slab K2 and visit it in one orientation, and a K3 formulation the product does not ship at a
+    box must be refused (DLPD_ERR_UNSUPPORTED), not silently replaced."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    from deeplocalproteindocking_amd._lib import DlpdLib
+    from deeplocalproteindocking_amd.engine import DockingEngine
+    lib = DlpdLib(build_emu.build(variants=False))
+    assert lib.call("dlpd_orientation_supported", 64) == 1 and lib.call("dlpd_orientation_supported", 80) == 0
+    z = lambda *s: torch.zeros(*s)
+    eng80 = DockingEngine(80, 2, z(1, 2), z(1), z(1, 1), z(1), max_conf=4, batch=1, device="cpu", lib=lib, channels_last=False)
+    assert eng80.orient is False and eng80.switches()["k1_slab_orientation"] is False
+    eng64 = DockingEngine(64, 2, z(1, 2), z(1), z(1, 1), z(1), max_conf=4, batch=1, device="cpu", lib=lib, channels_last=False)
+    assert eng64.orient is True
+    # K3 at box 64: the product ships the role-split formulation only (the channel-owning one is a test variant)
+    bad = DockingEngine(64, 1, z(1, 1), z(1), z(1, 1), z(1), max_conf=4, batch=1, device="cpu", lib=lib, k3_form=1, has_clash=False)
+    bad.set_receptor(z(1, 64, 64, 64))
+    bad.set_ligand(z(1, 64, 64, 64))
+    with pytest.raises(RuntimeError, match="UNSUPPORTED"):
+        bad.score_batch(torch.eye(3).reshape(1, 3, 3).contiguous())
+    # K1 at boxes 64 / 80: the role-split formulation is a test variant as well
+    with pytest.raises(RuntimeError, match="UNSUPPORTED"):
+        lib.call("dlpd_zfft_channels_last_form", 1, 1, 1, 1, 4, 5, 0, 64, 32.0, 0, 2, 0)

@@ -235,14 +235,15 @@ def _k1_both_formulations(lib, device, L, C, nb, extent=0, seed=13):
     cl = torch.empty(lib.call("dlpd_channels_last_floats", C, L), device=device)
     lib.call("dlpd_make_channels_last", _ptr(vol), _ptr(cl), C, L, st)
     outs = []
-    for form in (1, 2):
-        out = torch.full((nb * CT * NZ * L * L * 2,), 7.0, device=device)       # (channel C of the workspace stays untouched)
+    for form, fill in ((1, 7.0), (2, 7.0), (2, -3.0)):
+        out = torch.full((nb * CT * NZ * L * L * 2,), fill, device=device)      # (channel C of the workspace stays untouched)
         lib.call("dlpd_zfft_channels_last_form", _ptr(cl), _ptr(R), _ptr(out), nb, C, CT, 0, L, L / 2.0 if not extent else extent / 2.0,
                  extent, form, st)
-        outs.append(out)
+        outs.append(out.view(nb, CT, NZ, L, L, 2))
     assert torch.equal(outs[0], outs[1])
-    v = outs[1].view(nb, CT, NZ, L, L, 2)
-    assert bool((v[:, C] == 7.0).all()) and float(v[:, :C].abs().max()) > 1.0 and not bool((v[:, :C] == 7.0).any())
+    # every element of channels [0, C) is written (the result does not depend on what the buffer held), channel C is not
+    assert torch.equal(outs[1][:, :C], outs[2][:, :C]) and float(outs[1][:, :C].abs().max()) > 1.0
+    assert bool((outs[1][:, C] == 7.0).all()) and bool((outs[2][:, C] == -3.0).all())
     return outs[1]
 
 
