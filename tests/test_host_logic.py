@@ -171,7 +171,10 @@ def test_docker_interface_surface():
     for m in ("load_batch", "new_log", "cleanup", "update_top", "write_conformations", "dockE3", "dockSE3",
               "dock_volumes"):
         assert callable(getattr(Docker, m))
-    assert list(inspect.signature(Docker.dockSE3).parameters) == ["self", "ureceptor", "uligand", "batch_size"]
+    # the reference's positional arguments first (Docker.py:135,184); `prepared` is an optional superset keyword
+    for m in (Docker.dockSE3, Docker.dockE3):
+        p = inspect.signature(m).parameters
+        assert list(p) == ["self", "ureceptor", "uligand", "batch_size", "prepared"] and p["prepared"].default is None
     dk = _docker()
     # no coords_backend argument (the reference's constructor has none): the build's own is created on first use
     from deeplocalproteindocking_amd.Utils.FullAtom import CoordsBackend
@@ -357,3 +360,22 @@ def test_engine_gating_on_the_product_dispatch_tables():
     # K1 at boxes 64 / 80: the role-split formulation is a test variant as well
     with pytest.raises(RuntimeError, match="UNSUPPORTED"):
         lib.call("dlpd_zfft_channels_last_form", 1, 1, 1, 1, 4, 5, 0, 64, 32.0, 0, 2, 0)
+
+
+def test_bench_secondary_roofline_from_the_sq_counters():
+    """bench.py's ``roofline.secondary``: the counter averages of K2<128> as rocprofv3 reported them on an MI355X
+    (profiles/r05_pmc_units.txt) give the figures the calibration was checked against -- 2.0 GHz from GRBM_GUI_ACTIVE / 8
+    XCDs over the launch duration, 1.9 resident waves per SIMD for a kernel compiled for two, LDS active 45 % of the
+    cycles, vector issue >= 21 % -- and a kernel without a usable cycle counter falls back to an ASSUMED clock, flagged."""
+    import bench
+    c = {"GRBM_GUI_ACTIVE": 4.178e7, "SQ_ACTIVE_INST_VALU": 5.654e8, "SQ_INSTS_VALU": 5.651e8, "SQ_LDS_IDX_ACTIVE": 5.985e8,
+         "SQ_LDS_BANK_CONFLICT": 1.076e8, "SQ_WAVE_CYCLES": 2.583e9}
+    s = bench.secondary_from_counters(c, 2596.1e3)
+    assert abs(s["clock_GHz"] - 2.012) < 0.01 and not s["clock_assumed"]
+    assert abs(s["waves_per_simd"] - 1.93) < 0.02
+    assert abs(s["lds_active_frac"] - 0.448) < 0.005 and abs(s["valu_issue_frac"] - 0.211) < 0.005
+    assert abs(s["valu_active_frac"] - 0.423) < 0.005
+    assert abs(s["valu_plus_lds_frac"] - (s["valu_issue_frac"] + s["lds_active_frac"])) < 1e-12
+    t = bench.secondary_from_counters(dict(c, GRBM_GUI_ACTIVE=0.0), 2596.1e3)
+    assert t["clock_assumed"] and t["clock_GHz"] == 2.0
+    assert bench.secondary_from_counters({}, None) is None
