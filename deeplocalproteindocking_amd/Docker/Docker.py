@@ -745,7 +745,13 @@ class Docker:
             self.dock_volumes(p.receptor_volumes, p.ligand_volumes, p.receptor_forbidden, None, batch_size=None,
                               clash_provider=provider, model_batch=batch_size, prepared=p)
 
-    E3_OVERLAP = True       # dockE3: projection + representation of batch i + 1 on a stream of their own beside the engine
+    # dockE3: projection + representation of batch i + 1 on a stream of their own beside the engine's half of batch i.
+    # MEASURED (round 5, box 80, E3MultiResRepr4x4(8), 16 rotations per launch): 15.08 ms per launch overlapped against
+    # 15.03 serial (projection 0.36 + representation 9.29 + engine 6.33) -- nothing: every kernel of either half fills the
+    # chip on its own, and the engine's K2 / K3 blocks (113-140 KB of LDS) cannot share a CU with a convolution block
+    # (61 KB), so the two streams take turns instead of running side by side.  Off by default (one stream less to reason
+    # about, EXPERIMENTS.md R5); the lists are identical either way (test_dockE3_overlapped_plugin_gives_the_serial_list).
+    E3_OVERLAP = False
 
     def dockE3(self, ureceptor, uligand, batch_size, prepared=None):
         """Docker.py:135-182: the ligand is rotated in coordinate space and re-projected and
@@ -753,8 +759,8 @@ class Docker:
         engine takes the batch's volumes as they are (no volume rotation); the stand-alone ops, or a
         call of the model itself, where the engine has no layout for the model (see dock_volumes).
         On the fused engine the two halves of a batch use different units -- the plugin's convolutions the matrix
-        cores, the engine vector units, LDS and HBM -- so batch i + 1 is projected and represented on a second stream
-        while the engine scores batch i (``E3_OVERLAP``; the list does not depend on it)."""
+        cores, the engine vector units, LDS and HBM -- so batch i + 1 CAN be projected and represented on a second stream
+        while the engine scores batch i (``E3_OVERLAP``; the list does not depend on it; measured: no gain, off)."""
         be = self._need_backend()
         from deeplocalproteindocking_amd.ops import VolumeConvolution, filter_volumes
         self.top_list = []

@@ -76,6 +76,8 @@ print("undisturbed rerun: checksums identical %s, list identical %s" % (s2 == ba
 side = torch.cuda.Stream(device=dev)
 x11 = torch.rand(1, 11, 80, 80, 80, device=dev)
 x16 = torch.rand(1, 16, 80, 80, 80, device=dev)
+from deeplocalproteindocking_amd import ops
+w16 = torch.randn(16, 16, 5, 5, 5, device=dev) * 0.05
 big1 = torch.rand(64, 1024, 1024, device=dev)
 big2 = torch.empty_like(big1)
 nbad = 0
@@ -92,6 +94,10 @@ for rep in range(REPS):
                         a = (a @ a).tanh_()
                 elif LOAD == "conv1":
                     model.representation.sequence_res0[2](x16)
+                elif LOAD == "conv1f32":                      # the exact-f32 convolution: MFMA 16x16x4 f32, no AccVGPRs
+                    ops.conv3d(x16, w16, precision="f32")
+                elif LOAD == "conv1bf16":                     # the same layer through the bf16 x 3 kernel (AccVGPR accumulators)
+                    ops.conv3d(x16, w16, precision="split_bf16")
                 elif LOAD == "copy":
                     big2.copy_(big1)
                 else:

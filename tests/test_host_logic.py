@@ -263,6 +263,10 @@ def test_bench_reads_the_dominant_kernels_traffic_from_a_counter_pass(tmp_path, 
     assert traffic == (2.0 * 1000.0 + 3000.0) * 1024.0 and "measured in this run" in src
     assert "raw FETCH_SIZE 1024000 bytes x 2" in src and "raw WRITE_SIZE 3072000 bytes" in src      # auditable
     assert bench.live_pmc_traffic(args, "topk_select", 128) == (None, None)
+    # K3's wide configurations read 64-byte runs (8-row tiles): their FETCH_SIZE is taken at face value
+    assert bench.fetch_scale("k3_zifft_filter", 160, 24) == 2.0 and bench.fetch_scale("k3_zifft_filter", 160, 32) == 1.0
+    assert bench.fetch_scale("k3_zifft_filter", 128, 32) == 2.0 and bench.fetch_scale("k3_zifft_filter", 128, 48) == 1.0
+    assert bench.fetch_scale("k2_xy_corr", 160, 48) == 2.0
 
 
 def _g7_net(g, m):

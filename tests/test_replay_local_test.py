@@ -152,7 +152,7 @@ def test_synthetic_benchmark_directory_is_what_the_loader_reads(tmp_path):
     assert all(os.path.exists(i[k][0]) for i in items for k in (1, 2, 3, 4, 5)) and int(items[0][6][0]) == 1
 
 
-def _sweep(root, log_name, nproc, extra_args=(), extra_env=None, port=29671):
+def _sweep(root, log_name, nproc, extra_args=(), extra_env=None, port=29671, rccl=False):
     """deeplocalproteindocking_amd/local_test.py (the rank-aware driver) in fresh processes -> (report, stdout)."""
     env = dict(os.environ)
     env.update({"DLPD_DATA_DIR": os.path.join(root, "data"), "DLPD_MODELS_DIR": os.path.join(root, "models"),
@@ -165,7 +165,7 @@ def _sweep(root, log_name, nproc, extra_args=(), extra_env=None, port=29671):
     script = os.path.join(ROOT, "deeplocalproteindocking_amd", "local_test.py")
     launch = [sys.executable, script] if nproc == 1 else \
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
-         "127.0.0.1", "--master-port", str(port), script, "-backend", "gloo", "-same_device", "1"]
+         "127.0.0.1", "--master-port", str(port), script] + ([] if rccl else ["-backend", "gloo", "-same_device", "1"])
     cmd = launch + ["-angle_inc", "20", "-seed", "7", "-init_weights", "1", "-report", "1", "-threshold_clash", "40.0",
                     "-start", "0", "-end", "3"] + list(extra_args)
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=1500)
@@ -213,3 +213,22 @@ def test_rank_aware_sweep_two_ranks_on_this_gpu_equals_one_rank(tmp_path):
         assert open(os.path.join(pre["test_dir"], name + ".dat"), "rb").read() == \
             open(os.path.join(one["test_dir"], name + ".dat"), "rb").read()
     print("sweep, one rank: %.2f targets/s prepared ahead vs %.2f" % (pre["targets_per_s"], one["targets_per_s"]))
+
+
+@pytest.mark.gpu
+def test_rank_aware_sweep_over_rccl_equals_one_rank(tmp_path):
+    """The same sweep with one GPU per rank and the `nccl` (= RCCL) backend -- the decision broadcast, the random-rotation
+    broadcast and the per-target all-gather on device tensors.  Needs two GPUs; skipped on the one-GPU boxes."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL)")
+    import __graft_entry__ as entry
+    entry.build()
+    root = str(tmp_path)
+    make_benchmark(root, targets=(("1SYN", 150, 90, 21), ("2SYN", 120, 100, 41)))
+    two, _ = _sweep(root, "logN2", 2, ["-rewrite", "1", "-end", "2"], port=29677, rccl=True)
+    one, _ = _sweep(root, "logN1", 1, ["-rewrite", "1", "-end", "2", "-prefetch", "0"])
+    assert two["world_size"] == 2 and two["processed"] == 2
+    for name in ("1SYN", "2SYN"):
+        assert open(os.path.join(two["test_dir"], name + ".dat"), "rb").read() == \
+            open(os.path.join(one["test_dir"], name + ".dat"), "rb").read()
