@@ -88,7 +88,11 @@ for rep in range(REPS):
         torch.cuda.set_device(dev)
         with torch.cuda.stream(side), torch.no_grad():
             while not stop.is_set():
-                if LOAD == "matmul":
+                if LOAD == "matmul_bf16":                    # a library bf16 GEMM (hipBLASLt: the bf16 matrix instructions)
+                    a = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
+                    for _ in range(10):
+                        a = (a @ a).tanh_()
+                elif LOAD == "matmul":
                     a = torch.randn(2048, 2048, device=dev)
                     for _ in range(10):
                         a = (a @ a).tanh_()
