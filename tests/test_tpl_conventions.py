@@ -297,3 +297,28 @@ def test_docker_takes_the_fixture_and_docks_under_it(fixture_path, emu):
     scale = max(float(v.abs().max()) for v in Vs)
     assert len(got) == K and max(abs(a[4] - b[4]) for a, b in zip(got, want)) <= 1e-4 * scale
     assert sum(a[:4] == b[:4] for a, b in zip(got, want)) >= K - 4
+
+
+def test_input_clamp_on_a_box_without_a_compiled_plan_takes_the_ops_path(emu):
+    """clip_mode "input" is not combined with the embedded-box engine (the clamp acts on the ROTATED volumes, which the
+    embedded path never materialises): Docker must route such a pair to the stand-alone ops -- before any engine buffer is
+    allocated or kernel launched -- and the engine itself refuses the combination at construction."""
+    L, C, K = 12, 3, 20
+    rec, lig, recf, ligf, W = _conv_case(L, C, 11)
+    from deeplocalproteindocking_amd.Models import GlobalDockingModel, SimpleFilter
+    filt = SimpleFilter([C])
+    with torch.no_grad():
+        filt.fc[0].weight.copy_(W[0]); filt.fc[0].bias.copy_(W[1]); filt.fc[2].weight.copy_(W[2]); filt.fc[2].bias.copy_(W[3])
+    thr = 0.13 * L ** 3
+    model = GlobalDockingModel(None, filt, threshold_clash=thr, clip=0.3, lib=emu)
+    R = orc.euler_to_matrix([0.5, -2.1, 1.0], [1.1, 0.3, 2.0], [-0.4, 1.7, 0.2])
+    dk = Docker(model, box_size=L, resolution=1.0, max_conf=K, rotations=R, device="cpu", lib=emu,
+                conventions=VolumeConventions(clip_mode="input"))
+    got = dk.dock_volumes([rec[None]], [lig[None]], recf, ligf, write=False)
+    assert dk.path == "ops" and dk.engine is None
+    want, Vs = orc.dock_volumes([rec[None]], [lig[None]], recf[None, None], ligf[None, None], R, *W, thr, K,
+                                clip=0.3, faithful_topk=False, return_V=True, clip_mode="input")
+    scale = max(float(v.abs().max()) for v in Vs)
+    assert len(got) == K and max(abs(a[4] - b[4]) for a, b in zip(got, want)) <= 1e-4 * scale
+    with pytest.raises(RuntimeError, match="not combined with embedded boxes"):
+        DockingEngine(32, C, *W, clip=0.3, threshold_clash=thr, max_conf=K, batch=2, device="cpu", lib=emu, extent=12, clip_mode="input")
