@@ -260,6 +260,9 @@ __global__ void __launch_bounds__(256) k_conv3d_pack(const float* __restrict__ w
 // half an LDS fragment read and, at 16 output channels, an eighth of a global one -- matrix pipe, LDS and the vector
 // memory path each sit near half of their rate, and what would raise the arithmetic per fragment (more output-channel
 // tiles per wave) the 16-channel layers do not have.  A fragments TWO tap groups ahead: 9.5 against 9.2-9.3 ms.
+#ifndef DLPD_CONV_DIAG
+#define DLPD_CONV_DIAG 0                     // diagnostic builds only (EXPERIMENTS.md R5): 1 no matrix instructions, 2 no staging stores, 4 no B reads
+#endif
 #ifndef DLPD_CONVS_RW
 #define DLPD_CONVS_RW 4
 #endif
@@ -333,9 +336,13 @@ k_conv3d_bf16x3(const float* __restrict__ X, const float4* __restrict__ Wp, floa
       pm.z = __uint_as_float(mm[4] | (mm[5] << 16)); pm.w = __uint_as_float(mm[6] | (mm[7] << 16));
       pl.x = __uint_as_float(ll[0] | (ll[1] << 16)); pl.y = __uint_as_float(ll[2] | (ll[3] << 16));
       pl.z = __uint_as_float(ll[4] | (ll[5] << 16)); pl.w = __uint_as_float(ll[6] | (ll[7] << 16));
+#if !(DLPD_CONV_DIAG & 2)
       Xs[v] = ph;
       Xs[NVOX + v] = pm;
       Xs[2 * NVOX + v] = pl;
+#else
+      if (ph.x == 1.2345f) Xs[v] = pm + pl;             // (diagnostic build: the staging stores are skipped)
+#endif
     }
     __syncthreads();
     // ---- all tap groups of the chunk; A fragments one group ahead
@@ -357,7 +364,19 @@ k_conv3d_bf16x3(const float* __restrict__ X, const float4* __restrict__ Wp, floa
 #pragma unroll
       for (int sp = 0; sp < 3; sp++)
 #pragma unroll
-        for (int r = 0; r < RW; r++) bf[sp][r] = Xs[sp * NVOX + vbase[r] + off];
+        for (int r = 0; r < RW; r++)
+#if !(DLPD_CONV_DIAG & 4)
+          bf[sp][r] = Xs[sp * NVOX + vbase[r] + off];
+#elif (DLPD_CONV_DIAG & 8)
+        {                                                                 // (diagnostic build: no B reads, PSEUDO-RANDOM operand bits)
+          unsigned h = (unsigned)(off * 2654435761u) ^ (unsigned)(lane * 40503u) ^ (unsigned)((sp * 7 + r) * 2246822519u) ^ (unsigned)tg * 3266489917u;
+          h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+          const unsigned m = 0x3FFF3FFFu;                                 // finite bf16 pairs (exponent below all-ones)
+          bf[sp][r] = make_float4(__uint_as_float(h & m), __uint_as_float((h * 3u) & m), __uint_as_float((h * 5u) & m), __uint_as_float((h * 7u) & m));
+        }
+#else
+          bf[sp][r] = make_float4((float)off, (float)sp, (float)r, 1.f);   // (diagnostic build: no B fragment reads, constant operands)
+#endif
       DLPD_SCHED_FENCE();
 #pragma unroll
       for (int r = 0; r < RW; r++) {
@@ -365,12 +384,17 @@ k_conv3d_bf16x3(const float* __restrict__ X, const float4* __restrict__ Wp, floa
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
           dlpd_acc4 c = acc[r][mt];
+#if !(DLPD_CONV_DIAG & 1)
           c = DLPD_MFMA_16x16x32_BF16(a_cur[2][mt], bf[0][r], c);      // w_l x_h   (small terms first)
           c = DLPD_MFMA_16x16x32_BF16(a_cur[0][mt], bf[2][r], c);      // w_h x_l
           c = DLPD_MFMA_16x16x32_BF16(a_cur[1][mt], bf[1][r], c);      // w_m x_m
           c = DLPD_MFMA_16x16x32_BF16(a_cur[1][mt], bf[0][r], c);      // w_m x_h
           c = DLPD_MFMA_16x16x32_BF16(a_cur[0][mt], bf[1][r], c);      // w_h x_m
           c = DLPD_MFMA_16x16x32_BF16(a_cur[0][mt], bf[0][r], c);      // w_h x_h
+#else
+          // (diagnostic build: the matrix instructions replaced by a few vector adds that keep every operand alive)
+          c[0] += a_cur[0][mt].x + a_cur[1][mt].y + a_cur[2][mt].z + bf[0][r].x + bf[1][r].y + bf[2][r].z;
+#endif
           acc[r][mt] = c;
         }
       }
