@@ -21,6 +21,12 @@
 #include "dlpd_k1.h"
 #include "dlpd_k3.h"
 
+#ifndef DLPD_K1CL_PAD
+#define DLPD_K1CL_PAD 13                 // pencil row padding of the channels-last K1 (complex elements)
+#endif
+#ifndef DLPD_K1CL_PXOR
+#define DLPD_K1CL_PXOR 0                 // diagnostic builds only (EXPERIMENTS.md R5)
+#endif
 #define DLPD_K1_UNROLL 2                 // samples per thread whose gathers are issued together (2..16 measured equal: not latency-bound)
 template <int N> DLPD_D void init_twiddles(cplx* tw, int tid, int nthreads) {
   for (int k = tid; k < N; k += nthreads) {
@@ -284,7 +290,7 @@ k_rotate_zfft_cl(const float4* __restrict__ cl, const float* __restrict__ R, cpl
   constexpr int L = N / 2, NZ = N / 2 + 1, NP = K1ClCfg<N>::NP, CC = K1ClCfg<N>::CC, YG = K1ClCfg<N>::YG, NPR = YG / 2;
   constexpr int LPV = CC / 4, SKEW = 16 / LPV;         // lanes per voxel; bank skew (complex) between channel quads
   static_assert(CC * NPR == NP && L % YG == 0 && (NP * FftPlan<N>::T) % 64 == 0, "whole waves of pencils per block");
-  constexpr int RS = N + 13;
+  constexpr int RS = N + DLPD_K1CL_PAD;
   constexpr int T = FftPlan<N>::T, R1 = FftPlan<N>::R1, R2 = FftPlan<N>::R2;
   constexpr int NT = NP * T;
   DLPD_DYN_SHARED(cplx, S);
@@ -314,7 +320,7 @@ k_rotate_zfft_cl(const float4* __restrict__ cl, const float* __restrict__ R, cpl
     }
   }
   __syncthreads();
-  const int p = tid % NP, t = tid / NP;
+  const int p = (tid % NP) ^ DLPD_K1CL_PXOR, t = tid / NP;   // (PXOR != 0: diagnostic builds, which lane transforms which pencil)
   cplx* Sp = S + p * RS + SKEW * (p / (4 * NPR));
   {
     FftPass<N, R1, 1, -1, T, L> ps;
@@ -364,7 +370,7 @@ __global__ void __launch_bounds__(256) k_make_channels_last(const float* __restr
 
 template <int N> static int launch_k1_cl(const float4* cl, const float* R, cplx* A, int C, int nb, float c0, hipStream_t st,
                                          int CT_out, int c_base, int ext = 0) {
-  constexpr int L = N / 2, RS = N + 13;
+  constexpr int L = N / 2, RS = N + DLPD_K1CL_PAD;
   const int Cq = ((C + DLPD_K1CL_CC - 1) / DLPD_K1CL_CC) * (DLPD_K1CL_CC / 4);
   const size_t shmem = (size_t)(K1ClCfg<N>::NP * RS + N) * sizeof(cplx);
   int rc = dlpd_set_max_dyn_shared((const void*)k_rotate_zfft_cl<N>, shmem);
