@@ -383,3 +383,15 @@ def test_bench_secondary_roofline_from_the_sq_counters():
     t = bench.secondary_from_counters(dict(c, GRBM_GUI_ACTIVE=0.0), 2596.1e3)
     assert t["clock_assumed"] and t["clock_GHz"] == 2.0
     assert bench.secondary_from_counters({}, None) is None
+
+
+def test_no_product_default_runs_the_plugin_beside_the_pipeline():
+    """EXPERIMENTS.md R5: the plugin's bf16 x 3 convolution on a second stream beside the search changed the last bits of a few
+    scores.  The two places that could put it there are off by default: dockE3's overlapped loop and the sweep's preparing
+    stream."""
+    import inspect
+    from deeplocalproteindocking_amd import local_test
+    from deeplocalproteindocking_amd.Docker import Docker
+    assert Docker.E3_OVERLAP is False
+    assert inspect.signature(local_test.sweep).parameters["prepare_stream"].default is False
+    assert inspect.signature(Docker.prepare).parameters["stream"].default is None
