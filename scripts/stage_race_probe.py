@@ -32,7 +32,9 @@ with torch.no_grad():
 torch.cuda.synchronize()
 eng = dk.engine
 Rb = torch.from_numpy(R[16:32]).to(device=dev, dtype=torch.float32).contiguous()
-BUF = {"coarse": lambda: eng.pre, "k1_rotate_zfft": lambda: eng.wsA, "k2_xy_corr": lambda: eng.wsB, "k3_zifft_filter": lambda: eng.V}
+BUF = {"coarse_k1": lambda: eng.wsA1, "coarse_k2": lambda: eng.wsB1, "coarse": lambda: eng.pre, "k1_rotate_zfft": lambda: eng.wsA,
+       "k2_xy_corr": lambda: eng.wsB, "k3_zifft_filter": lambda: eng.V}
+ORDER = ("coarse_k1", "coarse_k2", "coarse", "k1_rotate_zfft", "k2_xy_corr", "k3_zifft_filter")
 ref = {}
 
 
@@ -41,10 +43,13 @@ def record(name):
         ref[name] = BUF[name]().clone()
 
 
+record.sub_stages = True
 eng.score_batch(Rb, mark=record)
 torch.cuda.synchronize()
 again = {}
-eng.score_batch(Rb, mark=lambda n: again.__setitem__(n, BUF[n]().clone()) if n in BUF else None)
+m2 = lambda n: again.__setitem__(n, BUF[n]().clone()) if n in BUF else None
+m2.sub_stages = True
+eng.score_batch(Rb, mark=m2)
 torch.cuda.synchronize()
 print("undisturbed rerun identical:", {k: bool(torch.equal(ref[k], again[k])) for k in ref}, flush=True)
 del again
@@ -67,10 +72,28 @@ def worker():
 
 
 th = None
-if LOAD != "none":
+if LOAD not in ("none", "topk"):
     th = threading.Thread(target=worker, daemon=True)
     th.start()
     time.sleep(0.1)
+# third party: the engine's own full radix select (what runs on its top-K stream during the second batch of a search),
+# repeated on a stream of its own while the batch is scored ("topk" alone, or "<load>+topk")
+TOPK = "topk" in sys.argv[2:] or (len(sys.argv) > 3 and "topk" in sys.argv[3])
+th2 = None
+if TOPK:
+    side2 = torch.cuda.Stream(device=dev)
+    Vsel = eng.V.clone()
+
+    def selector():
+        torch.cuda.set_device(dev)
+        with torch.cuda.stream(side2):
+            while not stop.is_set():
+                for _ in range(4):
+                    eng.top.select(Vsel.reshape(16, -1), 16, None)
+                side2.synchronize()
+    th2 = threading.Thread(target=selector, daemon=True)
+    th2.start()
+    time.sleep(0.05)
 bad = {k: 0 for k in BUF}
 first_bad = {}
 detail = []
@@ -84,20 +107,34 @@ for it in range(ITER):
             n = int(d.sum())
             if n:
                 diffs[name] = (n, d)
+    check.sub_stages = True
     eng.score_batch(Rb, mark=check)
     torch.cuda.synchronize()
     if diffs:
-        order = [k for k in ("coarse", "k1_rotate_zfft", "k2_xy_corr", "k3_zifft_filter") if k in diffs]
+        order = [k for k in ORDER if k in diffs]
         first = order[0]
         bad[first] += 1
         if len(detail) < 6:
             n, d = diffs[first]
             idx = d.reshape(-1).nonzero().reshape(-1)
-            detail.append("iteration %d: first differing stage %s, %d elements differ (flat indices %s ...), later stages %s" % (
-                it, first, n, idx[:6].tolist(), {k: diffs[k][0] for k in order[1:]}))
+            msg = "iteration %d: first differing stage %s, %d elements differ (flat indices %s ...), later stages %s" % (
+                it, first, n, idx[:6].tolist(), {k: diffs[k][0] for k in order[1:]})
+            if first == "coarse_k1":
+                L1, C1 = eng.L1, eng.C1
+                dd = d.view(16, C1, L1 + 1, L1, L1, 2).nonzero()
+                a = ref[first].view(16, C1, L1 + 1, L1, L1, 2)
+                g = BUF[first]().view(16, C1, L1 + 1, L1, L1, 2)
+                msg += "\n      wsA1 max |diff| %.3g;" % float((a - g).abs().max())
+                for dim, nm in enumerate(("b", "c", "k", "x", "y")):
+                    u = dd[:, dim].unique()
+                    msg += " %s: %s%s" % (nm, u[:12].tolist(), "..." if len(u) > 12 else "")
+            detail.append(msg)
 stop.set()
 if th is not None:
     th.join()
+if th2 is not None:
+    th2.join()
+print("top-K selector beside it: %s" % TOPK)
 print("load %s: %d iterations in %.1f s; iterations whose FIRST differing stage was:" % (LOAD, ITER, time.time() - t0), bad)
 for d in detail:
     print("  ", d)
