@@ -116,13 +116,7 @@ k_rotate_zfft_cl_rs(const float4* __restrict__ cl, const float* __restrict__ R, 
   cplx* work = S + INBUF * NP * RSI;
   cplx* tw = work + NP * RSW;
   const int tid = threadIdx.x, wave = DLPD_UNIFORM(tid >> 6), lane = tid & 63;      // (the role is a SCALAR condition)
-#if defined(K1R_ONLY_G)
-  const bool gatherer = true;
-#elif defined(K1R_ONLY_X)
-  const bool gatherer = false;
-#else
   const bool gatherer = wave < G::GW;
-#endif
   const int nchunk = Cq / (CC / 4), per = (L / YG) * nchunk;
   const int groups = nb * L, gper = (groups + 7) / 8;
   const int xcd = blockIdx.x & 7, first = (blockIdx.x >> 3) * items_per_block;

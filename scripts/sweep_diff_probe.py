@@ -7,11 +7,11 @@ root = tempfile.mkdtemp(prefix="dlpd_sweep_probe_")
 make_benchmark(root, targets=(("1SYN", 150, 90, 21), ("2SYN", 120, 100, 41), ("3SYN", 100, 60, 61)))
 runs = {}
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-MODES = sys.argv[2].split(",") if len(sys.argv) > 2 else [""]
-combos = [("w1_plain", 1, 0, "")] + [("w2_ahead_%s_%d" % (m or "default", i), 2, 1, m) for m in MODES for i in range(REPS)]
-for tag, nproc, pre, mode in combos:
-    rep, _ = _sweep(root, "log_" + tag, nproc, ["-rewrite", "1", "-prefetch", str(pre)], port=29700 + len(runs) % 200,
-                    extra_env={"DLPD_DEBUG_PREPARE": mode})
+# (the DLPD_DEBUG_PREPARE switches of local_test.sweep that the first version of this probe drove -- preparing thread on the caller's
+#  stream / synchronised at its end / prepared pairs kept alive -- were removed again once the cause was narrowed: EXPERIMENTS.md R5)
+combos = [("w1_plain", 1, 0)] + [("w2_ahead_%d" % i, 2, 1) for i in range(REPS)]
+for tag, nproc, pre in combos:
+    rep, _ = _sweep(root, "log_" + tag, nproc, ["-rewrite", "1", "-prefetch", str(pre)], port=29700 + len(runs) % 200)
     runs[tag] = {n: open(os.path.join(rep["test_dir"], n + ".dat")).read().splitlines() for n in ("1SYN", "2SYN", "3SYN")}
     print(tag, "targets/s %.2f" % rep["targets_per_s"], [round(t["seconds"], 2) for t in rep["targets"]], flush=True)
 base = runs["w1_plain"]
