@@ -104,6 +104,20 @@ __device__ __forceinline__ dlpd_f2v dlpd_f2_splat(float a) { dlpd_f2v r = {a, a}
 __device__ __forceinline__ float dlpd_f2_get(dlpd_f2v v, int i) { return i ? v.y : v.x; }
 __device__ __forceinline__ dlpd_f2v dlpd_pk_fma(dlpd_f2v a, dlpd_f2v b, dlpd_f2v c) { return __builtin_elementwise_fma(a, b, c); }
 
+// table[bin] += 1 for every lane of the wave with `hit`, WITHOUT an LDS atomic: the lanes that name the same bin are found
+// with a ballot and one of them adds the group's size by a plain read-modify-write; rounds until every lane is served.  All 64
+// lanes must call it together; `table` must be private to the wave.  (Why not ds_add_u32: EXPERIMENTS.md R5 / k_topk_hist.)
+__device__ __forceinline__ void dlpd_lds_count(unsigned* table, unsigned bin, bool hit, int lane) {
+  unsigned long long todo = __ballot(hit);
+  while (todo) {
+    const int leader = __builtin_ctzll(todo);
+    const unsigned lb = __shfl(bin, leader);
+    const unsigned long long same = __ballot(hit && bin == lb);
+    if (lane == leader) table[lb] += (unsigned)__popcll(same);
+    todo &= ~same;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Packed complex arithmetic: one complex number = one aligned VGPR pair, one VOP3P instruction
 // per complex add / rotate-add and two per complex multiply (FFT butterflies are VALU-issue

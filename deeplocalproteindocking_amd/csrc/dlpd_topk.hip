@@ -16,6 +16,9 @@
 // and a one-block bitonic sort of the K survivors.  No host synchronisation anywhere.
 #include <dlpd_platform.h>
 #include "dlpd_internal.h"
+#ifndef DLPD_TOPK_DIAG
+#define DLPD_TOPK_DIAG 0                     // diagnostic builds only (EXPERIMENTS.md R5): kernels of the radix select left out (1 hist, 2 scan, 4 collect, 8 sort)
+#endif
 
 typedef unsigned long long u64;
 
@@ -56,12 +59,23 @@ __global__ void __launch_bounds__(256) k_topk_init(TopkState* st, int nb, unsign
   if (threadIdx.x == 0) { st[b].kth = 0; st[b].krem = K; st[b].done = 0; st[b].ncand = 0; }
 }
 
+// Histogram of one digit of the keys of rotation b (all voxels in pass 0, afterwards those that share the selected prefix).
+// NO LDS ATOMICS: every wave counts into a table of its own, and inside a wave the lanes that hit the same bin are
+// combined with a ballot -- one lane adds the group's size with a plain read-modify-write -- until every lane is served
+// (a handful of rounds: the scores of a rotation share their leading bits).  Round 5 found that the `ds_add_u32` version of
+// this kernel, running beside a workgroup that feeds `v_mfma_f32_16x16x32_bf16` from `ds_read_b128` (the plugin's bf16 x 3
+// convolution), changed the results of the N = 80 FFT kernels that shared the CU with both (EXPERIMENTS.md R5: 259 of 300
+// scorings; 0 of 150 with plain LDS updates) -- lanes 48-63 of their transform waves, low mantissa bits.  The counts are the
+// same, so the select is bit-identical; the table costs 32 KB of LDS instead of 8 (this kernel runs only while the running
+// list fills, and for callers without candidate lists).
 __global__ void __launch_bounds__(TOPK_HIST_THREADS)
 k_topk_hist(const float* __restrict__ V, long long nvox, TopkState* st, int pass) {
   const int b = blockIdx.y;
   if (st[b].done) return;
-  __shared__ unsigned lh[TOPK_BINS];
-  for (int i = threadIdx.x; i < TOPK_BINS; i += blockDim.x) lh[i] = 0;
+  constexpr int NW = TOPK_HIST_THREADS / 64;
+  __shared__ unsigned lh[NW][TOPK_BINS];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < NW * TOPK_BINS; i += blockDim.x) (&lh[0][0])[i] = 0;
   __syncthreads();
   const int shift = kShift[pass], bits = kBits[pass];
   const unsigned mask = (1u << bits) - 1u;
@@ -71,13 +85,25 @@ k_topk_hist(const float* __restrict__ V, long long nvox, TopkState* st, int pass
   const long long per = (nvox + gridDim.x - 1) / gridDim.x;
   const long long beg = (long long)blockIdx.x * per;
   const long long end = beg + per < nvox ? beg + per : nvox;
-  for (long long i = beg + threadIdx.x; i < end; i += blockDim.x) {
-    const u64 key = ((u64)f2key(v[i]) << 32) | (u64)i;
-    if (pass == 0 || (key >> hs) == (kth >> hs)) atomicAdd(&lh[(unsigned)(key >> shift) & mask], 1u);
+  unsigned* mine = lh[wave];
+  for (long long i0 = beg; i0 < end; i0 += blockDim.x) {          // every lane of the block runs the same number of rounds
+    const long long i = i0 + threadIdx.x;
+    bool hit = false;
+    unsigned bin = 0;
+    if (i < end) {
+      const u64 key = ((u64)f2key(v[i]) << 32) | (u64)i;
+      hit = pass == 0 || (key >> hs) == (kth >> hs);
+      bin = (unsigned)(key >> shift) & mask;
+    }
+    dlpd_lds_count(mine, bin, hit, lane);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < TOPK_BINS; i += blockDim.x)
-    if (lh[i]) atomicAdd(&st[b].hist[i], lh[i]);
+  for (int i = threadIdx.x; i < TOPK_BINS; i += blockDim.x) {
+    unsigned sum = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) sum += lh[w][i];
+    if (sum) atomicAdd(&st[b].hist[i], sum);
+  }
 }
 
 __global__ void __launch_bounds__(256) k_topk_scan(TopkState* st, int pass) {
@@ -445,19 +471,28 @@ int dlpd_topk_select_cand(const float* V, int nb, long long nvox, int K, float* 
                 cap, K, out_score, out_idx);
   }
   for (int pass = 0; pass < TOPK_NPASS; pass++) {
+#if !(DLPD_TOPK_DIAG & 1)
     DLPD_LAUNCH(k_topk_hist, dim3(TOPK_HIST_BLOCKS, nb), dim3(TOPK_HIST_THREADS), 0, st, V, nvox, state, pass);
+#endif
+#if !(DLPD_TOPK_DIAG & 2)
     DLPD_LAUNCH(k_topk_scan, dim3(nb), dim3(256), 0, st, state, pass);
+#endif
   }
+#if !(DLPD_TOPK_DIAG & 4)
   DLPD_LAUNCH(k_topk_collect, dim3(TOPK_HIST_BLOCKS, nb), dim3(TOPK_HIST_THREADS), 0, st, V, nvox, state, cand, K);
+#endif
   int KP = 1;
   while (KP < K) KP <<= 1;
   u64* sortbuf = cand + (size_t)nb * K;                 // (nb, KP), allocated for K > TOPK_LDSK only
+#if !(DLPD_TOPK_DIAG & 8)
   if (K > TOPK_LDSK)
     DLPD_LAUNCH(k_topk_sort<true>, dim3(nb), dim3(1024), 0, st, V, nvox, (const TopkState*)state, (const u64*)cand, K,
                 out_score, out_idx, sortbuf, KP);
   else
     DLPD_LAUNCH(k_topk_sort<false>, dim3(nb), dim3(1024), 0, st, V, nvox, (const TopkState*)state, (const u64*)cand, K,
                 out_score, out_idx, (u64*)nullptr, 0);
+#endif
+  (void)sortbuf;
   return dlpd_check_launch();
 }
 

@@ -71,12 +71,10 @@ def sweep(docker, targets, test_dir, group="SE3", rewrite=False, batch_size=2, p
         from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dlpd-prepare")
         # The preparing thread enqueues its device work on the CALLER'S stream (stream = None), in order with the search's
-        # launches: what overlaps with the search is the host side (PDB parsing, typing, launch overhead), which is the
-        # larger part.  A stream of its own (prepare_stream=True) also overlaps the projection / representation kernels --
-        # and was measured to change the last bits of a few scores in about 5 % of the sweeps: the plugin's bf16 x 3
-        # convolution, co-resident on a CU with the coarse grid's K1 (k_rotate_zfft_cl<80>), perturbs that kernel's
-        # pencils 48-63 (EXPERIMENTS.md, round 5; scripts/search_race_probe.py reproduces it) -- within the 1e-4 parity
-        # band, but not the byte-identical .dat files this driver promises.
+        # launches: what overlaps with the search is the host side (PDB parsing, typing, launch overhead).  A stream of
+        # its own (prepare_stream=True) also overlaps the projection / representation kernels -- a target's preparation is
+        # 0.01-0.1 s of the 23 s its search takes (profiles/r05_s_soak_sweep.json), so there is nothing to gain, and it was
+        # this option that exposed round 5's LDS-atomics interaction (EXPERIMENTS.md R5; since removed at its source).
         stream = torch.cuda.Stream(device=dev) if (on_gpu and prepare_stream) else None
     pending = {}                                      # target index -> Future of its PreparedPair
     def prepare_in_background(j, slot):

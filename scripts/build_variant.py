@@ -20,11 +20,12 @@ def main():
     ap.add_argument("--k3r", default="")
     ap.add_argument("--k2q", default="")
     ap.add_argument("--k1r", default="")
+    ap.add_argument("--topk", default="")
     ap.add_argument("--conv", default="")
     ap.add_argument("--corr-src", default=None, help="alternative source file for dlpd_corr.hip")
     args = ap.parse_args()
     entry.build()
-    extra = {"dlpd_corr.hip": args.corr.split(), "dlpd_k2.hip": args.k2.split(), "dlpd_k3r.hip": args.k3r.split(), "dlpd_k2q.hip": args.k2q.split(), "dlpd_k1r.hip": args.k1r.split(),
+    extra = {"dlpd_corr.hip": args.corr.split(), "dlpd_k2.hip": args.k2.split(), "dlpd_k3r.hip": args.k3r.split(), "dlpd_k2q.hip": args.k2q.split(), "dlpd_k1r.hip": args.k1r.split(), "dlpd_topk.hip": args.topk.split(),
              "dlpd_conv.hip": args.conv.split()}
     out_dir = os.path.join(ROOT, "build_variants")
     os.makedirs(out_dir, exist_ok=True)

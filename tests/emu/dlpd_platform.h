@@ -204,6 +204,9 @@ static inline unsigned long long __ballot(int pred) {
   return m;
 }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+// (the fibers of a wave run one after the other here: a plain increment IS the wave's combined count; the ballot rounds of
+//  the device version would cost three wave collectives per voxel and round)
+static inline void dlpd_lds_count(unsigned* table, unsigned bin, bool hit, int) { if (hit) table[bin] += 1u; }
 
 template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <typename T> static inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }

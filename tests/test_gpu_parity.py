@@ -967,6 +967,80 @@ def test_no_result_depends_on_lds_a_kernel_never_wrote(dev, tmp_path):
     assert not problems, "\n".join(problems)
 
 
+def test_scores_do_not_change_beside_the_plugin_and_the_radix_select(dev):
+    """Regression test of round 5's cross-stream finding (EXPERIMENTS.md R5).  One batch of the reference's real shapes is
+    scored again and again while two more streams of the process are kept busy: the representation plugin's bf16 x 3
+    convolutions and the engine's own full radix select.  With `ds_add_u32` in the select's histogram kernel this changed
+    the output of the coarse grid's K1 / K2 -- the pipeline kernels small enough to share a CU with both -- in 259 of 300
+    scorings (lanes 48-63 of a transform wave, low mantissa bits); the histogram now counts without LDS atomics and every
+    stage's output must be the same bits as in the undisturbed run."""
+    import threading
+    import time
+    from deeplocalproteindocking_amd.engine import DockingEngine
+    from deeplocalproteindocking_amd.Models import SE3MultiResReprScalar
+    torch.manual_seed(5)
+    g = torch.Generator().manual_seed(5)
+    L, C, C1 = 80, 16, 32
+    rec, lig = torch.randn(C, L, L, L, generator=g) * 0.1, torch.randn(C, L, L, L, generator=g) * 0.1
+    rec1, lig1 = torch.randn(C1, 40, 40, 40, generator=g) * 0.1, torch.randn(C1, 40, 40, 40, generator=g) * 0.1
+    recf, ligf = torch.rand(L, L, L, generator=g), torch.rand(L, L, L, generator=g)
+    W1, b1 = torch.randn(24, C + C1, generator=g) * 0.3, torch.randn(24, generator=g) * 0.1
+    W2, b2 = torch.randn(1, 24, generator=g), torch.randn(1, generator=g)
+    eng = DockingEngine(L, C, W1, b1, W2, b2, clip=5.0, threshold_clash=0.12 * L ** 3, max_conf=2000, batch=16, device=dev, coarse_channels=C1)
+    eng.set_receptor(rec, recf, rec1)
+    eng.set_ligand(lig, ligf, lig1)
+    R = torch.from_numpy(_rots(16, seed=8)).float().to(dev).contiguous()
+    buffers = {"coarse_k1": lambda: eng.wsA1, "coarse_k2": lambda: eng.wsB1, "coarse": lambda: eng.pre, "k1_rotate_zfft": lambda: eng.wsA,
+               "k2_xy_corr": lambda: eng.wsB, "k3_zifft_filter": lambda: eng.V}
+    ref = {}
+
+    def record(name):
+        if name in buffers:
+            ref[name] = buffers[name]().clone()
+    record.sub_stages = True
+    eng.score_batch(R, mark=record)
+    torch.cuda.synchronize()
+    assert set(ref) == set(buffers)
+    plugin = SE3MultiResReprScalar(multiplier=8).to(dev).eval()
+    x11 = torch.rand(1, 11, L, L, L, device=dev)
+    Vsel = eng.V.clone()
+    stop = threading.Event()
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+
+    def convolve():
+        torch.cuda.set_device(dev)
+        with torch.cuda.stream(streams[0]), torch.no_grad():
+            while not stop.is_set():
+                plugin(x11)
+                streams[0].synchronize()
+
+    def select():
+        torch.cuda.set_device(dev)
+        with torch.cuda.stream(streams[1]):
+            while not stop.is_set():
+                for _ in range(4):
+                    eng.top.select(Vsel.reshape(16, -1), 16, None)
+                streams[1].synchronize()
+    threads = [threading.Thread(target=convolve, daemon=True), threading.Thread(target=select, daemon=True)]
+    for t in threads:
+        t.start()
+    time.sleep(0.1)
+    changed = {}
+    try:
+        for it in range(80):
+            def check(name):
+                if name in buffers and not torch.equal(buffers[name](), ref[name]):
+                    changed.setdefault(name, []).append(it)
+            check.sub_stages = True
+            eng.score_batch(R, mark=check)
+            torch.cuda.synchronize()
+    finally:
+        stop.set()
+        for t in threads:
+            t.join()
+    assert not changed, {k: len(v) for k, v in changed.items()}
+
+
 def test_k3_role_split_equals_the_channel_owning_k3(dev, variants):
     """k_zifft_filter_rs (dedicated transform / filter waves, the default) bit for bit against k_zifft_filter[_tiles]
     (every wave owns a channel) and against the oracle: 48 channels x 64^3 (13 groups of 4, the last one the clash
