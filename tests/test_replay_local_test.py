@@ -155,8 +155,9 @@ def test_synthetic_benchmark_directory_is_what_the_loader_reads(tmp_path):
 def _same_dat_up_to_the_parity_band(a, b, n=2000):
     """Two .dat files of one target: byte-identical, or -- for runs in which two PROCESSES shared one GPU -- the same poses
     with scores inside the 1e-4 parity band and at most a handful of rows displaced.  (On one GPU the other rank's plugin
-    convolution can run beside this rank's coarse K1, which now and then changes the last bits of one rotation's scores:
-    EXPERIMENTS.md R5.  One process per GPU -- the production layout, and the RCCL test below -- is byte-identical.)"""
+    convolution ran beside this rank's search, which -- until the histogram kernel lost its LDS atomics, EXPERIMENTS.md R5 --
+    now and then changed the last bits of one rotation's scores; the comparison stays tolerant of that class of effect for
+    the shared-GPU layout only.  One process per GPU -- the production layout, and the RCCL test below -- is byte-identical.)"""
     if a == b:
         return True
     ra = [[float(v) for v in l.split(b"\t")] for l in a.strip().split(b"\n")]
