@@ -86,6 +86,9 @@ def parse_args():
                     help="A/B switch: K2 of boxes 80 / 40 reads the receptor spectrum in its natural layout (not the packed copy)")
     ap.add_argument("--k3_form", type=int, default=0, choices=(0, 1, 2),
                     help="kernel formulation of the fused K3 (include/dlpd.h, dlpd_zifft_filter_form): 0 = library default")
+    ap.add_argument("--force_group", action="store_true",
+                    help="initialise the process group and run every collective even with ONE rank (a one-rank RCCL "
+                         "communicator: how a one-GPU box exercises the nccl branches of this file)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="collective backend of the multi-rank run: nccl (= RCCL over xGMI, one GPU per rank) or gloo")
     ap.add_argument("--same_device", action="store_true",
@@ -346,19 +349,19 @@ def sharded_search(eng, R_all, ids_global, rank, world, K, dist, dev):
     eng.reset_top()
     if on_gpu:
         torch.cuda.synchronize()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
     if len(mine):
         eng.search(R_all[mine], rot_ids=mine)
     ent = eng.top_entries()
-    if world > 1:
-        ent = all_gather_top_entries(ent, K, world, None, dev)
+    if dist is not None:
+        ent = all_gather_top_entries(ent, K, world, None, dev, always=True)
         dist.barrier()
     if on_gpu:
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=collective_device(dist, dev))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0].item())
@@ -386,10 +389,12 @@ def run_rank(args):
     dev = torch.device("cuda", 0 if args.same_device else local_rank)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_group:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group(args.backend, device_id=dev if args.backend == "nccl" else None)
 
     from deeplocalproteindocking_amd.engine import DockingEngine
@@ -451,7 +456,7 @@ def run_rank(args):
         V_first = torch.cat(Vs)
 
     def barrier():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -461,12 +466,12 @@ def run_rank(args):
     timer = StageTimer()
     time_steps(eng, Rd, idd, tr_of, qd_of, nb, t_first, args.steps, mark=timer.mark)
     entries = eng.top_entries()                              # waits for the side stream; D2H of this rank's list
-    if world > 1:                                            # single all-gather + deterministic merge
+    if dist is not None:                                            # single all-gather + deterministic merge
         from deeplocalproteindocking_amd.Docker.Docker import all_gather_top_entries
-        entries = all_gather_top_entries(entries, K, world, None, dev)
+        entries = all_gather_top_entries(entries, K, world, None, dev, always=True)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([elapsed, setup_s, host_inputs_s, device_setup_s], dtype=torch.float64, device=collective_device(dist, dev))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, setup_s, host_inputs_s, device_setup_s = (float(v) for v in t.tolist())
@@ -512,8 +517,8 @@ def run_rank(args):
         sub = seq_all[:min(args.gather_rotations, len(seq_all))]
         ent, dt = sharded_search(eng, R_all, sub, rank, world, K, dist, dev)
         gather_check = {"rotations": int(len(sub)), "list_sha256": list_sha256(ent), "list_entries": int(len(ent[0])),
-                        "world_size_seen": (dist.get_world_size() if world > 1 else 1),
-                        "backend": (dist.get_backend() if world > 1 else None), "seconds": dt,
+                        "world_size_seen": (dist.get_world_size() if dist is not None else 1),
+                        "backend": (dist.get_backend() if dist is not None else None), "seconds": dt,
                         "sample": "the first %d rotations of the single-process visiting sequence, sharded r::W, one "
                                   "all-gather + deterministic merge; the hash is the same at every world size" % len(sub)}
     if args.strong_s > 0:
@@ -611,8 +616,8 @@ def run_rank(args):
                        "timed_steps": "batches spread evenly over the rank's whole %d-batch visiting sequence "
                                       "(all four search groups)" % shard_batches,
                        "translations_per_rotation": N ** 3, "sharding": "rotations interleaved over %d rank(s)" % world,
-                       "world_size_seen_by_the_collective": (dist.get_world_size() if world > 1 else 1),
-                       "collective_backend": (dist.get_backend() if world > 1 else None),
+                       "world_size_seen_by_the_collective": (dist.get_world_size() if dist is not None else 1),
+                       "collective_backend": (dist.get_backend() if dist is not None else None),
                        "kernel_switches": switches,
                        "environment": {k: v for k, v in os.environ.items() if k.startswith("DLPD_")},
                        "clip": 5.0, "threshold_clash": wl["thr"],
@@ -651,7 +656,7 @@ def run_rank(args):
             out["cpu_baseline"] = cpu_baseline(wl["rec"], wl["lig"], wl["recf"], wl["ligf"], [w.cpu() for w in wl["W"]],
                                                R_cpu, grp_cpu, wl["thr"], K, V_first)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

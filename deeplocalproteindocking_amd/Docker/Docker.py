@@ -159,7 +159,7 @@ class Docker:
     def __init__(self, docking_model, angle_inc=15.0, box_size=80, resolution=1.25, max_conf=1000,
                  randomize_rot=False, rotations=None, device="cuda", coords_backend=None,
                  rank=0, world_size=1, process_group=None, lib=None, launch_batch=None, rotation_center=None,
-                 conventions=None, rotation_seed=None):
+                 conventions=None, rotation_seed=None, collectives_with_one_rank=False):
         self.docking_model = docking_model
         self.log = None
 
@@ -180,8 +180,11 @@ class Docker:
         # Docker.py:42-45.  Rotation-sharded over ranks, every rank must score the SAME rotated receptor: rank 0's
         # matrix is broadcast (here when the process group already exists, else at the start of the first dock* call);
         # rotation_seed makes it reproducible (None: a fresh one per Docker, as "random" says).
+        # collectives_with_one_rank: run the broadcasts and the all-gather for a group of ONE rank too -- how a one-GPU box
+        # takes this class through RCCL itself (local_test.py -force_group 1); the results are the same by construction
+        self.collectives_with_one_rank = bool(collectives_with_one_rank)
         self.randomize_rot = randomize_rot
-        self._randR_shared = self.world_size <= 1
+        self._randR_shared = self.world_size <= 1 and not self.collectives_with_one_rank
         if self.randomize_rot:
             self.randR = random_rotation(seed=rotation_seed)
             self._share_random_rotation(required=False)
@@ -641,7 +644,8 @@ class Docker:
 
     def _gather(self, entries):
         """One all-gather of the fixed-size per-rank lists + deterministic merge (every rank)."""
-        return all_gather_top_entries(entries, self.max_conf, self.world_size, self.process_group, self.device)
+        return all_gather_top_entries(entries, self.max_conf, self.world_size, self.process_group, self.device,
+                                      always=self.collectives_with_one_rank)
 
     # ------------------------------------------------------------------ PDB-level entries
     def _need_backend(self):

@@ -39,7 +39,7 @@ def _collective_device(docker):
 
 def _broadcast_flags(docker, flags, n):
     """rank 0's list of n booleans -> every rank (one broadcast of n int64; identity for a single rank)."""
-    if docker.world_size <= 1:
+    if docker.world_size <= 1 and not docker.collectives_with_one_rank:
         return [bool(f) for f in flags]
     import torch.distributed as dist
     group = docker.process_group
@@ -127,7 +127,12 @@ def sweep(docker, targets, test_dir, group="SE3", rewrite=False, batch_size=2, p
             pool.shutdown(wait=True)
         docker.cleanup()
     total = time.perf_counter() - t_sweep
+    backend = None
+    if docker.world_size > 1 or docker.collectives_with_one_rank:
+        import torch.distributed as dist
+        backend = dist.get_backend(docker.process_group)
     return {"test_dir": test_dir, "world_size": docker.world_size, "rank": docker.rank, "group": group,
+            "collective_backend": backend,
             "processed": processed, "skipped": skipped, "seconds": total,
             "targets_per_s": processed / total if total > 0 else 0.0, "prepared_ahead": pool is not None,
             "preparation_s_behind_a_search": hidden, "targets": report}
@@ -154,6 +159,8 @@ def parse_args(argv=None):
     ap.add_argument("-prefetch", default=1, type=int, help="prepare the next target while the current one is searched")
     ap.add_argument("-backend", default="nccl", choices=("nccl", "gloo"), help="collective backend (nccl = RCCL)")
     ap.add_argument("-same_device", default=0, type=int, help="every rank on cuda:0 (one-GPU box; needs -backend gloo)")
+    ap.add_argument("-force_group", default=0, type=int,
+                    help="initialise the process group and run every collective with ONE rank too (one-GPU RCCL check)")
     return ap.parse_args(argv)
 
 
@@ -178,10 +185,12 @@ def main(argv=None):
         raise SystemExit("local_test.py: -same_device needs -backend gloo (RCCL wants one device per rank)")
     dev = torch.device("cuda", 0 if args.same_device else local_rank)
     torch.cuda.set_device(dev)                          # (local_test.py:44 sets device 0)
-    if world > 1:
+    if world > 1 or args.force_group:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group(args.backend, device_id=dev if args.backend == "nccl" else None)
 
     dataset_name, subset_name = args.dataset.split(":")[:2]
@@ -201,12 +210,13 @@ def main(argv=None):
     if args.init_weights and rank == 0 and not os.path.exists(checkpoint):
         os.makedirs(mdl_dir, exist_ok=True)
         docking_model.save(mdl_dir, epoch=args.load_epoch)
-    if world > 1:
+    if world > 1 or args.force_group:
         dist.barrier()                                  # the checkpoint (and test_dir) exist before anyone reads them
     docking_model.load(mdl_dir, epoch=args.load_epoch)
 
     docker = Docker(docking_model=docking_model, angle_inc=args.angle_inc, box_size=80, resolution=1.25,
-                    max_conf=2000, randomize_rot=True, device=dev, rank=rank, world_size=world, rotation_seed=args.seed)
+                    max_conf=2000, randomize_rot=True, device=dev, rank=rank, world_size=world, rotation_seed=args.seed,
+                    collectives_with_one_rank=bool(args.force_group))
 
     targets = []
     for n, data in enumerate(stream_test):
@@ -219,7 +229,7 @@ def main(argv=None):
                 prefetch=bool(args.prefetch), say=say)
     if args.report and rank == 0:
         print("SWEEP " + json.dumps(rep), flush=True)
-    if world > 1:
+    if world > 1 or args.force_group:
         dist.barrier()
         dist.destroy_process_group()
     return rep

@@ -436,7 +436,7 @@ def _sweep_targets(root, write=False):
     return out
 
 
-def _run_sweep(rank, world, port, out, root, test_dir, rewrite, prefetch, group="SE3", ntargets=3):
+def _run_sweep(rank, world, port, out, root, test_dir, rewrite, prefetch, group="SE3", ntargets=3, group_of_one=False):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -447,20 +447,21 @@ def _run_sweep(rank, world, port, out, root, test_dir, rewrite, prefetch, group=
     from deeplocalproteindocking_amd.Docker import Docker
     from deeplocalproteindocking_amd.Utils.FullAtom import CoordsBackend
     from deeplocalproteindocking_amd import local_test
-    if world > 1:
+    if world > 1 or group_of_one:
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     targets = _sweep_targets(root)[:ntargets]
     R = orc.euler_to_matrix(0.3 + 0.03 * np.arange(5), 1.1 - 0.02 * np.arange(5), -2.0 + 0.025 * np.arange(5))
     torch.manual_seed(2000 + rank)
     lib = emu_lib()
     dk = Docker(_tiny_model(), box_size=32, resolution=1.25, max_conf=40, rotations=R, device="cpu", lib=lib,
-                coords_backend=CoordsBackend(lib=lib), randomize_rot=True, rotation_seed=900 + rank, rank=rank, world_size=world)
+                coords_backend=CoordsBackend(lib=lib), randomize_rot=True, rotation_seed=900 + rank, rank=rank, world_size=world,
+                collectives_with_one_rank=group_of_one)
     said = []
     rep = local_test.sweep(dk, targets, test_dir, group=group, rewrite=rewrite, batch_size=2, prefetch=prefetch,
                            say=lambda *a: said.append(" ".join(str(x) for x in a)))
     assert dk.log is None                                          # closed by the sweep
     out[rank] = {"rep": rep, "said": said, "randR": dk.randR.reshape(9).tolist()}
-    if world > 1:
+    if world > 1 or group_of_one:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -515,4 +516,18 @@ def test_benchmark_sweep_E3_prepared_ahead_equals_unprepared(tmp_path):
     _run_sweep(0, 1, 0, a, root, da, True, True, "E3", 2)
     _run_sweep(0, 1, 0, b, root, db, True, False, "E3", 2)
     assert [t["prepared_ahead"] for t in a[0]["rep"]["targets"]] == [False, True]
+    assert _dat_files(da) == _dat_files(db) and len(_dat_files(da)) == 2
+
+
+def test_benchmark_sweep_on_a_process_group_of_one_rank_equals_the_ungrouped_sweep(tmp_path):
+    """`collectives_with_one_rank` (local_test.py -force_group 1: how a one-GPU box takes the sweep through RCCL): the plan
+    and decision broadcasts, the random-rotation broadcast and the all-gather run for a group of one and change nothing."""
+    root, da, db = str(tmp_path / "pdb"), str(tmp_path / "a"), str(tmp_path / "b")
+    os.makedirs(da), os.makedirs(db)
+    _sweep_targets(root, write=True)
+    a, b = {}, {}
+    _run_sweep(0, 1, 29741, a, root, da, True, True, "SE3", 2, True)
+    _run_sweep(0, 1, 0, b, root, db, True, True, "SE3", 2)
+    assert a[0]["rep"]["collective_backend"] == "gloo" and b[0]["rep"]["collective_backend"] is None
+    assert a[0]["randR"] == b[0]["randR"]
     assert _dat_files(da) == _dat_files(db) and len(_dat_files(da)) == 2

@@ -787,6 +787,22 @@ def test_bench_multi_rank_leg_runs_the_hip_pipeline_with_two_ranks_on_this_gpu(d
         assert abs(line["setup"]["host_inputs_s"] + line["setup"]["device_setup_s"] - line["per_rank_setup_s"]) < 0.5
 
 
+def test_bench_collectives_run_on_rccl_with_one_rank(dev):
+    """bench.py's nccl (= RCCL) branches on the one GPU of this box: `--force_group` makes a one-rank communicator, so
+    the process-group initialisation with `device_id`, the barriers, the all-gather of the device-resident list and the
+    max-over-ranks reduction on a device tensor all run through RCCL itself; the merged list must equal the ungrouped
+    run's (same sha256)."""
+    common = ["--gpus", "1", "--steps", "4", "--warmup", "2", "--cpu_rotations", "0", "--no_real_shapes", "--sustained_s", "0",
+              "--gather_rotations", "256", "--strong_s", "0"]
+    rccl = _bench_line(["--force_group", "--backend", "nccl"] + common)
+    plain = _bench_line(common)
+    assert rccl["config"]["collective_backend"] == "nccl" and rccl["config"]["world_size_seen_by_the_collective"] == 1
+    assert plain["config"]["collective_backend"] is None
+    assert rccl["gather_check"]["backend"] == "nccl" and rccl["gather_check"]["list_entries"] == 2000
+    assert rccl["gather_check"]["list_sha256"] == plain["gather_check"]["list_sha256"]
+    assert rccl["n_gpus"] == 1 and rccl["top_entries"] == 2000 and rccl["value"] > 0
+
+
 def test_bench_refuses_same_device_with_rccl(dev):
     import os
     import subprocess

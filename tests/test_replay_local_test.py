@@ -236,6 +236,26 @@ def test_rank_aware_sweep_two_ranks_on_this_gpu_equals_one_rank(tmp_path):
 
 
 @pytest.mark.gpu
+def test_rank_aware_sweep_on_a_one_rank_rccl_group_equals_the_ungrouped_sweep(tmp_path):
+    """What a one-GPU box can run of the RCCL side of the sweep: `-force_group 1 -backend nccl` makes a communicator of one
+    rank, and the plan / decision broadcasts, the random-rotation broadcast and the per-target all-gather all go through
+    RCCL on device tensors (the code path of the 8-GPU sweep, with one participant).  Same .dat bytes as without a group."""
+    import __graft_entry__ as entry
+    entry.build()
+    root = str(tmp_path)
+    make_benchmark(root, targets=(("1SYN", 150, 90, 21), ("2SYN", 120, 100, 41)))
+    grouped, _ = _sweep(root, "logR1", 1, ["-rewrite", "1", "-end", "2", "-force_group", "1", "-backend", "nccl"],
+                        extra_env={"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29679"})
+    plain, _ = _sweep(root, "logP1", 1, ["-rewrite", "1", "-end", "2"])
+    assert grouped["collective_backend"] == "nccl" and plain["collective_backend"] is None
+    assert grouped["world_size"] == 1 and grouped["processed"] == 2
+    assert [t["randR"] for t in grouped["targets"]] == [t["randR"] for t in plain["targets"]]
+    for name in ("1SYN", "2SYN"):
+        assert open(os.path.join(grouped["test_dir"], name + ".dat"), "rb").read() == \
+            open(os.path.join(plain["test_dir"], name + ".dat"), "rb").read()
+
+
+@pytest.mark.gpu
 def test_rank_aware_sweep_over_rccl_equals_one_rank(tmp_path):
     """The same sweep with one GPU per rank and the `nccl` (= RCCL) backend -- the decision broadcast, the random-rotation
     broadcast and the per-target all-gather on device tensors.  Needs two GPUs; skipped on the one-GPU boxes."""
