@@ -105,17 +105,21 @@ __device__ __forceinline__ float dlpd_f2_get(dlpd_f2v v, int i) { return i ? v.y
 __device__ __forceinline__ dlpd_f2v dlpd_pk_fma(dlpd_f2v a, dlpd_f2v b, dlpd_f2v c) { return __builtin_elementwise_fma(a, b, c); }
 
 // table[bin] += 1 for every lane of the wave with `hit`, WITHOUT an LDS atomic: the lanes that name the same bin are found
-// with a ballot and one of them adds the group's size by a plain read-modify-write; rounds until every lane is served.  All 64
-// lanes must call it together; `table` must be private to the wave.  (Why not ds_add_u32: EXPERIMENTS.md R5 / k_topk_hist.)
+// with ballots (scalar work only: `v_readlane` of the group's bin, one compare, one population count per DIFFERENT bin in
+// the wave), the first lane of every group keeps the group's size, and then all of those lanes -- their bins are different --
+// add their sizes with ONE plain read-modify-write.  All 64 lanes must call it together; `table` must be private to the
+// wave.  (Why not ds_add_u32: EXPERIMENTS.md R5 / k_topk_hist.)
 __device__ __forceinline__ void dlpd_lds_count(unsigned* table, unsigned bin, bool hit, int lane) {
   unsigned long long todo = __ballot(hit);
+  unsigned mine = 0;
   while (todo) {
-    const int leader = __builtin_ctzll(todo);
-    const unsigned lb = __shfl(bin, leader);
-    const unsigned long long same = __ballot(hit && bin == lb);
-    if (lane == leader) table[lb] += (unsigned)__popcll(same);
+    const int first = __builtin_ctzll(todo);                                   // uniform: an SGPR
+    const unsigned fb = (unsigned)__builtin_amdgcn_readlane((int)bin, first);
+    const unsigned long long same = __ballot(hit && bin == fb);
+    if (lane == first) mine = (unsigned)__popcll(same);
     todo &= ~same;
   }
+  if (mine) table[bin] += mine;
 }
 
 // ------------------------------------------------------------------------------------------

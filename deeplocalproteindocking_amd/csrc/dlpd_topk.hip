@@ -61,8 +61,8 @@ __global__ void __launch_bounds__(256) k_topk_init(TopkState* st, int nb, unsign
 
 // Histogram of one digit of the keys of rotation b (all voxels in pass 0, afterwards those that share the selected prefix).
 // NO LDS ATOMICS: every wave counts into a table of its own, and inside a wave the lanes that hit the same bin are
-// combined with a ballot -- one lane adds the group's size with a plain read-modify-write -- until every lane is served
-// (a handful of rounds: the scores of a rotation share their leading bits).  Round 5 found that the `ds_add_u32` version of
+// grouped with ballots (scalar work per different bin), then the first lane of every group adds the group's size with one plain
+// read-modify-write (dlpd_lds_count; few groups per wave: the scores of a rotation share their leading bits).  Round 5 found that the `ds_add_u32` version of
 // this kernel, running beside a workgroup that feeds `v_mfma_f32_16x16x32_bf16` from `ds_read_b128` (the plugin's bf16 x 3
 // convolution), changed the results of the N = 80 FFT kernels that shared the CU with both (EXPERIMENTS.md R5: 259 of 300
 // scorings; 0 of 150 with plain LDS updates) -- lanes 48-63 of their transform waves, low mantissa bits.  The counts are the
@@ -82,20 +82,28 @@ k_topk_hist(const float* __restrict__ V, long long nvox, TopkState* st, int pass
   const u64 kth = st[b].kth;
   const int hs = shift + bits;
   const float* v = V + (size_t)b * nvox;
-  const long long per = (nvox + gridDim.x - 1) / gridDim.x;
+  constexpr int STEP = 4 * TOPK_HIST_THREADS;                       // four consecutive scores per lane and round (one 16-byte load)
+  const long long per = ((nvox + gridDim.x - 1) / gridDim.x + STEP - 1) / STEP * STEP;
   const long long beg = (long long)blockIdx.x * per;
   const long long end = beg + per < nvox ? beg + per : nvox;
+  const bool vec = (nvox & 3) == 0 && ((size_t)v & 15) == 0;
   unsigned* mine = lh[wave];
-  for (long long i0 = beg; i0 < end; i0 += blockDim.x) {          // every lane of the block runs the same number of rounds
-    const long long i = i0 + threadIdx.x;
-    bool hit = false;
-    unsigned bin = 0;
-    if (i < end) {
-      const u64 key = ((u64)f2key(v[i]) << 32) | (u64)i;
-      hit = pass == 0 || (key >> hs) == (kth >> hs);
-      bin = (unsigned)(key >> shift) & mask;
+  for (long long i0 = beg; i0 < end; i0 += STEP) {                 // every lane of the block runs the same number of rounds
+    const long long i = i0 + 4 * (long long)threadIdx.x;
+    float x[4] = {0.f, 0.f, 0.f, 0.f};
+    if (vec && i + 3 < end) {
+      const float4 q = *reinterpret_cast<const float4*>(v + i);
+      x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; j++) if (i + j < end) x[j] = v[i + j];
     }
-    dlpd_lds_count(mine, bin, hit, lane);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const u64 key = ((u64)f2key(x[j]) << 32) | (u64)(i + j);
+      const bool hit = i + j < end && (pass == 0 || (key >> hs) == (kth >> hs));
+      dlpd_lds_count(mine, (unsigned)(key >> shift) & mask, hit, lane);
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < TOPK_BINS; i += blockDim.x) {
