@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(256) k_conv3d_pack(const float* __restrict__ w
 // memory path each sit near half of their rate, and what would raise the arithmetic per fragment (more output-channel
 // tiles per wave) the 16-channel layers do not have.  A fragments TWO tap groups ahead: 9.5 against 9.2-9.3 ms.
 #ifndef DLPD_CONV_DIAG
-#define DLPD_CONV_DIAG 0                     // diagnostic builds only (EXPERIMENTS.md R5): 1 no matrix instructions, 2 no staging stores, 4 no B reads
+#define DLPD_CONV_DIAG 0                     // diagnostic builds only (EXPERIMENTS.md R5): 1 no matrix instructions, 2 no staging stores, 4 no B reads, 16 no A loads in the loop, 32 no staging loads
 #endif
 #ifndef DLPD_CONVS_RW
 #define DLPD_CONVS_RW 4
@@ -326,7 +326,11 @@ k_conv3d_bf16x3(const float* __restrict__ X, const float4* __restrict__ Wp, floa
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         const int ci = C::CK * ch + j;
+#if !(DLPD_CONV_DIAG & 32)
         const float x = (ok && ci < CIN) ? src[(size_t)ci * D3] : 0.f;
+#else
+        const float x = (ok && ci < CIN) ? (float)(v + j) : 0.f;             // (diagnostic build: no staging loads)
+#endif
         conv_split3(x, hh[j], mm[j], ll[j]);
       }
       float4 ph, pm, pl;
@@ -352,13 +356,20 @@ k_conv3d_bf16x3(const float* __restrict__ X, const float4* __restrict__ Wp, floa
     for (int sp = 0; sp < 3; sp++)
 #pragma unroll
       for (int mt = 0; mt < MT; mt++) a_cur[sp][mt] = wch[(size_t)(sp * NTG) * 4 * COUT + mt * 16];
+#if (DLPD_CONV_DIAG & 16)
+    const float4 a_fix = a_cur[0][0];                           // (diagnostic build: no A fragment loads inside the loop)
+#endif
 #pragma unroll 1
     for (int tg = 0; tg < NTG; tg++) {
       const int tgn = tg + 1 < NTG ? tg + 1 : tg;
 #pragma unroll
       for (int sp = 0; sp < 3; sp++)
 #pragma unroll
+#if !(DLPD_CONV_DIAG & 16)
         for (int mt = 0; mt < MT; mt++) a_nxt[sp][mt] = wch[(size_t)(sp * NTG + tgn) * 4 * COUT + mt * 16];
+#else
+        for (int mt = 0; mt < MT; mt++) { a_nxt[sp][mt] = a_fix; a_nxt[sp][mt].x += (float)(tgn + sp + mt); }
+#endif
       const int off = toff[4 * tg + kg];
       float4 bf[3][RW];
 #pragma unroll
