@@ -194,20 +194,53 @@ DLPD_D void bitonic_sort_u64(u64* a, int n, int tid, int nt) {
   __syncthreads();
 }
 
+// Block-wide sum / minimum, the same value in every thread, and a block-wide exclusive count -- all WITHOUT LDS atomics
+// (round 5: see k_topk_hist): butterflies inside a wave, one plain LDS word per wave, plain reads.  Every thread of
+// the block must call them; `scr` = 32 words of LDS.
+DLPD_D int block_sum(int v, int* scr, int tid, int nt) {
+  for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
+  __syncthreads();
+  if ((tid & 63) == 0) scr[tid >> 6] = v;
+  __syncthreads();
+  int s = 0;
+  for (int w = 0; w < (nt + 63) / 64; w++) s += scr[w];
+  return s;
+}
+DLPD_D unsigned block_min(unsigned v, int* scr, int tid, int nt) {
+  for (int m = 32; m > 0; m >>= 1) { const unsigned o = __shfl_xor(v, m); v = o < v ? o : v; }
+  __syncthreads();
+  if ((tid & 63) == 0) scr[tid >> 6] = (int)v;
+  __syncthreads();
+  unsigned s = 0xffffffffu;
+  for (int w = 0; w < (nt + 63) / 64; w++) { const unsigned o = (unsigned)scr[w]; s = o < s ? o : s; }
+  return s;
+}
+// position of this thread among the threads of the block with `yes` (in thread order), and their number
+DLPD_D int block_rank(bool yes, int* scr, int tid, int nt, int& total) {
+  const unsigned long long m = __ballot(yes);
+  const int lane = tid & 63, wave = tid >> 6;
+  const int before = __popcll(m & ((1ull << lane) - 1ull));
+  __syncthreads();
+  if (lane == 0) scr[wave] = __popcll(m);
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int w = 0; w < (nt + 63) / 64; w++) { const int c = scr[w]; base += w < wave ? c : 0; tot += c; }
+  total = tot;
+  return base + before;
+}
+
 // one block per rotation: sort the K survivors, apply the zero-fill quirk, write (score, idx)
 template <bool LARGE> __global__ void __launch_bounds__(1024)
 k_topk_sort(const float* __restrict__ V, long long nvox, const TopkState* st, const u64* __restrict__ cand, int K,
             float* __restrict__ out_score, int* __restrict__ out_idx, u64* __restrict__ sortbuf, int KPs) {
   __shared__ u64 keys_lds[LARGE ? 1 : TOPK_LDSK];
   u64* keys = LARGE ? sortbuf + (size_t)blockIdx.x * KPs : keys_lds;      // LARGE: K > TOPK_LDSK, sorted in global scratch
-  __shared__ int nneg_s;
-  __shared__ unsigned pmin_s;
+  __shared__ int scr[32];
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   if (st[b].done == 2) return;                       // served from K3's candidate list
   int KP = 1;
   while (KP < K) KP <<= 1;
   for (int i = tid; i < KP; i += nt) keys[i] = (i < K) ? cand[(size_t)b * K + i] : ~(u64)0;
-  if (tid == 0) { nneg_s = 0; pmin_s = 0xffffffffu; }
   bitonic_sort_u64(keys, KP, tid, nt);
   // number of strictly negative entries (canonical key < key(+0.0)) and their smallest index
   int local = 0;
@@ -218,9 +251,8 @@ k_topk_sort(const float* __restrict__ V, long long nvox, const TopkState* st, co
       const unsigned id = (unsigned)(keys[i] & 0xffffffffu);
       lmin = id < lmin ? id : lmin;
     }
-  if (local) { atomicAdd(&nneg_s, local); atomicMin(&pmin_s, lmin); }
-  __syncthreads();
-  const int q = nneg_s;
+  const int q = block_sum(local, scr, tid, nt);
+  const unsigned pmin_s = block_min(lmin, scr, tid, nt);
   // zero-fill: picked voxels were set to 0.0, so after the negatives the minimum is the first
   // zero in flat order among {original zeros} U {picked voxels}; with no zero at all the
   // smallest positive is picked once and then repeats with 0.0.
@@ -352,7 +384,7 @@ k_topk_merge(const float* __restrict__ cs, const int* __restrict__ ci, const int
   const int CAP = 2 * KP;
   u64* hi = LARGE ? glist + 2 + 2 * (size_t)K : sm;      // LARGE: the pair arrays live behind the list (dlpd_topk_glist_bytes)
   u64* lo = hi + CAP;
-  __shared__ int s_cnt, s_new;
+  __shared__ int scr[32];
   u64* ghi = glist + 2;
   u64* glo = glist + 2 + K;
   int count = (int)glist[0];
@@ -360,7 +392,6 @@ k_topk_merge(const float* __restrict__ cs, const int* __restrict__ ci, const int
     hi[i] = (i < count) ? ghi[i] : ~(u64)0;
     lo[i] = (i < count) ? glo[i] : ~(u64)0;
   }
-  if (tid == 0) { s_cnt = 0; s_new = 0; }
   __syncthreads();
   int nnew = 0;                                           // appended, not yet merged (uniform)
   // (score key, rotation) of the current K-th entry: a candidate survives iff its own pair sorts before it --
@@ -376,11 +407,7 @@ k_topk_merge(const float* __restrict__ cs, const int* __restrict__ ci, const int
         const u64 sk = f2key(cs[(size_t)r * K + i]);
         if (((sk << 32) | rot) < tau) local++;
       }
-      if (local) atomicAdd(&s_cnt, local);
-      __syncthreads();
-      const int nsurv = s_cnt;
-      __syncthreads();
-      if (tid == 0) s_cnt = 0;
+      const int nsurv = block_sum(local, scr, tid, nt);
       if (nnew + nsurv <= CAP - KP || attempt == 1) break;
       // flush: merge what is pending so the new rotation fits
       if (LARGE && nnew <= TOPK_LDSK) rank_merge_pairs(hi, lo, KP, count, nnew, K, sm, tid, nt);
@@ -391,21 +418,21 @@ k_topk_merge(const float* __restrict__ cs, const int* __restrict__ ci, const int
       for (int i = count + tid; i < KP; i += nt) { hi[i] = ~(u64)0; lo[i] = ~(u64)0; }
       __syncthreads();
       tau = (count == K) ? hi[K - 1] : ~(u64)0;
-      if (tid == 0) s_new = 0;
-      __syncthreads();
     }
-    for (int i = tid; i < K; i += nt) {
-      const float s = cs[(size_t)r * K + i];
+    for (int i0 = 0; i0 < K; i0 += nt) {                     // (every thread runs every round: block_rank has barriers)
+      const int i = i0 + tid;
+      const float s = i < K ? cs[(size_t)r * K + i] : 0.f;
       const u64 sk = f2key(s);
-      if (((sk << 32) | rot) < tau) {
-        const int slot = KP + atomicAdd(&s_new, 1);
+      const bool survives = i < K && ((sk << 32) | rot) < tau;
+      int added;
+      const int slot = KP + nnew + block_rank(survives, scr, tid, nt, added);
+      if (survives) {
         const u64 negzero = (__float_as_uint(s) == 0x80000000u) ? 1 : 0;
         hi[slot] = (sk << 32) | rot;
         lo[slot] = ((u64)i << 32) | (negzero << 31) | (u64)(unsigned)ci[(size_t)r * K + i];
       }
+      nnew += added;
     }
-    __syncthreads();
-    nnew = s_new;
     __syncthreads();
   }
   if (nnew > 0) {

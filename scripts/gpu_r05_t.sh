@@ -26,4 +26,4 @@ python bench.py --cpu_rotations 0 --sustained_s 0 --strong_s 0 --no_real_shapes 
 import sys, json
 d = json.loads(sys.stdin.read())
 print('bench: %.3f ms/step, value %.3e, gather hash %s' % (d['ms_per_step'], d['value'], d['gather_check']['list_sha256'][:16]))"
-timeout 900 python scripts/search_race_probe.py repr 40 2>&1 | tail -3
+timeout 900 python scripts/search_race_probe.py 20 repr 2>&1 | tail -2

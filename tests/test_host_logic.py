@@ -395,3 +395,41 @@ def test_no_product_default_runs_the_plugin_beside_the_pipeline():
     assert Docker.E3_OVERLAP is False
     assert inspect.signature(local_test.sweep).parameters["prepare_stream"].default is False
     assert inspect.signature(Docker.prepare).parameters["stream"].default is None
+
+
+def test_product_library_has_no_lds_atomic_instruction():
+    """Round 5 traced wrong low mantissa bits in OTHER kernels' results to the LDS atomics of k_topk_hist running beside a
+    bf16 matrix-instruction kernel on the same CU (EXPERIMENTS.md R5).  The product library therefore carries no LDS atomic at
+    all (counts go through ballots, butterflies and plain LDS words): every gfx950 code object inside csrc/libdlpd.so is
+    disassembled and searched for the ds_* read-modify-write instructions."""
+    import re
+    import struct
+    import subprocess
+    import tempfile
+    import __graft_entry__ as entry
+    entry.build()
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    assert os.path.exists(objdump)
+    data = open(entry.LIB, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    lines = kernels = 0
+    found = set()
+    for m in re.finditer(re.escape(magic), data):
+        p = m.start()
+        n = struct.unpack_from("<Q", data, p + 24)[0]
+        q = p + 32
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", data, q)
+            triple = data[q + 24:q + 24 + tl].decode()
+            q += 24 + tl
+            if "gfx950" not in triple or not size:
+                continue
+            with tempfile.NamedTemporaryFile(suffix=".co") as f:
+                f.write(data[p + off:p + off + size])
+                f.flush()
+                text = subprocess.run([objdump, "-d", f.name], capture_output=True, text=True, check=True).stdout
+            lines += text.count("\n")
+            kernels += len(re.findall(r"^[0-9a-f]+ <_Z\w+>:", text, flags=re.M))
+            found |= set(re.findall(r"\bds_(?:add|sub|rsub|inc|dec|min|max|and|or|xor|mskor|cmpst|cmpswap|wrxchg|pk_add|append|consume)\w*", text))
+    assert lines > 100000 and kernels > 50, (lines, kernels)          # the scan really saw the library's kernels
+    assert not found, sorted(found)
