@@ -435,6 +435,14 @@ def run_rank(args):
     eng.reset_top()
     time_steps(eng, Rd, idd, tr_of, qd_of, nb, w0, args.warmup)
     eng.finish()
+    # the warm-up covers the step's collective too: the first all-gather of a communicator sets up its connections
+    # (RCCL does that lazily), which belongs to the job's start-up, not to a step
+    warm_gather_s = timed_gather_s = 0.0
+    if dist is not None:
+        from deeplocalproteindocking_amd.Docker.Docker import all_gather_top_entries
+        t_g = time.perf_counter()
+        all_gather_top_entries(eng.top_entries(), K, world, None, dev, always=True)
+        warm_gather_s = time.perf_counter() - t_g
 
     # CPU-baseline sample: cpu_rotations / 4 rotations from the head of each search group; their GPU scores
     # (each through the K1/K2 variant the search uses for it) are kept for the parity figure
@@ -466,9 +474,10 @@ def run_rank(args):
     timer = StageTimer()
     time_steps(eng, Rd, idd, tr_of, qd_of, nb, t_first, args.steps, mark=timer.mark)
     entries = eng.top_entries()                              # waits for the side stream; D2H of this rank's list
-    if dist is not None:                                            # single all-gather + deterministic merge
-        from deeplocalproteindocking_amd.Docker.Docker import all_gather_top_entries
+    if dist is not None:                                     # single all-gather + deterministic merge
+        t_g = time.perf_counter()
         entries = all_gather_top_entries(entries, K, world, None, dev, always=True)
+        timed_gather_s = time.perf_counter() - t_g
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -634,6 +643,8 @@ def run_rank(args):
             "top_entries": int(len(entries[0])),
         }
         out["per_rank_setup_s"] = setup_s
+        if dist is not None:       # rank 0's all-gather + merge: inside the timed region, and the untimed first one of the warm-up
+            out["collective"] = {"gather_and_merge_s_in_timed_region": timed_gather_s, "first_gather_s_in_warmup": warm_gather_s}
         # the part a real pair pays once (upload, receptor spectrum, channels-last copy, workspaces) vs the part that only
         # the synthetic benchmark has (drawing the volumes on the host; a real pair gets them from the representation)
         out["setup"] = {"host_inputs_s": host_inputs_s, "device_setup_s": device_setup_s,
