@@ -484,6 +484,7 @@ class Docker:
             eng.set_filter(W1.cpu(), b1.cpu(), W2.cpu(), b2.cpu())
             eng.clip, eng.threshold = getattr(model, "clip", 5.0), float(model.threshold_clash)
         eng.set_receptor(rec[0], receptor_forbidden, rec[1] if two_res else None)
+        eng.holds_pair = None                            # (prepare() names the PreparedPair this content belongs to)
         if slot == 0:
             self.engine, self._engine_key = eng, key
         return eng
@@ -713,6 +714,9 @@ class Docker:
                     # (the clash channel comes from re-projected atoms: the stored forbidden volume is never read)
                     eng.set_ligand(lig[0], torch.zeros(L, L, L), lig[1] if eng.C1 > 0 else None)
                 p.engine = eng
+                if eng is not None:
+                    eng.holds_pair = p                   # (checked when the pair is docked: a later prepare() into the same
+                                                         #  slot replaces the receptor / ligand this engine holds)
             if on_stream:
                 p.ready = torch.cuda.Event()
                 p.ready.record(stream)
@@ -724,6 +728,8 @@ class Docker:
             return self.prepare(ureceptor, uligand, group)
         if (prepared.group, prepared.ureceptor, prepared.uligand) != (group, ureceptor, uligand):
             raise Exception("Prepared pair does not belong to this call", prepared.group, prepared.ureceptor, prepared.uligand)
+        if prepared.engine is not None and getattr(prepared.engine, "holds_pair", None) is not prepared:
+            raise Exception("Prepared pair was overwritten: another pair was prepared into engine slot %d after it" % prepared.slot)
         prepared.wait(self.device)
         return prepared
 

@@ -77,7 +77,9 @@ def sweep(docker, targets, test_dir, group="SE3", rewrite=False, batch_size=2, p
         # this option that exposed round 5's LDS-atomics interaction (EXPERIMENTS.md R5; since removed at its source).
         stream = torch.cuda.Stream(device=dev) if (on_gpu and prepare_stream) else None
     pending = {}                                      # target index -> Future of its PreparedPair
+    pending_slot = {}                                 # target index -> the engine slot that preparation fills
     def prepare_in_background(j, slot):
+        pending_slot[j] = slot
         def work():
             if on_gpu:
                 torch.cuda.set_device(dev)            # (the device is a per-thread setting)
@@ -91,6 +93,7 @@ def sweep(docker, targets, test_dir, group="SE3", rewrite=False, batch_size=2, p
         for n, (name, rec_path, lig_path) in enumerate(targets):
             go = _broadcast_flags(docker, [docker.new_log(paths[n], rewrite=bool(rewrite))] if docker.rank == 0 else [], 1)[0]
             ahead = pending.pop(n, None)
+            pending_slot.pop(n, None)
             if not go:
                 say("Skipping", name)
                 skipped += 1
@@ -99,12 +102,14 @@ def sweep(docker, targets, test_dir, group="SE3", rewrite=False, batch_size=2, p
                 continue
             say("Processing", name)
             t0 = time.perf_counter()
-            slot = processed % 2 if pool is not None else 0
+            # an unprepared target must not take the engine slot a LATER target is being prepared into (possible when the plan
+            # expected this one to be skipped and its log changed meanwhile)
+            slot = next(k for k in (0, 1) if k not in pending_slot.values()) if pool is not None else 0
             prepared = ahead.result() if ahead is not None else docker.prepare(rec_path, lig_path, group, slot=slot)
             t_ready = time.perf_counter()
             if pool is not None:
                 nxt = next((j for j in range(n + 1, n_targets) if plan[j]), None)
-                if nxt is not None:
+                if nxt is not None and nxt not in pending:    # (already under way when an earlier target was expected to be skipped)
                     prepare_in_background(nxt, 1 - prepared.slot)
             with torch.no_grad():
                 (docker.dockE3 if group == "E3" else docker.dockSE3)(rec_path, lig_path, batch_size, prepared=prepared)

@@ -4,7 +4,8 @@
 # 4-degree searches and the config-4-shaped end-to-end soak.  Outputs under gpurun_out/r05_z/ (copied to profiles/r05_z_*).
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT
-OUT=$ROOT/gpurun_out/r05_z
+TAG=${1:-r05_z}
+OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 timeout 2400 python -m pytest tests -q -m gpu --durations=12 > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
 timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 300 $OUT/bench_default.err
@@ -12,9 +13,9 @@ timeout 600 python bench.py --gpus 2 --backend gloo --same_device --cpu_rotation
 timeout 600 python bench.py --workload real --cpu_rotations 0 --no_pmc > $OUT/bench_real.json 2>/dev/null
 timeout 600 python bench.py --workload c48l80 --cpu_rotations 0 --no_pmc > $OUT/bench_c48l80.json 2>/dev/null
 timeout 600 python bench.py --workload config1 --cpu_rotations 0 --no_pmc > $OUT/bench_config1.json 2>/dev/null
-bash scripts/profile_gpu.sh r05_z > /dev/null 2>&1; cp gpurun_out/prof_r05_z/summary.txt $OUT/summary.txt; cp gpurun_out/prof_r05_z/kernel_stats.csv $OUT/kernel_stats.csv; cp gpurun_out/prof_r05_z/command.txt $OUT/command.txt
-bash scripts/profile_gpu.sh r05_z_real --workload real > /dev/null 2>&1; cp gpurun_out/prof_r05_z_real/summary.txt $OUT/real_shapes_summary.txt; cp gpurun_out/prof_r05_z_real/kernel_stats.csv $OUT/real_shapes_kernel_stats.csv; cp gpurun_out/prof_r05_z_real/command.txt $OUT/real_shapes_command.txt
-bash scripts/profile_gpu.sh r05_z_c48l80 --workload c48l80 > /dev/null 2>&1; cp gpurun_out/prof_r05_z_c48l80/summary.txt $OUT/c48l80_summary.txt
+bash scripts/profile_gpu.sh ${TAG} > /dev/null 2>&1; cp gpurun_out/prof_${TAG}/summary.txt $OUT/summary.txt; cp gpurun_out/prof_${TAG}/kernel_stats.csv $OUT/kernel_stats.csv; cp gpurun_out/prof_${TAG}/command.txt $OUT/command.txt
+bash scripts/profile_gpu.sh ${TAG}_real --workload real > /dev/null 2>&1; cp gpurun_out/prof_${TAG}_real/summary.txt $OUT/real_shapes_summary.txt; cp gpurun_out/prof_${TAG}_real/kernel_stats.csv $OUT/real_shapes_kernel_stats.csv; cp gpurun_out/prof_${TAG}_real/command.txt $OUT/real_shapes_command.txt
+bash scripts/profile_gpu.sh ${TAG}_c48l80 --workload c48l80 > /dev/null 2>&1; cp gpurun_out/prof_${TAG}_c48l80/summary.txt $OUT/c48l80_summary.txt
 (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/convprof -- python3 $ROOT/scripts/conv_bench.py > $OUT/conv_bench.txt 2>&1; cp $(find $OUT/convprof -name "*kernel_stats.csv" | head -1) $OUT/conv_kernel_stats.csv; rm -rf $OUT/convprof)
 timeout 600 python scripts/soak_full_search.py --angle_inc 6 --runs 16,12 --out $OUT/soak_full_search_6deg.json > /dev/null 2>&1
 timeout 900 python scripts/soak_full_search.py --angle_inc 4 --runs 16 --out $OUT/soak_full_search_4deg.json > /dev/null 2>&1

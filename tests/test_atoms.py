@@ -831,3 +831,26 @@ def test_dockE3_overlapped_plugin_gives_the_serial_list(tmp_path):
     assert serial == run(False) and len(serial) == 2000
     different = [i for i in range(30) if run(True) != serial]
     assert not different, "overlapped runs %s differ from the serial list" % different
+
+
+def test_a_prepared_pair_overwritten_in_its_engine_slot_refuses_to_dock(tmp_path):
+    """Docker.prepare(slot=s) fills engine s with the pair's receptor spectrum and ligand; a second prepare into the SAME slot
+    replaces that content, and docking the first pair afterwards would silently score the second pair's receptor -- it raises."""
+    from emu_lib import emu_lib
+    from deeplocalproteindocking_amd.Docker import Docker
+    from deeplocalproteindocking_amd.Utils.FullAtom import CoordsBackend
+    lib = emu_lib()
+    pa, pb, pc = _typed(tmp_path, 12, seed=61)[0], _typed(tmp_path, 9, seed=62)[0], _typed(tmp_path, 10, seed=63)[0]
+    R = orc.euler_to_matrix(np.array([0.2, 1.1]), np.array([0.7, 2.0]), np.array([-0.4, 0.9]))
+    dk = Docker(_tiny_model(), box_size=32, resolution=1.25, max_conf=20, rotations=R, device="cpu", lib=lib,
+                coords_backend=CoordsBackend(lib=lib))
+    first = dk.prepare(pa, pb, "SE3", slot=1)
+    second = dk.prepare(pc, pb, "SE3", slot=1)
+    with pytest.raises(Exception, match="overwritten"):
+        dk.dockSE3(pa, pb, 2, prepared=first)
+    dk.log = None
+    dk.dockSE3(pc, pb, 2, prepared=second)                     # the pair the slot holds docks
+    assert dk.path == "fused" and len(dk.top_list) == 20
+    third = dk.prepare(pa, pb, "SE3", slot=0)                  # and the other slot is independent
+    dk.dockSE3(pa, pb, 2, prepared=third)
+    assert len(dk.top_list) == 20

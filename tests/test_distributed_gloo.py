@@ -436,7 +436,8 @@ def _sweep_targets(root, write=False):
     return out
 
 
-def _run_sweep(rank, world, port, out, root, test_dir, rewrite, prefetch, group="SE3", ntargets=3, group_of_one=False):
+def _run_sweep(rank, world, port, out, root, test_dir, rewrite, prefetch, group="SE3", ntargets=3, group_of_one=False,
+               plan_misses=None):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -456,6 +457,15 @@ def _run_sweep(rank, world, port, out, root, test_dir, rewrite, prefetch, group=
     dk = Docker(_tiny_model(), box_size=32, resolution=1.25, max_conf=40, rotations=R, device="cpu", lib=lib,
                 coords_backend=CoordsBackend(lib=lib), randomize_rot=True, rotation_seed=900 + rank, rank=rank, world_size=world,
                 collectives_with_one_rank=group_of_one)
+    if plan_misses:                                  # the plan takes this target for finished; at its turn it is not
+        honest, asked = dk.log_is_complete, []
+
+        def first_answer_is_wrong(path):             # (the plan asks first; new_log asks again when the target's turn comes)
+            if path.endswith(plan_misses + ".dat") and not asked:
+                asked.append(path)
+                return True
+            return honest(path)
+        dk.log_is_complete = first_answer_is_wrong
     said = []
     rep = local_test.sweep(dk, targets, test_dir, group=group, rewrite=rewrite, batch_size=2, prefetch=prefetch,
                            say=lambda *a: said.append(" ".join(str(x) for x in a)))
@@ -531,3 +541,17 @@ def test_benchmark_sweep_on_a_process_group_of_one_rank_equals_the_ungrouped_swe
     assert a[0]["rep"]["collective_backend"] == "gloo" and b[0]["rep"]["collective_backend"] is None
     assert a[0]["randR"] == b[0]["randR"]
     assert _dat_files(da) == _dat_files(db) and len(_dat_files(da)) == 2
+
+
+def test_benchmark_sweep_target_the_plan_did_not_expect_keeps_clear_of_the_prepared_engine(tmp_path):
+    """The plan (read before the sweep) takes T1 for finished, so T2 is prepared ahead -- into the second engine -- while T0 is
+    searched; at T1's turn its log turns out NOT to be finished (someone truncated it): it is prepared on the spot and must
+    take the engine T2's preparation does not hold.  Same files as the plain sweep."""
+    root, da, db = str(tmp_path / "pdb"), str(tmp_path / "a"), str(tmp_path / "b")
+    os.makedirs(da), os.makedirs(db)
+    _sweep_targets(root, write=True)
+    a, b = {}, {}
+    _run_sweep(0, 1, 0, a, root, da, False, True, "SE3", 3, False, "T1")
+    _run_sweep(0, 1, 0, b, root, db, True, False, "SE3", 3)
+    assert [(t["target"], t["prepared_ahead"]) for t in a[0]["rep"]["targets"]] == [("T0", False), ("T1", False), ("T2", True)]
+    assert _dat_files(da) == _dat_files(db) and len(_dat_files(da)) == 3
