@@ -400,6 +400,7 @@ k_topk_merge(const float* __restrict__ cs, const int* __restrict__ ci, const int
   u64 tau = (count == K) ? hi[K - 1] : ~(u64)0;
   for (int r = 0; r < nb; r++) {
     const u64 rot = (u64)(unsigned)rot_ids[r];
+    int nsurv = 0;
     for (int attempt = 0; attempt < 2; attempt++) {
       // count survivors of this rotation against tau
       int local = 0;
@@ -407,7 +408,7 @@ k_topk_merge(const float* __restrict__ cs, const int* __restrict__ ci, const int
         const u64 sk = f2key(cs[(size_t)r * K + i]);
         if (((sk << 32) | rot) < tau) local++;
       }
-      const int nsurv = block_sum(local, scr, tid, nt);
+      nsurv = block_sum(local, scr, tid, nt);
       if (nnew + nsurv <= CAP - KP || attempt == 1) break;
       // flush: merge what is pending so the new rotation fits
       if (LARGE && nnew <= TOPK_LDSK) rank_merge_pairs(hi, lo, KP, count, nnew, K, sm, tid, nt);
@@ -419,6 +420,7 @@ k_topk_merge(const float* __restrict__ cs, const int* __restrict__ ci, const int
       __syncthreads();
       tau = (count == K) ? hi[K - 1] : ~(u64)0;
     }
+    if (nsurv == 0) continue;                                // (the usual case once the list has settled: nothing to append)
     for (int i0 = 0; i0 < K; i0 += nt) {                     // (every thread runs every round: block_rank has barriers)
       const int i = i0 + tid;
       const float s = i < K ? cs[(size_t)r * K + i] : 0.f;
