@@ -2,7 +2,9 @@
 
 Run in the authoring container only (needs /root/reference):
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py              # rewrite the fixtures
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py --check      # regenerate elsewhere, compare array for array
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py --out DIR    # write them into DIR
 
 The reference's hot-path arithmetic lives in TorchProteinLibrary / se3cnn, which are not
 installed, so those imports are replaced by MagicMock modules; every object whose OUTPUT is
@@ -35,8 +37,9 @@ sys.dont_write_bytecode = True
 import numpy as np
 import torch
 
-HERE = os.path.dirname(os.path.abspath(__file__))
-REPO = os.path.abspath(os.path.join(HERE, "..", ".."))
+FIXTURES = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(FIXTURES, "..", ".."))
+HERE = FIXTURES            # where the .npz files are written (--out DIR / --check: a directory of their own)
 REF = "/root/reference"
 sys.path.insert(0, REPO)
 
@@ -53,7 +56,29 @@ def install_stubs():
     sys.modules["src"] = src
 
 
+def check(fresh_dir):
+    """Every array of every committed fixture equals the freshly generated one (dtype, shape and values)."""
+    bad = 0
+    for f in sorted(os.listdir(FIXTURES)):
+        if not f.endswith(".npz"):
+            continue
+        a, b = np.load(os.path.join(FIXTURES, f), allow_pickle=False), np.load(os.path.join(fresh_dir, f), allow_pickle=False)
+        same = sorted(a.files) == sorted(b.files) and all(
+            a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind == "f")
+            for k in a.files)
+        print("%-28s %3d arrays  %s" % (f, len(a.files), "identical" if same else "DIFFERENT"))
+        bad += 0 if same else 1
+    return bad
+
+
 def main():
+    global HERE
+    if len(sys.argv) > 1 and sys.argv[1] in ("--out", "--check"):
+        # --out DIR: write the fixtures there instead of over the committed ones; --check: regenerate into a temporary
+        # directory and compare array for array with the committed ones (exit code = number of differing files)
+        import tempfile
+        HERE = sys.argv[2] if sys.argv[1] == "--out" else tempfile.mkdtemp(prefix="dlpd_golden_")
+        os.makedirs(HERE, exist_ok=True)
     install_stubs()
     import importlib
     from oracle import docking_oracle as orc
@@ -287,6 +312,8 @@ def main():
         if f.endswith(".npz"):
             h = hashlib.sha256(open(os.path.join(HERE, f), "rb").read()).hexdigest()[:16]
             print(f, os.path.getsize(os.path.join(HERE, f)), h)
+    if len(sys.argv) > 1 and sys.argv[1] == "--check":
+        sys.exit(check(HERE))
 
 
 if __name__ == "__main__":
