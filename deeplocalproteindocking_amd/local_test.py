@@ -164,6 +164,8 @@ def parse_args(argv=None):
     ap.add_argument("-prefetch", default=1, type=int, help="prepare the next target while the current one is searched")
     ap.add_argument("-backend", default="nccl", choices=("nccl", "gloo"), help="collective backend (nccl = RCCL)")
     ap.add_argument("-same_device", default=0, type=int, help="every rank on cuda:0 (one-GPU box; needs -backend gloo)")
+    ap.add_argument("-prepare_stream", default=0, type=int,
+                    help="prepare the next target on a stream of its own (default: on the caller's stream; no gain measured)")
     ap.add_argument("-force_group", default=0, type=int,
                     help="initialise the process group and run every collective with ONE rank too (one-GPU RCCL check)")
     return ap.parse_args(argv)
@@ -231,7 +233,7 @@ def main(argv=None):
         targets.append((pdb_name[0], ureceptor[0], uligand[0]))
     say = print if rank == 0 else (lambda *a, **k: None)
     rep = sweep(docker, targets, test_dir, group=args.group, rewrite=bool(args.rewrite), batch_size=2,
-                prefetch=bool(args.prefetch), say=say)
+                prefetch=bool(args.prefetch), say=say, prepare_stream=bool(args.prepare_stream))
     if args.report and rank == 0:
         print("SWEEP " + json.dumps(rep), flush=True)
     if world > 1 or args.force_group:
