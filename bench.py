@@ -800,8 +800,7 @@ def e3_measurement(dev, nb, nsteps=6):
             eng.step(None, ids, volumes=(v[0], l.sum(dim=1), v[1] if eng.C1 else None))
         ms_serial, _ = timed(body, n=2 * nsteps)
         eng.finish()
-        # ... and as Docker.dockE3 runs it: the plugin's half of batch i + 1 on a second stream beside the engine's half of
-        # batch i (Docker._dockE3_fused, E3_OVERLAP)
+        # ... and through Docker's own batch loop (Docker._dockE3_fused: the same two halves, one stream)
         nbat = 4 * nsteps
         batches = [list(range(nb))] * nbat
 
@@ -809,20 +808,19 @@ def e3_measurement(dev, nb, nsteps=6):
             l = be.project(lc, ln, lo, L, res, dev, R=Rb, shift=dk.box_center)
             return l, model.representation(l)
 
-        dk.E3_OVERLAP = True
-
-        def pipelined():
+        def docker_loop():
             dk._dockE3_fused(eng, batches, represent, None, nb)
             eng.finish()
-        ms_pipe, _ = timed(pipelined, n=2)
-        ms_all = ms_pipe / nbat
+        ms_loop, _ = timed(docker_loop, n=2)
+        ms_all = ms_loop / nbat
         eng.finish()
         natoms = int(lnat.sum()) if hasattr(lnat, "sum") else None
         out = {"workload": "Docker.dockE3 at box 80, E3MultiResRepr4x4(multiplier=8) -> %s channels, synthetic %d / %d-residue pair"
                            % (repr_.get_num_outputs(), 160, 110),
                "rotations_per_launch": nb, "ms_projection": ms_proj, "ms_representation": ms_repr, "ms_engine": ms_eng,
-               "ms_per_launch": min(ms_all, ms_serial), "ms_per_launch_serial": ms_serial, "ms_per_launch_plugin_on_second_stream": ms_all,
-               "docker_default": "serial (Docker.E3_OVERLAP = False: the overlap measured no gain)", "rot_per_s": nb / (min(ms_all, ms_serial) * 1e-3),
+               "ms_per_launch": min(ms_all, ms_serial), "ms_per_launch_serial": ms_serial, "ms_per_launch_docker_loop": ms_all,
+               "tile_occupancy": bool(getattr(repr_, "use_tile_occupancy", False)),
+               "rot_per_s": nb / (min(ms_all, ms_serial) * 1e-3),
                "value": nb / (min(ms_all, ms_serial) * 1e-3) * (2.0 * L) ** 3,
                "unit": "pose scores/s", "ligand_atoms": natoms, "path": "fused engine on the batch's own volumes",
                "conv_precision": __import__("deeplocalproteindocking_amd.ops", fromlist=["CONV_PRECISION"]).CONV_PRECISION}

@@ -755,22 +755,13 @@ class Docker:
             self.dock_volumes(p.receptor_volumes, p.ligand_volumes, p.receptor_forbidden, None, batch_size=None,
                               clash_provider=provider, model_batch=batch_size, prepared=p)
 
-    # dockE3: projection + representation of batch i + 1 on a stream of their own beside the engine's half of batch i.
-    # MEASURED (round 5, box 80, E3MultiResRepr4x4(8), 16 rotations per launch): 15.08 ms per launch overlapped against
-    # 15.03 serial (projection 0.36 + representation 9.29 + engine 6.33) -- nothing: every kernel of either half fills the
-    # chip on its own, and the engine's K2 / K3 blocks (113-140 KB of LDS) cannot share a CU with a convolution block
-    # (61 KB), so the two streams take turns instead of running side by side.  Off by default (one stream less to reason
-    # about, EXPERIMENTS.md R5); the lists are identical either way (test_dockE3_overlapped_plugin_gives_the_serial_list).
-    E3_OVERLAP = False
 
     def dockE3(self, ureceptor, uligand, batch_size, prepared=None):
         """Docker.py:135-182: the ligand is rotated in coordinate space and re-projected and
         re-represented every batch (the plugin's cost), then scored by the same kernels: the fused
         engine takes the batch's volumes as they are (no volume rotation); the stand-alone ops, or a
         call of the model itself, where the engine has no layout for the model (see dock_volumes).
-        On the fused engine the two halves of a batch use different units -- the plugin's convolutions the matrix
-        cores, the engine vector units, LDS and HBM -- so batch i + 1 CAN be projected and represented on a second stream
-        while the engine scores batch i (``E3_OVERLAP``; the list does not depend on it; measured: no gain, off)."""
+        The two halves of a batch run one after the other on the caller's stream (``_dockE3_fused``)."""
         be = self._need_backend()
         from deeplocalproteindocking_amd.ops import VolumeConvolution, filter_volumes
         self.top_list = []
@@ -849,12 +840,12 @@ class Docker:
         self.write_conformations()
 
     def _dockE3_fused(self, eng, batches, represent, Lc, nbatch):
-        """The batch loop of dockE3 on the fused engine.  On a GPU the plugin's half of batch i + 1 (projection,
-        representation, the type sum for the clash channel) is enqueued on ``self._e3_stream`` BEFORE the engine's half
-        of batch i on the caller's stream, so the two run side by side; events order each hand-over, and the volumes --
-        allocated on the plugin's stream -- are marked as used by the engine's stream for the caching allocator."""
+        """The batch loop of dockE3 on the fused engine: projection + representation of a batch, then the engine's half,
+        on ONE stream.  (Round 5 built the plugin's half of batch i + 1 on a second stream beside the engine's half of
+        batch i: no gain -- 15.08 against 15.03 ms per launch, both halves fill the chip -- and that co-residency of the
+        plugin's matrix-instruction convolution with the pipeline's LDS kernels is exactly what perturbs the pipeline's low
+        bits on this hardware, EXPERIMENTS.md R5; removed.)"""
         dev = self.device
-        overlap = self.E3_OVERLAP and dev.type == "cuda" and len(batches) > 1
         ebuf = {}
 
         def volumes_of(ligand, ligand_volumes, nb, slot):
@@ -871,40 +862,7 @@ class Docker:
                 vols = tuple(None if buf is None else buf[:nb] for buf in ebuf[slot])
             return vols
 
-        if not overlap:
-            for bid in batches:
-                ligand, ligand_volumes = represent(bid)
-                bid_dev = torch.as_tensor(bid, dtype=torch.int32).to(dev)
-                eng.step(None, bid_dev, volumes=volumes_of(ligand, ligand_volumes, len(bid), 0))
-            return
-        if getattr(self, "_e3_stream", None) is None:
-            self._e3_stream = torch.cuda.Stream(device=dev)
-        side, main = self._e3_stream, torch.cuda.current_stream(dev)
-        side.wait_stream(main)                              # receptor side, engine reset: all issued on the caller's stream
-        consumed = [None, None]                             # per buffer slot: the engine has read the volumes of that slot
-
-        def produce(i):
-            with torch.cuda.stream(side):
-                if consumed[i & 1] is not None:
-                    side.wait_event(consumed[i & 1])        # (embedded boxes: the slot's corner buffers are free again)
-                ligand, ligand_volumes = represent(batches[i])
-                vols = volumes_of(ligand, ligand_volumes, len(batches[i]), i & 1)
-                bid_dev = torch.as_tensor(batches[i], dtype=torch.int32).to(dev)
-                ev = torch.cuda.Event()
-                ev.record(side)
-            return vols, bid_dev, ev
-
-        nxt = produce(0)
-        for i in range(len(batches)):
-            vols, bid_dev, ev = nxt
-            if i + 1 < len(batches):
-                nxt = produce(i + 1)                        # enqueued ahead of the engine's half of batch i
-            main.wait_event(ev)
-            for t in vols + (bid_dev,):
-                if t is not None:
-                    t.record_stream(main)
-            eng.step(None, bid_dev, volumes=vols)
-            done = torch.cuda.Event()
-            done.record(main)
-            consumed[i & 1] = done
-        main.wait_stream(side)
+        for bid in batches:
+            ligand, ligand_volumes = represent(bid)
+            bid_dev = torch.as_tensor(bid, dtype=torch.int32).to(dev)
+            eng.step(None, bid_dev, volumes=volumes_of(ligand, ligand_volumes, len(bid), 0))

@@ -101,6 +101,8 @@ class E3MultiResRepr4x4(Module):
     # lib: None -> the product library on a GPU; tests pass the emulated one
     hip_lib = None
     use_hip_conv = True
+    # skip the all-zero tiles of the bias-free convolutions (same bits; ops.conv3d); DLPD_TILE_OCCUPANCY=0: compute everywhere
+    use_tile_occupancy = os.environ.get("DLPD_TILE_OCCUPANCY", "1") != "0"
 
     def _run(self, seq, x):
         """The Sequential.  GPU inference: Conv3d(+ReLU) pairs and the max-pool on the HIP kernels (exact f32 on
@@ -109,6 +111,11 @@ class E3MultiResRepr4x4(Module):
         from deeplocalproteindocking_amd import ops
         mods = list(seq)
         native = self.use_hip_conv and _hip_inference(x, self.hip_lib)
+        # tile occupancy of x (ops.conv3d): the layers have no bias, so what lies outside the protein's neighbourhood stays
+        # exactly zero from layer to layer and is not computed; one map is made of the input, every convolution writes its
+        # output's (None: unknown -- after the pooling, after a torch module -- and made again when a convolution needs it)
+        occ = None
+        sparse = native and self.use_tile_occupancy and ops.CONV_PRECISION == "split_bf16"
         i = 0
         while i < len(mods):
             m = mods[i]
@@ -119,7 +126,13 @@ class E3MultiResRepr4x4(Module):
                       and ops.conv3d_supported(m.weight, x.shape[2], self.hip_lib))
                 if ok or not _torch_conv_allowed("Conv3d%s on %s" % (tuple(m.weight.shape), tuple(x.shape))):
                     relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-                    x = ops.conv3d(x, m.weight, relu=relu, lib=self.hip_lib, stride=m.stride[0])
+                    if sparse:
+                        if occ is None:
+                            occ = ops.tile_occupancy(x, lib=self.hip_lib)
+                        x, occ = ops.conv3d(x, m.weight, relu=relu, lib=self.hip_lib, stride=m.stride[0], occupancy=occ,
+                                            return_occupancy=True)
+                    else:
+                        x = ops.conv3d(x, m.weight, relu=relu, lib=self.hip_lib, stride=m.stride[0])
                     i += 2 if relu else 1
                     continue
             elif native and isinstance(m, nn.MaxPool3d):
@@ -127,9 +140,11 @@ class E3MultiResRepr4x4(Module):
                       and not m.return_indices and cubic)
                 if ok or not _torch_conv_allowed("MaxPool3d(%s, %s, %s)" % (m.kernel_size, m.stride, m.padding)):
                     x = ops.maxpool3d_5s2(x, lib=self.hip_lib)
+                    occ = None
                     i += 1
                     continue
             x = m(x)
+            occ = None
             i += 1
         return x
 

@@ -73,6 +73,9 @@ SIGNATURES = {
     "dlpd_conv3d_split_packed_bytes": (ctypes.c_size_t, [_i, _i, _i]),
     "dlpd_conv3d_split_pack": (_i, [_p, _p, _i, _i, _i, _p]),
     "dlpd_conv3d_split": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "dlpd_conv3d_tile_occupancy_bytes": (_sz, [_i, _i]),
+    "dlpd_conv3d_tile_occupancy": (_i, [_p, _p, _i, _i, _i, _p]),
+    "dlpd_conv3d_split_sparse": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dlpd_topk_workspace_bytes": (_sz, [_i, _i]),
     "dlpd_topk_select": (_i, [_p, _i, _ll, _i, _p, _p, _p, _p]),
     "dlpd_topk_select_cand": (_i, [_p, _i, _ll, _i, _p, _p, _p, _p, _p, _i, _p]),

@@ -272,7 +272,7 @@ template <int KS> struct ConvSCfg {
   static constexpr int XS = TX + KS - 1, YS = TY + KS - 1, ZS = ZT + KS - 1;
   static constexpr int NVOX = XS * YS * ZS;
   static constexpr int NTAP = KS * KS * KS, NTG = (NTAP + 3) / 4;
-  static constexpr size_t LDS_BYTES = (size_t)3 * NVOX * 16 + (size_t)NTG * 4 * sizeof(int);
+  static constexpr size_t LDS_BYTES = (size_t)3 * NVOX * 16 + (size_t)NTG * 4 * sizeof(int) + 16;
 };
 
 // x = h + m + l in bf16 (bit patterns)
@@ -284,15 +284,39 @@ DLPD_D void conv_split3(float x, unsigned& h, unsigned& m, unsigned& l) {
   l = dlpd_f2bf(r2);
 }
 
-template <int KS, int COUT, int RELU, int STRIDE> __global__ void __launch_bounds__(ConvSCfg<KS>::NT)
+// TILE OCCUPANCY (round 5).  The plugins' convolutions have no bias, so an output tile whose receptive field holds only
+// zeros IS zero -- and a protein fills a fraction of its box (the density splat is zero a few Angstrom away from the atoms,
+// and every layer only widens the non-zero region by its kernel radius).  `occ_in[volume][tile x][tile y][tile z]` (one
+// byte per 4 x 4 x 16 input tile, non-zero = the tile holds a non-zero value in some channel) lets a block whose 27
+// neighbouring tiles are all empty skip staging and matrix work and write its zeros straight away; `occ_out` receives the
+// same for the tile it wrote (stride 1: the next layer's occ_in, for free).  Bit-identical: the full computation of such a
+// tile adds products of zeros to a +0.0 accumulator.  Either pointer may be null (dense behaviour / no map produced).
+// SPARSE = false is the kernel without any of this (its own instantiation: the dense callers run the code they always ran).
+template <int KS, int COUT, int RELU, int STRIDE, bool SPARSE> __global__ void __launch_bounds__(ConvSCfg<KS>::NT)
 k_conv3d_bf16x3(const float* __restrict__ X, const float4* __restrict__ Wp, float* __restrict__ Y, int CIN, int D,
-                int cout_total, int co_base, int nzb) {
+                int cout_total, int co_base, int nzb, const unsigned char* __restrict__ occ_in,
+                unsigned char* __restrict__ occ_out) {
   typedef ConvSCfg<KS> C;
   constexpr int MT = COUT / 16, H = C::H, NTG = C::NTG, NVOX = C::NVOX, RW = C::RW, NT = C::NT;
   DLPD_DYN_SHARED(float4, Xs);                                 // [3][NVOX] 16-byte cells
   int* toff = reinterpret_cast<int*>(Xs + 3 * NVOX);           // [4 NTG] voxel offset of every tap (0 for the padding taps)
+  int* any_s = toff + 4 * NTG;                                 // [2] block-wide flags of the tile-occupancy logic
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int x0 = blockIdx.x * C::TX, y0 = blockIdx.y * C::TY, b = blockIdx.z / nzb, z0 = (blockIdx.z % nzb) * C::ZT;
+  const int ntx = gridDim.x, nty = gridDim.y, tzb = blockIdx.z % nzb;
+  bool empty = false;
+  if (SPARSE && occ_in) {                                      // (block-uniform)
+    if (tid == 0) any_s[0] = 0;
+    __syncthreads();
+    if (tid < 27) {
+      const int nx = (int)blockIdx.x + tid / 9 - 1, ny = (int)blockIdx.y + (tid / 3) % 3 - 1, nz = tzb + tid % 3 - 1;
+      if (nx >= 0 && nx < ntx && ny >= 0 && ny < nty && nz >= 0 && nz < nzb &&
+          occ_in[(((size_t)b * ntx + nx) * nty + ny) * nzb + nz])
+        any_s[0] = 1;                                          // (plain store of the same value by whoever finds one)
+    }
+    __syncthreads();
+    empty = any_s[0] == 0;
+  }
   const size_t D3 = (size_t)D * D * D;
   const float* Xb = X + (size_t)b * CIN * D3;
   const int kg = lane >> 4, n = lane & 15;
@@ -313,7 +337,7 @@ k_conv3d_bf16x3(const float* __restrict__ X, const float4* __restrict__ Wp, floa
     vbase[r] = ((row / C::TY) * C::YS + (row % C::TY)) * C::ZS + n;
     skip[r] = STRIDE == 2 && (((row / C::TY) | (row % C::TY)) & 1);      // stride 2: rows of odd x or y produce no output
   }
-  const int nchunk = (CIN + C::CK - 1) / C::CK;
+  const int nchunk = (SPARSE && empty) ? 0 : (CIN + C::CK - 1) / C::CK;    // an empty neighbourhood: nothing to stage, the zeros go out as they are
   for (int ch = 0; ch < nchunk; ch++) {
     __syncthreads();                                           // previous chunk consumed (first pass: toff written)
     // ---- staging: one voxel (8 channels) per thread and step; split into the three bf16 planes
@@ -418,6 +442,7 @@ k_conv3d_bf16x3(const float* __restrict__ X, const float4* __restrict__ Wp, floa
   }
   // ---- epilogue: lane holds output channels 4 kg + j, voxel n (the C/D layout of every 16x16 form)
   const int kq = kg;
+  bool nonzero = false;
 #pragma unroll
   for (int r = 0; r < RW; r++) {
     const int row = RW * wave + r, gx = x0 + row / C::TY, gy = y0 + row % C::TY, gz = z0 + n;
@@ -431,9 +456,40 @@ k_conv3d_bf16x3(const float* __restrict__ X, const float4* __restrict__ Wp, floa
       for (int j = 0; j < 4; j++) {
         float v = dlpd_acc4_get(acc[r][mt], j);
         if (RELU) v = fmaxf(v, 0.f);
+        if (SPARSE) nonzero |= v != 0.f;
         Y[((size_t)b * cout_total + co_base + mt * 16 + 4 * kq + j) * Do3 +
           ((size_t)(gx / STRIDE) * Do + gy / STRIDE) * Do + gz / STRIDE] = v;
       }
+  }
+  if (SPARSE && occ_out && STRIDE == 1) {                                // the written tile's own occupancy (zeroed by the host before the launch)
+    if (tid == 0) any_s[1] = 0;
+    __syncthreads();
+    if (nonzero) any_s[1] = 1;
+    __syncthreads();
+    if (tid == 0 && any_s[1]) occ_out[(((size_t)b * ntx + blockIdx.x) * nty + blockIdx.y) * nzb + tzb] = 1;
+  }
+}
+
+// occ[volume][tile x][tile y][tile z] = 1 where the 4 x 4 x 16 tile of x (B, CIN, D^3) holds a non-zero value in some channel
+// (the tiling of k_conv3d_bf16x3).  One block per (tile x, tile y, volume): thread = (x, y, z mod 16), z tiles in turn.
+__global__ void __launch_bounds__(256) k_conv3d_tile_occupancy(const float* __restrict__ X, unsigned char* __restrict__ occ,
+                                                               int CIN, int D, int nzb) {
+  __shared__ int any_s;
+  const int tid = threadIdx.x, zl = tid & 15, xy = tid >> 4;
+  const int gx = blockIdx.x * 4 + (xy >> 2), gy = blockIdx.y * 4 + (xy & 3), b = blockIdx.z;
+  const size_t D3 = (size_t)D * D * D;
+  const float* src = X + (size_t)b * CIN * D3 + ((size_t)gx * D + gy) * D;
+  for (int zt = 0; zt < nzb; zt++) {
+    const int gz = 16 * zt + zl;
+    bool nz = false;
+    if (gx < D && gy < D && gz < D)
+      for (int c = 0; c < CIN; c++) nz |= src[(size_t)c * D3 + gz] != 0.f;
+    __syncthreads();
+    if (tid == 0) any_s = 0;
+    __syncthreads();
+    if (nz) any_s = 1;
+    __syncthreads();
+    if (tid == 0) occ[(((size_t)b * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y) * nzb + zt] = any_s ? 1 : 0;
   }
 }
 
@@ -461,15 +517,19 @@ __global__ void __launch_bounds__(256) k_conv3d_split_pack(const float* __restri
 }
 
 template <int KS, int COUT> static int launch_conv_split(const float* X, const float4* W, float* Y, int B, int CIN, int D,
-                                                         int relu, int stride, int cout_total, int co_base, hipStream_t st) {
+                                                         int relu, int stride, int cout_total, int co_base, hipStream_t st,
+                                                         const unsigned char* occ_in, unsigned char* occ_out) {
   typedef ConvSCfg<KS> C;
   const int nzb = (D + C::ZT - 1) / C::ZT;
   dim3 grid((D + C::TX - 1) / C::TX, (D + C::TY - 1) / C::TY, B * nzb), block(C::NT);
-#define DLPD_CS(R, S) { int rc = dlpd_set_max_dyn_shared((const void*)k_conv3d_bf16x3<KS, COUT, R, S>, C::LDS_BYTES); if (rc) return rc; \
-    DLPD_LAUNCH((k_conv3d_bf16x3<KS, COUT, R, S>), grid, block, C::LDS_BYTES, st, X, W, Y, CIN, D, cout_total, co_base, nzb); }
+#define DLPD_CS1(R, S, SP) { int rc = dlpd_set_max_dyn_shared((const void*)k_conv3d_bf16x3<KS, COUT, R, S, SP>, C::LDS_BYTES); if (rc) return rc; \
+    DLPD_LAUNCH((k_conv3d_bf16x3<KS, COUT, R, S, SP>), grid, block, C::LDS_BYTES, st, X, W, Y, CIN, D, cout_total, co_base, nzb, \
+                occ_in, occ_out); }
+#define DLPD_CS(R, S) { if (occ_in || occ_out) DLPD_CS1(R, S, true) else DLPD_CS1(R, S, false) }
   if (stride == 2) { if (relu) DLPD_CS(1, 2) else DLPD_CS(0, 2) }
   else { if (relu) DLPD_CS(1, 1) else DLPD_CS(0, 1) }
 #undef DLPD_CS
+#undef DLPD_CS1
   return dlpd_check_launch();
 }
 
@@ -544,20 +604,41 @@ int dlpd_conv3d_split_pack(const float* w, void* wp, int cin, int cout, int ks, 
   return dlpd_check_launch();
 }
 
+size_t dlpd_conv3d_tile_occupancy_bytes(int B, int D) {
+  return (size_t)B * ((D + 3) / 4) * ((D + 3) / 4) * ((D + 15) / 16);
+}
+
+int dlpd_conv3d_tile_occupancy(const float* x, unsigned char* occ, int B, int cin, int D, void* stream) {
+  if (!x || !occ || B <= 0 || cin <= 0 || D <= 0) return DLPD_ERR_ARG;
+  DLPD_LAUNCH(k_conv3d_tile_occupancy, dim3((D + 3) / 4, (D + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, x, occ, cin, D,
+              (D + 15) / 16);
+  return dlpd_check_launch();
+}
+
+int dlpd_conv3d_split_sparse(const float* x, const void* wp, float* y, const unsigned char* occ_in, unsigned char* occ_out,
+                             int B, int cin, int cout, int D, int ks, int relu, int stride, void* stream);
+
 int dlpd_conv3d_split(const float* x, const void* wp, float* y, int B, int cin, int cout, int D, int ks, int relu, int stride,
                       void* stream) {
+  return dlpd_conv3d_split_sparse(x, wp, y, nullptr, nullptr, B, cin, cout, D, ks, relu, stride, stream);
+}
+
+int dlpd_conv3d_split_sparse(const float* x, const void* wp, float* y, const unsigned char* occ_in, unsigned char* occ_out,
+                             int B, int cin, int cout, int D, int ks, int relu, int stride, void* stream) {
   if (!x || !wp || !y || B <= 0 || (stride != 1 && stride != 2)) return DLPD_ERR_ARG;
   if (!dlpd_conv3d_supported(cin, cout, ks, D)) return DLPD_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
+  if (stride != 1) occ_out = nullptr;                          // (the strided output has another tiling)
+  if (occ_out && hipMemsetAsync(occ_out, 0, dlpd_conv3d_tile_occupancy_bytes(B, D), st) != hipSuccess) return DLPD_ERR_LAUNCH;
   const size_t per32 = (size_t)((cin + 7) / 8) * 3 * ((ks * ks * ks + 3) / 4) * 4 * 32 * 8 * sizeof(unsigned short) / 16;   // float4 cells
   for (int g = 0; 32 * g < cout; g++) {
     const int gw = conv_group_width(cout, g), base = 32 * g;
     const float4* wg = reinterpret_cast<const float4*>(wp) + per32 * g;
     int rc = DLPD_ERR_UNSUPPORTED;
-    if (ks == 3 && gw == 16) rc = launch_conv_split<3, 16>(x, wg, y, B, cin, D, relu, stride, cout, base, st);
-    else if (ks == 3 && gw == 32) rc = launch_conv_split<3, 32>(x, wg, y, B, cin, D, relu, stride, cout, base, st);
-    else if (ks == 5 && gw == 16) rc = launch_conv_split<5, 16>(x, wg, y, B, cin, D, relu, stride, cout, base, st);
-    else if (ks == 5 && gw == 32) rc = launch_conv_split<5, 32>(x, wg, y, B, cin, D, relu, stride, cout, base, st);
+    if (ks == 3 && gw == 16) rc = launch_conv_split<3, 16>(x, wg, y, B, cin, D, relu, stride, cout, base, st, occ_in, occ_out);
+    else if (ks == 3 && gw == 32) rc = launch_conv_split<3, 32>(x, wg, y, B, cin, D, relu, stride, cout, base, st, occ_in, occ_out);
+    else if (ks == 5 && gw == 16) rc = launch_conv_split<5, 16>(x, wg, y, B, cin, D, relu, stride, cout, base, st, occ_in, occ_out);
+    else if (ks == 5 && gw == 32) rc = launch_conv_split<5, 32>(x, wg, y, B, cin, D, relu, stride, cout, base, st, occ_in, occ_out);
     if (rc) return rc;
   }
   return DLPD_OK;

@@ -52,7 +52,7 @@ def _broadcast_flags(docker, flags, n):
     return [bool(v) for v in buf.cpu().tolist()]
 
 
-def sweep(docker, targets, test_dir, group="SE3", rewrite=False, batch_size=2, prefetch=True, say=print, prepare_stream=False):
+def sweep(docker, targets, test_dir, group="SE3", rewrite=False, batch_size=2, prefetch=True, say=print):
     """Dock every target of ``targets`` = [(pdb_name, receptor_path, ligand_path), ...] into ``test_dir/<pdb_name>.dat``
     (local_test.py:57-75), on all ranks of ``docker``'s process group.  -> report dict (the same on every rank except
     for the timings, which are the rank's own)."""
@@ -66,16 +66,15 @@ def sweep(docker, targets, test_dir, group="SE3", rewrite=False, batch_size=2, p
                             if docker.rank == 0 else [], n_targets)
     dev = docker.device
     on_gpu = dev.type == "cuda"
-    pool = stream = None
+    pool = None
     if prefetch and n_targets > 1:
         from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dlpd-prepare")
-        # The preparing thread enqueues its device work on the CALLER'S stream (stream = None), in order with the search's
-        # launches: what overlaps with the search is the host side (PDB parsing, typing, launch overhead).  A stream of
-        # its own (prepare_stream=True) also overlaps the projection / representation kernels -- a target's preparation is
-        # 0.01-0.1 s of the 23 s its search takes (profiles/r05_s_soak_sweep.json), so there is nothing to gain, and it was
-        # this option that exposed round 5's LDS-atomics interaction (EXPERIMENTS.md R5; since removed at its source).
-        stream = torch.cuda.Stream(device=dev) if (on_gpu and prepare_stream) else None
+        # The preparing thread enqueues its device work on the CALLER'S stream, in order with the search's launches: what
+        # overlaps with the search is the host side (PDB parsing, typing, launch overhead).  A stream of its own would also
+        # overlap the projection / representation kernels -- nothing to gain (a target's preparation is 0.01-0.1 s of the 23 s
+        # its search takes, profiles/r05_s_soak_sweep.json), and the plugin's matrix-instruction convolution co-resident with
+        # the pipeline's LDS kernels is what perturbs the pipeline's low bits on this hardware (EXPERIMENTS.md R5): not offered.
     pending = {}                                      # target index -> Future of its PreparedPair
     pending_slot = {}                                 # target index -> the engine slot that preparation fills
     def prepare_in_background(j, slot):
@@ -83,7 +82,7 @@ def sweep(docker, targets, test_dir, group="SE3", rewrite=False, batch_size=2, p
         def work():
             if on_gpu:
                 torch.cuda.set_device(dev)            # (the device is a per-thread setting)
-            return docker.prepare(targets[j][1], targets[j][2], group, slot=slot, stream=stream)
+            return docker.prepare(targets[j][1], targets[j][2], group, slot=slot)
         pending[j] = pool.submit(work)
 
     sync = (lambda: torch.cuda.synchronize(dev)) if on_gpu else (lambda: None)
@@ -164,8 +163,6 @@ def parse_args(argv=None):
     ap.add_argument("-prefetch", default=1, type=int, help="prepare the next target while the current one is searched")
     ap.add_argument("-backend", default="nccl", choices=("nccl", "gloo"), help="collective backend (nccl = RCCL)")
     ap.add_argument("-same_device", default=0, type=int, help="every rank on cuda:0 (one-GPU box; needs -backend gloo)")
-    ap.add_argument("-prepare_stream", default=0, type=int,
-                    help="prepare the next target on a stream of its own (default: on the caller's stream; no gain measured)")
     ap.add_argument("-force_group", default=0, type=int,
                     help="initialise the process group and run every collective with ONE rank too (one-GPU RCCL check)")
     return ap.parse_args(argv)
@@ -233,7 +230,7 @@ def main(argv=None):
         targets.append((pdb_name[0], ureceptor[0], uligand[0]))
     say = print if rank == 0 else (lambda *a, **k: None)
     rep = sweep(docker, targets, test_dir, group=args.group, rewrite=bool(args.rewrite), batch_size=2,
-                prefetch=bool(args.prefetch), say=say, prepare_stream=bool(args.prepare_stream))
+                prefetch=bool(args.prefetch), say=say)
     if args.report and rank == 0:
         print("SWEEP " + json.dumps(rep), flush=True)
     if world > 1 or args.force_group:

@@ -164,13 +164,28 @@ def conv3d_supported(weight, D, lib=None):
 CONV_PRECISION = "split_bf16"      # default arithmetic of conv3d: "split_bf16" (3 x bf16 terms, six products: f32-grade) | "f32"
 
 
-def conv3d(x, weight, relu=False, lib=None, stride=1, precision=None):
+def tile_occupancy(x, lib=None):
+    """Which 4 x 4 x 16 tiles of x (B, C, D, D, D) hold a non-zero value: uint8 (B, ceil(D/4), ceil(D/4), ceil(D/16)), the
+    ``occupancy`` argument of conv3d."""
+    lib = lib or get_lib()
+    x = x.contiguous()
+    B, cin, D = x.shape[0], x.shape[1], x.shape[2]
+    occ = torch.empty(B, (D + 3) // 4, (D + 3) // 4, (D + 15) // 16, dtype=torch.uint8, device=x.device)
+    assert occ.numel() == lib.call("dlpd_conv3d_tile_occupancy_bytes", B, D)
+    lib.call("dlpd_conv3d_tile_occupancy", _ptr(x), _ptr(occ), B, cin, D, _stream(x.device))
+    return occ
+
+
+def conv3d(x, weight, relu=False, lib=None, stride=1, precision=None, occupancy=None, return_occupancy=False):
     """[relu] Conv3d(x, weight, padding=k//2, stride=1|2, bias=None) of the representation plugins
     (ProteinRepresentationModels.py:38-61,85-114) on the matrix cores (inference only: no autograd).
     x (B, cin, D, D, D) float32; weight (cout, cin, k, k, k).
     precision: "f32" = exact f32 products on the f32-input matrix instruction; "split_bf16" = every value as three
     bf16 terms, six bf16 products per f32 product, f32 accumulation (equal to the f32 form to a few 1e-7 relative,
-    2-3x faster); None = ``ops.CONV_PRECISION``."""
+    2-3x faster); None = ``ops.CONV_PRECISION``.
+    occupancy (split_bf16 only): ``tile_occupancy(x)`` -- output tiles whose neighbouring input tiles are all empty are
+    written as zeros without being computed (there is no bias: they ARE zero; same bits).  return_occupancy: -> (y, the
+    occupancy of y or None), which the next layer takes -- a representation network pays for one map, of its input."""
     lib = lib or get_lib()
     x = x.contiguous()
     if x.dtype != torch.float32 or x.dim() != 5 or not (x.shape[2] == x.shape[3] == x.shape[4]):
@@ -189,9 +204,20 @@ def conv3d(x, weight, relu=False, lib=None, stride=1, precision=None):
         raise RuntimeError("dlpd: conv3d stride %r not supported (1 or 2)" % (stride,))
     Do = (D - 1) // stride + 1
     y = torch.empty(B, cout, Do, Do, Do, dtype=torch.float32, device=x.device)
-    lib.call("dlpd_conv3d_split" if split else "dlpd_conv3d_strided", _ptr(x), _ptr(wp), _ptr(y), B, cin, cout, D, ks,
-             int(bool(relu)), int(stride), _stream(x.device))
-    return y
+    occ_out = None
+    if split and (occupancy is not None or return_occupancy):
+        if occupancy is not None and (occupancy.dtype != torch.uint8 or occupancy.device != x.device or
+                                      occupancy.numel() != lib.call("dlpd_conv3d_tile_occupancy_bytes", B, D)):
+            raise RuntimeError("dlpd: conv3d occupancy does not belong to this input (shape %s)" % (tuple(occupancy.shape),))
+        if return_occupancy and stride == 1:
+            occ_out = torch.empty(B, (D + 3) // 4, (D + 3) // 4, (D + 15) // 16, dtype=torch.uint8, device=x.device)
+        lib.call("dlpd_conv3d_split_sparse", _ptr(x), _ptr(wp), _ptr(y),
+                 _ptr(occupancy.contiguous()) if occupancy is not None else None, _ptr(occ_out) if occ_out is not None else None,
+                 B, cin, cout, D, ks, int(bool(relu)), int(stride), _stream(x.device))
+    else:
+        lib.call("dlpd_conv3d_split" if split else "dlpd_conv3d_strided", _ptr(x), _ptr(wp), _ptr(y), B, cin, cout, D, ks,
+                 int(bool(relu)), int(stride), _stream(x.device))
+    return (y, occ_out) if return_occupancy else y
 
 
 _PACKED = {}

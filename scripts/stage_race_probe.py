@@ -1,7 +1,7 @@
 """Diagnostic: which STAGE of the scoring pipeline gives different bits when another stream of the process is busy?
 One batch of 16 rotations is scored again and again (same inputs) while a host thread keeps a second stream busy with the
 representation plugin's convolutions; after every stage the buffer it wrote is compared with the undisturbed run's.
-usage: stage_race_probe.py <iterations> [load: repr|matmul|none] [poison]"""
+usage: stage_race_probe.py <iterations> [load: repr|e3repr|matmul|none] [topk]"""
 import os, sys, tempfile, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -55,6 +55,12 @@ print("undisturbed rerun identical:", {k: bool(torch.equal(ref[k], again[k])) fo
 del again
 side = torch.cuda.Stream(device=dev)
 x11 = torch.rand(1, 11, 80, 80, 80, device=dev)
+e3net = x_blob = None
+if LOAD == "e3repr":                # the E3 plugin on a protein-like input (zero away from a blob): the tile-occupancy (sparse) kernel
+    from deeplocalproteindocking_amd.Models import E3MultiResRepr4x4
+    e3net = E3MultiResRepr4x4(multiplier=8).to(dev).eval()
+    x_blob = torch.zeros(4, 11, 80, 80, 80, device=dev)
+    x_blob[:, :, 24:52, 20:48, 28:60] = torch.rand(4, 11, 28, 28, 32, device=dev)
 stop = threading.Event()
 
 
@@ -64,6 +70,8 @@ def worker():
         while not stop.is_set():
             if LOAD == "repr":
                 model.representation(x11)
+            elif LOAD == "e3repr":
+                e3net(x_blob)
             elif LOAD == "matmul":
                 a = torch.randn(2048, 2048, device=dev)
                 for _ in range(10):
@@ -128,6 +136,14 @@ for it in range(ITER):
                 for dim, nm in enumerate(("b", "c", "k", "x", "y")):
                     u = dd[:, dim].unique()
                     msg += " %s: %s%s" % (nm, u[:12].tolist(), "..." if len(u) > 12 else "")
+            else:
+                a, g = ref[first], BUF[first]()
+                fa, fg = (torch.view_as_real(a), torch.view_as_real(g)) if a.is_complex() else (a, g)
+                dd = (fa != fg).nonzero()
+                msg += "\n      shape %s, max |diff| %.3g (max |value| %.3g), NaNs %d;" % (tuple(fa.shape), float((fa - fg).abs().nan_to_num(0).max()), float(fa.abs().max()), int(fg.isnan().sum()))
+                for dim in range(dd.shape[1]):
+                    u = dd[:, dim].unique()
+                    msg += " dim%d: %s%s" % (dim, u[:10].tolist(), "... (%d)" % len(u) if len(u) > 10 else "")
             detail.append(msg)
 stop.set()
 if th is not None:

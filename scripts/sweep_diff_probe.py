@@ -9,11 +9,9 @@ runs = {}
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 # (the DLPD_DEBUG_PREPARE switches of local_test.sweep that the first version of this probe drove -- preparing thread on the caller's
 #  stream / synchronised at its end / prepared pairs kept alive -- were removed again once the cause was narrowed: EXPERIMENTS.md R5)
-MODE = sys.argv[2] if len(sys.argv) > 2 else "w2"       # w2: two ranks sharing the GPU; stream: one rank, preparation on a stream of its own
-combos = [("w1_plain", 1, 0)] + [("%s_ahead_%d" % (MODE, i), 2 if MODE == "w2" else 1, 1) for i in range(REPS)]
+combos = [("w1_plain", 1, 0)] + [("w2_ahead_%d" % i, 2, 1) for i in range(REPS)]
 for tag, nproc, pre in combos:
-    extra = ["-prepare_stream", "1"] if (MODE == "stream" and pre) else []
-    rep, _ = _sweep(root, "log_" + tag, nproc, ["-rewrite", "1", "-prefetch", str(pre)] + extra, port=29700 + len(runs) % 200)
+    rep, _ = _sweep(root, "log_" + tag, nproc, ["-rewrite", "1", "-prefetch", str(pre)], port=29700 + len(runs) % 200)
     runs[tag] = {n: open(os.path.join(rep["test_dir"], n + ".dat")).read().splitlines() for n in ("1SYN", "2SYN", "3SYN")}
     print(tag, "targets/s %.2f" % rep["targets_per_s"], [round(t["seconds"], 2) for t in rep["targets"]], flush=True)
 base = runs["w1_plain"]

@@ -797,42 +797,6 @@ def test_e3_plugin_on_the_hip_convolutions_reproduces_the_reference_class(golden
         ops.CONV_PRECISION = saved
 
 
-@pytest.mark.gpu
-def test_dockE3_overlapped_plugin_gives_the_serial_list(tmp_path):
-    """dockE3 on the fused engine runs the plugin's half of batch i + 1 (projection, representation) on a second stream
-    beside the engine's half of batch i (Docker.E3_OVERLAP).  The ranked list must be the one of the serial loop, entry
-    for entry, run after run -- a hand-over that is not ordered (or two kernels that disturb each other when they share
-    the chip) shows up here as a list that changes between repetitions."""
-    import __graft_entry__ as entry
-    entry.build()
-    from synth_pdb import write_protein_like_pdb
-    from deeplocalproteindocking_amd.Docker import Docker
-    from deeplocalproteindocking_amd.Models import E3MultiResRepr4x4, GlobalDockingModel, SimpleFilter
-    dev = torch.device("cuda:0")
-    rec_pdb, lig_pdb = str(tmp_path / "rec.pdb"), str(tmp_path / "lig.pdb")
-    write_protein_like_pdb(rec_pdb, 150, 21)
-    write_protein_like_pdb(lig_pdb, 90, 22)
-    ang = np.random.RandomState(4).uniform(-np.pi, np.pi, size=(160, 3))
-    R = orc.euler_to_matrix(ang[:, 0], np.abs(ang[:, 1]), ang[:, 2])
-    torch.manual_seed(79)
-    repr_ = E3MultiResRepr4x4(multiplier=8)
-    model = GlobalDockingModel(repr_, SimpleFilter(repr_.get_num_outputs()), threshold_clash=40.0).to(dev)
-
-    def run(overlap):
-        dk = Docker(model, box_size=80, resolution=1.25, max_conf=2000, rotations=R, device=dev, randomize_rot=True, rotation_seed=5)
-        dk.E3_OVERLAP = overlap
-        with torch.no_grad():
-            dk.dockE3(rec_pdb, lig_pdb, batch_size=2)
-        assert dk.path == "fused"
-        top = list(dk.top_list)
-        dk.release_engine()
-        return top
-    serial = run(False)
-    assert serial == run(False) and len(serial) == 2000
-    different = [i for i in range(30) if run(True) != serial]
-    assert not different, "overlapped runs %s differ from the serial list" % different
-
-
 def test_a_prepared_pair_overwritten_in_its_engine_slot_refuses_to_dock(tmp_path):
     """Docker.prepare(slot=s) fills engine s with the pair's receptor spectrum and ligand; a second prepare into the SAME slot
     replaces that content, and docking the first pair afterwards would silently score the second pair's receptor -- it raises."""

@@ -435,6 +435,15 @@ def test_conv3d_matches_torch_at_plugin_shapes(dev, cin, cout, ks, D):
     assert ops.CONV_PRECISION == "split_bf16"         # what the plugins run by default
 
 
+@pytest.mark.parametrize("cin,cmid,cout,ks,D,lo,hi", [(11, 16, 16, 5, 80, 22, 50), (16, 32, 64, 3, 40, 0, 9), (11, 16, 32, 5, 37, 30, 37)])
+def test_conv3d_tile_occupancy_skips_empty_tiles_with_the_same_bits(dev, cin, cmid, cout, ks, D, lo, hi):
+    """The bias-free convolutions with their empty tiles skipped (ops.conv3d(occupancy=...), what the E3 plugin runs per
+    batch of rotations) against the same convolutions computed everywhere, at the plugin's box sizes: same bits, and the
+    occupancy map every layer hands on equals the map of its output."""
+    from test_kernels_emu import _sparse_conv_checks
+    _sparse_conv_checks(None, dev, cin, cmid, cout, ks, D, lo, hi, B=3)
+
+
 def test_conv3d_stride2_and_se3_plugin_never_touch_torch_convolutions(dev, monkeypatch):
     """The stride-2 5^3 layer (ProteinRepresentationModels.py:51) on the matrix-core kernel at the reference's
     size (16 -> 32 channels, 80^3 -> 40^3), and the whole SE3MultiResReprScalar(8) forward with torch's conv3d

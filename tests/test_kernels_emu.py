@@ -799,3 +799,43 @@ def test_packed_receptor_exists_only_where_k2_rereads_it(emu):
             emu.call("dlpd_xy_correlate_packed", _ptr(x), _ptr(x), _ptr(x), 1, 1, L, 0)
     assert emu.call("dlpd_receptor_packed_floats", 3, 40) == 3 * 41 * 80 * 80 * 2
     assert emu.call("dlpd_receptor_packed_floats", 3, 80) == 3 * 81 * 160 * 160 * 2
+
+
+def _blob_input(B, cin, D, seed, lo, hi):
+    """(B, cin, D^3) input that is zero outside the box [lo, hi)^3 -- what a density splat of a protein looks like."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.zeros(B, cin, D, D, D)
+    x[:, :, lo:hi, lo:hi, lo:hi] = torch.randn(B, cin, hi - lo, hi - lo, hi - lo, generator=g)
+    return x, g
+
+
+def _sparse_conv_checks(lib, device, cin, cmid, cout, ks, D, lo, hi, B=1):
+    """Two chained bias-free convolutions with tile occupancy (empty tiles written as zeros, not computed) against the same
+    convolutions without: the same bits; the occupancy map a layer hands on equals the map computed from its output; and
+    tiles are really skipped (the map of the input has empty tiles)."""
+    from deeplocalproteindocking_amd import ops
+    x, g = _blob_input(B, cin, D, 7 + D, lo, hi)
+    w1 = torch.randn(cmid, cin, ks, ks, ks, generator=g) * 0.1
+    w2 = torch.randn(cout, cmid, 3, 3, 3, generator=g) * 0.1
+    x, w1, w2 = x.to(device), w1.to(device), w2.to(device)
+    occ0 = ops.tile_occupancy(x, lib=lib)
+    assert occ0.shape == (B, (D + 3) // 4, (D + 3) // 4, (D + 15) // 16) and 0 < int(occ0.sum()) < occ0.numel()
+    y1, occ1 = ops.conv3d(x, w1, relu=True, lib=lib, precision="split_bf16", occupancy=occ0, return_occupancy=True)
+    y2, occ2 = ops.conv3d(y1, w2, relu=False, lib=lib, precision="split_bf16", occupancy=occ1, return_occupancy=True)
+    d1 = ops.conv3d(x, w1, relu=True, lib=lib, precision="split_bf16")
+    d2 = ops.conv3d(d1, w2, relu=False, lib=lib, precision="split_bf16")
+    assert torch.equal(y1, d1) and torch.equal(y2, d2)
+    assert torch.equal(occ1, ops.tile_occupancy(d1, lib=lib)) and torch.equal(occ2, ops.tile_occupancy(d2, lib=lib))
+    # a stride-2 layer takes a map and hands none on (its output has another tiling)
+    y3, occ3 = ops.conv3d(x, w1, lib=lib, stride=2, precision="split_bf16", occupancy=occ0, return_occupancy=True)
+    assert occ3 is None and torch.equal(y3, ops.conv3d(x, w1, lib=lib, stride=2, precision="split_bf16"))
+    # a map of the wrong size is refused
+    with pytest.raises(RuntimeError, match="occupancy"):
+        ops.conv3d(x, w1, lib=lib, precision="split_bf16", occupancy=occ0[:, :1])
+    want = torch.relu(torch.nn.functional.conv3d(x.cpu().double(), w1.cpu().double(), padding=ks // 2))
+    assert (y1.cpu().double() - want).abs().max() <= 1e-5 * want.abs().max()
+
+
+@pytest.mark.parametrize("cin,cmid,cout,ks,D,lo,hi", [(11, 16, 16, 5, 13, 1, 4), (5, 32, 16, 3, 17, 9, 15), (8, 16, 48, 5, 12, 0, 3)])
+def test_conv3d_tile_occupancy_skips_empty_tiles_with_the_same_bits(emu, cin, cmid, cout, ks, D, lo, hi):
+    _sparse_conv_checks(emu, "cpu", cin, cmid, cout, ks, D, lo, hi)
