@@ -155,9 +155,10 @@ def test_synthetic_benchmark_directory_is_what_the_loader_reads(tmp_path):
 def _same_dat_up_to_the_parity_band(a, b, n=2000):
     """Two .dat files of one target: byte-identical, or -- for runs in which two PROCESSES shared one GPU -- the same poses
     with scores inside the 1e-4 parity band and at most a handful of rows displaced.  (On one GPU the other rank's plugin
-    convolution ran beside this rank's search, which -- until the histogram kernel lost its LDS atomics, EXPERIMENTS.md R5 --
-    now and then changed the last bits of one rotation's scores; the comparison stays tolerant of that class of effect for
-    the shared-GPU layout only.  One process per GPU -- the production layout, and the RCCL test below -- is byte-identical.)"""
+    convolution runs beside this rank's search, and that co-residency now and then changes low bits of a rotation's scores on
+    this hardware -- EXPERIMENTS.md R5; a single process never schedules the two together.  The comparison is tolerant of that
+    effect for the shared-GPU layout only; one process per GPU -- the production layout, and the RCCL test below -- is
+    byte-identical.)"""
     if a == b:
         return True
     ra = [[float(v) for v in l.split(b"\t")] for l in a.strip().split(b"\n")]
@@ -199,7 +200,7 @@ def _sweep(root, log_name, nproc, extra_args=(), extra_env=None, port=29671, rcc
 def test_rank_aware_sweep_two_ranks_on_this_gpu_equals_one_rank(tmp_path):
     """BASELINE config 5's driver on hardware, as far as a one-GPU box goes: local_test.py's target loop over a
     three-target synthetic benchmark by TWO ranks (both on this GPU, gloo transport), rotations of every target sharded,
-    rank 0 writing, the next target prepared on a second stream and host thread -- against the single-rank sweep
+    rank 0 writing, the next target prepared by a second host thread -- against the single-rank sweep
     without preparation ahead: the same .dat bytes; then the resume rule across ranks."""
     import __graft_entry__ as entry
     entry.build()
@@ -227,7 +228,7 @@ def test_rank_aware_sweep_two_ranks_on_this_gpu_equals_one_rank(tmp_path):
     assert again["processed"] == 1 and again["skipped"] == 2 and [t["target"] for t in again["targets"]] == ["2SYN"]
     assert "Skipping 1SYN" in stdout and "Processing 2SYN" in stdout and "Skipping 3SYN" in stdout
     assert _same_dat_up_to_the_parity_band(open(dat, "rb").read(), whole)
-    # one rank, targets prepared ahead: the same files again (the second engine and the side stream on one process)
+    # one rank, targets prepared ahead: the same files again (the second engine and the preparing host thread in one process)
     pre, _ = _sweep(root, "logW1p", 1, ["-rewrite", "1", "-prefetch", "1"])
     for name in ("1SYN", "2SYN", "3SYN"):
         assert open(os.path.join(pre["test_dir"], name + ".dat"), "rb").read() == \
