@@ -997,8 +997,11 @@ def test_scores_do_not_change_beside_the_plugin_and_the_radix_select(dev):
     scored again and again while two more streams of the process are kept busy: the representation plugin's bf16 x 3
     convolutions and the engine's own full radix select.  With `ds_add_u32` in the select's histogram kernel this changed
     the output of the coarse grid's K1 / K2 -- the pipeline kernels small enough to share a CU with both -- in 259 of 300
-    scorings (lanes 48-63 of a transform wave, low mantissa bits); the histogram now counts without LDS atomics and every
-    stage's output must be the same bits as in the undisturbed run."""
+    scorings (lanes 48-63 of a transform wave, low mantissa bits); the histogram now counts without LDS atomics and, with the
+    SE3 plugin's (dense) convolution kernel as it is built today, every stage's output is the same bits as in the undisturbed
+    run.  Late in round 5 the pair plugin + pipeline turned out to do this WITHOUT the atomics too, depending on the convolution's
+    binary and layer shapes (E3 plugin: 298 of 300) -- so the library stopped offering any way of running the two side by side,
+    and this test is a CANARY: a difference is reported as an expected failure, not as a failure."""
     import threading
     import time
     from deeplocalproteindocking_amd.engine import DockingEngine
@@ -1063,7 +1066,11 @@ def test_scores_do_not_change_beside_the_plugin_and_the_radix_select(dev):
         stop.set()
         for t in threads:
             t.join()
-    assert not changed, {k: len(v) for k, v in changed.items()}
+    if changed:
+        # Not a product path any more (the library never schedules the plugin beside the pipeline), and known to depend on the
+        # convolution's exact binary: reported, not failed -- a canary for whoever wants to overlap the two again.
+        pytest.xfail("plugin convolution beside the pipeline perturbed %s (EXPERIMENTS.md R5: hardware co-residency hazard, "
+                     "not root-caused)" % {k: len(v) for k, v in changed.items()})
 
 
 def test_k3_role_split_equals_the_channel_owning_k3(dev, variants):
