@@ -77,12 +77,16 @@ def sweep(docker, targets, test_dir, group="SE3", rewrite=False, batch_size=2, p
         # the pipeline's LDS kernels is what perturbs the pipeline's low bits on this hardware (EXPERIMENTS.md R5): not offered.
     pending = {}                                      # target index -> Future of its PreparedPair
     pending_slot = {}                                 # target index -> the engine slot that preparation fills
+    caller_stream = torch.cuda.current_stream(dev) if on_gpu else None     # (the current stream is a per-thread setting too)
+
     def prepare_in_background(j, slot):
         pending_slot[j] = slot
         def work():
-            if on_gpu:
-                torch.cuda.set_device(dev)            # (the device is a per-thread setting)
-            return docker.prepare(targets[j][1], targets[j][2], group, slot=slot)
+            if not on_gpu:
+                return docker.prepare(targets[j][1], targets[j][2], group, slot=slot)
+            torch.cuda.set_device(dev)                # (the device is a per-thread setting)
+            with torch.cuda.stream(caller_stream):    # literally the stream the search is enqueued on
+                return docker.prepare(targets[j][1], targets[j][2], group, slot=slot)
         pending[j] = pool.submit(work)
 
     sync = (lambda: torch.cuda.synchronize(dev)) if on_gpu else (lambda: None)
