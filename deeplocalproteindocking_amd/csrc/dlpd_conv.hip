@@ -272,7 +272,7 @@ template <int KS> struct ConvSCfg {
   static constexpr int XS = TX + KS - 1, YS = TY + KS - 1, ZS = ZT + KS - 1;
   static constexpr int NVOX = XS * YS * ZS;
   static constexpr int NTAP = KS * KS * KS, NTG = (NTAP + 3) / 4;
-  static constexpr size_t LDS_BYTES = (size_t)3 * NVOX * 16 + (size_t)NTG * 4 * sizeof(int) + 16;
+  static constexpr size_t LDS_BYTES = (size_t)3 * NVOX * 16 + (size_t)NTG * 4 * sizeof(int) + 32;
 };
 
 // x = h + m + l in bf16 (bit patterns)
@@ -286,10 +286,12 @@ DLPD_D void conv_split3(float x, unsigned& h, unsigned& m, unsigned& l) {
 
 // TILE OCCUPANCY (round 5).  The plugins' convolutions have no bias, so an output tile whose receptive field holds only
 // zeros IS zero -- and a protein fills a fraction of its box (the density splat is zero a few Angstrom away from the atoms,
-// and every layer only widens the non-zero region by its kernel radius).  `occ_in[volume][tile x][tile y][tile z]` (one
-// byte per 4 x 4 x 16 input tile, non-zero = the tile holds a non-zero value in some channel) lets a block whose 27
-// neighbouring tiles are all empty skip staging and matrix work and write its zeros straight away; `occ_out` receives the
-// same for the tile it wrote (stride 1: the next layer's occ_in, for free).  Bit-identical: the full computation of such a
+// and every layer only widens the non-zero region by its kernel radius).  `occ_in[volume][tile x][tile y][z cell]` (one
+// byte per 4 x 4 x 4 cell of the input -- the (x, y) tiling of this kernel, a quarter of its 16-voxel z tile --, non-zero = the
+// cell holds a non-zero value in some channel) lets a block whose neighbourhood -- its own and the 8 adjacent tile columns,
+// over its z range widened by one cell either way: 54 cells, a superset of its halo -- is all empty skip staging and matrix
+// work and write its zeros straight away; `occ_out` receives the same for the four cells it wrote (stride 1: the next layer's
+// occ_in, for free).  Bit-identical: the full computation of such a
 // tile adds products of zeros to a +0.0 accumulator.  Either pointer may be null (dense behaviour / no map produced).
 // SPARSE = false is the kernel without any of this (its own instantiation: the dense callers run the code they always ran).
 template <int KS, int COUT, int RELU, int STRIDE, bool SPARSE> __global__ void __launch_bounds__(ConvSCfg<KS>::NT)
@@ -300,7 +302,7 @@ k_conv3d_bf16x3(const float* __restrict__ X, const float4* __restrict__ Wp, floa
   constexpr int MT = COUT / 16, H = C::H, NTG = C::NTG, NVOX = C::NVOX, RW = C::RW, NT = C::NT;
   DLPD_DYN_SHARED(float4, Xs);                                 // [3][NVOX] 16-byte cells
   int* toff = reinterpret_cast<int*>(Xs + 3 * NVOX);           // [4 NTG] voxel offset of every tap (0 for the padding taps)
-  int* any_s = toff + 4 * NTG;                                 // [2] block-wide flags of the tile-occupancy logic
+  int* any_s = toff + 4 * NTG;                                 // [8] block-wide flags of the tile-occupancy logic
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int x0 = blockIdx.x * C::TX, y0 = blockIdx.y * C::TY, b = blockIdx.z / nzb, z0 = (blockIdx.z % nzb) * C::ZT;
   const int ntx = gridDim.x, nty = gridDim.y, tzb = blockIdx.z % nzb;
@@ -308,10 +310,11 @@ k_conv3d_bf16x3(const float* __restrict__ X, const float4* __restrict__ Wp, floa
   if (SPARSE && occ_in) {                                      // (block-uniform)
     if (tid == 0) any_s[0] = 0;
     __syncthreads();
-    if (tid < 27) {
-      const int nx = (int)blockIdx.x + tid / 9 - 1, ny = (int)blockIdx.y + (tid / 3) % 3 - 1, nz = tzb + tid % 3 - 1;
-      if (nx >= 0 && nx < ntx && ny >= 0 && ny < nty && nz >= 0 && nz < nzb &&
-          occ_in[(((size_t)b * ntx + nx) * nty + ny) * nzb + nz])
+    if (tid < 54) {                                            // 3 x 3 tile columns x the 6 z cells [4 tzb - 1, 4 tzb + 4]
+      const int nzs = (D + 3) / 4;
+      const int nx = (int)blockIdx.x + tid / 18 - 1, ny = (int)blockIdx.y + (tid / 6) % 3 - 1, nz = 4 * tzb + tid % 6 - 1;
+      if (nx >= 0 && nx < ntx && ny >= 0 && ny < nty && nz >= 0 && nz < nzs &&
+          occ_in[(((size_t)b * ntx + nx) * nty + ny) * nzs + nz])
         any_s[0] = 1;                                          // (plain store of the same value by whoever finds one)
     }
     __syncthreads();
@@ -461,23 +464,27 @@ k_conv3d_bf16x3(const float* __restrict__ X, const float4* __restrict__ Wp, floa
           ((size_t)(gx / STRIDE) * Do + gy / STRIDE) * Do + gz / STRIDE] = v;
       }
   }
-  if (SPARSE && occ_out && STRIDE == 1) {                                // the written tile's own occupancy (zeroed by the host before the launch)
-    if (tid == 0) any_s[1] = 0;
+  if (SPARSE && occ_out && STRIDE == 1) {                      // the written tile's own occupancy, per 4-voxel z cell (zeroed by the host)
+    if (tid < 4) any_s[4 + tid] = 0;
     __syncthreads();
-    if (nonzero) any_s[1] = 1;
+    if (nonzero) any_s[4 + (n >> 2)] = 1;                      // (a lane's outputs are the channels of ONE voxel z0 + n)
     __syncthreads();
-    if (tid == 0 && any_s[1]) occ_out[(((size_t)b * ntx + blockIdx.x) * nty + blockIdx.y) * nzb + tzb] = 1;
+    const int nzs = (D + 3) / 4;
+    if (tid < 4 && 4 * tzb + tid < nzs && any_s[4 + tid])
+      occ_out[(((size_t)b * ntx + blockIdx.x) * nty + blockIdx.y) * nzs + 4 * tzb + tid] = 1;
   }
 }
 
-// occ[volume][tile x][tile y][tile z] = 1 where the 4 x 4 x 16 tile of x (B, CIN, D^3) holds a non-zero value in some channel
-// (the tiling of k_conv3d_bf16x3).  One block per (tile x, tile y, volume): thread = (x, y, z mod 16), z tiles in turn.
+// occ[volume][tile x][tile y][z cell] = 1 where the 4 x 4 x 4 cell of x (B, CIN, D^3) holds a non-zero value in some channel
+// ((x, y) tiles of k_conv3d_bf16x3, a quarter of its z tile).  One block per (tile x, tile y, volume): thread = (x, y, z mod 16),
+// z tiles in turn.
 __global__ void __launch_bounds__(256) k_conv3d_tile_occupancy(const float* __restrict__ X, unsigned char* __restrict__ occ,
                                                                int CIN, int D, int nzb) {
-  __shared__ int any_s;
+  __shared__ int any_s[4];
   const int tid = threadIdx.x, zl = tid & 15, xy = tid >> 4;
   const int gx = blockIdx.x * 4 + (xy >> 2), gy = blockIdx.y * 4 + (xy & 3), b = blockIdx.z;
   const size_t D3 = (size_t)D * D * D;
+  const int nzs = (D + 3) / 4;
   const float* src = X + (size_t)b * CIN * D3 + ((size_t)gx * D + gy) * D;
   for (int zt = 0; zt < nzb; zt++) {
     const int gz = 16 * zt + zl;
@@ -485,11 +492,12 @@ __global__ void __launch_bounds__(256) k_conv3d_tile_occupancy(const float* __re
     if (gx < D && gy < D && gz < D)
       for (int c = 0; c < CIN; c++) nz |= src[(size_t)c * D3 + gz] != 0.f;
     __syncthreads();
-    if (tid == 0) any_s = 0;
+    if (tid < 4) any_s[tid] = 0;
     __syncthreads();
-    if (nz) any_s = 1;
+    if (nz) any_s[zl >> 2] = 1;
     __syncthreads();
-    if (tid == 0) occ[(((size_t)b * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y) * nzb + zt] = any_s ? 1 : 0;
+    if (tid < 4 && 4 * zt + tid < nzs)
+      occ[(((size_t)b * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y) * nzs + 4 * zt + tid] = any_s[tid] ? 1 : 0;
   }
 }
 
@@ -605,7 +613,7 @@ int dlpd_conv3d_split_pack(const float* w, void* wp, int cin, int cout, int ks, 
 }
 
 size_t dlpd_conv3d_tile_occupancy_bytes(int B, int D) {
-  return (size_t)B * ((D + 3) / 4) * ((D + 3) / 4) * ((D + 15) / 16);
+  return (size_t)B * ((D + 3) / 4) * ((D + 3) / 4) * ((D + 3) / 4);
 }
 
 int dlpd_conv3d_tile_occupancy(const float* x, unsigned char* occ, int B, int cin, int D, void* stream) {

@@ -165,12 +165,12 @@ CONV_PRECISION = "split_bf16"      # default arithmetic of conv3d: "split_bf16" 
 
 
 def tile_occupancy(x, lib=None):
-    """Which 4 x 4 x 16 tiles of x (B, C, D, D, D) hold a non-zero value: uint8 (B, ceil(D/4), ceil(D/4), ceil(D/16)), the
+    """Which 4 x 4 x 4 cells of x (B, C, D, D, D) hold a non-zero value: uint8 (B, ceil(D/4), ceil(D/4), ceil(D/4)), the
     ``occupancy`` argument of conv3d."""
     lib = lib or get_lib()
     x = x.contiguous()
     B, cin, D = x.shape[0], x.shape[1], x.shape[2]
-    occ = torch.empty(B, (D + 3) // 4, (D + 3) // 4, (D + 15) // 16, dtype=torch.uint8, device=x.device)
+    occ = torch.empty(B, (D + 3) // 4, (D + 3) // 4, (D + 3) // 4, dtype=torch.uint8, device=x.device)
     assert occ.numel() == lib.call("dlpd_conv3d_tile_occupancy_bytes", B, D)
     lib.call("dlpd_conv3d_tile_occupancy", _ptr(x), _ptr(occ), B, cin, D, _stream(x.device))
     return occ
@@ -210,7 +210,7 @@ def conv3d(x, weight, relu=False, lib=None, stride=1, precision=None, occupancy=
                                       occupancy.numel() != lib.call("dlpd_conv3d_tile_occupancy_bytes", B, D)):
             raise RuntimeError("dlpd: conv3d occupancy does not belong to this input (shape %s)" % (tuple(occupancy.shape),))
         if return_occupancy and stride == 1:
-            occ_out = torch.empty(B, (D + 3) // 4, (D + 3) // 4, (D + 15) // 16, dtype=torch.uint8, device=x.device)
+            occ_out = torch.empty(B, (D + 3) // 4, (D + 3) // 4, (D + 3) // 4, dtype=torch.uint8, device=x.device)
         lib.call("dlpd_conv3d_split_sparse", _ptr(x), _ptr(wp), _ptr(y),
                  _ptr(occupancy.contiguous()) if occupancy is not None else None, _ptr(occ_out) if occ_out is not None else None,
                  B, cin, cout, D, ks, int(bool(relu)), int(stride), _stream(x.device))

@@ -280,9 +280,9 @@ int dlpd_conv3d_split(const float* x, const void* wp, float* y, int B, int cin, 
                       int stride, void* stream);
 /* Tile occupancy: the plugins' convolutions have no bias (ProteinRepresentationModels.py:85-96: bias=False), so an output
  * tile whose receptive field is all zero is zero, and a protein fills a fraction of its box.  occ (B, ceil(D/4), ceil(D/4),
- * ceil(D/16)) bytes, non-zero where the 4 x 4 x 16 tile of the volume holds a non-zero value in some channel:
- * dlpd_conv3d_tile_occupancy computes it for any (B, cin, D^3) tensor; dlpd_conv3d_split_sparse skips the tiles whose 27
- * neighbouring input tiles are empty (occ_in; null = dense) and writes the map of ITS output (occ_out; null = none; not
+ * ceil(D/4)) bytes, non-zero where the 4 x 4 x 4 cell of the volume holds a non-zero value in some channel:
+ * dlpd_conv3d_tile_occupancy computes it for any (B, cin, D^3) tensor; dlpd_conv3d_split_sparse skips the 4 x 4 x 16 output
+ * tiles whose neighbouring input cells (a superset of the halo) are empty (occ_in; null = dense) and writes the map of ITS output (occ_out; null = none; not
  * written for stride 2) -- the next layer's occ_in.  Results are bit-identical to dlpd_conv3d_split. */
 size_t dlpd_conv3d_tile_occupancy_bytes(int B, int D);
 int dlpd_conv3d_tile_occupancy(const float* x, unsigned char* occ, int B, int cin, int D, void* stream);

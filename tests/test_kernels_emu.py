@@ -819,7 +819,7 @@ def _sparse_conv_checks(lib, device, cin, cmid, cout, ks, D, lo, hi, B=1):
     w2 = torch.randn(cout, cmid, 3, 3, 3, generator=g) * 0.1
     x, w1, w2 = x.to(device), w1.to(device), w2.to(device)
     occ0 = ops.tile_occupancy(x, lib=lib)
-    assert occ0.shape == (B, (D + 3) // 4, (D + 3) // 4, (D + 15) // 16) and 0 < int(occ0.sum()) < occ0.numel()
+    assert occ0.shape == (B, (D + 3) // 4, (D + 3) // 4, (D + 3) // 4) and 0 < int(occ0.sum()) < occ0.numel()
     y1, occ1 = ops.conv3d(x, w1, relu=True, lib=lib, precision="split_bf16", occupancy=occ0, return_occupancy=True)
     y2, occ2 = ops.conv3d(y1, w2, relu=False, lib=lib, precision="split_bf16", occupancy=occ1, return_occupancy=True)
     d1 = ops.conv3d(x, w1, relu=True, lib=lib, precision="split_bf16")
