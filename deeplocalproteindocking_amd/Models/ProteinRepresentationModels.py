@@ -104,7 +104,7 @@ class E3MultiResRepr4x4(Module):
     # skip the all-zero tiles of the bias-free convolutions (same bits; ops.conv3d); DLPD_TILE_OCCUPANCY=0: compute everywhere
     use_tile_occupancy = os.environ.get("DLPD_TILE_OCCUPANCY", "1") != "0"
 
-    def _run(self, seq, x):
+    def _run(self, seq, x, occ=None, return_occupancy=False):
         """The Sequential.  GPU inference: Conv3d(+ReLU) pairs and the max-pool on the HIP kernels (exact f32 on
         the matrix cores), anything they cannot take is an error unless DLPD_ALLOW_TORCH_CONV=1; CPU / autograd:
         plain torch."""
@@ -113,8 +113,8 @@ class E3MultiResRepr4x4(Module):
         native = self.use_hip_conv and _hip_inference(x, self.hip_lib)
         # tile occupancy of x (ops.conv3d): the layers have no bias, so what lies outside the protein's neighbourhood stays
         # exactly zero from layer to layer and is not computed; one map is made of the input, every convolution writes its
-        # output's (None: unknown -- after the pooling, after a torch module -- and made again when a convolution needs it)
-        occ = None
+        # output's and so does the pooling (None: unknown -- after a torch module -- and made again when a layer needs it);
+        # ``occ`` = the map of x if the caller has it (the second Sequential takes the first one's)
         sparse = native and self.use_tile_occupancy and ops.CONV_PRECISION == "split_bf16"
         i = 0
         while i < len(mods):
@@ -139,18 +139,22 @@ class E3MultiResRepr4x4(Module):
                 ok = (m.kernel_size == 5 and m.stride == 2 and m.padding == 2 and m.dilation == 1 and not m.ceil_mode
                       and not m.return_indices and cubic)
                 if ok or not _torch_conv_allowed("MaxPool3d(%s, %s, %s)" % (m.kernel_size, m.stride, m.padding)):
-                    x = ops.maxpool3d_5s2(x, lib=self.hip_lib)
-                    occ = None
+                    if sparse:
+                        if occ is None:
+                            occ = ops.tile_occupancy(x, lib=self.hip_lib)
+                        x, occ = ops.maxpool3d_5s2(x, lib=self.hip_lib, occupancy=occ, return_occupancy=True)
+                    else:
+                        x = ops.maxpool3d_5s2(x, lib=self.hip_lib)
                     i += 1
                     continue
             x = m(x)
             occ = None
             i += 1
-        return x
+        return (x, occ if sparse else None) if return_occupancy else x
 
     def forward(self, volume):
-        vol1 = self._run(self.conv1, volume)
-        vol2 = self._run(self.conv2, vol1)
+        vol1, occ1 = self._run(self.conv1, volume, None, True)
+        vol2 = self._run(self.conv2, vol1, occ1)
         return [vol1, vol2]
 
 

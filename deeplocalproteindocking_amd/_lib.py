@@ -65,6 +65,7 @@ SIGNATURES = {
     "dlpd_zifft_preact_form": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _f, _i, _p]),
     "dlpd_zifft_real_part": (_i, [_p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "dlpd_maxpool3d_5s2": (_i, [_p, _p, _i, _i, _p]),
+    "dlpd_maxpool3d_5s2_sparse": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "dlpd_conv3d_supported": (_i, [_i, _i, _i, _i]),
     "dlpd_conv3d_packed_floats": (ctypes.c_size_t, [_i, _i, _i]),
     "dlpd_conv3d_pack": (_i, [_p, _p, _i, _i, _i, _p]),

@@ -570,12 +570,111 @@ __global__ void __launch_bounds__(256) k_maxpool3d_5s2(const float* __restrict__
   }
 }
 
+// The same pooling, tiled (round 5: the one-thread-per-output kernel above took 1.3 ms of the E3 plugin's 4.5 per batch -- 125
+// strided reads per output).  A block produces a 4 x 4 x 20 tile of one volume: its 11 x 11 x 43 inputs go to LDS once (43-float
+// runs; -inf outside the volume, as torch pads), then the window maximum is taken one axis at a time -- z, y, x: 5 + 5 + 5
+// comparisons instead of 125; a maximum does not depend on the order it is taken in.  occ_in (the input's occupancy cells,
+// dlpd_conv3d_tile_occupancy; C channels per map volume): a tile whose inputs are all in empty cells is +0.0 and is written
+// without reading them; occ_out: the cells of the OUTPUT grid that hold a non-zero value (zeroed by the host; any channel).
+#define DLPD_MP_OX 4
+#define DLPD_MP_OZ 20
+__global__ void __launch_bounds__(256) k_maxpool3d_5s2_tiled(const float* __restrict__ x, float* __restrict__ y, int D, int Do,
+                                                             int nzt, int C, const unsigned char* __restrict__ occ_in,
+                                                             unsigned char* __restrict__ occ_out) {
+  constexpr int OX = DLPD_MP_OX, OZ = DLPD_MP_OZ, IX = 2 * OX + 3, IZ = 2 * OZ + 3;
+  __shared__ float in[IX * IX * IZ];             // 20.8 KB
+  __shared__ float m1[IX * IX * OZ];             // max over z
+  __shared__ float m2[IX * OX * OZ];             // ... and y
+  __shared__ int flag[8];
+  const int tid = threadIdx.x;
+  const int vol = blockIdx.z / nzt, zt = blockIdx.z % nzt, b = vol / C;
+  const int ox0 = blockIdx.x * OX, oy0 = blockIdx.y * OX, oz0 = zt * OZ;
+  const int ix0 = 2 * ox0 - 2, iy0 = 2 * oy0 - 2, iz0 = 2 * oz0 - 2;
+  const float* src = x + (size_t)vol * D * D * D;
+  float* dst = y + (size_t)vol * Do * Do * Do;
+  bool empty = false;
+  if (occ_in) {                                  // (block-uniform) the occupancy cells the input region touches
+    const int nc = (D + 3) / 4;
+    const int cx0 = (ix0 < 0 ? 0 : ix0) >> 2, cy0 = (iy0 < 0 ? 0 : iy0) >> 2, cz0 = (iz0 < 0 ? 0 : iz0) >> 2;
+    const int cx1 = (ix0 + IX - 1 >= D ? D - 1 : ix0 + IX - 1) >> 2, cy1 = (iy0 + IX - 1 >= D ? D - 1 : iy0 + IX - 1) >> 2;
+    const int cz1 = (iz0 + IZ - 1 >= D ? D - 1 : iz0 + IZ - 1) >> 2;
+    const int nx = cx1 - cx0 + 1, ny = cy1 - cy0 + 1, nz = cz1 - cz0 + 1;
+    if (tid == 0) flag[0] = 0;
+    __syncthreads();
+    for (int i = tid; i < nx * ny * nz; i += 256) {
+      const int cz = cz0 + i % nz, cy = cy0 + (i / nz) % ny, cx = cx0 + i / (nz * ny);
+      if (occ_in[(((size_t)b * nc + cx) * nc + cy) * nc + cz]) flag[0] = 1;
+    }
+    __syncthreads();
+    empty = flag[0] == 0;
+  }
+  if (empty) {
+    for (int i = tid; i < OX * OX * OZ; i += 256) {
+      const int oz = oz0 + i % OZ, oy = oy0 + (i / OZ) % OX, ox = ox0 + i / (OZ * OX);
+      if (ox < Do && oy < Do && oz < Do) dst[((size_t)ox * Do + oy) * Do + oz] = 0.f;
+    }
+    return;
+  }
+  for (int i = tid; i < IX * IX * IZ; i += 256) {
+    const int zz = i % IZ, yy = (i / IZ) % IX, xx = i / (IZ * IX);
+    const int gx = ix0 + xx, gy = iy0 + yy, gz = iz0 + zz;
+    const bool ok = gx >= 0 && gx < D && gy >= 0 && gy < D && gz >= 0 && gz < D;
+    in[i] = ok ? src[((size_t)gx * D + gy) * D + gz] : -INFINITY;
+  }
+  __syncthreads();
+  for (int i = tid; i < IX * IX * OZ; i += 256) {
+    const int oz = i % OZ, r = i / OZ;
+    const float* p = in + r * IZ + 2 * oz;
+    m1[i] = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), p[4]);
+  }
+  __syncthreads();
+  for (int i = tid; i < IX * OX * OZ; i += 256) {
+    const int oz = i % OZ, oy = (i / OZ) % OX, xx = i / (OZ * OX);
+    const float* p = m1 + (xx * IX + 2 * oy) * OZ + oz;
+    m2[i] = fmaxf(fmaxf(fmaxf(p[0], p[OZ]), fmaxf(p[2 * OZ], p[3 * OZ])), p[4 * OZ]);
+  }
+  __syncthreads();
+  if (tid < 8) flag[tid] = 0;
+  __syncthreads();
+  for (int i = tid; i < OX * OX * OZ; i += 256) {
+    const int oz = i % OZ, oy = (i / OZ) % OX, ox = i / (OZ * OX);
+    const float* p = m2 + ((2 * ox) * OX + oy) * OZ + oz;
+    const float v = fmaxf(fmaxf(fmaxf(p[0], p[OX * OZ]), fmaxf(p[2 * OX * OZ], p[3 * OX * OZ])), p[4 * OX * OZ]);
+    if (ox0 + ox < Do && oy0 + oy < Do && oz0 + oz < Do) {
+      dst[((size_t)(ox0 + ox) * Do + oy0 + oy) * Do + oz0 + oz] = v;
+      if (occ_out && v != 0.f) flag[oz >> 2] = 1;              // (OZ = 20: five 4-voxel cells, aligned: oz0 is a multiple of 20)
+    }
+  }
+  if (occ_out) {
+    __syncthreads();
+    const int nco = (Do + 3) / 4;
+    if (tid < OZ / 4 && (oz0 >> 2) + tid < nco && flag[tid])
+      occ_out[(((size_t)b * nco + blockIdx.x) * nco + blockIdx.y) * nco + (oz0 >> 2) + tid] = 1;
+  }
+}
+
 extern "C" {
+
+size_t dlpd_conv3d_tile_occupancy_bytes(int B, int D);
+
+int dlpd_maxpool3d_5s2_sparse(const float* x, float* y, const unsigned char* occ_in, unsigned char* occ_out, int B, int C, int D,
+                              void* stream) {
+  if (!x || !y || B <= 0 || C <= 0 || D < 1) return DLPD_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int Do = (D + 4 - 5) / 2 + 1;
+  const int nzt = (Do + DLPD_MP_OZ - 1) / DLPD_MP_OZ, nxy = (Do + DLPD_MP_OX - 1) / DLPD_MP_OX;
+  if (occ_out && hipMemsetAsync(occ_out, 0, dlpd_conv3d_tile_occupancy_bytes(B, Do), st) != hipSuccess) return DLPD_ERR_LAUNCH;
+  if ((long long)B * C * nzt > 65535) return DLPD_ERR_UNSUPPORTED;
+  DLPD_LAUNCH(k_maxpool3d_5s2_tiled, dim3(nxy, nxy, B * C * nzt), dim3(256), 0, st, x, y, D, Do, nzt, C, occ_in, occ_out);
+  return dlpd_check_launch();
+}
 
 int dlpd_maxpool3d_5s2(const float* x, float* y, int nvol, int D, void* stream) {
   if (!x || !y || nvol <= 0 || D < 1) return DLPD_ERR_ARG;
   const int Do = (D + 4 - 5) / 2 + 1;
-  const size_t total = (size_t)nvol * Do * Do * Do;
+  if ((long long)nvol * ((Do + DLPD_MP_OZ - 1) / DLPD_MP_OZ) <= 65535)
+    return dlpd_maxpool3d_5s2_sparse(x, y, nullptr, nullptr, nvol, 1, D, stream);
+  const size_t total = (size_t)nvol * Do * Do * Do;             // (more volumes than a grid's z extent takes: the one-thread-per-output form)
   size_t nblk = (total + 255) / 256;
   if (nblk > 131072) nblk = 131072;
   DLPD_LAUNCH(k_maxpool3d_5s2, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x, y, nvol, D, Do);

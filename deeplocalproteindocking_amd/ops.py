@@ -249,12 +249,22 @@ def _packed_weights(weight, w, lib, device, split=False):
     return wp
 
 
-def maxpool3d_5s2(x, lib=None):
-    """MaxPool3d(kernel_size=5, stride=2, padding=2) of the E3 plugin, (B, C, D, D, D) float32 (inference)."""
+def maxpool3d_5s2(x, lib=None, occupancy=None, return_occupancy=False):
+    """MaxPool3d(kernel_size=5, stride=2, padding=2) of the E3 plugin, (B, C, D, D, D) float32 (inference).
+    occupancy: ``tile_occupancy(x)`` (or what the convolution that made x handed on) -- output tiles whose inputs lie in
+    empty cells are zeros and are written without reading them; return_occupancy: -> (y, the occupancy of y)."""
     lib = lib or get_lib()
     x = x.contiguous()
     B, C, D = x.shape[0], x.shape[1], x.shape[2]
     Do = (D - 1) // 2 + 1
     y = torch.empty(B, C, Do, Do, Do, dtype=torch.float32, device=x.device)
-    lib.call("dlpd_maxpool3d_5s2", _ptr(x), _ptr(y), B * C, D, _stream(x.device))
-    return y
+    if occupancy is None and not return_occupancy:
+        lib.call("dlpd_maxpool3d_5s2", _ptr(x), _ptr(y), B * C, D, _stream(x.device))
+        return y
+    if occupancy is not None and (occupancy.dtype != torch.uint8 or occupancy.device != x.device or
+                                  occupancy.numel() != lib.call("dlpd_conv3d_tile_occupancy_bytes", B, D)):
+        raise RuntimeError("dlpd: maxpool3d_5s2 occupancy does not belong to this input (shape %s)" % (tuple(occupancy.shape),))
+    occ_out = torch.empty(B, (Do + 3) // 4, (Do + 3) // 4, (Do + 3) // 4, dtype=torch.uint8, device=x.device) if return_occupancy else None
+    lib.call("dlpd_maxpool3d_5s2_sparse", _ptr(x), _ptr(y), _ptr(occupancy.contiguous()) if occupancy is not None else None,
+             _ptr(occ_out), B, C, D, _stream(x.device))
+    return (y, occ_out) if return_occupancy else y

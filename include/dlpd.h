@@ -292,6 +292,11 @@ int dlpd_conv3d_split_sparse(const float* x, const void* wp, float* y, const uns
 /* MaxPool3d(kernel 5, stride 2, padding 2) of the E3 plugin (ProteinRepresentationModels.py:101):
  * x (nvol, D^3) -> y (nvol, Do^3), Do = (D - 1) / 2 + 1. */
 int dlpd_maxpool3d_5s2(const float* x, float* y, int nvol, int D, void* stream);
+/* The same with occupancy maps (dlpd_conv3d_tile_occupancy): x (B, C, D^3); occ_in (the input's cells; null = read everything):
+ * output tiles whose inputs lie in empty cells are written as +0.0 without reading them; occ_out (null = none): the cells of
+ * the (B, C, Do^3) output that hold a non-zero value in some channel -- the next convolution's occ_in. */
+int dlpd_maxpool3d_5s2_sparse(const float* x, float* y, const unsigned char* occ_in, unsigned char* occ_out, int B, int C, int D,
+                              void* stream);
 
 /* Docker.update_top pick loop, src/Docker/Docker.py:89-98: per rotation the K picks in pick order
  * (incl. the zero-fill behaviour).  V (nb, nvox); out (nb, K). */

@@ -444,6 +444,14 @@ def test_conv3d_tile_occupancy_skips_empty_tiles_with_the_same_bits(dev, cin, cm
     _sparse_conv_checks(None, dev, cin, cmid, cout, ks, D, lo, hi, B=3)
 
 
+@pytest.mark.parametrize("C,D,lo,hi", [(16, 80, 22, 50), (5, 37, 0, 9), (32, 40, 30, 40)])
+def test_maxpool_tiled_with_occupancy_equals_torch(dev, C, D, lo, hi):
+    """The E3 plugin's pooling on the tiled kernel (separable maximum through LDS), with and without occupancy maps, at the
+    plugin's sizes and an odd one: torch's values exactly, and the map it hands on equals the map of its output."""
+    from test_kernels_emu import _sparse_pool_checks
+    _sparse_pool_checks(None, dev, C, D, lo, hi, B=3)
+
+
 def test_conv3d_stride2_and_se3_plugin_never_touch_torch_convolutions(dev, monkeypatch):
     """The stride-2 5^3 layer (ProteinRepresentationModels.py:51) on the matrix-core kernel at the reference's
     size (16 -> 32 channels, 80^3 -> 40^3), and the whole SE3MultiResReprScalar(8) forward with torch's conv3d

@@ -839,3 +839,26 @@ def _sparse_conv_checks(lib, device, cin, cmid, cout, ks, D, lo, hi, B=1):
 @pytest.mark.parametrize("cin,cmid,cout,ks,D,lo,hi", [(11, 16, 16, 5, 13, 1, 4), (5, 32, 16, 3, 17, 9, 15), (8, 16, 48, 5, 12, 0, 3)])
 def test_conv3d_tile_occupancy_skips_empty_tiles_with_the_same_bits(emu, cin, cmid, cout, ks, D, lo, hi):
     _sparse_conv_checks(emu, "cpu", cin, cmid, cout, ks, D, lo, hi)
+
+
+def _sparse_pool_checks(lib, device, C, D, lo, hi, B=1):
+    """MaxPool3d(5, 2, 2) on the tiled kernel: equal to torch's (a maximum of the same values), with an occupancy map of the
+    input the same bits as without, and the map it hands on equals the map of its output."""
+    from deeplocalproteindocking_amd import ops
+    x, g = _blob_input(B, C, D, 11 + D, lo, hi)
+    x[:, :, lo:hi, lo:hi, lo:hi] -= 0.3                             # (negative values too: the layer in front of the pooling has no ReLU)
+    x = x.to(device)
+    want = torch.nn.functional.max_pool3d(x.cpu(), kernel_size=5, stride=2, padding=2)
+    y0 = ops.maxpool3d_5s2(x, lib=lib)
+    assert torch.equal(y0.cpu(), want)
+    occ = ops.tile_occupancy(x, lib=lib)
+    y1, occ1 = ops.maxpool3d_5s2(x, lib=lib, occupancy=occ, return_occupancy=True)
+    assert torch.equal(y1, y0) and 0 < int(occ.sum()) < occ.numel()
+    assert torch.equal(occ1, ops.tile_occupancy(y0, lib=lib))
+    y2, occ2 = ops.maxpool3d_5s2(x, lib=lib, return_occupancy=True)
+    assert torch.equal(y2, y0) and torch.equal(occ2, occ1)
+
+
+@pytest.mark.parametrize("C,D,lo,hi", [(3, 13, 1, 5), (2, 40, 22, 31)])
+def test_maxpool_tiled_with_occupancy_equals_torch(emu, C, D, lo, hi):
+    _sparse_pool_checks(emu, "cpu", C, D, lo, hi)
