@@ -761,6 +761,16 @@ def test_dockE3_reference_configuration_on_gpu(tmp_path):
     assert max(abs(a[4] - b[4]) for a, b in zip(dk.top_list, want)) <= 1e-4 * scale
     assert sum(a[:4] == b[:4] for a, b in zip(dk.top_list, want)) >= K - 2
     assert dk.path == "fused"
+    # the plugin skipped the tiles that are zero away from the ligand (the default); computing everywhere gives the same list
+    assert repr_.use_tile_occupancy
+    skipping = list(dk.top_list)
+    repr_.use_tile_occupancy = False
+    try:
+        with torch.no_grad():
+            dk.dockE3(frec, flig, batch_size=2)
+    finally:
+        repr_.use_tile_occupancy = True
+    assert dk.top_list == skipping
     # the same at box 72 (no compiled plan): every batch's volumes inside the 80 / 40 engine
     L2 = 72
     want2, scale2 = _dock_reference_shape_e3(be, model.cpu(), frec, flig, R, L2, res, K)
