@@ -787,6 +787,13 @@ def e3_measurement(dev, nb, nsteps=6):
             return (time.perf_counter() - t0) / n * 1e3, r
         ms_proj, lig = timed(lambda: be.project(lc, ln, lo, L, res, dev, R=Rb, shift=dk.box_center))
         ms_repr, vols = timed(lambda: model.representation(lig))
+        ms_repr_dense = None
+        if getattr(repr_, "use_tile_occupancy", False):            # the same network computing every tile (same bits)
+            repr_.use_tile_occupancy = False
+            try:
+                ms_repr_dense, _ = timed(lambda: model.representation(lig))
+            finally:
+                repr_.use_tile_occupancy = True
         forb = lig.sum(dim=1)
 
         def engine_step():
@@ -820,6 +827,7 @@ def e3_measurement(dev, nb, nsteps=6):
                "rotations_per_launch": nb, "ms_projection": ms_proj, "ms_representation": ms_repr, "ms_engine": ms_eng,
                "ms_per_launch": min(ms_all, ms_serial), "ms_per_launch_serial": ms_serial, "ms_per_launch_docker_loop": ms_all,
                "tile_occupancy": bool(getattr(repr_, "use_tile_occupancy", False)),
+               "ms_representation_computing_every_tile": ms_repr_dense,
                "rot_per_s": nb / (min(ms_all, ms_serial) * 1e-3),
                "value": nb / (min(ms_all, ms_serial) * 1e-3) * (2.0 * L) ** 3,
                "unit": "pose scores/s", "ligand_atoms": natoms, "path": "fused engine on the batch's own volumes",
