@@ -306,7 +306,17 @@ def test_bench_eight_rank_launch_plumbing():
 # ---------------------------------------------------------------------------------------------------------------
 # the reference's production call (local_test.py:55: randomize_rot=True) on a rotation-sharded search
 # ---------------------------------------------------------------------------------------------------------------
-def _run_random_rot(rank, world, port, out, tmp, method="dockSE3", late_group=False, randR=None):
+def _random_rot_inputs(tmp):
+    """The receptor / ligand PDB files of the random-rotation cases, written ONCE by the test process: a rank only ever
+    reads them (two ranks writing the same path raced: one truncated the file the other was parsing)."""
+    from test_atoms import write_fake_pdb
+    frec, flig = os.path.join(str(tmp), "p5.pdb"), os.path.join(str(tmp), "p6.pdb")
+    write_fake_pdb(frec, 14, 5)
+    write_fake_pdb(flig, 9, 6)
+    return frec, flig
+
+
+def _run_random_rot(rank, world, port, out, tmp, frec, flig, method="dockSE3", late_group=False, randR=None):
     """One rank of Docker(randomize_rot=True).dockSE3 / dockE3 from PDB files on the emulated kernels.  Every rank has
     its OWN RNG state (global seed and rotation_seed differ per rank), as any rank-dependent seeding would give it; rank
     0 alone opens the .dat.  late_group: the process group is created AFTER the Docker (the matrix is then shared at the
@@ -317,7 +327,7 @@ def _run_random_rot(rank, world, port, out, tmp, method="dockSE3", late_group=Fa
     torch.set_num_threads(1)
     from emu_lib import emu_lib
     from oracle import docking_oracle as orc
-    from test_atoms import _assert_scores_are_informative, _tiny_model, _typed
+    from test_atoms import _assert_scores_are_informative, _tiny_model
     from deeplocalproteindocking_amd.Docker import Docker
     from deeplocalproteindocking_amd.Docker.Docker import random_rotation
     from deeplocalproteindocking_amd.Utils.FullAtom import CoordsBackend
@@ -327,8 +337,6 @@ def _run_random_rot(rank, world, port, out, tmp, method="dockSE3", late_group=Fa
     if world > 1 and not late_group:
         init()
     L, res, K = 32, 1.25, 40
-    frec, _, _, _ = _typed(tmp, 14, seed=5)
-    flig, _, _, _ = _typed(tmp, 9, seed=6)
     model = _tiny_model()
     # five neighbouring rotations: their best scores are close, so the merged list draws on both shards
     R = orc.euler_to_matrix(0.3 + 0.03 * np.arange(5), 1.1 - 0.02 * np.arange(5), -2.0 + 0.025 * np.arange(5))
@@ -360,7 +368,8 @@ def _run_random_rot(rank, world, port, out, tmp, method="dockSE3", late_group=Fa
 def _random_rot_case(tmp_path, method, late_group, base_port, counter_check=True):
     d2, d1 = tmp_path / "w2", tmp_path / "w1"
     d2.mkdir(), d1.mkdir()
-    out, procs = _spawn(_run_random_rot, 2, base_port + (os.getpid() % 1500), str(d2), method, late_group)
+    frec, flig = _random_rot_inputs(tmp_path)
+    out, procs = _spawn(_run_random_rot, 2, base_port + (os.getpid() % 1500), str(d2), frec, flig, method, late_group)
     _join(procs)
     r0, r1 = out[0], out[1]
     assert r0["own"] != r1["own"]                                  # the ranks drew different matrices ...
@@ -368,7 +377,7 @@ def _random_rot_case(tmp_path, method, late_group, base_port, counter_check=True
     assert r0["top"] == r1["top"] and len(r0["top"]) == 40
     assert len({t[0] % 2 for t in r0["top"]}) == 2                 # entries from both shards
     single = {}
-    _run_random_rot(0, 1, 0, single, str(d1), method, False, r0["randR"])
+    _run_random_rot(0, 1, 0, single, str(d1), frec, flig, method, False, r0["randR"])
     assert single[0]["top"] == r0["top"]
     assert single[0]["dat"] == r0["dat"] and len(r0["dat"].splitlines()) == 40
     if not counter_check:
@@ -377,7 +386,7 @@ def _random_rot_case(tmp_path, method, late_group, base_port, counter_check=True
     other = {}
     d3 = tmp_path / "w1b"
     d3.mkdir()
-    _run_random_rot(0, 1, 0, other, str(d3), method, False, r1["own"])
+    _run_random_rot(0, 1, 0, other, str(d3), frec, flig, method, False, r1["own"])
     assert other[0]["top"] != r0["top"]
 
 
@@ -555,3 +564,31 @@ def test_benchmark_sweep_target_the_plan_did_not_expect_keeps_clear_of_the_prepa
     _run_sweep(0, 1, 0, b, root, db, True, False, "SE3", 3)
     assert [(t["target"], t["prepared_ahead"]) for t in a[0]["rep"]["targets"]] == [("T0", False), ("T1", False), ("T2", True)]
     assert _dat_files(da) == _dat_files(db) and len(_dat_files(da)) == 3
+
+
+def test_no_rank_function_writes_an_input_file():
+    """Source check: the functions that run INSIDE a spawned rank (every `_spawn` target in this file and what
+    test_replay_local_test.py starts) never create a PDB file -- inputs are written once by the test process.  Two ranks
+    writing the same path is a race (one truncates the file the other parses), and these tests are the multi-rank
+    evidence of SURVEY 8(e)."""
+    import ast
+    import inspect
+    src = open(__file__).read()
+    tree = ast.parse(src)
+    funcs = {n.name: n for n in tree.body if isinstance(n, ast.FunctionDef)}
+    targets = set()
+    for n in ast.walk(tree):
+        if isinstance(n, ast.Call) and getattr(n.func, "id", "") == "_spawn" and isinstance(n.args[0], ast.Name):
+            targets.add(n.args[0].id)
+        if isinstance(n, ast.Call) and getattr(n.func, "attr", "") == "Process":
+            targets |= {k.value.id for k in n.keywords if k.arg == "target" and isinstance(k.value, ast.Name)}
+    targets.discard("target")                                       # _spawn's own parameter
+    assert {"_run", "_run8", "_gather_only", "_run_random_rot", "_run_sweep"} <= targets
+    writers = ("write_fake_pdb", "write_protein_like_pdb", "_typed", "_random_rot_inputs")
+    for name in sorted(targets):
+        body = ast.get_source_segment(src, funcs[name])
+        calls = {getattr(c.func, "id", getattr(c.func, "attr", "")) for c in ast.walk(funcs[name]) if isinstance(c, ast.Call)}
+        assert not calls & set(writers), (name, calls & set(writers))
+        if "_sweep_targets(" in body:                                # naming the files is fine, writing them is not
+            assert "write=True" not in body
+    assert inspect.signature(_sweep_targets).parameters["write"].default is False
