@@ -444,3 +444,22 @@ def test_product_library_has_no_lds_atomic_instruction():
             found |= set(re.findall(r"\bds_(?:add|sub|rsub|inc|dec|min|max|and|or|xor|mskor|cmpst|cmpswap|wrxchg|pk_add|append|consume)\w*", text))
     assert lines > 100000 and kernels > 50, (lines, kernels)          # the scan really saw the library's kernels
     assert not found, sorted(found)
+
+
+def test_history_holds_no_compiled_object():
+    """Built artefacts travel to the GPU box with the snapshot but stay out of the history (.gitignore): no tracked file
+    may be an ELF image or an offload bundle (a bundler extraction once committed 18 code objects)."""
+    import subprocess
+    if not os.path.isdir(os.path.join(ROOT, ".git")):
+        pytest.skip("not a git checkout (the GPU box's snapshot has no .git)")
+    files = subprocess.run(["git", "ls-files", "-z"], cwd=ROOT, capture_output=True, check=True).stdout.split(b"\0")
+    bad = []
+    for f in files:
+        p = os.path.join(ROOT.encode(), f)
+        if not f or not os.path.isfile(p):
+            continue
+        with open(p, "rb") as fh:
+            head = fh.read(24)
+        if head[:4] == b"\x7fELF" or head.startswith(b"__CLANG_OFFLOAD_BUNDLE__") or b".hipv4-" in f or b".host-x86_64" in f:
+            bad.append(f.decode())
+    assert not bad, bad
