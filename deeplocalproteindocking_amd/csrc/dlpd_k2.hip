@@ -59,6 +59,23 @@ extern "C" int dlpd_debug_read_stamps_k2(unsigned long long* host16) {
 #define DLPD_K2_DIRECT_OUT 1
 #endif
 #define DLPD_K2_THREADS(N) ((N) * 4)               // N/16 waves; each owns 8 pencils per step (wave-local FFT passes)
+// ROW-GROUP SHIFT (round 6).  Row `row` of the slab starts at row*RS + 8 * ((row / R1) & 1): the rows of every other group
+// of R1 rows sit 8 elements to the right, in the 8 spare elements of the row stride.  Why: the first column pass stores
+// rows R1*t + r, and the two t of a 16-lane ds_write_b64 group are R1 rows apart -- any row stride times 16 is 0 (mod 16
+// slots), so unshifted both t hit the same 8 slots (the kernel's one bank conflict: SQ_LDS_BANK_CONFLICT = 18 % of its
+// LDS-active cycles through round 5); shifted, the odd t use the other 8.  Every other access of the kernel touches rows
+// of ONE group parity per instruction (row phases: a wave's 8 rows lie in one group; column passes: rows t + 8r and
+// j + R1*r differ below bit log2(R1) only), so its conflict-free pattern moves as a whole.  The shift is part of the row
+// base (row phases) or of the compile-time offset (column passes): no instruction, no register.  64 bytes: 16-byte pair
+// accesses stay aligned.  Off: -DDLPD_K2_ROWSHIFT=0 (variant builds).
+#ifndef DLPD_K2_ROWSHIFT
+#define DLPD_K2_ROWSHIFT 1
+#endif
+template <int RS, int GS, int GX> struct ColAddrG {
+  static constexpr bool IS_ROW = false;
+  int base;      // swz(col)
+  DLPD_HD int operator()(int e) const { return e * RS + ((e >> GS) & 1) * GX + base; }
+};
 template <int N, int MODE> __global__ void __launch_bounds__(DLPD_K2_THREADS(N))
 k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __restrict__ out,
           int CT, int nb, int nsplit, long long rec_bstride, float scale, int transposed) {
@@ -80,6 +97,9 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
   constexpr bool DIRECT_OUT = DLPD_K2_DIRECT_OUT && MODE == 1 && InvP2::FULL && InvP2::PER == 2;
   // register hand-over forward-x pass 2 -> inverse-x pass 1 (power-of-two plans only)
   constexpr bool HANDOVER = InvP1::PER == 1 && InvP1::NBF == T && (R1 % T == 0) && FwdP2::NBF <= R1;
+  // row-group shift (above): power-of-two plans only (N = 80 keeps its blocked intermediates instead)
+  constexpr int GX = (DLPD_K2_ROWSHIFT && N != 80) ? 8 : 0, GS = (R1 == 16) ? 4 : 3;
+  static_assert(GX == 0 || ((1 << GS) == R1 && R1 >= 8 && RS >= N + GX), "groups of R1 rows, a wave's 8 rows in one group");
   DLPD_DYN_SHARED(cplx, S);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // 1-D grid of NZ*CT*nsplit blocks.  The batch is cut into nsplit parts handled by blocks whose
@@ -95,6 +115,7 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
   if (b_beg >= b_end) return;
   // row phase: lane = 8*q + t  (pencil q of the set, thread t); column phase: lane = 8*t + c8
   const int qr = lane >> 3, c8 = lane & 7;
+  auto rb = [&](int row) { return row * RS + ((row >> GS) & 1) * GX; };       // start of a slab row
   // Blocked intermediate of the two-pass transforms (FftPassW::store_blk) where it pays: the 10 x 8 plan of N = 80
   // (first-pass stores 104 / 80 -> 40 LDS-array cycles per pencil set); at N = 128 the column stores would go
   // 128 -> 64 by the same model, but the kernel measured 0.1 ms SLOWER with it (2.46 -> 2.56 ms), so it keeps the
@@ -131,21 +152,21 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
 #pragma unroll
       for (int j = 0; j < NLD; j++) {
         const int f = lane + 64 * j, row = wave * 8 + f / (L / 2), col = 2 * (f % (L / 2));
-        if (NA4 % 64 == 0 || f < NA4) slab_store_pair(S + row * RS, col, apref[j]);
+        if (NA4 % 64 == 0 || f < NA4) slab_store_pair(S + rb(row), col, apref[j]);
       }
     } else {
 #pragma unroll
       for (int j = 0; j < NLD; j++) {
         const int f = lane + 64 * j, y = f >> 2, row = wave * 8 + 2 * (f & 3);
         if (NA4 % 64 == 0 || f < NA4) {
-          S[row * RS + slab_swz(y)] = c_make(apref[j].x, apref[j].y);
-          S[(row + 1) * RS + slab_swz(y)] = c_make(apref[j].z, apref[j].w);
+          S[rb(row) + slab_swz(y)] = c_make(apref[j].x, apref[j].y);
+          S[rb(row + 1) + slab_swz(y)] = c_make(apref[j].z, apref[j].w);
         }
       }
     }
   };
   auto forward_rows = [&]() {                      // y-forward of the wave's rows 8w..8w+7 (wave-local)
-    const RowAddr<RS> ad = {(wave * 8 + qr) * RS};
+    const RowAddr<RS> ad = {rb(wave * 8 + qr)};
     const RowMid<R1 + 1> md = {ad.base};           // blocked intermediate (FftPassW::store_blk)
     const int tr = lane & 7;
     {
@@ -169,7 +190,7 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
 #pragma unroll
     for (int j = 0; j < NST; j++) {
       const int f = lane + 64 * j, row = set * 8 + f / (N / 2), col = 2 * (f % (N / 2));
-      const float4 v = slab_load_pair(S + row * RS, col);
+      const float4 v = slab_load_pair(S + rb(row), col);
       DLPD_STORE_STREAM(o + f, make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc));
     }
   };
@@ -203,7 +224,7 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
 #pragma unroll 1
     for (int set = wave; set < NSET; set += W) {
       const int col = set * 8 + c8;
-      const ColAddr<RS> ad = {slab_swz(col)};
+      const ColAddrG<RS, GS, GX> ad = {slab_swz(col)};
       const int tc = lane >> 3;
       // receptor values: the first set's were requested in the row phase (ahead of the second row set's output
       // stores), the second set's are requested here, before its first x pass
@@ -278,7 +299,7 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
     // wait for the write-back of the whole slab (A loads 0.25 ms, receptor loads 0.15 ms of 2.56: variant builds).
     auto inverse_rows_out = [&](int set) {
       if (MODE == 1) {
-        const RowAddr<RS> ad = {(set * 8 + qr) * RS};
+        const RowAddr<RS> ad = {rb(set * 8 + qr)};
         const int tr = lane & 7;
         const RowMid<R1 + 1> md = {ad.base};
         {
@@ -295,7 +316,7 @@ k_xy_corr(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __rest
           // bank-conflict free (lane groups of ds_read_b128, MI355X_MICROARCH.md).
           const int t2 = lane & 7, q2 = ((lane >> 5) & 1) | (((lane >> 3) & 3) << 1);
           InvP2A ps;
-          ps.load_pairs(S + (set * 8 + q2) * RS, t2, tw);
+          ps.load_pairs(S + rb(set * 8 + q2), t2, tw);
           float4* o = reinterpret_cast<float4*>(out + (((size_t)b * CT + c) * NZ + kz) * N * N + (size_t)(set * 8 + q2) * N);
 #pragma unroll
           for (int r = 0; r < R2; r++)
