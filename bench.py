@@ -46,12 +46,16 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 # SURVEY.md section 8(d), MB per rotation: stage-boundary model and compulsory floor
 SURVEY_MB_PER_ROT = {"config2": (3080.3, 468.9), "config1": (41.6, 6.1), "c48l80": (6003.7, 913.2),
-                     "real": (3054.6, 392.2)}
+                     "real": (3054.6, 392.2), "real_protein": (3054.6, 392.2)}
 WORKLOADS = {   # name: (C fine, L, C coarse, rotation-set angle, description)
     "config2": (48, 64, 0, 6, "BASELINE config 2: single synthetic 48-channel 64^3 pair"),
     "config1": (4, 32, 0, 20, "BASELINE config 1: single synthetic 4-channel 32^3 pair"),
     "c48l80": (48, 80, 0, 6, "BASELINE config 5 shape: synthetic 48-channel 80^3 pair (grid 160^3)"),
     "real": (16, 80, 32, 6, "reference model shapes (configs 4/5): synthetic [16 @ 80^3, 32 @ 40^3] pair (grid 160^3)"),
+    # the same shapes with PROTEIN-SHAPED contents: the E3 plugin's representation of a synthetic 160 / 110-residue pair
+    # (what Docker.dockSE3 searches, Docker.py:204-209,218) -- zero away from the protein, unlike "real"'s dense random volumes
+    "real_protein": (16, 80, 32, 6, "reference model shapes with protein-shaped contents: E3MultiResRepr4x4(8) representation "
+                                    "[16 @ 80^3, 32 @ 40^3] of a synthetic 160 / 110-residue pair (grid 160^3)"),
 }
 
 
@@ -71,6 +75,8 @@ def parse_args():
     ap.add_argument("--cpu_rotations", type=int, default=16,
                     help="rotations of the CPU baseline sample, spread over the four search groups (0: skip)")
     ap.add_argument("--no_real_shapes", action="store_true", help="skip the short N = 160 measurement")
+    ap.add_argument("--k1_occupancy", default="auto", choices=("auto", "on", "off"),
+                    help="per-rotation occupancy maps in the channels-last K1: auto = where the ligand leaves most cells empty")
     ap.add_argument("--no_pmc", action="store_true",
                     help="roofline.traffic from the committed profiles/ file instead of two rocprofv3 --pmc child passes of this run")
     ap.add_argument("--sustained_s", type=float, default=8.0,
@@ -268,22 +274,55 @@ def algorithmic_bytes(C, L, C1, nb, K, has_clash=True, unfused=False, HP=24, pre
     return alg
 
 
+def protein_pair_volumes(dev, L=80, res=1.25):
+    """Representation volumes of a synthetic protein-sized pair as Docker.dockSE3 prepares them (Docker.py:204-209): PDB
+    files -> typed coordinates -> 11-type densities at box 80 -> E3MultiResRepr4x4(multiplier=8) on the HIP convolutions;
+    forbidden volumes = the summed densities (Docker.py:221-225).  -> host tensors rec [fine, coarse], lig [...], recf, ligf"""
+    import tempfile
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from synth_pdb import write_protein_like_pdb
+    from deeplocalproteindocking_amd.Models import E3MultiResRepr4x4
+    from deeplocalproteindocking_amd.Utils.FullAtom import CoordsBackend
+    with tempfile.TemporaryDirectory(prefix="dlpd_rp_") as tmp, torch.no_grad():
+        be = CoordsBackend()
+        torch.manual_seed(3)
+        repr_ = E3MultiResRepr4x4(multiplier=8).to(dev).eval()
+        centre = torch.full((1, 3), L * res / 2.0, dtype=torch.double)
+        out = []
+        for name, nres, seed in (("rec", 160, 31), ("lig", 110, 32)):
+            f = os.path.join(tmp, name + ".pdb")
+            write_protein_like_pdb(f, nres, seed)
+            coords, _, rn, _, an, nat = be.pdb2coords([f])
+            typed, counts, offs = be.assign_types(coords, rn, an, nat)
+            a, b = be.get_bbox(typed, be.last_num_typed)
+            typed = be.translate(typed, -(a + b) * 0.5 + centre, be.last_num_typed)
+            dens = be.project(typed, counts, offs, L, res, dev)
+            vols = repr_(dens)
+            out.append(([v[0].float().cpu() for v in vols], dens.sum(dim=1)[0].float().cpu()))
+        (rec, recf), (lig, ligf) = out
+    return rec, lig, recf, ligf
+
+
 def build_workload(name, args, dev):
     """-> engine (receptor + ligand resident), host copies for the CPU baseline, metadata."""
     import torch
     from deeplocalproteindocking_amd.engine import DockingEngine
     from deeplocalproteindocking_amd.Models import SimpleFilter
     C, L, C1, angle, desc = WORKLOADS[name]
-    if name == args.workload:
+    if name == args.workload and name != "real_protein":
         C, L = args.channels or C, args.box or L
     t_host = time.perf_counter()
-    rec0, lig0 = synthetic_volumes(C, L, 0)
-    recf, ligf = synthetic_forbidden(L)
-    rec, lig = [rec0], [lig0]
-    if C1:
-        r1, l1 = synthetic_volumes(C1, L // 2, 1)
-        rec.append(r1)
-        lig.append(l1)
+    if name == "real_protein":
+        rec, lig, recf, ligf = protein_pair_volumes(dev, L)
+    else:
+        rec0, lig0 = synthetic_volumes(C, L, 0)
+        recf, ligf = synthetic_forbidden(L)
+        rec, lig = [rec0], [lig0]
+        if C1:
+            r1, l1 = synthetic_volumes(C1, L // 2, 1)
+            rec.append(r1)
+            lig.append(l1)
     torch.manual_seed(1)
     filt = SimpleFilter([C] + ([C1] if C1 else []))
     thr = clash_threshold(recf, ligf)
@@ -297,7 +336,8 @@ def build_workload(name, args, dev):
     host_inputs_s = time.perf_counter() - t_host
     eng = DockingEngine(L, C, *W, clip=5.0, threshold_clash=thr, has_clash=True, max_conf=args.max_conf,
                         batch=args.batch, device=dev, coarse_channels=C1, k3_form=args.k3_form, k1_form=getattr(args, "k1_form", 0),
-                        packed_receptor=not getattr(args, "natural_receptor", False))
+                        packed_receptor=not getattr(args, "natural_receptor", False),
+                        sparse_k1={"auto": None, "on": True, "off": False}[getattr(args, "k1_occupancy", "auto")])
     eng.set_receptor(rec[0], recf, rec[1] if C1 else None)
     eng.set_ligand(lig[0], ligf, lig[1] if C1 else None)
     return eng, dict(C=C, L=L, C1=C1, angle=angle, desc=desc, rec=rec, lig=lig, recf=recf, ligf=ligf, W=W, thr=thr,
@@ -545,13 +585,24 @@ def run_rank(args):
                             ("the first %d rotations of the visiting sequence: the complete set would exceed --strong_s %.0f s "
                              "at this world size" % (len(ids_strong), args.strong_s))}
 
-    real_shapes = c48l80 = e3 = None
+    real_shapes = c48l80 = e3 = real_protein = None
     if rank == 0 and world == 1 and args.workload == "config2" and not args.no_real_shapes:
         del eng
         torch.cuda.empty_cache()
         real_shapes = short_measurement("real", args, dev, R_all, nb)
         if not args.no_extras:
             c48l80 = short_measurement("c48l80", args, dev, R_all, nb, nsteps=12)
+            try:
+                # protein-shaped contents at the same shapes: with the K1 occupancy maps (the default for such a ligand) and without
+                real_protein = short_measurement("real_protein", args, dev, R_all, nb)
+                args.k1_occupancy, keep = "off", args.k1_occupancy
+                try:
+                    dense = short_measurement("real_protein", args, dev, R_all, nb)
+                finally:
+                    args.k1_occupancy = keep
+                real_protein["without_k1_occupancy_maps"] = {"ms_per_step": dense["ms_per_step"], "stages": dense["stages"]}
+            except Exception as exc:
+                real_protein = {"error": repr(exc)}
             try:
                 e3 = e3_measurement(dev, nb)
             except Exception as exc:                             # an extra must never cost the headline line
@@ -661,6 +712,8 @@ def run_rank(args):
             out["real_shapes"] = real_shapes
         if c48l80 is not None:
             out["c48l80"] = c48l80
+        if real_protein is not None:
+            out["real_protein"] = real_protein
         if e3 is not None:
             out["e3"] = e3
         if world == 1 and args.cpu_rotations > 0 and V_first is not None:
@@ -786,7 +839,20 @@ def e3_measurement(dev, nb, nsteps=6):
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / n * 1e3, r
         ms_proj, lig = timed(lambda: be.project(lc, ln, lo, L, res, dev, R=Rb, shift=dk.box_center))
-        ms_repr, vols = timed(lambda: model.representation(lig))
+        # the plugin as Docker._dockE3_fused calls it: tiles away from the ligand are neither computed nor written, the
+        # volumes travel with their occupancy maps (round 6); "written": the same with every voxel written (round 5)
+        import contextlib
+        with_maps = bool(getattr(repr_, "supports_unwritten_outputs", False)) and dk.unwritten_activations
+
+        def represent_as_docker(x):
+            with (repr_.outputs_with_maps() if with_maps else contextlib.nullcontext()):
+                return model.representation(x)
+
+        def maps_of(v):
+            o = (getattr(v[0], "dlpd_occupancy", None), getattr(v[1], "dlpd_occupancy", None) if eng.C1 else None)
+            return o if o[0] is not None else None
+        ms_repr, vols = timed(lambda: represent_as_docker(lig))
+        ms_repr_written, _ = timed(lambda: model.representation(lig))
         ms_repr_dense = None
         if getattr(repr_, "use_tile_occupancy", False):            # the same network computing every tile (same bits)
             repr_.use_tile_occupancy = False
@@ -797,14 +863,14 @@ def e3_measurement(dev, nb, nsteps=6):
         forb = lig.sum(dim=1)
 
         def engine_step():
-            eng.step(None, ids, volumes=(vols[0], forb, vols[1] if eng.C1 else None))
+            eng.step(None, ids, volumes=(vols[0], forb, vols[1] if eng.C1 else None), occupancy=maps_of(vols))
             eng.finish()
         ms_eng, _ = timed(engine_step)
 
         def body():
             l = be.project(lc, ln, lo, L, res, dev, R=Rb, shift=dk.box_center)
-            v = model.representation(l)
-            eng.step(None, ids, volumes=(v[0], l.sum(dim=1), v[1] if eng.C1 else None))
+            v = represent_as_docker(l)
+            eng.step(None, ids, volumes=(v[0], l.sum(dim=1), v[1] if eng.C1 else None), occupancy=maps_of(v))
         ms_serial, _ = timed(body, n=2 * nsteps)
         eng.finish()
         # ... and through Docker's own batch loop (Docker._dockE3_fused: the same two halves, one stream)
@@ -825,11 +891,15 @@ def e3_measurement(dev, nb, nsteps=6):
         out = {"workload": "Docker.dockE3 at box 80, E3MultiResRepr4x4(multiplier=8) -> %s channels, synthetic %d / %d-residue pair"
                            % (repr_.get_num_outputs(), 160, 110),
                "rotations_per_launch": nb, "ms_projection": ms_proj, "ms_representation": ms_repr, "ms_engine": ms_eng,
-               "ms_per_launch": min(ms_all, ms_serial), "ms_per_launch_serial": ms_serial, "ms_per_launch_docker_loop": ms_all,
+               # the headline is ONE designated measurement: Docker's own batch loop (Docker._dockE3_fused); the hand-written
+               # serial loop of the same three calls is reported beside it, not mixed in
+               "ms_per_launch": ms_all, "ms_per_launch_serial": ms_serial, "ms_per_launch_docker_loop": ms_all,
                "tile_occupancy": bool(getattr(repr_, "use_tile_occupancy", False)),
+               "unwritten_activations": with_maps,
+               "ms_representation_writing_every_voxel": ms_repr_written,
                "ms_representation_computing_every_tile": ms_repr_dense,
-               "rot_per_s": nb / (min(ms_all, ms_serial) * 1e-3),
-               "value": nb / (min(ms_all, ms_serial) * 1e-3) * (2.0 * L) ** 3,
+               "rot_per_s": nb / (ms_all * 1e-3),
+               "value": nb / (ms_all * 1e-3) * (2.0 * L) ** 3,
                "unit": "pose scores/s", "ligand_atoms": natoms, "path": "fused engine on the batch's own volumes",
                "conv_precision": __import__("deeplocalproteindocking_amd.ops", fromlist=["CONV_PRECISION"]).CONV_PRECISION}
         dk.release_engine()

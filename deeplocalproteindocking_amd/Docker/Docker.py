@@ -209,6 +209,9 @@ class Docker:
         # box sizes without a compiled plan: on the fused kernels inside the next compiled box (_dock_volumes_embedded);
         # False: the plan-free stand-alone ops (ops.VolumeConvolution._forward_generic), any box up to 128
         self.embed_uncompiled_boxes = True
+        # dockE3 on the fused engine: a plugin with occupancy maps does not write the tiles it skips (the engine goes by the
+        # maps); False: every voxel of the batch's volumes is written (same lists; DLPD_UNWRITTEN_ACTIVATIONS=0)
+        self.unwritten_activations = os.environ.get("DLPD_UNWRITTEN_ACTIVATIONS", "1") != "0"
         self._top = None            # DeviceTopList behind update_top()
         self.top_list = []
         self.engine = None
@@ -862,7 +865,19 @@ class Docker:
                 vols = tuple(None if buf is None else buf[:nb] for buf in ebuf[slot])
             return vols
 
+        # A plugin whose layers carry occupancy maps (E3MultiResRepr4x4: bias-free convolutions) hands the maps on with its
+        # volumes; the engine's K1 then never reads an empty cell, so the plugin need not WRITE the tiles it skips
+        # (``outputs_with_maps``).  Not with an embedded box: the copy into the larger box reads every voxel.
+        import contextlib
+        rep = getattr(self.docking_model, "representation", None)
+        with_maps = (not Lc) and bool(getattr(rep, "supports_unwritten_outputs", False)) and self.unwritten_activations
         for bid in batches:
-            ligand, ligand_volumes = represent(bid)
+            with (rep.outputs_with_maps() if with_maps else contextlib.nullcontext()):
+                ligand, ligand_volumes = represent(bid)
             bid_dev = torch.as_tensor(bid, dtype=torch.int32).to(dev)
-            eng.step(None, bid_dev, volumes=volumes_of(ligand, ligand_volumes, len(bid), 0))
+            occ = None
+            if not Lc:
+                o0 = getattr(ligand_volumes[0], "dlpd_occupancy", None)
+                o1 = getattr(ligand_volumes[1], "dlpd_occupancy", None) if eng.C1 else None
+                occ = (o0, o1) if (o0 is not None or o1 is not None) else None
+            eng.step(None, bid_dev, volumes=volumes_of(ligand, ligand_volumes, len(bid), 0), occupancy=occ)

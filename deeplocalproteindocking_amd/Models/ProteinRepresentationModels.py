@@ -103,8 +103,27 @@ class E3MultiResRepr4x4(Module):
     use_hip_conv = True
     # skip the all-zero tiles of the bias-free convolutions (same bits; ops.conv3d); DLPD_TILE_OCCUPANCY=0: compute everywhere
     use_tile_occupancy = os.environ.get("DLPD_TILE_OCCUPANCY", "1") != "0"
+    # Unwritten activations (round 6): inside ``with repr.outputs_with_maps():`` the tile-occupancy layers do not WRITE the
+    # tiles they skip either (that was most of the plugin's time per dockE3 batch) and never read a cell their input's map
+    # marks empty; the returned volumes then carry their maps (``v.dlpd_occupancy``, uint8 (B, ceil(D/4)^3)) and are
+    # undefined where the map is 0 -- only for a consumer that goes by the map (the fused engine's volumes path,
+    # DockingEngine.step(occupancy=...); Docker._dockE3_fused is the one caller).  Outside the context every voxel is written.
+    supports_unwritten_outputs = True
+    _unwritten = False
 
-    def _run(self, seq, x, occ=None, return_occupancy=False):
+    def outputs_with_maps(self):
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            old, self._unwritten = self._unwritten, True
+            try:
+                yield self
+            finally:
+                self._unwritten = old
+        return ctx()
+
+    def _run(self, seq, x, occ=None, return_occupancy=False, unwritten=False):
         """The Sequential.  GPU inference: Conv3d(+ReLU) pairs and the max-pool on the HIP kernels (exact f32 on
         the matrix cores), anything they cannot take is an error unless DLPD_ALLOW_TORCH_CONV=1; CPU / autograd:
         plain torch."""
@@ -116,6 +135,7 @@ class E3MultiResRepr4x4(Module):
         # output's and so does the pooling (None: unknown -- after a torch module -- and made again when a layer needs it);
         # ``occ`` = the map of x if the caller has it (the second Sequential takes the first one's)
         sparse = native and self.use_tile_occupancy and ops.CONV_PRECISION == "split_bf16"
+        unwritten = bool(unwritten and sparse)
         i = 0
         while i < len(mods):
             m = mods[i]
@@ -130,7 +150,7 @@ class E3MultiResRepr4x4(Module):
                         if occ is None:
                             occ = ops.tile_occupancy(x, lib=self.hip_lib)
                         x, occ = ops.conv3d(x, m.weight, relu=relu, lib=self.hip_lib, stride=m.stride[0], occupancy=occ,
-                                            return_occupancy=True)
+                                            return_occupancy=True, unwritten=unwritten and m.stride[0] == 1)
                     else:
                         x = ops.conv3d(x, m.weight, relu=relu, lib=self.hip_lib, stride=m.stride[0])
                     i += 2 if relu else 1
@@ -142,7 +162,7 @@ class E3MultiResRepr4x4(Module):
                     if sparse:
                         if occ is None:
                             occ = ops.tile_occupancy(x, lib=self.hip_lib)
-                        x, occ = ops.maxpool3d_5s2(x, lib=self.hip_lib, occupancy=occ, return_occupancy=True)
+                        x, occ = ops.maxpool3d_5s2(x, lib=self.hip_lib, occupancy=occ, return_occupancy=True, unwritten=unwritten)
                     else:
                         x = ops.maxpool3d_5s2(x, lib=self.hip_lib)
                     i += 1
@@ -153,8 +173,13 @@ class E3MultiResRepr4x4(Module):
         return (x, occ if sparse else None) if return_occupancy else x
 
     def forward(self, volume):
-        vol1, occ1 = self._run(self.conv1, volume, None, True)
-        vol2 = self._run(self.conv2, vol1, occ1)
+        uw = self._unwritten
+        vol1, occ1 = self._run(self.conv1, volume, None, True, unwritten=uw)
+        vol2, occ2 = self._run(self.conv2, vol1, occ1, True, unwritten=uw and occ1 is not None)
+        if occ1 is not None:                       # (tile-occupancy path: the maps travel with the volumes)
+            vol1.dlpd_occupancy = occ1
+        if occ2 is not None:
+            vol2.dlpd_occupancy = occ2
         return [vol1, vol2]
 
 

@@ -31,6 +31,7 @@ SIGNATURES = {
     "dlpd_rotate_trilinear": (_i, [_p, _p, _p, _i, _i, _i, _ll, _f, _p]),
     "dlpd_zfft": (_i, [_p, _p, _p, _i, _i, _i, _ll, _i, _f, _p]),
     "dlpd_zfft_into": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _ll, _i, _f, _p]),
+    "dlpd_zfft_volumes_occ": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _ll, _p]),
     "dlpd_project_atoms": (_i, [_p, _p, _p, _p, _f, _f, _f, _p, _i, _i, _i, _i, _f, _i, _p]),
     "dlpd_project_atoms_ext": (_i, [_p, _p, _p, _p, _f, _f, _f, _p, _i, _i, _i, _i, _f, _i, _f, _i, _f, _f, _p]),
     "dlpd_rfft3d_padded": (_i, [_p, _p, _p, _i, _i, _f, _p]),
@@ -48,6 +49,8 @@ SIGNATURES = {
     "dlpd_zfft_oriented_ext": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _ll, _i, _f, _i, _i, _p]),
     "dlpd_zfft_channels_last_ext": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
     "dlpd_zfft_channels_last_form": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
+    "dlpd_rotated_occupancy": (_i, [_p, _p, _p, _i, _i, _f, _p]),
+    "dlpd_zfft_channels_last_occ": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
     "dlpd_xy_correlate_oriented": (_i, [_p, _p, _p, _i, _i, _i, _ll, _i, _p]),
     "dlpd_score_rotations_oriented": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _f, _i, _i, _f, _f,
                                            _p, _p, _p, _i, _p]),
@@ -65,7 +68,7 @@ SIGNATURES = {
     "dlpd_zifft_preact_form": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _f, _i, _p]),
     "dlpd_zifft_real_part": (_i, [_p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "dlpd_maxpool3d_5s2": (_i, [_p, _p, _i, _i, _p]),
-    "dlpd_maxpool3d_5s2_sparse": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "dlpd_maxpool3d_5s2_sparse": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "dlpd_conv3d_supported": (_i, [_i, _i, _i, _i]),
     "dlpd_conv3d_packed_floats": (ctypes.c_size_t, [_i, _i, _i]),
     "dlpd_conv3d_pack": (_i, [_p, _p, _i, _i, _i, _p]),
@@ -76,7 +79,7 @@ SIGNATURES = {
     "dlpd_conv3d_split": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dlpd_conv3d_tile_occupancy_bytes": (_sz, [_i, _i]),
     "dlpd_conv3d_tile_occupancy": (_i, [_p, _p, _i, _i, _i, _p]),
-    "dlpd_conv3d_split_sparse": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "dlpd_conv3d_split_sparse": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dlpd_topk_workspace_bytes": (_sz, [_i, _i]),
     "dlpd_topk_select": (_i, [_p, _i, _ll, _i, _p, _p, _p, _p]),
     "dlpd_topk_select_cand": (_i, [_p, _i, _ll, _i, _p, _p, _p, _p, _p, _i, _p]),

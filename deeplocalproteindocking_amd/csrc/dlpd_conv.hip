@@ -272,7 +272,7 @@ template <int KS> struct ConvSCfg {
   static constexpr int XS = TX + KS - 1, YS = TY + KS - 1, ZS = ZT + KS - 1;
   static constexpr int NVOX = XS * YS * ZS;
   static constexpr int NTAP = KS * KS * KS, NTG = (NTAP + 3) / 4;
-  static constexpr size_t LDS_BYTES = (size_t)3 * NVOX * 16 + (size_t)NTG * 4 * sizeof(int) + 32;
+  static constexpr size_t LDS_BYTES = (size_t)3 * NVOX * 16 + (size_t)NTG * 4 * sizeof(int) + 32 + 64;   // + any_s[8] + nbr_s[54]
 };
 
 // x = h + m + l in bf16 (bit patterns)
@@ -294,15 +294,20 @@ DLPD_D void conv_split3(float x, unsigned& h, unsigned& m, unsigned& l) {
 // occ_in, for free).  Bit-identical: the full computation of such a
 // tile adds products of zeros to a +0.0 accumulator.  Either pointer may be null (dense behaviour / no map produced).
 // SPARSE = false is the kernel without any of this (its own instantiation: the dense callers run the code they always ran).
+// UNWRITTEN ACTIVATIONS (round 6, `unwritten` != 0, needs occ_in): the tensors travel together with their maps -- a block
+// whose neighbourhood is empty writes NOTHING (its cells stay 0 in occ_out), and no voxel of a cell that occ_in marks
+// empty is ever read: the staging takes it as the zero it stands for (the cell may hold zeros a computed tile wrote, or
+// memory nobody wrote).  Same values in every cell a map marks; the zeros of the other cells exist only in the map.
 template <int KS, int COUT, int RELU, int STRIDE, bool SPARSE> __global__ void __launch_bounds__(ConvSCfg<KS>::NT)
 k_conv3d_bf16x3(const float* __restrict__ X, const float4* __restrict__ Wp, float* __restrict__ Y, int CIN, int D,
                 int cout_total, int co_base, int nzb, const unsigned char* __restrict__ occ_in,
-                unsigned char* __restrict__ occ_out) {
+                unsigned char* __restrict__ occ_out, int unwritten) {
   typedef ConvSCfg<KS> C;
   constexpr int MT = COUT / 16, H = C::H, NTG = C::NTG, NVOX = C::NVOX, RW = C::RW, NT = C::NT;
   DLPD_DYN_SHARED(float4, Xs);                                 // [3][NVOX] 16-byte cells
   int* toff = reinterpret_cast<int*>(Xs + 3 * NVOX);           // [4 NTG] voxel offset of every tap (0 for the padding taps)
   int* any_s = toff + 4 * NTG;                                 // [8] block-wide flags of the tile-occupancy logic
+  unsigned char* nbr_s = reinterpret_cast<unsigned char*>(any_s + 8);   // [54] occ_in of the neighbourhood (0 outside the volume)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int x0 = blockIdx.x * C::TX, y0 = blockIdx.y * C::TY, b = blockIdx.z / nzb, z0 = (blockIdx.z % nzb) * C::ZT;
   const int ntx = gridDim.x, nty = gridDim.y, tzb = blockIdx.z % nzb;
@@ -313,13 +318,16 @@ k_conv3d_bf16x3(const float* __restrict__ X, const float4* __restrict__ Wp, floa
     if (tid < 54) {                                            // 3 x 3 tile columns x the 6 z cells [4 tzb - 1, 4 tzb + 4]
       const int nzs = (D + 3) / 4;
       const int nx = (int)blockIdx.x + tid / 18 - 1, ny = (int)blockIdx.y + (tid / 6) % 3 - 1, nz = 4 * tzb + tid % 6 - 1;
-      if (nx >= 0 && nx < ntx && ny >= 0 && ny < nty && nz >= 0 && nz < nzs &&
-          occ_in[(((size_t)b * ntx + nx) * nty + ny) * nzs + nz])
-        any_s[0] = 1;                                          // (plain store of the same value by whoever finds one)
+      const bool full = nx >= 0 && nx < ntx && ny >= 0 && ny < nty && nz >= 0 && nz < nzs &&
+                        occ_in[(((size_t)b * ntx + nx) * nty + ny) * nzs + nz];
+      nbr_s[tid] = full ? 1 : 0;
+      if (full) any_s[0] = 1;                                  // (plain store of the same value by whoever finds one)
     }
     __syncthreads();
     empty = any_s[0] == 0;
+    if (empty && unwritten) return;                            // (block-uniform) nothing read, nothing written
   }
+  const bool by_map = SPARSE && occ_in && unwritten;           // voxels of empty cells are zeros that nobody may have written
   const size_t D3 = (size_t)D * D * D;
   const float* Xb = X + (size_t)b * CIN * D3;
   const int kg = lane >> 4, n = lane & 15;
@@ -347,7 +355,9 @@ k_conv3d_bf16x3(const float* __restrict__ X, const float4* __restrict__ Wp, floa
     for (int v = tid; v < NVOX; v += NT) {
       const int zz = v % C::ZS, yy = (v / C::ZS) % C::YS, xx = v / (C::ZS * C::YS);
       const int gx = x0 + xx - H, gy = y0 + yy - H, gz = z0 + zz - H;
-      const bool ok = gx >= 0 && gx < D && gy >= 0 && gy < D && gz >= 0 && gz < D;
+      bool ok = gx >= 0 && gx < D && gy >= 0 && gy < D && gz >= 0 && gz < D;
+      if (by_map)      // (gx >> 2) - blockIdx.x + 1 in 0..2 (halo <= 2), (gz >> 2) - 4 tzb + 1 in 0..5: the 54 cells loaded above
+        ok = ok && nbr_s[(((gx >> 2) - (int)blockIdx.x + 1) * 3 + ((gy >> 2) - (int)blockIdx.y + 1)) * 6 + ((gz >> 2) - 4 * tzb + 1)];
       const float* src = Xb + ((size_t)(ok ? gx : 0) * D + (ok ? gy : 0)) * D + (ok ? gz : 0);
       unsigned hh[8], mm[8], ll[8];
 #pragma unroll
@@ -526,13 +536,13 @@ __global__ void __launch_bounds__(256) k_conv3d_split_pack(const float* __restri
 
 template <int KS, int COUT> static int launch_conv_split(const float* X, const float4* W, float* Y, int B, int CIN, int D,
                                                          int relu, int stride, int cout_total, int co_base, hipStream_t st,
-                                                         const unsigned char* occ_in, unsigned char* occ_out) {
+                                                         const unsigned char* occ_in, unsigned char* occ_out, int unwritten) {
   typedef ConvSCfg<KS> C;
   const int nzb = (D + C::ZT - 1) / C::ZT;
   dim3 grid((D + C::TX - 1) / C::TX, (D + C::TY - 1) / C::TY, B * nzb), block(C::NT);
 #define DLPD_CS1(R, S, SP) { int rc = dlpd_set_max_dyn_shared((const void*)k_conv3d_bf16x3<KS, COUT, R, S, SP>, C::LDS_BYTES); if (rc) return rc; \
     DLPD_LAUNCH((k_conv3d_bf16x3<KS, COUT, R, S, SP>), grid, block, C::LDS_BYTES, st, X, W, Y, CIN, D, cout_total, co_base, nzb, \
-                occ_in, occ_out); }
+                occ_in, occ_out, unwritten); }
 #define DLPD_CS(R, S) { if (occ_in || occ_out) DLPD_CS1(R, S, true) else DLPD_CS1(R, S, false) }
   if (stride == 2) { if (relu) DLPD_CS(1, 2) else DLPD_CS(0, 2) }
   else { if (relu) DLPD_CS(1, 1) else DLPD_CS(0, 1) }
@@ -542,35 +552,8 @@ template <int KS, int COUT> static int launch_conv_split(const float* X, const f
 }
 
 // MaxPool3d(kernel 5, stride 2, padding 2) of the E3 plugin (ProteinRepresentationModels.py:101): out-of-range
-// taps do not take part (torch pads with -inf).  One thread per output voxel, z fastest; the 125 taps of
-// neighbouring outputs overlap, so the reads are served by L1/L2.
-__global__ void __launch_bounds__(256) k_maxpool3d_5s2(const float* __restrict__ x, float* __restrict__ y, int nvol,
-                                                       int D, int Do) {
-  const size_t total = (size_t)nvol * Do * Do * Do;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int oz = (int)(i % Do), oy = (int)((i / Do) % Do), ox = (int)((i / ((size_t)Do * Do)) % Do);
-    const size_t v = i / ((size_t)Do * Do * Do);
-    const float* src = x + v * (size_t)D * D * D;
-    float m = -INFINITY;
-    for (int dx = -2; dx <= 2; dx++) {
-      const int ix = 2 * ox + dx;
-      if (ix < 0 || ix >= D) continue;
-      for (int dy = -2; dy <= 2; dy++) {
-        const int iy = 2 * oy + dy;
-        if (iy < 0 || iy >= D) continue;
-        const float* row = src + ((size_t)ix * D + iy) * D;
-#pragma unroll
-        for (int dz = -2; dz <= 2; dz++) {
-          const int iz = 2 * oz + dz;
-          if (iz >= 0 && iz < D) m = fmaxf(m, row[iz]);
-        }
-      }
-    }
-    y[i] = m;
-  }
-}
-
-// The same pooling, tiled (round 5: the one-thread-per-output kernel above took 1.3 ms of the E3 plugin's 4.5 per batch -- 125
+// taps do not take part (torch pads with -inf).
+// Tiled (round 5: a one-thread-per-output kernel took 1.3 ms of the E3 plugin's 4.5 per batch -- 125
 // strided reads per output).  A block produces a 4 x 4 x 20 tile of one volume: its 11 x 11 x 43 inputs go to LDS once (43-float
 // runs; -inf outside the volume, as torch pads), then the window maximum is taken one axis at a time -- z, y, x: 5 + 5 + 5
 // comparisons instead of 125; a maximum does not depend on the order it is taken in.  occ_in (the input's occupancy cells,
@@ -580,7 +563,7 @@ __global__ void __launch_bounds__(256) k_maxpool3d_5s2(const float* __restrict__
 #define DLPD_MP_OZ 20
 __global__ void __launch_bounds__(256) k_maxpool3d_5s2_tiled(const float* __restrict__ x, float* __restrict__ y, int D, int Do,
                                                              int nzt, int C, const unsigned char* __restrict__ occ_in,
-                                                             unsigned char* __restrict__ occ_out) {
+                                                             unsigned char* __restrict__ occ_out, int unwritten) {
   constexpr int OX = DLPD_MP_OX, OZ = DLPD_MP_OZ, IX = 2 * OX + 3, IZ = 2 * OZ + 3;
   __shared__ float in[IX * IX * IZ];             // 20.8 KB
   __shared__ float m1[IX * IX * OZ];             // max over z
@@ -608,6 +591,7 @@ __global__ void __launch_bounds__(256) k_maxpool3d_5s2_tiled(const float* __rest
     __syncthreads();
     empty = flag[0] == 0;
   }
+  if (empty && unwritten) return;                // unwritten activations (k_conv3d_bf16x3): the map says it all
   if (empty) {
     for (int i = tid; i < OX * OX * OZ; i += 256) {
       const int oz = oz0 + i % OZ, oy = oy0 + (i / OZ) % OX, ox = ox0 + i / (OZ * OX);
@@ -619,7 +603,10 @@ __global__ void __launch_bounds__(256) k_maxpool3d_5s2_tiled(const float* __rest
     const int zz = i % IZ, yy = (i / IZ) % IX, xx = i / (IZ * IX);
     const int gx = ix0 + xx, gy = iy0 + yy, gz = iz0 + zz;
     const bool ok = gx >= 0 && gx < D && gy >= 0 && gy < D && gz >= 0 && gz < D;
-    in[i] = ok ? src[((size_t)gx * D + gy) * D + gz] : -INFINITY;
+    // (unwritten activations: a voxel of an empty cell is the zero its map stands for and is not read)
+    const int nc = (D + 3) / 4;
+    const bool zero = ok && unwritten && occ_in && !occ_in[(((size_t)b * nc + (gx >> 2)) * nc + (gy >> 2)) * nc + (gz >> 2)];
+    in[i] = zero ? 0.f : (ok ? src[((size_t)gx * D + gy) * D + gz] : -INFINITY);
   }
   __syncthreads();
   for (int i = tid; i < IX * IX * OZ; i += 256) {
@@ -658,27 +645,31 @@ extern "C" {
 size_t dlpd_conv3d_tile_occupancy_bytes(int B, int D);
 
 int dlpd_maxpool3d_5s2_sparse(const float* x, float* y, const unsigned char* occ_in, unsigned char* occ_out, int B, int C, int D,
-                              void* stream) {
-  if (!x || !y || B <= 0 || C <= 0 || D < 1) return DLPD_ERR_ARG;
+                              int unwritten, void* stream) {
+  if (!x || !y || B <= 0 || C <= 0 || D < 1 || (unwritten && !occ_in)) return DLPD_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int Do = (D + 4 - 5) / 2 + 1;
   const int nzt = (Do + DLPD_MP_OZ - 1) / DLPD_MP_OZ, nxy = (Do + DLPD_MP_OX - 1) / DLPD_MP_OX;
   if (occ_out && hipMemsetAsync(occ_out, 0, dlpd_conv3d_tile_occupancy_bytes(B, Do), st) != hipSuccess) return DLPD_ERR_LAUNCH;
-  if ((long long)B * C * nzt > 65535) return DLPD_ERR_UNSUPPORTED;
-  DLPD_LAUNCH(k_maxpool3d_5s2_tiled, dim3(nxy, nxy, B * C * nzt), dim3(256), 0, st, x, y, D, Do, nzt, C, occ_in, occ_out);
-  return dlpd_check_launch();
+  // a grid's z extent holds 65,535 blocks: more (volume, z tile) pairs than that go in several launches of whole map volumes
+  const int per = 65535 / (C * nzt);                            // batch entries (C volumes each) per launch
+  if (per < 1) return DLPD_ERR_UNSUPPORTED;
+  const size_t D3 = (size_t)D * D * D, Do3 = (size_t)Do * Do * Do;
+  for (int b0 = 0; b0 < B; b0 += per) {
+    const int nbl = (B - b0 < per) ? B - b0 : per;
+    DLPD_LAUNCH(k_maxpool3d_5s2_tiled, dim3(nxy, nxy, nbl * C * nzt), dim3(256), 0, st, x + (size_t)b0 * C * D3, y + (size_t)b0 * C * Do3,
+                D, Do, nzt, C, occ_in ? occ_in + dlpd_conv3d_tile_occupancy_bytes(b0, D) : nullptr,
+                occ_out ? occ_out + dlpd_conv3d_tile_occupancy_bytes(b0, Do) : nullptr, unwritten);
+    int rc = dlpd_check_launch();
+    if (rc) return rc;
+  }
+  return DLPD_OK;
 }
 
 int dlpd_maxpool3d_5s2(const float* x, float* y, int nvol, int D, void* stream) {
   if (!x || !y || nvol <= 0 || D < 1) return DLPD_ERR_ARG;
   const int Do = (D + 4 - 5) / 2 + 1;
-  if ((long long)nvol * ((Do + DLPD_MP_OZ - 1) / DLPD_MP_OZ) <= 65535)
-    return dlpd_maxpool3d_5s2_sparse(x, y, nullptr, nullptr, nvol, 1, D, stream);
-  const size_t total = (size_t)nvol * Do * Do * Do;             // (more volumes than a grid's z extent takes: the one-thread-per-output form)
-  size_t nblk = (total + 255) / 256;
-  if (nblk > 131072) nblk = 131072;
-  DLPD_LAUNCH(k_maxpool3d_5s2, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x, y, nvol, D, Do);
-  return dlpd_check_launch();
+  return dlpd_maxpool3d_5s2_sparse(x, y, nullptr, nullptr, nvol, 1, D, 0, stream);      // (chunked launches for many volumes)
 }
 
 size_t dlpd_conv3d_packed_floats(int cin, int cout, int ks) {
@@ -723,16 +714,18 @@ int dlpd_conv3d_tile_occupancy(const float* x, unsigned char* occ, int B, int ci
 }
 
 int dlpd_conv3d_split_sparse(const float* x, const void* wp, float* y, const unsigned char* occ_in, unsigned char* occ_out,
-                             int B, int cin, int cout, int D, int ks, int relu, int stride, void* stream);
+                             int B, int cin, int cout, int D, int ks, int relu, int stride, int unwritten, void* stream);
 
 int dlpd_conv3d_split(const float* x, const void* wp, float* y, int B, int cin, int cout, int D, int ks, int relu, int stride,
                       void* stream) {
-  return dlpd_conv3d_split_sparse(x, wp, y, nullptr, nullptr, B, cin, cout, D, ks, relu, stride, stream);
+  return dlpd_conv3d_split_sparse(x, wp, y, nullptr, nullptr, B, cin, cout, D, ks, relu, stride, 0, stream);
 }
 
 int dlpd_conv3d_split_sparse(const float* x, const void* wp, float* y, const unsigned char* occ_in, unsigned char* occ_out,
-                             int B, int cin, int cout, int D, int ks, int relu, int stride, void* stream) {
+                             int B, int cin, int cout, int D, int ks, int relu, int stride, int unwritten, void* stream) {
   if (!x || !wp || !y || B <= 0 || (stride != 1 && stride != 2)) return DLPD_ERR_ARG;
+  // unwritten activations: the output is only meaningful with its map, which the strided form does not produce
+  if (unwritten && (!occ_in || !occ_out || stride != 1)) return DLPD_ERR_ARG;
   if (!dlpd_conv3d_supported(cin, cout, ks, D)) return DLPD_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (stride != 1) occ_out = nullptr;                          // (the strided output has another tiling)
@@ -742,10 +735,10 @@ int dlpd_conv3d_split_sparse(const float* x, const void* wp, float* y, const uns
     const int gw = conv_group_width(cout, g), base = 32 * g;
     const float4* wg = reinterpret_cast<const float4*>(wp) + per32 * g;
     int rc = DLPD_ERR_UNSUPPORTED;
-    if (ks == 3 && gw == 16) rc = launch_conv_split<3, 16>(x, wg, y, B, cin, D, relu, stride, cout, base, st, occ_in, occ_out);
-    else if (ks == 3 && gw == 32) rc = launch_conv_split<3, 32>(x, wg, y, B, cin, D, relu, stride, cout, base, st, occ_in, occ_out);
-    else if (ks == 5 && gw == 16) rc = launch_conv_split<5, 16>(x, wg, y, B, cin, D, relu, stride, cout, base, st, occ_in, occ_out);
-    else if (ks == 5 && gw == 32) rc = launch_conv_split<5, 32>(x, wg, y, B, cin, D, relu, stride, cout, base, st, occ_in, occ_out);
+    if (ks == 3 && gw == 16) rc = launch_conv_split<3, 16>(x, wg, y, B, cin, D, relu, stride, cout, base, st, occ_in, occ_out, unwritten);
+    else if (ks == 3 && gw == 32) rc = launch_conv_split<3, 32>(x, wg, y, B, cin, D, relu, stride, cout, base, st, occ_in, occ_out, unwritten);
+    else if (ks == 5 && gw == 16) rc = launch_conv_split<5, 16>(x, wg, y, B, cin, D, relu, stride, cout, base, st, occ_in, occ_out, unwritten);
+    else if (ks == 5 && gw == 32) rc = launch_conv_split<5, 32>(x, wg, y, B, cin, D, relu, stride, cout, base, st, occ_in, occ_out, unwritten);
     if (rc) return rc;
   }
   return DLPD_OK;

@@ -167,7 +167,7 @@ extern "C" int dlpd_debug_read_stamps_k1(unsigned long long* host16) {
 template <int N> __global__ void __launch_bounds__((N / 4) * FftPlan<N>::T)
 k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* __restrict__ A,
               int CT, int nb, long long vol_bstride, int do_rotate, float c0, int CT_out, int c_base,
-              int transposed, const float4* __restrict__ quads, int ext) {
+              int transposed, const float4* __restrict__ quads, int ext, const unsigned char* __restrict__ occ) {
   constexpr int L = N / 2, NZ = N / 2 + 1, RS = N + 1, NP = L / 2;
   constexpr int T = FftPlan<N>::T, R1 = FftPlan<N>::R1, R2 = FftPlan<N>::R2;
   constexpr int NT = NP * T;
@@ -226,10 +226,30 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
                   : trilinear_fetch(v, L, px, py, pz);
     }
   } else {
+    // occ (given volumes only, untransposed): the batch entry's occupancy map, one byte per 4 x 4 x 4 cell (the maps of
+    // dlpd_conv3d_split_sparse): voxels of empty cells are the zeros the map stands for and are NOT read (with unwritten
+    // activations nobody wrote them); a plane whose cells are all empty goes out as zeros without a transform
+    constexpr int NC = (L + 3) / 4;
+    const unsigned char* ob = occ ? occ + ((size_t)b * NC + (x >> 2)) * NC * NC : nullptr;
+    if (ob) {
+      __shared__ int occ_any;
+      if (tid == 0) occ_any = 0;
+      __syncthreads();
+      for (int i = tid; i < NC * NC; i += NT)
+        if (ob[i]) occ_any = 1;                                // (plain store of the same value by whoever finds one)
+      __syncthreads();
+      if (!occ_any) {                                          // (block-uniform)
+        cplx* a = A + ((size_t)b * CT_out + c_base + c) * NZ * L * L + (size_t)x * L;
+        for (int s = tid; s < NP * NZ; s += NT)
+          DLPD_STORE_STREAM(reinterpret_cast<float4*>(a + (size_t)(s / NP) * L * L + 2 * (s % NP)), make_float4(0.f, 0.f, 0.f, 0.f));
+        return;
+      }
+    }
     for (int s = tid; s < L * L; s += NT) {
       const int y = s / L, z = s % L;
       // transposed: this block is the plane y_orig = x, its in-plane index runs over x_orig
-      Sf[((y >> 1) * RS + z) * 2 + (y & 1)] = tr_flag ? v[((size_t)y * L + x) * L + z] : v[((size_t)x * L + y) * L + z];
+      const bool zero = ob && !ob[(y >> 2) * NC + (z >> 2)];
+      Sf[((y >> 1) * RS + z) * 2 + (y & 1)] = zero ? 0.f : (tr_flag ? v[((size_t)y * L + x) * L + z] : v[((size_t)x * L + y) * L + z]);
     }
   }
   DLPD_STAMP(0);
@@ -284,9 +304,15 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
 //   rows, which puts the 8-byte stores of a voxel's lanes (channel quads 4 YG/2 pencils apart: same bank otherwise)
 //   on disjoint banks.
 // ------------------------------------------------------------------------------------------
-template <int N> __global__ void __launch_bounds__(K1ClCfg<N>::NP * FftPlan<N>::T)
+// OCC (round 6, its own instantiation: the dense callers run the code they always ran): `occ` (nb, ceil(L/4)^3) bytes,
+// [x cell][y cell][z cell] per rotation, 0 = every sample of that 4 x 4 x 4 cell of the ROTATED volume is zero
+// (dlpd_rotated_occupancy: a conservative map made from the stored ligand's own map).  A real ligand's representation is
+// zero away from the protein, so most pencils of a rotated volume are empty: a task in an empty cell skips its sixteen
+// loads (the sample is the +0.0 the sum of zero products is), a block whose cells are all empty skips the transform too
+// and writes its zeros.  Exact; same spectra as without the map.
+template <int N, bool OCC> __global__ void __launch_bounds__(K1ClCfg<N>::NP * FftPlan<N>::T)
 k_rotate_zfft_cl(const float4* __restrict__ cl, const float* __restrict__ R, cplx* __restrict__ A,
-                 int C, int Cq, int nb, float c0, int CT_out, int c_base, int ext) {
+                 int C, int Cq, int nb, float c0, int CT_out, int c_base, int ext, const unsigned char* __restrict__ occ) {
   constexpr int L = N / 2, NZ = N / 2 + 1, NP = K1ClCfg<N>::NP, CC = K1ClCfg<N>::CC, YG = K1ClCfg<N>::YG, NPR = YG / 2;
   constexpr int LPV = CC / 4, SKEW = 16 / LPV;         // lanes per voxel; bank skew (complex) between channel quads
   static_assert(CC * NPR == NP && L % YG == 0 && (NP * FftPlan<N>::T) % 64 == 0, "whole waves of pencils per block");
@@ -303,6 +329,31 @@ k_rotate_zfft_cl(const float4* __restrict__ cl, const float* __restrict__ R, cpl
   if (seq / per >= gper || g >= groups) return;
   const int inner = seq % per, yg = inner / nchunk, chunk = inner % nchunk;
   const int b = g / L, x = g % L;
+  constexpr int NC = (L + 3) / 4, YC = YG / 4;                 // cells per axis; y cells of a block's rows
+  static_assert(YG % 4 == 0, "a block's rows are whole cells");
+  __shared__ unsigned char occ_s[OCC ? YC * NC : 1];
+  __shared__ int occ_any;
+  if (OCC) {
+    const unsigned char* ob = occ + (((size_t)b * NC + (x >> 2)) * NC + (yg * YG >> 2)) * NC;
+    if (tid == 0) occ_any = 0;
+    __syncthreads();
+    if (tid < YC * NC) {
+      const unsigned char o = ob[tid];
+      occ_s[tid] = o;
+      if (o) occ_any = 1;                                      // (plain store of the same value by whoever finds one)
+    }
+    __syncthreads();
+    if (!occ_any) {                                            // (block-uniform) nothing to gather or transform: the zeros go out
+      for (int s = tid; s < NP * NZ; s += NT) {
+        const int pm = s % NP, k = s / NP;
+        const int c = chunk * CC + pm / NPR, m = pm % NPR;
+        if (c < C)
+          DLPD_STORE_STREAM(reinterpret_cast<float4*>(A + (((size_t)b * CT_out + c_base + c) * NZ + k) * L * L + (size_t)x * L +
+                                                      yg * YG + 2 * m), make_float4(0.f, 0.f, 0.f, 0.f));
+      }
+      return;
+    }
+  }
   init_twiddles<N>(tw, tid, NT);
   {
     const K1ClRot rot = k1cl_load_rotation(R + (size_t)b * 9);
@@ -310,7 +361,10 @@ k_rotate_zfft_cl(const float4* __restrict__ cl, const float* __restrict__ R, cpl
       const int q = task % LPV, z = (task / LPV) % L, m = (task / LPV) / L;
       const float4* src = cl + chunk * (CC / 4) + q;
       float4 acc[2];
-      k1cl_sample_rows(src, Cq, L, ext, c0, rot, x, yg * YG + 2 * m, z, acc);
+      if (OCC && !occ_s[((2 * m) >> 2) * NC + (z >> 2)])       // rows 2m, 2m + 1 lie in one cell
+        acc[0] = acc[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      else
+        k1cl_sample_rows(src, Cq, L, ext, c0, rot, x, yg * YG + 2 * m, z, acc);
       // rows 2m (real part) and 2m+1 (imaginary part) of the four channels' pencils
       cplx* P = S + ((4 * q) * NPR + m) * RS + SKEW * q + z;
       P[0] = c_make(acc[0].x, acc[1].x);
@@ -369,17 +423,55 @@ __global__ void __launch_bounds__(256) k_make_channels_last(const float* __restr
 }
 
 template <int N> static int launch_k1_cl(const float4* cl, const float* R, cplx* A, int C, int nb, float c0, hipStream_t st,
-                                         int CT_out, int c_base, int ext = 0) {
+                                         int CT_out, int c_base, int ext = 0, const unsigned char* occ = nullptr) {
   constexpr int L = N / 2, RS = N + DLPD_K1CL_PAD;
   const int Cq = ((C + DLPD_K1CL_CC - 1) / DLPD_K1CL_CC) * (DLPD_K1CL_CC / 4);
   const size_t shmem = (size_t)(K1ClCfg<N>::NP * RS + N) * sizeof(cplx);
-  int rc = dlpd_set_max_dyn_shared((const void*)k_rotate_zfft_cl<N>, shmem);
-  if (rc) return rc;
   const int per = (L / K1ClCfg<N>::YG) * (Cq / (K1ClCfg<N>::CC / 4));
   const int gper = (nb * L + 7) / 8;
   dim3 grid((unsigned)(8 * gper * per)), block(K1ClCfg<N>::NP * FftPlan<N>::T);
-  DLPD_LAUNCH((k_rotate_zfft_cl<N>), grid, block, shmem, st, cl, R, A, C, Cq, nb, c0, CT_out, c_base, (ext > 0 && ext < L) ? ext : L);
+  const int e = (ext > 0 && ext < L) ? ext : L;
+  if (occ) {
+    int rc = dlpd_set_max_dyn_shared((const void*)k_rotate_zfft_cl<N, true>, shmem);
+    if (rc) return rc;
+    DLPD_LAUNCH((k_rotate_zfft_cl<N, true>), grid, block, shmem, st, cl, R, A, C, Cq, nb, c0, CT_out, c_base, e, occ);
+  } else {
+    int rc = dlpd_set_max_dyn_shared((const void*)k_rotate_zfft_cl<N, false>, shmem);
+    if (rc) return rc;
+    DLPD_LAUNCH((k_rotate_zfft_cl<N, false>), grid, block, shmem, st, cl, R, A, C, Cq, nb, c0, CT_out, c_base, e, occ);
+  }
   return dlpd_check_launch();
+}
+
+// occ_out[b][cell] = 1 unless every sample of output cell `cell` of the volume rotated by R[b] is certainly zero: the samples
+// of the cell's 4^3 voxels lie within +-e_a of the mapped cell centre on source axis a (e_a = 1.5 * the absolute row sum
+// of the sample matrix) and read the corners floor(p), floor(p) + 1 -- if every source cell that range touches is empty in
+// occ_src (one map for all channels of the stored ligand, dlpd_conv3d_tile_occupancy), all their products are zero.
+// Same sample map as k1cl_sample_rows (p = c0 + M (voxel - c0), M columns r0..r2 | r3..r5 | r6..r8).
+__global__ void __launch_bounds__(256) k_rotated_occupancy(const unsigned char* __restrict__ occ_src, const float* __restrict__ R,
+                                                           unsigned char* __restrict__ occ_out, int nb, int L, float c0) {
+  const int nc = (L + 3) / 4, nc3 = nc * nc * nc;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb * nc3; i += gridDim.x * blockDim.x) {
+    const int b = i / nc3, cell = i % nc3, cz = cell % nc, cy = (cell / nc) % nc, cx = cell / (nc * nc);
+    const float* r = R + (size_t)b * 9;
+    // centre of the cell's voxels that exist (the last cell of a box that is no multiple of 4 is smaller)
+    const float hx = 0.5f * (min(4 * cx + 3, L - 1) - 4 * cx), hy = 0.5f * (min(4 * cy + 3, L - 1) - 4 * cy),
+                hz = 0.5f * (min(4 * cz + 3, L - 1) - 4 * cz);
+    const float dx = 4 * cx + hx - c0, dy = 4 * cy + hy - c0, dz = 4 * cz + hz - c0;
+    bool any = false;
+    int lo[3], hi[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const float s = c0 + (r[a] * dx + r[3 + a] * dy + r[6 + a] * dz);
+      const float e = fabsf(r[a]) * hx + fabsf(r[3 + a]) * hy + fabsf(r[6 + a]) * hz + 1e-3f * (1.f + fabsf(s));   // (+ rounding slack)
+      lo[a] = max((int)floorf(s - e), 0) >> 2;
+      hi[a] = min((int)floorf(s + e) + 1, L - 1) >> 2;
+    }
+    for (int sx = lo[0]; sx <= hi[0]; sx++)
+      for (int sy = lo[1]; sy <= hi[1]; sy++)
+        for (int sz = lo[2]; sz <= hi[2]; sz++) any |= occ_src[(sx * nc + sy) * nc + sz] != 0;
+    occ_out[i] = any ? 1 : 0;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1206,12 +1298,13 @@ template <int HP> static int launch_filter_vec(const float* conv0, int C0, long 
 // ------------------------------------------------------------------------------------------
 template <int N> static int launch_k1(const float* vol, const float* R, cplx* A, int CT, int nb, long long vbs,
                                       int do_rotate, float c0, hipStream_t st, int CT_out = 0, int c_base = 0,
-                                      int transposed = 0, const float4* quads = nullptr, int ext = 0) {
+                                      int transposed = 0, const float4* quads = nullptr, int ext = 0,
+                                      const unsigned char* occ = nullptr) {
   constexpr int L = N / 2;
   const int groups = ((CT * nb + 7) / 8) * 8;
   dim3 grid(groups * L), block((N / 4) * FftPlan<N>::T);
   DLPD_LAUNCH((k_rotate_zfft<N>), grid, block, 0, st, vol, R, A, CT, nb, vbs, do_rotate, c0,
-              CT_out > 0 ? CT_out : CT, c_base, transposed ? 1 : 0, quads, (ext > 0 && ext < L) ? ext : L);
+              CT_out > 0 ? CT_out : CT, c_base, transposed ? 1 : 0, quads, (ext > 0 && ext < L) ? ext : L, occ);
   return dlpd_check_launch();
 }
 
@@ -1366,6 +1459,21 @@ int dlpd_zfft_oriented_ext(const float* vol, const float* R, void* wsA, int nb, 
   }
 }
 
+// given volumes (no rotation) with their occupancy maps: occ (nb, ceil(L/4)^3) bytes, one map per batch entry (all CT channels)
+int dlpd_zfft_volumes_occ(const float* vol, const unsigned char* occ, void* wsA, int nb, int CT, int CT_out, int c_base, int L,
+                          long long vol_bstride, void* stream) {
+  if (!vol || !occ || !wsA || nb <= 0 || CT <= 0 || c_base < 0 || c_base + CT > CT_out) return DLPD_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  cplx* A = (cplx*)wsA;
+  switch (L) {
+    case 32: return launch_k1<64>(vol, nullptr, A, CT, nb, vol_bstride, 0, 0.f, st, CT_out, c_base, 0, nullptr, 0, occ);
+    case 40: return launch_k1<80>(vol, nullptr, A, CT, nb, vol_bstride, 0, 0.f, st, CT_out, c_base, 0, nullptr, 0, occ);
+    case 64: return launch_k1<128>(vol, nullptr, A, CT, nb, vol_bstride, 0, 0.f, st, CT_out, c_base, 0, nullptr, 0, occ);
+    case 80: return launch_k1<160>(vol, nullptr, A, CT, nb, vol_bstride, 0, 0.f, st, CT_out, c_base, 0, nullptr, 0, occ);
+    default: return DLPD_ERR_UNSUPPORTED;
+  }
+}
+
 int dlpd_zfft_oriented(const float* vol, const float* R, void* wsA, int nb, int CT, int CT_out, int c_base, int L,
                        long long vol_bstride, int do_rotate, float center, int transposed, void* stream) {
   return dlpd_zfft_oriented_ext(vol, R, wsA, nb, CT, CT_out, c_base, L, vol_bstride, do_rotate, center, transposed, 0, stream);
@@ -1432,6 +1540,33 @@ int dlpd_zfft_channels_last_form(const float* cl, const float* R, void* wsA, int
     case 40: return launch_k1_cl<80>(c4, R, A, C, nb, center, st, CT_out, c_base, extent);
     case 64: return launch_k1_cl<128>(c4, R, A, C, nb, center, st, CT_out, c_base, extent);
     case 80: return launch_k1_cl<160>(c4, R, A, C, nb, center, st, CT_out, c_base, extent);
+    default: return DLPD_ERR_UNSUPPORTED;
+  }
+}
+
+// occ_src (ceil(L/4)^3 bytes: the stored ligand's cells, all channels) -> occ_out (nb maps): the cells of each ROTATED volume
+// that can hold a non-zero sample (conservative); R as K1 takes it
+int dlpd_rotated_occupancy(const unsigned char* occ_src, const float* R, unsigned char* occ_out, int nb, int L, float center,
+                           void* stream) {
+  if (!occ_src || !R || !occ_out || nb <= 0 || L <= 0) return DLPD_ERR_ARG;
+  const int nc = (L + 3) / 4, total = nb * nc * nc * nc;
+  DLPD_LAUNCH(k_rotated_occupancy, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, occ_src, R, occ_out, nb, L,
+              center);
+  return dlpd_check_launch();
+}
+
+// dlpd_zfft_channels_last_ext with the rotated volumes' occupancy maps (dlpd_rotated_occupancy): empty cells are not gathered
+int dlpd_zfft_channels_last_occ(const float* cl, const float* R, const unsigned char* occ, void* wsA, int nb, int C, int CT_out,
+                                int c_base, int L, float center, int extent, void* stream) {
+  if (!cl || !R || !occ || !wsA || nb <= 0 || C <= 0 || c_base < 0 || c_base + C > CT_out || extent < 0 || extent > L) return DLPD_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  cplx* A = (cplx*)wsA;
+  const float4* c4 = (const float4*)cl;
+  switch (L) {
+    case 32: return launch_k1_cl<64>(c4, R, A, C, nb, center, st, CT_out, c_base, extent, occ);
+    case 40: return launch_k1_cl<80>(c4, R, A, C, nb, center, st, CT_out, c_base, extent, occ);
+    case 64: return launch_k1_cl<128>(c4, R, A, C, nb, center, st, CT_out, c_base, extent, occ);
+    case 80: return launch_k1_cl<160>(c4, R, A, C, nb, center, st, CT_out, c_base, extent, occ);
     default: return DLPD_ERR_UNSUPPORTED;
   }
 }

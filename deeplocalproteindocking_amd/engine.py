@@ -127,7 +127,7 @@ class DockingEngine:
                  fine_unfused=None, channels_last=None, k3_form=0, coarse_center=None, extent=None,
                  orient=True, quads=True, prefilter=True, packed_receptor=True,
                  rotation_scale=1.0, coarse_rotation_scale=None, rotation_axis_order="xyz", clip_mode="output",
-                 rotation_transpose=False, keep_receptor_spectrum=False, k1_form=0):
+                 rotation_transpose=False, keep_receptor_spectrum=False, k1_form=0, sparse_k1=None):
         """coarse_channels > 0: the reference's two-resolution layout -- C channels at L^3 plus
         ``coarse_channels`` at (L/2)^3 (ProteinRepresentationModels.py:72-76); W1 is (H, C+coarse).
         extent < L: the volumes are extent^3 boxes in the corner of the L^3 ones (a box size without a compiled plan
@@ -210,6 +210,12 @@ class DockingEngine:
         if self._spectrum_is_temporary and self.recP is not None:
             self.recF = None
         self.prefilter = bool(prefilter)
+        # Search-side sparsity (round 6): a ligand whose channels are zero in most 4^3 cells of its box (any real protein's
+        # representation) gets per-rotation occupancy maps, and the channels-last K1 skips what they mark empty -- same
+        # spectra.  None: decided per ligand in set_ligand (on below SPARSE_K1_MAX_FILL of the cells occupied); True / False force it.
+        self.sparse_k1_wanted = sparse_k1
+        self.sparse_k1 = self.sparse_k1_coarse = False
+        self.lig_fill = self.lig_fill_coarse = None
         self.window = None
         if self.extent:
             # the reference's (2 extent)^3 translation grid inside this engine's (2L)^3 one: index t for 0 <= t <= extent
@@ -289,6 +295,8 @@ class DockingEngine:
                 "k3_unfused": bool(self.fine_unfused), "topk_candidate_lists": bool(self.prefilter),
                 "k2_packed_receptor": {"fine": self.recP is not None, "coarse": self.recP1 is not None},
                 "embedded_extent": self.extent or None,
+                "k1_occupancy_maps": {"fine": bool(self.sparse_k1), "coarse": bool(self.sparse_k1_coarse),
+                                      "ligand_cells_occupied": {"fine": self.lig_fill, "coarse": self.lig_fill_coarse}},
                 "rotation": {"center": self.center, "scale": self.rot_scale, "axis_order": self.rot_axis_order,
                              "transpose": self.rot_transpose},
                 "clip_mode": self.clip_mode}
@@ -356,6 +364,43 @@ class DockingEngine:
         else:
             self.lib.call("dlpd_xy_correlate_oriented", _ptr(wsA), _ptr(rec), _ptr(wsB), nb, CT, L, 0, tr, st)
 
+    SPARSE_K1_MAX_FILL = 0.7
+
+    def _ligand_occupancy(self):
+        """Cell maps of the stored ligand (all score channels) and the decision whether K1 goes by per-rotation maps."""
+        from . import ops
+        self.sparse_k1 = self.sparse_k1_coarse = False
+        if not self.use_cl or self.sparse_k1_wanted is False:
+            return
+        nc = (self.L + 3) // 4
+        self.occ_src = ops.tile_occupancy(self.lig[: self.C].unsqueeze(0), lib=self.lib)
+        self.lig_fill = float(self.occ_src.float().mean())
+        self.sparse_k1 = bool(self.sparse_k1_wanted) or self.lig_fill < self.SPARSE_K1_MAX_FILL
+        if self.sparse_k1 and not hasattr(self, "occ_rot"):
+            self.occ_rot = torch.empty(self.batch, nc, nc, nc, dtype=torch.uint8, device=self.device)
+        if self.C1:
+            nc1 = (self.L1 + 3) // 4
+            self.occ_src1 = ops.tile_occupancy(self.lig1.unsqueeze(0), lib=self.lib)
+            self.lig_fill_coarse = float(self.occ_src1.float().mean())
+            self.sparse_k1_coarse = bool(self.sparse_k1_wanted) or self.lig_fill_coarse < self.SPARSE_K1_MAX_FILL
+            if self.sparse_k1_coarse and not hasattr(self, "occ_rot1"):
+                self.occ_rot1 = torch.empty(self.batch, nc1, nc1, nc1, dtype=torch.uint8, device=self.device)
+
+    def _k1_channels_last(self, coarse, R, nb, st):
+        """Rotation + z transform of the score channels from the channels-last copy, by occupancy maps where the ligand is sparse."""
+        call = self.lib.call
+        if coarse:
+            cl, wsA, C, CT, L, c0, ext, sparse = self.ligcl1, self.wsA1, self.C1, self.C1, self.L1, self.center1, self.extent1, self.sparse_k1_coarse
+            occ_src, occ_rot = (self.occ_src1, self.occ_rot1) if sparse else (None, None)
+        else:
+            cl, wsA, C, CT, L, c0, ext, sparse = self.ligcl, self.wsA, self.C, self.CT, self.L, self.center, self.extent, self.sparse_k1
+            occ_src, occ_rot = (self.occ_src, self.occ_rot) if sparse else (None, None)
+        if sparse and self._k1_form_at(L) in (0, 1):
+            call("dlpd_rotated_occupancy", _ptr(occ_src), _ptr(R), _ptr(occ_rot), nb, L, c0, st)
+            call("dlpd_zfft_channels_last_occ", _ptr(cl), _ptr(R), _ptr(occ_rot), _ptr(wsA), nb, C, CT, 0, L, c0, ext, st)
+        else:
+            call("dlpd_zfft_channels_last_form", _ptr(cl), _ptr(R), _ptr(wsA), nb, C, CT, 0, L, c0, ext, self._k1_form_at(L), st)
+
     def set_ligand(self, lig_volumes, lig_forbidden=None, lig_coarse=None):
         L = self.L
         if self.C1:
@@ -368,6 +413,7 @@ class DockingEngine:
             self.lib.call("dlpd_make_channels_last", _ptr(self.lig), _ptr(self.ligcl), self.C, L, st)
             if self.C1:
                 self.lib.call("dlpd_make_channels_last", _ptr(self.lig1), _ptr(self.ligcl1), self.C1, self.L1, st)
+        self._ligand_occupancy()
         # quad layout for the rotation gather (include/dlpd.h), once per pair: 4x the ligand's bytes
         if self.use_quads:
             st = _stream(self.device)
@@ -393,18 +439,21 @@ class DockingEngine:
         return np.abs(R[:, 0, 2]) > np.abs(R[:, 1, 2])
 
     # ---- hot loop ------------------------------------------------------------------------
-    def score_batch(self, R, mark=None, out=None, volumes=None, transposed=False, quads=False, cset=None):
+    def score_batch(self, R, mark=None, out=None, volumes=None, transposed=False, quads=False, cset=None, occupancy=None):
         """R (nb,3,3) float32 on the device, nb <= batch.  Returns V[:nb] (view of the engine's
         buffer, overwritten by the next call): Docker.py:218-232.  mark(name): optional callback
         after each stage (timing).
         volumes = (lig (nb,C,L,L,L), forbidden (nb,L,L,L) | None, coarse (nb,C1,L/2,..) | None): the
         batch's ligand volumes are given as they are (dockE3: re-projected and re-represented per
         rotation, Docker.py:163-172) instead of rotating the stored ligand by R.
+        occupancy = (fine map, coarse map | None) with ``volumes``: uint8 (nb, ceil(L/4)^3) maps of the cells that hold a
+        non-zero value (ops.conv3d(return_occupancy=True)); cells marked empty are never read -- the volumes may be
+        unwritten there (ops.conv3d(unwritten=True)).
         transposed: slab orientation for ALL rotations of the batch (include/dlpd.h); search() groups the
         rotations for which it pays (prefers_transposed) into batches of their own."""
         self._cset_used = None
         if volumes is not None:
-            return self._score_volumes(volumes, mark, out, cset)
+            return self._score_volumes(volumes, mark, out, cset, occupancy)
         nb = R.shape[0]
         assert nb <= self.batch and R.dtype == torch.float32 and R.is_contiguous()
         tr = int(bool(transposed) and self.orient)
@@ -429,8 +478,7 @@ class DockingEngine:
             # coarse resolution first: rotate + correlate + clip -> real volumes the fine filter reads
             L1 = self.L1
             if self.use_cl:
-                call("dlpd_zfft_channels_last_form", _ptr(self.ligcl1), _ptr(R1), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1,
-                     self.center1, self.extent1, self._k1_form_at(L1), st)
+                self._k1_channels_last(True, R1, nb, st)
             elif use_quads:
                 call("dlpd_zfft_quads", _ptr(self.ligq1), _ptr(R1), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1,
                      self.center1, tr, st)
@@ -449,8 +497,7 @@ class DockingEngine:
             # clash channel from re-projected rotated ATOMS (Docker.py:221-224), scores from rotated volumes
             forb = provider(R_true).reshape(nb, L, L, L).contiguous()
             if self.use_cl:
-                call("dlpd_zfft_channels_last_form", _ptr(self.ligcl), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0, L,
-                     self.center, self.extent, self._k1_form_at(L), st)
+                self._k1_channels_last(False, R, nb, st)
             elif use_quads:
                 call("dlpd_zfft_quads", _ptr(self.ligq), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0, L,
                      self.center, tr, st)
@@ -460,8 +507,7 @@ class DockingEngine:
             call("dlpd_zfft_oriented", _ptr(forb), 0, _ptr(self.wsA), nb, 1, self.CT, self.C, L, L ** 3, 0, 0.0,
                  tr, st)                      # same orientation as the score channels
         elif self.use_cl:
-            call("dlpd_zfft_channels_last_form", _ptr(self.ligcl), _ptr(R), _ptr(self.wsA), nb, self.C, self.CT, 0, L,
-                 self.center, self.extent, self._k1_form_at(L), st)
+            self._k1_channels_last(False, R, nb, st)
             if self.has_clash:                # the ligand's forbidden volume: one channel, per-channel kernel
                 call("dlpd_zfft_oriented_ext", self.lig.data_ptr() + self.C * L ** 3 * 4, _ptr(R), _ptr(self.wsA), nb, 1,
                      self.CT, self.C, L, 0, 1, self.center, 0, self.extent, st)
@@ -474,10 +520,22 @@ class DockingEngine:
         mark("k1_rotate_zfft")
         return self._correlate_and_filter(nb, V, mark, tr, cset)
 
-    def _score_volumes(self, volumes, mark, out, cset=None):
+    def _score_volumes(self, volumes, mark, out, cset=None, occupancy=None):
         vl, vf, vc = volumes
         nb, L = vl.shape[0], self.L
         assert nb <= self.batch
+        occ0, occ1 = occupancy if occupancy is not None else (None, None)
+        if (occ0 is not None or occ1 is not None) and self._in_clip is not None:
+            raise RuntimeError("dlpd: occupancy maps are not combined with clip_mode 'input' (the clamp reads every voxel)")
+
+        def _occ(o, n, Lx):
+            if o is None:
+                return None
+            nc = (Lx + 3) // 4
+            if o.dtype != torch.uint8 or o.device.type != self.device.type or o.numel() != n * nc ** 3:
+                raise RuntimeError("dlpd: occupancy map %s does not belong to %d volumes of box %d" % (tuple(o.shape), n, Lx))
+            return o.contiguous()
+        occ0, occ1 = _occ(occ0, nb, L), (_occ(occ1, nb, self.L1) if self.C1 else None)
         f32c = lambda t: t.to(device=self.device, dtype=torch.float32).contiguous()
         call, st = self.lib.call, _stream(self.device)
         has_clip, clip = self._out_clip
@@ -490,17 +548,23 @@ class DockingEngine:
         if self.C1:
             L1 = self.L1
             vc = f32c(vc).reshape(nb, self.C1, L1, L1, L1)
-            call("dlpd_zfft", _ptr(vc), 0, _ptr(self.wsA1), nb, self.C1, L1, self.C1 * L1 ** 3, 0, 0.0, st)
+            if occ1 is not None:
+                call("dlpd_zfft_volumes_occ", _ptr(vc), _ptr(occ1), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1, self.C1 * L1 ** 3, st)
+            else:
+                call("dlpd_zfft", _ptr(vc), 0, _ptr(self.wsA1), nb, self.C1, L1, self.C1 * L1 ** 3, 0, 0.0, st)
             self._k2(True, nb, 0, st)
             self._coarse_preact(nb, has_clip, clip, st)
             mark("coarse")
         vl = f32c(vl).reshape(nb, self.C, L, L, L)
-        call("dlpd_zfft_into", _ptr(vl), 0, _ptr(self.wsA), nb, self.C, self.CT, 0, L, self.C * L ** 3, 0, 0.0, st)
+        if occ0 is not None:
+            call("dlpd_zfft_volumes_occ", _ptr(vl), _ptr(occ0), _ptr(self.wsA), nb, self.C, self.CT, 0, L, self.C * L ** 3, st)
+        else:
+            call("dlpd_zfft_into", _ptr(vl), 0, _ptr(self.wsA), nb, self.C, self.CT, 0, L, self.C * L ** 3, 0, 0.0, st)
         if self.has_clash:
             vf = f32c(vf).reshape(nb, L, L, L)
             call("dlpd_zfft_into", _ptr(vf), 0, _ptr(self.wsA), nb, 1, self.CT, self.C, L, L ** 3, 0, 0.0, st)
         mark("k1_rotate_zfft")
-        self._keep = (vl, vf, vc)                      # inputs stay alive until the stream has consumed them
+        self._keep = (vl, vf, vc, occ0, occ1)          # inputs stay alive until the stream has consumed them
         return self._correlate_and_filter(nb, V, mark, 0, cset)
 
     def _score_rotated_then_clamped(self, R, mark, out, cset, provider):
@@ -584,7 +648,7 @@ class DockingEngine:
         self.top.merge(rot_ids, nb)
 
     # ---- two-stream pipeline: top-K of batch i overlaps K1/K2 of batch i+1 -----------------
-    def step(self, R, rot_ids, mark=None, volumes=None, transposed=False, quads=False):
+    def step(self, R, rot_ids, mark=None, volumes=None, transposed=False, quads=False, occupancy=None):
         """One batch: score on the current stream; select + merge on a side stream (they are
         latency-bound one-block kernels that fit beside the FFT blocks).  V is double-buffered;
         call finish() before reading the list."""
@@ -593,7 +657,7 @@ class DockingEngine:
             if self.prefilter and not hasattr(self, "_cset_cpu"):
                 self._cset_cpu = self.top.new_candidate_set()
             V = self.score_batch(R, mark=mark, volumes=volumes, transposed=transposed, quads=quads,
-                                 cset=getattr(self, "_cset_cpu", None))
+                                 cset=getattr(self, "_cset_cpu", None), occupancy=occupancy)
             self.select_batch(V, nb, self._cset_used)
             self.merge_batch(rot_ids, nb)
             return
@@ -612,7 +676,7 @@ class DockingEngine:
         # (Holding the previous batch's select + merge back until K1 of THIS batch has been issued was measured:
         # K1 -0.06 ms, K2 +0.11 ms -- not kept.)
         V = self.score_batch(R, mark=mark, out=self._Vbuf[k], volumes=volumes, transposed=transposed, quads=quads,
-                             cset=self._csets[k])
+                             cset=self._csets[k], occupancy=occupancy)
         cset = self._cset_used
         self._launch_pending(main)
         # the side stream reads rot_ids later: keep the caller's tensor alive (and its memory out of the

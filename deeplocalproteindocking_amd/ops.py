@@ -176,7 +176,7 @@ def tile_occupancy(x, lib=None):
     return occ
 
 
-def conv3d(x, weight, relu=False, lib=None, stride=1, precision=None, occupancy=None, return_occupancy=False):
+def conv3d(x, weight, relu=False, lib=None, stride=1, precision=None, occupancy=None, return_occupancy=False, unwritten=False):
     """[relu] Conv3d(x, weight, padding=k//2, stride=1|2, bias=None) of the representation plugins
     (ProteinRepresentationModels.py:38-61,85-114) on the matrix cores (inference only: no autograd).
     x (B, cin, D, D, D) float32; weight (cout, cin, k, k, k).
@@ -185,9 +185,15 @@ def conv3d(x, weight, relu=False, lib=None, stride=1, precision=None, occupancy=
     2-3x faster); None = ``ops.CONV_PRECISION``.
     occupancy (split_bf16 only): ``tile_occupancy(x)`` -- output tiles whose neighbouring input tiles are all empty are
     written as zeros without being computed (there is no bias: they ARE zero; same bits).  return_occupancy: -> (y, the
-    occupancy of y or None), which the next layer takes -- a representation network pays for one map, of its input."""
+    occupancy of y or None), which the next layer takes -- a representation network pays for one map, of its input.
+    unwritten (needs occupancy, return_occupancy, stride 1): the tensors travel WITH their maps -- cells that ``occupancy``
+    marks empty are never read (they count as zeros, whatever the memory holds) and skipped output tiles are not written:
+    y is undefined wherever the returned map is 0.  Only for consumers that go by the map (the next layer, maxpool3d_5s2,
+    the engine's volumes path)."""
     lib = lib or get_lib()
     x = x.contiguous()
+    if unwritten and not (occupancy is not None and return_occupancy and stride == 1 and (precision or CONV_PRECISION) == "split_bf16"):
+        raise RuntimeError("dlpd: conv3d(unwritten=True) needs the input's occupancy, return_occupancy, stride 1 and split_bf16")
     if x.dtype != torch.float32 or x.dim() != 5 or not (x.shape[2] == x.shape[3] == x.shape[4]):
         raise RuntimeError("dlpd: conv3d expects (B, C, D, D, D) float32, got %s %s" % (x.dtype, tuple(x.shape)))
     B, cin, D = x.shape[0], x.shape[1], x.shape[2]
@@ -213,7 +219,7 @@ def conv3d(x, weight, relu=False, lib=None, stride=1, precision=None, occupancy=
             occ_out = torch.empty(B, (D + 3) // 4, (D + 3) // 4, (D + 3) // 4, dtype=torch.uint8, device=x.device)
         lib.call("dlpd_conv3d_split_sparse", _ptr(x), _ptr(wp), _ptr(y),
                  _ptr(occupancy.contiguous()) if occupancy is not None else None, _ptr(occ_out) if occ_out is not None else None,
-                 B, cin, cout, D, ks, int(bool(relu)), int(stride), _stream(x.device))
+                 B, cin, cout, D, ks, int(bool(relu)), int(stride), int(bool(unwritten)), _stream(x.device))
     else:
         lib.call("dlpd_conv3d_split" if split else "dlpd_conv3d_strided", _ptr(x), _ptr(wp), _ptr(y), B, cin, cout, D, ks,
                  int(bool(relu)), int(stride), _stream(x.device))
@@ -249,11 +255,14 @@ def _packed_weights(weight, w, lib, device, split=False):
     return wp
 
 
-def maxpool3d_5s2(x, lib=None, occupancy=None, return_occupancy=False):
+def maxpool3d_5s2(x, lib=None, occupancy=None, return_occupancy=False, unwritten=False):
     """MaxPool3d(kernel_size=5, stride=2, padding=2) of the E3 plugin, (B, C, D, D, D) float32 (inference).
     occupancy: ``tile_occupancy(x)`` (or what the convolution that made x handed on) -- output tiles whose inputs lie in
-    empty cells are zeros and are written without reading them; return_occupancy: -> (y, the occupancy of y)."""
+    empty cells are zeros and are written without reading them; return_occupancy: -> (y, the occupancy of y).
+    unwritten (needs occupancy and return_occupancy): as conv3d -- empty input cells are not read, empty output tiles not written."""
     lib = lib or get_lib()
+    if unwritten and not (occupancy is not None and return_occupancy):
+        raise RuntimeError("dlpd: maxpool3d_5s2(unwritten=True) needs the input's occupancy and return_occupancy")
     x = x.contiguous()
     B, C, D = x.shape[0], x.shape[1], x.shape[2]
     Do = (D - 1) // 2 + 1
@@ -266,5 +275,5 @@ def maxpool3d_5s2(x, lib=None, occupancy=None, return_occupancy=False):
         raise RuntimeError("dlpd: maxpool3d_5s2 occupancy does not belong to this input (shape %s)" % (tuple(occupancy.shape),))
     occ_out = torch.empty(B, (Do + 3) // 4, (Do + 3) // 4, (Do + 3) // 4, dtype=torch.uint8, device=x.device) if return_occupancy else None
     lib.call("dlpd_maxpool3d_5s2_sparse", _ptr(x), _ptr(y), _ptr(occupancy.contiguous()) if occupancy is not None else None,
-             _ptr(occ_out), B, C, D, _stream(x.device))
+             _ptr(occ_out), B, C, D, int(bool(unwritten)), _stream(x.device))
     return (y, occ_out) if return_occupancy else y

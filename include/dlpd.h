@@ -68,6 +68,13 @@ int dlpd_zfft(const float* vol, const float* R, void* wsA, int nb, int CT, int L
  * rotated volumes (Docker.py:218). */
 int dlpd_zfft_into(const float* vol, const float* R, void* wsA, int nb, int CT, int CT_out, int c_base, int L,
                    long long vol_bstride, int do_rotate, float center, void* stream);
+/* dlpd_zfft_into for GIVEN volumes (no rotation; Docker.dockE3's per-batch representation, Docker.py:163-172) that come with
+ * occupancy maps: occ (nb, ceil(L/4)^3) bytes, one map per batch entry for all its CT channels, non-zero where the 4 x 4 x 4
+ * cell holds a non-zero value (the maps dlpd_conv3d_split_sparse / dlpd_maxpool3d_5s2_sparse hand on).  Voxels of empty
+ * cells are taken as zero and NOT read (unwritten activations), x-planes without an occupied cell are written as zeros
+ * without a transform.  Same spectra as dlpd_zfft_into on the dense tensor. */
+int dlpd_zfft_volumes_occ(const float* vol, const unsigned char* occ, void* wsA, int nb, int CT, int CT_out, int c_base, int L,
+                          long long vol_bstride, void* stream);
 
 /* Slab orientation (speed only, results identical).  With transposed = 1 every rotation of the call is
  * processed with the roles of x and y exchanged and its slabs are stored as [kz][y][x]: the caller groups the
@@ -115,6 +122,16 @@ int dlpd_zfft_channels_last_ext(const float* cl, const float* R, void* wsA, int 
  * the spectra are bit-identical. */
 int dlpd_zfft_channels_last_form(const float* cl, const float* R, void* wsA, int nb, int C, int CT_out, int c_base, int L,
                                  float center, int extent, int form, void* stream);
+/* The same gather with per-rotation OCCUPANCY MAPS (round 6; Docker.py:218 for a ligand whose representation is zero away
+ * from the protein -- any real one).  dlpd_rotated_occupancy turns the stored ligand's cell map (occ_src, ceil(L/4)^3 bytes,
+ * dlpd_conv3d_tile_occupancy over all its channels) into one conservative map per rotation (occ_out, nb maps: 0 = every
+ * trilinear sample of that 4 x 4 x 4 cell of the rotated volume is certainly zero); R are the matrices K1 samples with.
+ * dlpd_zfft_channels_last_occ is dlpd_zfft_channels_last_ext that skips the loads of samples in empty cells and the
+ * transform of blocks without an occupied cell (their zeros are written).  Same spectra. */
+int dlpd_rotated_occupancy(const unsigned char* occ_src, const float* R, unsigned char* occ_out, int nb, int L, float center,
+                           void* stream);
+int dlpd_zfft_channels_last_occ(const float* cl, const float* R, const unsigned char* occ, void* wsA, int nb, int C, int CT_out,
+                                int c_base, int L, float center, int extent, void* stream);
 
 /* CoordsRotate + CoordsTranslate + TypedCoords2Volume (+ channel sum) of src/Docker/Docker.py:204,
  * 208,221-224 in one kernel: p' = R_b p + shift, density exp(-|r - p'|^2 / 2) on the 5^3 voxels
@@ -283,20 +300,28 @@ int dlpd_conv3d_split(const float* x, const void* wp, float* y, int B, int cin, 
  * ceil(D/4)) bytes, non-zero where the 4 x 4 x 4 cell of the volume holds a non-zero value in some channel:
  * dlpd_conv3d_tile_occupancy computes it for any (B, cin, D^3) tensor; dlpd_conv3d_split_sparse skips the 4 x 4 x 16 output
  * tiles whose neighbouring input cells (a superset of the halo) are empty (occ_in; null = dense) and writes the map of ITS output (occ_out; null = none; not
- * written for stride 2) -- the next layer's occ_in.  Results are bit-identical to dlpd_conv3d_split. */
+ * written for stride 2) -- the next layer's occ_in.  Results are bit-identical to dlpd_conv3d_split.
+ * unwritten != 0 (needs both maps, stride 1): the activations travel WITH their maps -- an output tile whose neighbourhood is
+ * empty is not written at all (its cells stay 0 in occ_out) and no voxel of a cell that occ_in marks empty is read (it is
+ * taken as the zero the map stands for): y holds the same values as before in every cell occ_out marks and is undefined
+ * elsewhere; every consumer must go by the map (the next layer with unwritten != 0, dlpd_maxpool3d_5s2_sparse,
+ * dlpd_zfft_volumes_occ).  Docker.dockE3's per-batch representation (Docker.py:163-167) spent most of its time writing the
+ * zeros of skipped tiles. */
 size_t dlpd_conv3d_tile_occupancy_bytes(int B, int D);
 int dlpd_conv3d_tile_occupancy(const float* x, unsigned char* occ, int B, int cin, int D, void* stream);
 int dlpd_conv3d_split_sparse(const float* x, const void* wp, float* y, const unsigned char* occ_in, unsigned char* occ_out,
-                             int B, int cin, int cout, int D, int ks, int relu, int stride, void* stream);
+                             int B, int cin, int cout, int D, int ks, int relu, int stride, int unwritten, void* stream);
 
 /* MaxPool3d(kernel 5, stride 2, padding 2) of the E3 plugin (ProteinRepresentationModels.py:101):
  * x (nvol, D^3) -> y (nvol, Do^3), Do = (D - 1) / 2 + 1. */
 int dlpd_maxpool3d_5s2(const float* x, float* y, int nvol, int D, void* stream);
 /* The same with occupancy maps (dlpd_conv3d_tile_occupancy): x (B, C, D^3); occ_in (the input's cells; null = read everything):
  * output tiles whose inputs lie in empty cells are written as +0.0 without reading them; occ_out (null = none): the cells of
- * the (B, C, Do^3) output that hold a non-zero value in some channel -- the next convolution's occ_in. */
+ * the (B, C, Do^3) output that hold a non-zero value in some channel -- the next convolution's occ_in.
+ * unwritten != 0 (needs occ_in): as dlpd_conv3d_split_sparse -- input voxels of empty cells are not read (zero), output tiles
+ * over empty cells are not written. */
 int dlpd_maxpool3d_5s2_sparse(const float* x, float* y, const unsigned char* occ_in, unsigned char* occ_out, int B, int C, int D,
-                              void* stream);
+                              int unwritten, void* stream);
 
 /* Docker.update_top pick loop, src/Docker/Docker.py:89-98: per rotation the K picks in pick order
  * (incl. the zero-fill behaviour).  V (nb, nvox); out (nb, K). */

@@ -771,6 +771,20 @@ def test_dockE3_reference_configuration_on_gpu(tmp_path):
     finally:
         repr_.use_tile_occupancy = True
     assert dk.top_list == skipping
+    # round 6: by default the skipped tiles are not WRITTEN either and the engine's K1 goes by the maps; with every
+    # fresh buffer full of NaNs (a read of an unwritten cell would surface) the list is the same as with every voxel
+    # written (unwritten_activations = False) -- entry for entry, bit for bit
+    from guard_alloc import GuardedAllocations
+    assert dk.unwritten_activations
+    with GuardedAllocations(empty_byte=0xFF) as guard:
+        with torch.no_grad():
+            dk.dockE3(frec, flig, batch_size=2)
+        assert guard.check() == []
+    assert dk.top_list == skipping
+    dk.unwritten_activations = False
+    with torch.no_grad():
+        dk.dockE3(frec, flig, batch_size=2)
+    assert dk.top_list == skipping
     # the same at box 72 (no compiled plan): every batch's volumes inside the 80 / 40 engine
     L2 = 72
     want2, scale2 = _dock_reference_shape_e3(be, model.cpu(), frec, flig, R, L2, res, K)

@@ -452,6 +452,16 @@ def test_maxpool_tiled_with_occupancy_equals_torch(dev, C, D, lo, hi):
     _sparse_pool_checks(None, dev, C, D, lo, hi, B=3)
 
 
+@pytest.mark.gpu
+def test_unwritten_activations_stand_for_the_same_tensors(dev):
+    """Round 6 (Docker.dockE3's representation, Docker.py:163-167): convolution / pooling layers that neither compute nor
+    WRITE their empty tiles and never read an empty cell, and the engine's K1 for given volumes going by the map
+    (dlpd_zfft_volumes_occ) -- same bits wherever a map marks a cell, same maps, same spectra; every output buffer starts as NaNs."""
+    from test_kernels_emu import _unwritten_chain_checks
+    _unwritten_chain_checks(None, dev, D=45, lo=18, hi=27, B=3)
+
+
+
 def test_conv3d_stride2_and_se3_plugin_never_touch_torch_convolutions(dev, monkeypatch):
     """The stride-2 5^3 layer (ProteinRepresentationModels.py:51) on the matrix-core kernel at the reference's
     size (16 -> 32 channels, 80^3 -> 40^3), and the whole SE3MultiResReprScalar(8) forward with torch's conv3d

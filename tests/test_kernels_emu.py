@@ -862,3 +862,167 @@ def _sparse_pool_checks(lib, device, C, D, lo, hi, B=1):
 @pytest.mark.parametrize("C,D,lo,hi", [(3, 13, 1, 5), (2, 40, 22, 31)])
 def test_maxpool_tiled_with_occupancy_equals_torch(emu, C, D, lo, hi):
     _sparse_pool_checks(emu, "cpu", C, D, lo, hi)
+
+
+class _NanEmpty(object):
+    """``torch.empty`` hands out NaN-filled float buffers (and 0xFF bytes) inside the block: a kernel that reads a cell
+    nobody wrote shows up as a NaN in its result."""
+
+    def __enter__(self):
+        self.orig = torch.empty
+
+        def empty(*a, **kw):
+            t = self.orig(*a, **kw)
+            if t.is_floating_point():
+                t.fill_(float("nan"))
+            elif t.dtype == torch.uint8:
+                t.fill_(255)
+            return t
+        torch.empty = empty
+        return self
+
+    def __exit__(self, *exc):
+        torch.empty = self.orig
+        return False
+
+
+def _cells(occ, D):
+    """uint8 (B, nc, nc, nc) cell map -> bool (B, 1, D, D, D) voxel mask"""
+    m = occ.bool().repeat_interleave(4, 1).repeat_interleave(4, 2).repeat_interleave(4, 3)[:, :D, :D, :D]
+    return m[:, None]
+
+
+def _unwritten_chain_checks(lib, device, D=21, lo=9, hi=15, B=1):
+    """conv k5 + ReLU -> conv k3 -> MaxPool(5, 2, 2) -> conv k3 with UNWRITTEN activations (empty tiles neither computed nor
+    written, empty input cells never read; every output buffer starts as NaNs) against the same chain writing everything:
+    the same bits in every cell the maps mark, the same maps, and the dense values outside the marked cells are zeros --
+    so (tensor, map) stands for the same tensor.  Then the engine's K1 for given volumes (dlpd_zfft_volumes_occ) on the
+    unwritten tensor + map: the same spectra as dlpd_zfft_into on the dense tensor."""
+    from deeplocalproteindocking_amd import ops
+    x, g = _blob_input(B, 11, D, 5, lo, hi)
+    w1 = torch.randn(16, 11, 5, 5, 5, generator=g) * 0.1
+    w2 = torch.randn(16, 16, 3, 3, 3, generator=g) * 0.1
+    w3 = torch.randn(32, 16, 3, 3, 3, generator=g) * 0.1
+    x, w1, w2, w3 = x.to(device), w1.to(device), w2.to(device), w3.to(device)
+    occ0 = ops.tile_occupancy(x, lib=lib)
+    kw = dict(lib=lib, precision="split_bf16", return_occupancy=True)
+    d1, m1 = ops.conv3d(x, w1, relu=True, occupancy=occ0, **kw)
+    d2, m2 = ops.conv3d(d1, w2, occupancy=m1, **kw)
+    d3, m3 = ops.maxpool3d_5s2(d2, lib=lib, occupancy=m2, return_occupancy=True)
+    d4, m4 = ops.conv3d(d3, w3, occupancy=m3, **kw)
+    with _NanEmpty():
+        u1, n1 = ops.conv3d(x, w1, relu=True, occupancy=occ0, unwritten=True, **kw)
+        u2, n2 = ops.conv3d(u1, w2, occupancy=n1, unwritten=True, **kw)
+        u3, n3 = ops.maxpool3d_5s2(u2, lib=lib, occupancy=n2, return_occupancy=True, unwritten=True)
+        u4, n4 = ops.conv3d(u3, w3, occupancy=n3, unwritten=True, **kw)
+    Dp = (D - 1) // 2 + 1
+    for d, m, u, n, Dx, skipped in ((d1, m1, u1, n1, D, True), (d2, m2, u2, n2, D, False), (d3, m3, u3, n3, Dp, False),
+                                    (d4, m4, u4, n4, Dp, False)):
+        assert torch.equal(m, n) and 0 < int(m.sum()) < m.numel() + (0 if skipped else 1)
+        live = _cells(m, Dx).expand_as(d)
+        assert torch.equal(d[live], u[live]) and not torch.isnan(u[live]).any()
+        assert (d[~live] == 0).all()
+        if skipped:                                                 # (behind the first layer every tile of this small box has an occupied neighbour)
+            assert torch.isnan(u[~live]).any()                      # tiles were really left unwritten
+    # the engine's K1 on given volumes (a box with a compiled plan): unwritten tensor + map == dense tensor
+    L = 32
+    x, g = _blob_input(B, 11, L, 6, 10, 19)
+    x = x.to(device)
+    occ0 = ops.tile_occupancy(x, lib=lib)
+    d1, m1 = ops.conv3d(x, w1, relu=False, occupancy=occ0, **kw)
+    with _NanEmpty():
+        u1, n1 = ops.conv3d(x, w1, relu=False, occupancy=occ0, unwritten=True, **kw)
+    call = (lib or __import__("deeplocalproteindocking_amd._lib", fromlist=["get_lib"]).get_lib()).call
+    NZ, C = L + 1, 16
+    A_d = torch.zeros(B, C + 1, NZ, L, L, 2, device=device)
+    A_u = torch.full((B, C + 1, NZ, L, L, 2), float("nan"), device=device)
+    st = torch.cuda.current_stream(device).cuda_stream if str(device) != "cpu" else 0
+    call("dlpd_zfft_into", d1.data_ptr(), 0, A_d.data_ptr(), B, C, C + 1, 0, L, C * L ** 3, 0, 0.0, st)
+    call("dlpd_zfft_volumes_occ", u1.data_ptr(), n1.data_ptr(), A_u.data_ptr(), B, C, C + 1, 0, L, C * L ** 3, st)
+    assert torch.equal(A_d[:, :C], A_u[:, :C]) and torch.isnan(A_u[:, C]).all()      # (the other channel is not touched)
+    assert int(n1.sum()) < n1.numel() // 2                          # ... with most of the box empty
+    # misuse is refused: unwritten needs the maps
+    with pytest.raises(RuntimeError, match="unwritten"):
+        ops.conv3d(x, w1, lib=lib, precision="split_bf16", unwritten=True)
+    with pytest.raises(RuntimeError, match="unwritten"):
+        ops.maxpool3d_5s2(x, lib=lib, unwritten=True)
+
+
+def test_unwritten_activations_stand_for_the_same_tensors_emulated(emu):
+    _unwritten_chain_checks(emu, "cpu")
+
+
+def _k1_occupancy_checks(lib, device, L, C, nb, lo, hi, seed=17, scale=1.0):
+    """The channels-last K1 going by per-rotation occupancy maps (dlpd_rotated_occupancy + dlpd_zfft_channels_last_occ, round 6:
+    the rotation of Docker.py:218 for a ligand that is zero away from the protein) against the same kernel without maps:
+    the same spectra bit for bit on oblique rotations; the maps are CONSERVATIVE -- every non-zero voxel of the really
+    rotated volume (dlpd_rotate_trilinear) lies in a marked cell -- and they do leave cells out."""
+    from deeplocalproteindocking_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    NZ, CT, nc = L + 1, C + 1, (L + 3) // 4
+    vol = torch.zeros(C, L, L, L)
+    vol[:, lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] = torch.randn(C, hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2], generator=g)
+    vol = vol.to(device)
+    ang = np.random.RandomState(seed).uniform(-np.pi, np.pi, size=(nb, 3))
+    Rm = orc.euler_to_matrix(ang[:, 0], np.abs(ang[:, 1]), ang[:, 2]) * scale
+    Rm[0] = np.eye(3) * scale                                        # (an axis-aligned one: cells map onto cells)
+    R = torch.from_numpy(Rm).float().contiguous().to(device)
+    st = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0
+    c0 = L / 2.0
+    cl = torch.empty(lib.call("dlpd_channels_last_floats", C, L), device=device)
+    lib.call("dlpd_make_channels_last", _ptr(vol), _ptr(cl), C, L, st)
+    occ_src = ops.tile_occupancy(vol.unsqueeze(0), lib=lib)
+    assert occ_src.shape == (1, nc, nc, nc) and 0 < int(occ_src.sum()) < occ_src.numel() // 2
+    occ = torch.full((nb, nc, nc, nc), 255, dtype=torch.uint8, device=device)
+    lib.call("dlpd_rotated_occupancy", _ptr(occ_src), _ptr(R), _ptr(occ), nb, L, c0, st)
+    assert int((occ > 1).sum()) == 0 and 0 < int(occ.sum()) < occ.numel()
+    rot = torch.empty(nb, C, L, L, L, device=device)
+    lib.call("dlpd_rotate_trilinear", _ptr(vol), _ptr(R), _ptr(rot), nb, C, L, 0, c0, st)
+    nz = (rot != 0).any(dim=1, keepdim=True)
+    assert not bool((nz & ~_cells(occ, L)).any())                    # conservative
+    assert bool((occ[0].bool() | ~occ_src[0].bool()).all()) or scale != 1.0  # identity: at least the ligand's own cells
+    want = torch.full((nb * CT * NZ * L * L * 2,), 7.0, device=device)
+    got = torch.full_like(want, float("nan"))
+    lib.call("dlpd_zfft_channels_last_ext", _ptr(cl), _ptr(R), _ptr(want), nb, C, CT, 0, L, c0, 0, st)
+    lib.call("dlpd_zfft_channels_last_occ", _ptr(cl), _ptr(R), _ptr(occ), _ptr(got), nb, C, CT, 0, L, c0, 0, st)
+    want, got = want.view(nb, CT, NZ, L, L, 2), got.view(nb, CT, NZ, L, L, 2)
+    assert torch.equal(got[:, :C], want[:, :C]) and bool(torch.isnan(got[:, C]).all())
+    return float(occ.float().mean())
+
+
+@pytest.mark.parametrize("L,C,lo,hi", [(32, 20, (9, 12, 6), (20, 19, 15)), (40, 16, (22, 3, 14), (31, 12, 26))])
+def test_k1_by_occupancy_maps_gives_the_same_spectra_emulated(emu, L, C, lo, hi):
+    _k1_occupancy_checks(emu, "cpu", L, C, 3, lo, hi)
+
+
+def test_engine_search_with_k1_occupancy_maps_gives_the_same_list_emulated(emu):
+    """DockingEngine decides per ligand (cells occupied < SPARSE_K1_MAX_FILL): a blob-shaped two-resolution ligand is searched
+    with the maps, a dense one without; forcing either way gives the same list entry for entry."""
+    from deeplocalproteindocking_amd.engine import DockingEngine
+    g = torch.Generator().manual_seed(23)
+    L, C, C1, H = 64, 8, 8, 4
+    blob = lambda c, l, a, b: torch.nn.functional.pad(torch.randn(c, b - a, b - a, b - a, generator=g) * 0.3, (a, l - b) * 3)
+    rec, lig = torch.randn(C, L, L, L, generator=g) * 0.05, blob(C, L, 22, 40)
+    rec1, lig1 = torch.randn(C1, 32, 32, 32, generator=g) * 0.05, blob(C1, 32, 10, 21)
+    recf, ligf = torch.rand(L, L, L, generator=g), blob(1, L, 24, 38)[0].abs()
+    W1, b1 = torch.randn(H, C + C1, generator=g) * 0.3, torch.randn(H, generator=g) * 0.1
+    W2, b2 = torch.randn(1, H, generator=g), torch.randn(1, generator=g)
+    R = torch.from_numpy(orc.euler_to_matrix([0.4, -1.3, 2.2], [0.9, 2.0, 0.3], [1.7, -0.2, -2.5])).float()
+    lists = {}
+    for mode in (None, True, False):
+        eng = DockingEngine(L, C, W1, b1, W2, b2, clip=5.0, threshold_clash=50.0, max_conf=60, batch=2, device="cpu", lib=emu,
+                            coarse_channels=C1, sparse_k1=mode)
+        eng.set_receptor(rec, recf, rec1)
+        eng.set_ligand(lig, ligf, lig1)
+        sw = eng.switches()["k1_occupancy_maps"]
+        assert sw["fine"] == sw["coarse"] == (mode is not False)
+        assert mode is False or sw["ligand_cells_occupied"]["fine"] < 0.1
+        eng.reset_top()
+        eng.search(R)
+        lists[mode] = eng.top_list()
+    assert lists[None] == lists[True] == lists[False] and len(lists[None]) == 60
+    eng.set_ligand(rec, ligf, rec1)                                  # a dense ligand on the last engine (maps off anyway) ...
+    eng2 = DockingEngine(L, C, W1, b1, W2, b2, max_conf=4, batch=2, device="cpu", lib=emu, coarse_channels=C1)
+    eng2.set_receptor(rec, recf, rec1)
+    eng2.set_ligand(rec, ligf, rec1)                                 # ... and on an undecided one: no maps
+    assert eng2.switches()["k1_occupancy_maps"]["fine"] is False and eng2.lig_fill == 1.0
