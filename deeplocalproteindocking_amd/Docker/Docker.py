@@ -127,9 +127,11 @@ LAUNCH_BATCH = 16      # rotations per launch of the fused pipeline (DESIGN.md s
 class PreparedPair(object):
     """Everything ``dockSE3`` / ``dockE3`` do for a target BEFORE the rotation loop (Docker.py:184-209 / :135-161): the
     two PDB files parsed, typed and centred, the receptor projected and represented, its spectrum in an engine, the
-    ligand's volumes (SE3) and its atoms on the device.  ``Docker.prepare`` builds one -- on a stream and a host thread
-    of its own if the caller wants the next target prepared while the current one is searched (local_test.py sweep) --
-    and the dock call consumes it.  ``ready`` orders the consumer's stream after the producer's."""
+    ligand's volumes (SE3) and its atoms on the device.  ``Docker.prepare`` builds one -- from a host thread of its own if
+    the caller wants the next target prepared while the current one is searched (local_test.py sweep), but on the CALLER'S
+    stream: device work of a preparation is never put beside a running search (see ``Docker.prepare``) -- and the dock
+    call consumes it.  ``ready`` is only set by the diagnostic ``stream=`` form and then orders the consumer's stream
+    after the producer's."""
 
     def __init__(self, group, ureceptor, uligand, slot):
         self.group, self.ureceptor, self.uligand, self.slot = group, ureceptor, uligand, slot
@@ -678,12 +680,22 @@ class Docker:
 
     def prepare(self, ureceptor, uligand, group="SE3", slot=0, stream=None):
         """The rotation-independent part of ``dockSE3`` / ``dockE3`` for one target (Docker.py:184-209 / :135-161) ->
-        ``PreparedPair``.  With ``stream`` (a torch.cuda.Stream) all its device work is enqueued there and ``slot`` names
-        the engine it fills (0 / 1), so that a sweep over targets (local_test.py:57-75) can prepare target n + 1 --
-        from a host thread of its own -- while target n is being searched in the other engine.  No collective is issued
-        here (the random receptor rotation is shared by ``dock*`` / the constructor, on the caller's thread)."""
+        ``PreparedPair``.  ``slot`` names the engine it fills (0 / 1), so that a sweep over targets (local_test.py:57-75)
+        can prepare target n + 1 -- from a host thread of its own -- while target n is being searched in the other engine;
+        its device work goes to the CALLER'S current stream, i.e. between two batches of the running search, never beside
+        them.  No collective is issued here (the random receptor rotation is shared by ``dock*`` / the constructor, on the
+        caller's thread).
+        ``stream`` is a DIAGNOSTIC argument (scripts/prepare_race_probe.py) and warns: a preparation on a second stream puts the
+        plugin's matrix-instruction convolution on the same CUs as the search's kernels, which on this hardware changes low
+        mantissa bits of a few scores (inside the 1e-4 parity band, but the .dat is then not byte-reproducible; an OPEN
+        defect, not root-caused: DESIGN.md section 8, EXPERIMENTS.md R5).  The product never passes it."""
         import contextlib
         import time
+        import warnings
+        if stream is not None:
+            warnings.warn("dlpd: Docker.prepare(stream=...) runs the representation beside the search's kernels; on this hardware "
+                          "that co-residency perturbs low bits of a few scores (results stay inside the 1e-4 parity band but are "
+                          "not byte-reproducible) -- diagnostic use only", RuntimeWarning, stacklevel=2)
         t0 = time.perf_counter()
         if group not in ("SE3", "E3"):
             raise Exception("Unknown equivariance group", group)

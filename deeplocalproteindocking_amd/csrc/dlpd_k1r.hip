@@ -32,11 +32,19 @@
 #include "dlpd_internal.h"
 #include "dlpd_k1.h"
 
+extern "C" int dlpd_grid_supported(int L);
 #ifndef DLPD_TEST_VARIANTS
 int dlpd_k1_role_split(const float4*, const float*, cplx*, int, int, float, hipStream_t, int, int, int, int) {
   return DLPD_ERR_UNSUPPORTED;               // the product library ships one K1 formulation (k_rotate_zfft_cl)
 }
+extern "C" int dlpd_k1_form_supported(int L, int form) {
+  return (form == 0 || form == 1) ? dlpd_grid_supported(L) : 0;
+}
 #else
+extern "C" int dlpd_k1_form_supported(int L, int form) {
+  if (form == 0 || form == 1) return dlpd_grid_supported(L);
+  return (form == 2 && (L == 64 || L == 80)) ? 1 : 0;
+}
 
 template <int N> struct K1RsCfg {
   static constexpr int L = N / 2, NZ = N / 2 + 1;

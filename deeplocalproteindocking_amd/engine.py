@@ -172,6 +172,13 @@ class DockingEngine:
         # kernel formulation of the channels-last K1 (include/dlpd.h, dlpd_zfft_channels_last_form): 0 = the library's
         # default, 1 = every wave gathers / transforms / stores in turn, 2 = role-split (boxes 64 and 80); same bits
         self.k1_form = int(k1_form)
+        if self.k1_form not in (0, 1, 2):
+            raise RuntimeError("dlpd: k1_form %r (0 = library default, 1 = phased, 2 = role-split)" % (k1_form,))
+        if self.k1_form == 2 and int(L) in (64, 80) and not lib.call("dlpd_k1_form_supported", int(L), 2):
+            # form 2 is a TEST-VARIANT kernel (-DDLPD_TEST_VARIANTS builds: tests/variants/libdlpd_variants.so): the product
+            # library refuses it at the first launch -- say so when the engine is built, not in the middle of a search
+            raise RuntimeError("dlpd: k1_form=2 (role-split K1) exists in -DDLPD_TEST_VARIANTS builds only; this library "
+                               "(%s) does not hold it" % getattr(lib, "path", "?"))
         self.fine_unfused = bool(fine_unfused)
         self.set_filter(W1, b1, W2, b2)
         nb, CT, NZ, N = self.batch, self.CT, self.NZ, self.N
@@ -362,6 +369,9 @@ class DockingEngine:
         if recP is not None and not tr:
             self.lib.call("dlpd_xy_correlate_packed", _ptr(wsA), _ptr(recP), _ptr(wsB), nb, CT, L, st)
         else:
+            if rec is None:          # (packed-receptor boxes drop the natural-layout spectrum: keep_receptor_spectrum=True keeps it)
+                raise RuntimeError("dlpd: this engine holds only the packed receptor spectrum; a transposed launch needs "
+                                   "keep_receptor_spectrum=True")
             self.lib.call("dlpd_xy_correlate_oriented", _ptr(wsA), _ptr(rec), _ptr(wsB), nb, CT, L, 0, tr, st)
 
     SPARSE_K1_MAX_FILL = 0.7

@@ -118,8 +118,10 @@ int dlpd_zfft_channels_last_ext(const float* cl, const float* R, void* wsA, int 
                                 float center, int extent, void* stream);
 /* ... with the kernel formulation named: 0 = the library's default, 1 = every wave gathers, transforms and stores in turn
  * (k_rotate_zfft_cl), 2 = gather waves and transform / store waves with fixed roles, one block per CU walking a range of
- * work items (k_rotate_zfft_cl_rs; boxes 64 and 80 only, DLPD_ERR_UNSUPPORTED elsewhere).  Same samples, same butterflies:
- * the spectra are bit-identical. */
+ * work items (k_rotate_zfft_cl_rs).  Same samples, same butterflies: the spectra are bit-identical.  Form 2 is a TEST VARIANT:
+ * it exists in -DDLPD_TEST_VARIANTS builds only (tests/variants/libdlpd_variants.so, boxes 64 and 80); libdlpd.so returns
+ * DLPD_ERR_UNSUPPORTED for it at every box -- dlpd_k1_form_supported(L, form) says what the loaded library holds. */
+int dlpd_k1_form_supported(int L, int form);
 int dlpd_zfft_channels_last_form(const float* cl, const float* R, void* wsA, int nb, int C, int CT_out, int c_base, int L,
                                  float center, int extent, int form, void* stream);
 /* The same gather with per-rotation OCCUPANCY MAPS (round 6; Docker.py:218 for a ligand whose representation is zero away

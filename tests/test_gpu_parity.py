@@ -453,6 +453,18 @@ def test_maxpool_tiled_with_occupancy_equals_torch(dev, C, D, lo, hi):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("L,C,lo,hi", [(64, 48, (20, 25, 12), (45, 40, 33)), (80, 16, (10, 30, 22), (38, 61, 50)), (40, 32, (22, 3, 14), (31, 12, 26)),
+                                       (32, 20, (9, 12, 6), (20, 19, 15))])
+def test_k1_by_occupancy_maps_gives_the_same_spectra(dev, L, C, lo, hi):
+    """Round 6, search side: the channels-last K1 of every compiled box going by per-rotation occupancy maps -- the same
+    spectra bit for bit as without, conservative maps, and cells really left out (16 oblique rotations per launch)."""
+    from test_kernels_emu import _k1_occupancy_checks
+    fill = _k1_occupancy_checks(None, dev, L, C, 16, lo, hi)
+    assert fill < 0.8
+    _k1_occupancy_checks(None, dev, L, C, 5, lo, hi, seed=3, scale=1.07)      # a scaled sample map (Utils/Conventions)
+
+
+@pytest.mark.gpu
 def test_unwritten_activations_stand_for_the_same_tensors(dev):
     """Round 6 (Docker.dockE3's representation, Docker.py:163-167): convolution / pooling layers that neither compute nor
     WRITE their empty tiles and never read an empty cell, and the engine's K1 for given volumes going by the map
@@ -1010,32 +1022,58 @@ def test_no_result_depends_on_lds_a_kernel_never_wrote(dev, tmp_path):
     assert not problems, "\n".join(problems)
 
 
-def test_scores_do_not_change_beside_the_plugin_and_the_radix_select(dev):
-    """Regression test of round 5's cross-stream finding (EXPERIMENTS.md R5).  One batch of the reference's real shapes is
-    scored again and again while two more streams of the process are kept busy: the representation plugin's bf16 x 3
-    convolutions and the engine's own full radix select.  With `ds_add_u32` in the select's histogram kernel this changed
-    the output of the coarse grid's K1 / K2 -- the pipeline kernels small enough to share a CU with both -- in 259 of 300
-    scorings (lanes 48-63 of a transform wave, low mantissa bits); the histogram now counts without LDS atomics and, with the
-    SE3 plugin's (dense) convolution kernel as it is built today, every stage's output is the same bits as in the undisturbed
-    run.  Late in round 5 the pair plugin + pipeline turned out to do this WITHOUT the atomics too, depending on the convolution's
-    binary and layer shapes (E3 plugin: 298 of 300) -- so the library stopped offering any way of running the two side by side,
-    and this test is a CANARY: a difference is reported as an expected failure, not as a failure."""
+@pytest.mark.parametrize("co_runner", ["se3_dense_convolution", "e3_tile_occupancy_convolution"])
+def test_scores_do_not_change_beside_the_plugin_and_the_radix_select(dev, co_runner, tmp_path):
+    """Regression test AND canary of round 5's cross-stream finding (EXPERIMENTS.md R5).  One batch of the reference's real
+    shapes is scored again and again while two more streams of the process are kept busy: a representation plugin's bf16 x 3
+    convolutions and the engine's own full radix select.
+    * co_runner = the SE3 plugin (dense convolution kernel): with `ds_add_u32` in the select's histogram kernel this pair
+      changed the coarse grid's K1 / K2 output in 259 of 300 scorings; the histogram now counts without LDS atomics and this
+      combination measured clean (0 of 300, profiles/r05_occ_probe3.log).  A HARD assertion: any difference fails.
+    * co_runner = the E3 plugin on a protein-like input (the tile-occupancy kernel): the KNOWN-BAD pair -- 298 of 300
+      scorings differ on today's hardware (low mantissa bits in lanes 48-63 of a pipeline wave; not root-caused, tracked as an
+      open defect in DESIGN.md section 8; stand-alone reproducer: scripts/micro/coresidency_repro.hip).  The product never
+      creates this co-residency (one stream for plugin and search), so a difference here is reported as an EXPECTED failure;
+      if it stops differing the test passes and the defect entry can be closed."""
     import threading
     import time
     from deeplocalproteindocking_amd.engine import DockingEngine
-    from deeplocalproteindocking_amd.Models import SE3MultiResReprScalar
-    torch.manual_seed(5)
-    g = torch.Generator().manual_seed(5)
+    from deeplocalproteindocking_amd.Models import E3MultiResRepr4x4, SE3MultiResReprScalar
+    known_bad = co_runner == "e3_tile_occupancy_convolution"
     L, C, C1 = 80, 16, 32
-    rec, lig = torch.randn(C, L, L, L, generator=g) * 0.1, torch.randn(C, L, L, L, generator=g) * 0.1
-    rec1, lig1 = torch.randn(C1, 40, 40, 40, generator=g) * 0.1, torch.randn(C1, 40, 40, 40, generator=g) * 0.1
-    recf, ligf = torch.rand(L, L, L, generator=g), torch.rand(L, L, L, generator=g)
-    W1, b1 = torch.randn(24, C + C1, generator=g) * 0.3, torch.randn(24, generator=g) * 0.1
-    W2, b2 = torch.randn(1, 24, generator=g), torch.randn(1, generator=g)
-    eng = DockingEngine(L, C, W1, b1, W2, b2, clip=5.0, threshold_clash=0.12 * L ** 3, max_conf=2000, batch=16, device=dev, coarse_channels=C1)
-    eng.set_receptor(rec, recf, rec1)
-    eng.set_ligand(lig, ligf, lig1)
-    R = torch.from_numpy(_rots(16, seed=8)).float().to(dev).contiguous()
+    if known_bad:
+        # the victim as scripts/stage_race_probe.py builds it (the configuration the 298 / 300 were measured in): the engine of
+        # a Docker.dockSE3 on a synthetic protein-sized pair (protein-shaped volumes, clash channel from re-projected atoms)
+        from synth_pdb import write_protein_like_pdb
+        from deeplocalproteindocking_amd.Docker import Docker
+        from deeplocalproteindocking_amd.Models import GlobalDockingModel, SimpleFilter
+        from deeplocalproteindocking_amd.Utils.Rotations import Rotations
+        pdb = {}
+        for name, n, seed in (("r1", 150, 21), ("l1", 90, 22)):
+            pdb[name] = str(tmp_path / (name + ".pdb"))
+            write_protein_like_pdb(pdb[name], n, seed)
+        torch.manual_seed(7)
+        repr_ = SE3MultiResReprScalar(multiplier=8)
+        model = GlobalDockingModel(repr_, SimpleFilter(repr_.get_num_outputs()), threshold_clash=40.0).to(dev).eval()
+        Rall = Rotations(20, allow_generated=True, verbose=False).R.numpy()
+        dk = Docker(model, box_size=L, resolution=1.25, max_conf=2000, rotations=Rall[:64], device=dev, randomize_rot=True, rotation_seed=7)
+        with torch.no_grad():
+            dk.dockSE3(pdb["r1"], pdb["l1"], batch_size=2)
+        torch.cuda.synchronize()
+        eng = dk.engine
+        R = torch.from_numpy(Rall[16:32]).to(device=dev, dtype=torch.float32).contiguous()
+    else:
+        torch.manual_seed(5)
+        g = torch.Generator().manual_seed(5)
+        rec, lig = torch.randn(C, L, L, L, generator=g) * 0.1, torch.randn(C, L, L, L, generator=g) * 0.1
+        rec1, lig1 = torch.randn(C1, 40, 40, 40, generator=g) * 0.1, torch.randn(C1, 40, 40, 40, generator=g) * 0.1
+        recf, ligf = torch.rand(L, L, L, generator=g), torch.rand(L, L, L, generator=g)
+        W1, b1 = torch.randn(24, C + C1, generator=g) * 0.3, torch.randn(24, generator=g) * 0.1
+        W2, b2 = torch.randn(1, 24, generator=g), torch.randn(1, generator=g)
+        eng = DockingEngine(L, C, W1, b1, W2, b2, clip=5.0, threshold_clash=0.12 * L ** 3, max_conf=2000, batch=16, device=dev, coarse_channels=C1)
+        eng.set_receptor(rec, recf, rec1)
+        eng.set_ligand(lig, ligf, lig1)
+        R = torch.from_numpy(_rots(16, seed=8)).float().to(dev).contiguous()
     buffers = {"coarse_k1": lambda: eng.wsA1, "coarse_k2": lambda: eng.wsB1, "coarse": lambda: eng.pre, "k1_rotate_zfft": lambda: eng.wsA,
                "k2_xy_corr": lambda: eng.wsB, "k3_zifft_filter": lambda: eng.V}
     ref = {}
@@ -1047,8 +1085,13 @@ def test_scores_do_not_change_beside_the_plugin_and_the_radix_select(dev):
     eng.score_batch(R, mark=record)
     torch.cuda.synchronize()
     assert set(ref) == set(buffers)
-    plugin = SE3MultiResReprScalar(multiplier=8).to(dev).eval()
-    x11 = torch.rand(1, 11, L, L, L, device=dev)
+    if known_bad:
+        plugin = E3MultiResRepr4x4(multiplier=8).to(dev).eval()
+        x11 = torch.zeros(4, 11, L, L, L, device=dev)             # zero away from a blob, as a protein's density is
+        x11[:, :, 24:52, 20:48, 28:60] = torch.rand(4, 11, 28, 28, 32, device=dev)
+    else:
+        plugin = SE3MultiResReprScalar(multiplier=8).to(dev).eval()
+        x11 = torch.rand(1, 11, L, L, L, device=dev)
     Vsel = eng.V.clone()
     stop = threading.Event()
     streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
@@ -1084,11 +1127,13 @@ def test_scores_do_not_change_beside_the_plugin_and_the_radix_select(dev):
         stop.set()
         for t in threads:
             t.join()
-    if changed:
-        # Not a product path any more (the library never schedules the plugin beside the pipeline), and known to depend on the
-        # convolution's exact binary: reported, not failed -- a canary for whoever wants to overlap the two again.
-        pytest.xfail("plugin convolution beside the pipeline perturbed %s (EXPERIMENTS.md R5: hardware co-residency hazard, "
-                     "not root-caused)" % {k: len(v) for k, v in changed.items()})
+    report = {k: len(v) for k, v in changed.items()}
+    if known_bad:
+        if changed:
+            pytest.xfail("KNOWN DEFECT (open, DESIGN.md section 8): the E3 plugin's convolution co-resident with the pipeline "
+                         "perturbed %s of 80 scorings per stage -- not a product path (one stream for plugin and search)" % report)
+        return                                                     # did not reproduce on this box: passes
+    assert not changed, "the SE3 plugin's convolution + radix select beside the pipeline changed %s (measured clean in round 5)" % report
 
 
 def test_k3_role_split_equals_the_channel_owning_k3(dev, variants):

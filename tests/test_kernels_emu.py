@@ -958,6 +958,9 @@ def _k1_occupancy_checks(lib, device, L, C, nb, lo, hi, seed=17, scale=1.0):
     the same spectra bit for bit on oblique rotations; the maps are CONSERVATIVE -- every non-zero voxel of the really
     rotated volume (dlpd_rotate_trilinear) lies in a marked cell -- and they do leave cells out."""
     from deeplocalproteindocking_amd import ops
+    if lib is None:
+        from deeplocalproteindocking_amd._lib import get_lib
+        lib = get_lib()
     g = torch.Generator().manual_seed(seed)
     NZ, CT, nc = L + 1, C + 1, (L + 3) // 4
     vol = torch.zeros(C, L, L, L)
