@@ -327,6 +327,16 @@ def build_workload(name, args, dev):
     filt = SimpleFilter([C] + ([C1] if C1 else []))
     thr = clash_threshold(recf, ligf)
     W = filt.parameters_tuple()
+    if name == "real_protein":
+        # A pose WITHOUT contact (all correlations zero: most of the grid for protein-shaped volumes) scores
+        # W2 relu(b1) + b2 whatever the rotation.  Training drives that constant to the neutral end of the scale; the seeded
+        # random filter puts it wherever it falls, possibly below every contact score -- the ranked list is then 2000 copies of
+        # the constant and every rotation's candidate list overflows into the full radix select.  The output bias is shifted
+        # so that the no-contact score is zero (a property of the workload's model, stated in its description).
+        W1_, b1_, W2_, b2_ = [w.clone() for w in W]
+        c0 = float((W2_.reshape(1, -1) @ torch.relu(b1_.reshape(-1, 1))).reshape(-1)[0] + b2_.reshape(-1)[0])
+        W = (W1_, b1_, W2_, b2_ - c0)
+        desc += "; filter output bias shifted so that a pose without contact scores 0"
     if getattr(args, "hidden", None) and name == args.workload:
         # another hidden width (select_model's multiplier moves it: ProteinRepresentationModels.py:24,35-36): Xavier-like
         g = torch.Generator().manual_seed(2)
@@ -812,6 +822,10 @@ def e3_measurement(dev, nb, nsteps=6):
         repr_ = E3MultiResRepr4x4(multiplier=8)
         model = GlobalDockingModel(repr_, SimpleFilter(repr_.get_num_outputs()), threshold_clash=3.0).to(dev)
         model.eval()
+        # (as in the real_protein workload: the seeded random filter's score of a pose WITHOUT contact is shifted to zero, so
+        #  that the ranked list is made of contact poses and the candidate lists of K3 work as they do for a trained model)
+        W1_, b1_, W2_, b2_ = model.filter.parameters_tuple()
+        model.filter.fc[2].bias.data -= (W2_.reshape(1, -1) @ torch.relu(b1_.reshape(-1, 1))).reshape(-1)[0] + b2_.reshape(-1)[0]
         be = CoordsBackend()
         rot = Rotations(20, allow_generated=True, verbose=False)
         dk = Docker(model, angle_inc=20, box_size=80, resolution=1.25, max_conf=2000, device=dev, coords_backend=be,
@@ -901,6 +915,7 @@ def e3_measurement(dev, nb, nsteps=6):
                "rot_per_s": nb / (ms_all * 1e-3),
                "value": nb / (ms_all * 1e-3) * (2.0 * L) ** 3,
                "unit": "pose scores/s", "ligand_atoms": natoms, "path": "fused engine on the batch's own volumes",
+               "filter": "seeded SimpleFilter, output bias shifted so that a pose without contact scores 0 (round 6)",
                "conv_precision": __import__("deeplocalproteindocking_amd.ops", fromlist=["CONV_PRECISION"]).CONV_PRECISION}
         dk.release_engine()
         del eng

@@ -18,7 +18,8 @@
 // build (from the repository root, after `python -c 'import __graft_entry__ as g; g.build()'`):
 //   hipcc --offload-arch=gfx950 -O2 -I include scripts/micro/coresidency_repro.hip -o scripts/micro/coresidency_repro \
 //         -L deeplocalproteindocking_amd/csrc -ldlpd -Wl,-rpath,$PWD/deeplocalproteindocking_amd/csrc
-// run:  scripts/micro/coresidency_repro [iterations = 300] [aggressor: 1 | 0]
+// run:  scripts/micro/coresidency_repro [iterations = 300] [aggressor: 1 | 0] [victim inputs: 0 blob | 1 dense] [aggressor input: 0 blob | 1 dense]
+//       (the last two bisect what the effect depends on; the per-stage tallies say which victim kernel differs first)
 //
 // RATE MEASURED IN ROUND 6: see profiles/r06_coresidency_repro.log (copied from the GPU box).
 #include <hip/hip_runtime.h>
@@ -67,13 +68,14 @@ static std::vector<float> blob(int C, int L, int lo, int hi, unsigned seed, floa
 
 int main(int argc, char** argv) {
   const int iters = argc > 1 ? atoi(argv[1]) : 300, with_aggressor = argc > 2 ? atoi(argv[2]) : 1;
+  const int victim_dense = argc > 3 ? atoi(argv[3]) : 0, aggressor_dense = argc > 4 ? atoi(argv[4]) : 0;
   const int L = 40, N = 2 * L, NZ = L + 1, C = 32, nb = 16, HP = 24;
   hipStream_t sv, sa;
   CK(hipStreamCreate(&sv));
   CK(hipStreamCreate(&sa));
   // ---- victim inputs
-  float* rec = dev_floats(blob(C, L, 8, 31, 11u, 0.3f));
-  float* lig = dev_floats(blob(C, L, 12, 27, 12u, 0.3f));
+  float* rec = dev_floats(blob(C, L, victim_dense ? 0 : 8, victim_dense ? L : 31, 11u, 0.3f));
+  float* lig = dev_floats(blob(C, L, victim_dense ? 0 : 12, victim_dense ? L : 27, 12u, 0.3f));
   std::vector<float> Rh(nb * 9);
   for (int b = 0; b < nb; b++) {                       // proper rotations: Rz(a) Rx(t) Rz(p)
     const double a = 0.3 + 0.37 * b, t = 0.2 + 0.17 * b, p = -1.0 + 0.29 * b;
@@ -101,19 +103,24 @@ int main(int argc, char** argv) {
   if (npk > 0) OK(dlpd_receptor_pack(spec, packed, C, L, sv));
   unsigned long long* sums;
   CK(hipMalloc(&sums, 16));
-  auto victim = [&](unsigned long long out[2]) {
+  CK(hipFree(sums));
+  CK(hipMalloc(&sums, 48));
+  // out[0..1]: checksums of the final planes; out[2..3] / out[4..5]: of K1's and K2's outputs (which stage differs first)
+  auto victim = [&](unsigned long long out[6]) {
+    CK(hipMemsetAsync(sums, 0, 48, sv));
     OK(dlpd_zfft_channels_last(cl, R, wsA, nb, C, C, 0, L, L / 2.0f, sv));
+    k_checksum<<<1024, 256, 0, sv>>>((const unsigned*)wsA, (size_t)nb * C * NZ * L * L * 2, sums + 2);
     if (npk > 0) OK(dlpd_xy_correlate_packed(wsA, packed, wsB, nb, C, L, sv));
     else OK(dlpd_xy_correlate_oriented(wsA, spec, wsB, nb, C, L, 0, 0, sv));
+    k_checksum<<<1024, 256, 0, sv>>>((const unsigned*)wsB, (size_t)nb * C * NZ * N * N * 2, sums + 4);
     OK(dlpd_zifft_preact(wsB, pre, nb, C, L, W1, b1, HP, 1, 5.0f, sv));
-    CK(hipMemsetAsync(sums, 0, 16, sv));
     k_checksum<<<1024, 256, 0, sv>>>((const unsigned*)pre, (size_t)nb * HP * N * N * N, sums);
-    CK(hipMemcpyAsync(out, sums, 16, hipMemcpyDeviceToHost, sv));
+    CK(hipMemcpyAsync(out, sums, 48, hipMemcpyDeviceToHost, sv));
     CK(hipStreamSynchronize(sv));
   };
   // ---- aggressor inputs: one 16 -> 16 channel 5^3 layer on a 4 x 16 x 80^3 blob
   const int D = 80, B = 4, CI = 16, CO = 16, KS = 5;
-  std::vector<float> xh = blob(B * CI, D, 24, 52, 21u, 1.0f);
+  std::vector<float> xh = blob(B * CI, D, aggressor_dense ? 0 : 24, aggressor_dense ? D : 52, 21u, 1.0f);
   float* x = dev_floats(xh);
   std::vector<float> wh((size_t)CO * CI * KS * KS * KS);
   for (auto& w : wh) w = 0.1f * unit(s);
@@ -131,7 +138,8 @@ int main(int argc, char** argv) {
   std::atomic<bool> stop(false);
   std::atomic<long> launches(0);
   std::thread agg;
-  unsigned long long ref[2], again[2], got[2];
+  unsigned long long ref[6], again[6], got[6];
+  int first_stage[3] = {0, 0, 0};
   victim(ref);
   victim(again);
   printf("undisturbed: %016llx %016llx; again identical: %s\n", ref[0], ref[1], (ref[0] == again[0] && ref[1] == again[1]) ? "yes" : "NO");
@@ -151,10 +159,16 @@ int main(int argc, char** argv) {
       if (first < 0) first = it;
       differing++;
     }
+    if (got[2] != ref[2] || got[3] != ref[3]) first_stage[0]++;
+    else if (got[4] != ref[4] || got[5] != ref[5]) first_stage[1]++;
+    else if (got[0] != ref[0] || got[1] != ref[1]) first_stage[2]++;
   }
   stop.store(true);
   if (agg.joinable()) agg.join();
   printf("aggressor %s (%ld convolution launches beside %d victim launches): %d of %d victim launches differ from the undisturbed bits"
          " (first at iteration %d)\n", with_aggressor ? "ON" : "off", launches.load(), iters, differing, iters, first);
+  printf("  victim inputs %s, aggressor input %s; first differing stage: K1 (rotation + z transform) %d, K2 (x-y correlation) %d, "
+         "K3 (z inverse + first layer) %d\n", victim_dense ? "dense" : "blob", aggressor_dense ? "dense" : "blob", first_stage[0],
+         first_stage[1], first_stage[2]);
   return differing ? 1 : 0;
 }
