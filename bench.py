@@ -75,6 +75,9 @@ def parse_args():
     ap.add_argument("--cpu_rotations", type=int, default=16,
                     help="rotations of the CPU baseline sample, spread over the four search groups (0: skip)")
     ap.add_argument("--no_real_shapes", action="store_true", help="skip the short N = 160 measurement")
+    ap.add_argument("--rotation_order", default="set", choices=("set", "random", "strided8"),
+                    help="diagnostic: which rotations share a launch -- set order (16 consecutive phi steps of one direction), a random "
+                         "permutation, or every 8th rotation (what one of 8 ranks sees under r::8 interleaving)")
     ap.add_argument("--k1_occupancy", default="auto", choices=("auto", "on", "off"),
                     help="per-rotation occupancy maps in the channels-last K1: auto = where the ligand leaves most cells empty")
     ap.add_argument("--no_pmc", action="store_true",
@@ -437,6 +440,10 @@ def run_rank(args):
     if args.same_device and args.backend == "nccl" and world > 1:
         raise SystemExit("bench.py: --same_device needs --backend gloo (RCCL wants one device per rank)")
     dev = torch.device("cuda", 0 if args.same_device else local_rank)
+    if args.same_device and world > 1 and rank == 0:
+        print("bench.py: --same_device puts %d ranks on ONE GPU: kernels of different processes share CUs, which on this hardware can "
+              "change low mantissa bits of a few scores (inside the 1e-4 parity band; INTEGRATION.md, 'Sharing the GPU') -- a test mode "
+              "for the multi-rank code path, not a way to run searches" % world, file=sys.stderr, flush=True)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1 or args.force_group:
@@ -467,6 +474,10 @@ def run_rank(args):
     generated = rot.source == "generated"
     shard = np.arange(rank, nrot_total, world)                # this rank's interleaved shard
     seq_ids, seq_key = visiting_sequence(DockingEngine, R_all, shard, nb)
+    if args.rotation_order != "set":         # (diagnostic: the list does not depend on the order, K1's gather locality might)
+        perm = np.random.RandomState(0).permutation(len(seq_ids)) if args.rotation_order == "random" else \
+            np.concatenate([np.arange(j, len(seq_ids), 8) for j in range(8)])
+        seq_ids, seq_key = seq_ids[perm], seq_key[perm]
     shard_batches = len(seq_ids) // nb
     # K timed + W warm-up steps = batches spread evenly over the whole sequence (K > shard_batches repeats batches)
     def spread(n):
@@ -679,6 +690,8 @@ def run_rank(args):
             "metric": metric, "value": poses / elapsed, "unit": "pose scores/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            **({"same_device_note": "ranks share one GPU: co-resident kernels of different processes can perturb low bits of a few scores "
+                                    "on this hardware (parity band only; INTEGRATION.md)"} if (args.same_device and world > 1) else {}),
             "config": {"workload": "%s, %d-degree SOI-sized rotation set (%d rotations, %s), max_conf=%d" %
                                    (wl["desc"] if (args.channels, args.box) == (None, None) else
                                     "synthetic %d-channel %d^3 pair" % (C, L), angle, nrot_total, rot_src, K),
@@ -954,7 +967,24 @@ def fetch_scale(stage, N, hidden_pad=None):
     if stage == "k3_zifft_filter" and hidden_pad is not None and hidden_pad > (24 if N == 160 else 32):
         return 1.0
     return FETCH_SCALE.get((stage, N), 2.0)
-STAGE_KERNELS = {"k1_rotate_zfft": ("k_rotate_zfft_cl<%d>", "k_rotate_zfft_cl_rs<%d>", "k_rotate_zfft<%d>"),
+# FETCH_SIZE per byte read, measured per load shape on a 4 GiB buffer read once (scripts/micro/fetch_size_shapes.hip,
+# profiles/r06_fetch_size_shapes.txt): 16 bytes per lane, 1 KB per wave instruction 0.500 (the guide's rule); 8 bytes per lane in
+# 64-byte runs 1 KB apart -- K2<128>'s receptor loads -- 0.727 (a mix of 128- and 64-byte requests); 16 bytes per lane in scattered
+# 64-byte runs 0.605
+FETCH_PER_BYTE = {"wide16": 0.500, "runs64_8B": 0.727, "runs64_16B": 0.605}
+
+
+def k2_natural_read_bytes(raw_fetch, nb, CT, L):
+    """K2<64 / 128> (k_xy_corr: natural-layout receptor) issues two load shapes: its A rows (wide: tallied at half) and the
+    receptor values (64-byte runs: tallied at 0.727).  raw = 0.5 A + 0.727 rec_fetched with A = the algorithmic A bytes (read
+    once, streaming) -> bytes really read, and how often the receptor slab crossed the fabric per launch."""
+    A = nb * CT * (L + 1) * L * L * 8.0
+    rec = CT * (L + 1) * (2 * L) ** 2 * 8.0
+    rec_fetched = max(raw_fetch - FETCH_PER_BYTE["wide16"] * A, 0.0) / FETCH_PER_BYTE["runs64_8B"]
+    return A + rec_fetched, rec_fetched / rec
+
+
+STAGE_KERNELS = {"k1_rotate_zfft": ("k_rotate_zfft_cl<%d,", "k_rotate_zfft_cl_rs<%d>", "k_rotate_zfft<%d>"),
                  "k2_xy_corr": ("k_xy_corr<%d, 1>", "k_xy_corr_q4<%d,", "k_xy_corr_quad<%d,"),
                  "k3_zifft_filter": ("k_zifft_filter_rs<%d,",)}
 
@@ -1016,6 +1046,15 @@ def live_pmc_traffic(args, stage, N, hidden_pad=None):
                     return None, None
                 per_launch[counter] = total / len(launches) * 1024.0            # KB -> bytes
         scale = fetch_scale(stage, N, hidden_pad)
+        if stage == "k2_xy_corr" and N in (64, 128) and not getattr(args, "channels", None) and not getattr(args, "box", None):
+            C_, L_, _, _, _ = WORKLOADS[args.workload]
+            reads, refetch = k2_natural_read_bytes(per_launch["FETCH_SIZE"], args.batch, C_ + 1, L_)
+            return reads + per_launch["WRITE_SIZE"], \
+                ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two child passes of bench.py --steps 6, per "
+                 "launch of %s...): raw FETCH_SIZE %.0f bytes taken apart by load shape (scripts/micro/fetch_size_shapes.hip: the A rows, "
+                 "16 bytes per lane, are tallied at 0.500 of their bytes, the receptor values, 64-byte runs, at 0.727) = %.0f bytes read -- "
+                 "the A rows once, the receptor slab %.2f times per launch of %d rotations -- + raw WRITE_SIZE %.0f bytes"
+                 % (pats[0], per_launch["FETCH_SIZE"], reads, refetch, args.batch, per_launch["WRITE_SIZE"]))
         return scale * per_launch["FETCH_SIZE"] + per_launch["WRITE_SIZE"], \
             ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two child passes of bench.py "
              "--steps 6, per launch of %s...): raw FETCH_SIZE %.0f bytes x %.0f (gfx950 tallies a 128-byte read request at 64 "

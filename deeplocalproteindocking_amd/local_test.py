@@ -192,6 +192,10 @@ def main(argv=None):
     if args.same_device and args.backend == "nccl" and world > 1:
         raise SystemExit("local_test.py: -same_device needs -backend gloo (RCCL wants one device per rank)")
     dev = torch.device("cuda", 0 if args.same_device else local_rank)
+    if args.same_device and world > 1 and rank == 0:
+        print("local_test.py: -same_device puts %d ranks on ONE GPU: kernels of different processes share CUs, which on this hardware "
+              "can change low mantissa bits of a few scores (inside the 1e-4 parity band; INTEGRATION.md, 'Sharing the GPU') -- a test "
+              "mode, not a way to run a sweep" % world, file=sys.stderr, flush=True)
     torch.cuda.set_device(dev)                          # (local_test.py:44 sets device 0)
     if world > 1 or args.force_group:
         import torch.distributed as dist

@@ -10,6 +10,22 @@
  *
  * Layouts: volumes are (.., L, L, L) float32, index [x][y][z], z contiguous.  N = 2L,
  * NZ = N/2 + 1.  Spectra are (.., NZ, N, N) complex64 indexed [kz][kx][ky].
+ *
+ * THE PATH -- the minimal call set of one search (Docker.py:184-238; what DockingEngine issues in steady state):
+ *   once per pair    dlpd_rfft3d_padded        receptor spectrum            (DockingModels.py:71, hoisted out of the loop)
+ *                    dlpd_receptor_pack        ... in K2's read order       (boxes 80 / 40 only)
+ *                    dlpd_make_channels_last   ligand copy K1 gathers from
+ *   per 16 rotations dlpd_zfft_channels_last   K1: rotation + z transform  (Docker.py:218)
+ *                    dlpd_project_atoms + dlpd_zfft_into   clash channel from rotated atoms (Docker.py:221-224)
+ *                    dlpd_xy_correlate_packed / dlpd_xy_correlate   K2     (DockingModels.py:70-71, Docker.py:225)
+ *                    dlpd_zifft_filter_cand    K3: z inverse + clip + MLP + clash mask + candidates (DockingModels.py:74-83, Docker.py:226-232)
+ *                    dlpd_topk_select_cand, dlpd_topk_merge_tau   the ranked list (Docker.py:86-105)
+ *   two resolutions  the same K1 / K2 on the coarse grid, then dlpd_zifft_preact (coarse) and dlpd_zifft_filter_cand(aux = its planes)
+ * Everything else in this header is a VARIANT of one of these stages -- suffix _ext (embedded box), _oriented / _quads (launch
+ * variants of the per-channel K1), _form (kernel formulation named: test cross-checks), _occ (occupancy maps: sparse ligands),
+ * _aux / un-suffixed (fewer features) -- a stand-alone operator of the plugin surface (dlpd_rotate_trilinear,
+ * dlpd_correlate_generic, dlpd_filter_*, dlpd_conv3d*, dlpd_maxpool3d_5s2*), or a size / capability query.  Test hooks
+ * (dlpd_debug_*) are declared in dlpd_debug.h, not here.
  */
 #ifndef DLPD_H
 #define DLPD_H
@@ -24,13 +40,6 @@ extern "C" {
 #define DLPD_ERR_LAUNCH 3
 
 int dlpd_version(void);
-/* TEST HOOK, no reference counterpart: on = 1 makes every kernel launch of this library be preceded by a kernel that fills
- * the LDS of every CU with NaNs (a result that depends on LDS the kernel never wrote then fails on every run instead of
- * once in a while beside another stream); 0 switches it off.  Never on in a timed or production run. */
-int dlpd_debug_poison_lds(int on);
-/* ... and its self-check: poison, then a kernel that writes nothing to its LDS counts the poisoned words it finds -> per mille
- * (0 .. 1000), -1 on a launch error.  counter8: 8 bytes of device memory. */
-int dlpd_debug_poison_selfcheck(void* counter8, void* stream);
 /* sha256 (64 hex digits) of the sources, headers and flags this library was built from; the build
  * script refuses a library whose hash differs from the sources next to it */
 const char* dlpd_source_hash(void);

@@ -22,8 +22,15 @@ def built_lib():
 
 def test_library_exports_every_declared_symbol(built_lib):
     header = open(os.path.join(ROOT, "include", "dlpd.h")).read()
-    names = set(re.findall(r"\b(dlpd_[a-z0-9_]+)\s*\(", header))
+    assert "dlpd_debug_" not in header                            # test hooks live in their own header ...
+    debug = open(os.path.join(ROOT, "include", "dlpd_debug.h")).read()
+    names = set(re.findall(r"\b(dlpd_[a-z0-9_]+)\s*\(", header)) | set(re.findall(r"\b(dlpd_debug_[a-z0-9_]+)\s*\(", debug))
     assert len(names) >= 15
+    # ... and every call of the minimal set the header's first comment names is declared below it
+    for n in ("dlpd_rfft3d_padded", "dlpd_receptor_pack", "dlpd_make_channels_last", "dlpd_zfft_channels_last", "dlpd_project_atoms",
+              "dlpd_zfft_into", "dlpd_xy_correlate_packed", "dlpd_xy_correlate", "dlpd_zifft_filter_cand", "dlpd_topk_select_cand",
+              "dlpd_topk_merge_tau", "dlpd_zifft_preact"):
+        assert header.count(n) >= 2 and n in names, n
     from deeplocalproteindocking_amd._lib import SIGNATURES
     assert names == set(SIGNATURES), names ^ set(SIGNATURES)
     import ctypes
