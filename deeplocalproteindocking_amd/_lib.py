@@ -50,8 +50,10 @@ SIGNATURES = {
     "dlpd_zfft_channels_last_ext": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
     "dlpd_zfft_channels_last_form": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
     "dlpd_k1_form_supported": (_i, [_i, _i]),
-    "dlpd_rotated_occupancy": (_i, [_p, _p, _p, _i, _i, _f, _p]),
-    "dlpd_zfft_channels_last_occ": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "dlpd_rotated_occupancy": (_i, [_p, _p, _p, _p, _i, _i, _f, _p]),
+    "dlpd_zfft_channels_last_occ": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
+    "dlpd_pencil_map_supported": (_i, [_i]),
+    "dlpd_xy_correlate_packed_occ": (_i, [_p, _p, _p, _i, _i, _i, _p, _i, _p]),
     "dlpd_xy_correlate_oriented": (_i, [_p, _p, _p, _i, _i, _i, _ll, _i, _p]),
     "dlpd_score_rotations_oriented": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _f, _i, _i, _f, _f,
                                            _p, _p, _p, _i, _p]),
@@ -120,7 +122,7 @@ class DlpdLib:
     def call(self, name, *args):
         rc = getattr(self, "_" + name)(*args)
         if SIGNATURES[name][0] is _i and name not in ("dlpd_version", "dlpd_grid_supported", "dlpd_conv3d_supported", "dlpd_orientation_supported",
-                                                      "dlpd_hidden_pad", "dlpd_fused_hidden_pad", "dlpd_generic_box_supported", "dlpd_debug_poison_selfcheck", "dlpd_k1_form_supported") and rc != 0:
+                                                      "dlpd_hidden_pad", "dlpd_fused_hidden_pad", "dlpd_generic_box_supported", "dlpd_debug_poison_selfcheck", "dlpd_k1_form_supported", "dlpd_pencil_map_supported") and rc != 0:
             raise RuntimeError("dlpd: %s failed: %s" % (name, ERRORS.get(rc, rc)))
         return rc
 

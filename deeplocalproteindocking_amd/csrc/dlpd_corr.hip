@@ -312,7 +312,8 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
 // and writes its zeros.  Exact; same spectra as without the map.
 template <int N, bool OCC> __global__ void __launch_bounds__(K1ClCfg<N>::NP * FftPlan<N>::T)
 k_rotate_zfft_cl(const float4* __restrict__ cl, const float* __restrict__ R, cplx* __restrict__ A,
-                 int C, int Cq, int nb, float c0, int CT_out, int c_base, int ext, const unsigned char* __restrict__ occ) {
+                 int C, int Cq, int nb, float c0, int CT_out, int c_base, int ext, const unsigned char* __restrict__ occ,
+                 int skip_empty) {
   constexpr int L = N / 2, NZ = N / 2 + 1, NP = K1ClCfg<N>::NP, CC = K1ClCfg<N>::CC, YG = K1ClCfg<N>::YG, NPR = YG / 2;
   constexpr int LPV = CC / 4, SKEW = 16 / LPV;         // lanes per voxel; bank skew (complex) between channel quads
   static_assert(CC * NPR == NP && L % YG == 0 && (NP * FftPlan<N>::T) % 64 == 0, "whole waves of pencils per block");
@@ -344,6 +345,7 @@ k_rotate_zfft_cl(const float4* __restrict__ cl, const float* __restrict__ R, cpl
     }
     __syncthreads();
     if (!occ_any) {                                            // (block-uniform) nothing to gather or transform: the zeros go out
+      if (skip_empty) return;                                  // ... unless the consumer goes by the pencil map (dlpd_xy_correlate_packed_occ)
       for (int s = tid; s < NP * NZ; s += NT) {
         const int pm = s % NP, k = s / NP;
         const int c = chunk * CC + pm / NPR, m = pm % NPR;
@@ -423,7 +425,7 @@ __global__ void __launch_bounds__(256) k_make_channels_last(const float* __restr
 }
 
 template <int N> static int launch_k1_cl(const float4* cl, const float* R, cplx* A, int C, int nb, float c0, hipStream_t st,
-                                         int CT_out, int c_base, int ext = 0, const unsigned char* occ = nullptr) {
+                                         int CT_out, int c_base, int ext = 0, const unsigned char* occ = nullptr, int skip_empty = 0) {
   constexpr int L = N / 2, RS = N + DLPD_K1CL_PAD;
   const int Cq = ((C + DLPD_K1CL_CC - 1) / DLPD_K1CL_CC) * (DLPD_K1CL_CC / 4);
   const size_t shmem = (size_t)(K1ClCfg<N>::NP * RS + N) * sizeof(cplx);
@@ -434,11 +436,11 @@ template <int N> static int launch_k1_cl(const float4* cl, const float* R, cplx*
   if (occ) {
     int rc = dlpd_set_max_dyn_shared((const void*)k_rotate_zfft_cl<N, true>, shmem);
     if (rc) return rc;
-    DLPD_LAUNCH((k_rotate_zfft_cl<N, true>), grid, block, shmem, st, cl, R, A, C, Cq, nb, c0, CT_out, c_base, e, occ);
+    DLPD_LAUNCH((k_rotate_zfft_cl<N, true>), grid, block, shmem, st, cl, R, A, C, Cq, nb, c0, CT_out, c_base, e, occ, skip_empty);
   } else {
     int rc = dlpd_set_max_dyn_shared((const void*)k_rotate_zfft_cl<N, false>, shmem);
     if (rc) return rc;
-    DLPD_LAUNCH((k_rotate_zfft_cl<N, false>), grid, block, shmem, st, cl, R, A, C, Cq, nb, c0, CT_out, c_base, e, occ);
+    DLPD_LAUNCH((k_rotate_zfft_cl<N, false>), grid, block, shmem, st, cl, R, A, C, Cq, nb, c0, CT_out, c_base, e, occ, 0);
   }
   return dlpd_check_launch();
 }
@@ -449,7 +451,8 @@ template <int N> static int launch_k1_cl(const float4* cl, const float* R, cplx*
 // occ_src (one map for all channels of the stored ligand, dlpd_conv3d_tile_occupancy), all their products are zero.
 // Same sample map as k1cl_sample_rows (p = c0 + M (voxel - c0), M columns r0..r2 | r3..r5 | r6..r8).
 __global__ void __launch_bounds__(256) k_rotated_occupancy(const unsigned char* __restrict__ occ_src, const float* __restrict__ R,
-                                                           unsigned char* __restrict__ occ_out, int nb, int L, float c0) {
+                                                           unsigned char* __restrict__ occ_out, unsigned char* __restrict__ pencil_out,
+                                                           int nb, int L, float c0) {
   const int nc = (L + 3) / 4, nc3 = nc * nc * nc;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb * nc3; i += gridDim.x * blockDim.x) {
     const int b = i / nc3, cell = i % nc3, cz = cell % nc, cy = (cell / nc) % nc, cx = cell / (nc * nc);
@@ -471,6 +474,8 @@ __global__ void __launch_bounds__(256) k_rotated_occupancy(const unsigned char* 
       for (int sy = lo[1]; sy <= hi[1]; sy++)
         for (int sz = lo[2]; sz <= hi[2]; sz++) any |= occ_src[(sx * nc + sy) * nc + sz] != 0;
     occ_out[i] = any ? 1 : 0;
+    // pencil map (zeroed by the host): (x cell, y cell) holds an occupied z cell -- plain stores of the same value
+    if (any && pencil_out) pencil_out[((size_t)b * nc + cx) * nc + cy] = 1;
   }
 }
 
@@ -1327,7 +1332,8 @@ int dlpd_k2_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb,
 int dlpd_k2_orientation_supported(int L);
 long long dlpd_k2_packed_receptor_floats(int CT, int L);
 int dlpd_k2_pack_receptor(const cplx* rec, void* packed, int CT, int L, hipStream_t st);
-int dlpd_k2_correlate_packed(const cplx* A, const cplx* packed, cplx* out, int CT, int nb, int L, hipStream_t st);
+int dlpd_k2_correlate_packed(const cplx* A, const cplx* packed, cplx* out, int CT, int nb, int L, hipStream_t st,
+                             const unsigned char* pmap = nullptr, int nmasked = 0);
 
 // channels per group.  One channel per wave (16-row tiles, N <= 128): as many as there are channel-owning waves -- 49
 // channels on 8 waves are six full groups and one with the clash channel alone, 1 % faster than seven groups of seven,
@@ -1546,27 +1552,30 @@ int dlpd_zfft_channels_last_form(const float* cl, const float* R, void* wsA, int
 
 // occ_src (ceil(L/4)^3 bytes: the stored ligand's cells, all channels) -> occ_out (nb maps): the cells of each ROTATED volume
 // that can hold a non-zero sample (conservative); R as K1 takes it
-int dlpd_rotated_occupancy(const unsigned char* occ_src, const float* R, unsigned char* occ_out, int nb, int L, float center,
-                           void* stream) {
+int dlpd_rotated_occupancy(const unsigned char* occ_src, const float* R, unsigned char* occ_out, unsigned char* pencil_out, int nb,
+                           int L, float center, void* stream) {
   if (!occ_src || !R || !occ_out || nb <= 0 || L <= 0) return DLPD_ERR_ARG;
   const int nc = (L + 3) / 4, total = nb * nc * nc * nc;
-  DLPD_LAUNCH(k_rotated_occupancy, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, occ_src, R, occ_out, nb, L,
-              center);
+  if (pencil_out && hipMemsetAsync(pencil_out, 0, (size_t)nb * nc * nc, (hipStream_t)stream) != hipSuccess) return DLPD_ERR_LAUNCH;
+  DLPD_LAUNCH(k_rotated_occupancy, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, occ_src, R, occ_out,
+              pencil_out, nb, L, center);
   return dlpd_check_launch();
 }
+// 1 where dlpd_xy_correlate_packed_occ exists: the packed-receptor boxes (80, 40)
+int dlpd_pencil_map_supported(int L) { return dlpd_k2_packed_receptor_floats(1, L) > 0 ? 1 : 0; }
 
 // dlpd_zfft_channels_last_ext with the rotated volumes' occupancy maps (dlpd_rotated_occupancy): empty cells are not gathered
 int dlpd_zfft_channels_last_occ(const float* cl, const float* R, const unsigned char* occ, void* wsA, int nb, int C, int CT_out,
-                                int c_base, int L, float center, int extent, void* stream) {
+                                int c_base, int L, float center, int extent, int skip_empty, void* stream) {
   if (!cl || !R || !occ || !wsA || nb <= 0 || C <= 0 || c_base < 0 || c_base + C > CT_out || extent < 0 || extent > L) return DLPD_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   cplx* A = (cplx*)wsA;
   const float4* c4 = (const float4*)cl;
   switch (L) {
-    case 32: return launch_k1_cl<64>(c4, R, A, C, nb, center, st, CT_out, c_base, extent, occ);
-    case 40: return launch_k1_cl<80>(c4, R, A, C, nb, center, st, CT_out, c_base, extent, occ);
-    case 64: return launch_k1_cl<128>(c4, R, A, C, nb, center, st, CT_out, c_base, extent, occ);
-    case 80: return launch_k1_cl<160>(c4, R, A, C, nb, center, st, CT_out, c_base, extent, occ);
+    case 32: return launch_k1_cl<64>(c4, R, A, C, nb, center, st, CT_out, c_base, extent, occ, skip_empty);
+    case 40: return launch_k1_cl<80>(c4, R, A, C, nb, center, st, CT_out, c_base, extent, occ, skip_empty);
+    case 64: return launch_k1_cl<128>(c4, R, A, C, nb, center, st, CT_out, c_base, extent, occ, skip_empty);
+    case 80: return launch_k1_cl<160>(c4, R, A, C, nb, center, st, CT_out, c_base, extent, occ, skip_empty);
     default: return DLPD_ERR_UNSUPPORTED;
   }
 }
@@ -1624,6 +1633,14 @@ int dlpd_receptor_pack(const void* rec, void* packed, int CT, int L, void* strea
 int dlpd_xy_correlate_packed(const void* wsA, const void* rec_packed, void* wsB, int nb, int CT, int L, void* stream) {
   if (!wsA || !rec_packed || !wsB || nb <= 0 || CT <= 0) return DLPD_ERR_ARG;
   return dlpd_k2_correlate_packed((const cplx*)wsA, (const cplx*)rec_packed, (cplx*)wsB, CT, nb, L, (hipStream_t)stream);
+}
+// ... going by a per-rotation pencil map (dlpd_rotated_occupancy's second output) for channels [0, nmasked): pencils the map
+// marks empty are not read from wsA (K1 with skip_empty did not write them); the packed-receptor boxes only
+int dlpd_xy_correlate_packed_occ(const void* wsA, const void* rec_packed, void* wsB, int nb, int CT, int L,
+                                 const unsigned char* pencil_map, int nmasked, void* stream) {
+  if (!wsA || !rec_packed || !wsB || !pencil_map || nb <= 0 || CT <= 0 || nmasked < 0 || nmasked > CT) return DLPD_ERR_ARG;
+  return dlpd_k2_correlate_packed((const cplx*)wsA, (const cplx*)rec_packed, (cplx*)wsB, CT, nb, L, (hipStream_t)stream, pencil_map,
+                                  nmasked);
 }
 
 // wsB -> real correlation volumes out (nb, CT, N^3), optional clamp

@@ -743,7 +743,7 @@ int dlpd_k2_forward(const cplx* A, cplx* out, int CT, int nb, int L, float scale
 
 // N = 160 with 4-lane pencils and affine LDS addressing: dlpd_k2q.hip (untransposed slabs)
 int dlpd_k2q_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, int L, long long rbs, int nsplit_override,
-                       hipStream_t st, int packed);
+                       hipStream_t st, int packed, const unsigned char* pmap = nullptr, int nmasked = 0);
 int dlpd_k2q_pack_receptor(const cplx* rec, void* packed, int CT, int L, hipStream_t st);
 #ifndef DLPD_K2_Q4
 #define DLPD_K2_Q4 1
@@ -777,9 +777,10 @@ int dlpd_k2_pack_receptor(const cplx* rec, void* packed, int CT, int L, hipStrea
   if (!dlpd_k2_packed_receptor_floats(CT, L)) return DLPD_ERR_UNSUPPORTED;
   return dlpd_k2q_pack_receptor(rec, packed, CT, L, st);
 }
-int dlpd_k2_correlate_packed(const cplx* A, const cplx* packed, cplx* out, int CT, int nb, int L, hipStream_t st) {
+int dlpd_k2_correlate_packed(const cplx* A, const cplx* packed, cplx* out, int CT, int nb, int L, hipStream_t st,
+                             const unsigned char* pmap, int nmasked) {
   if (!dlpd_k2_packed_receptor_floats(CT, L)) return DLPD_ERR_UNSUPPORTED;
-  return dlpd_k2q_correlate(A, packed, out, CT, nb, L, 0, k2_nsplit_override(), st, 1);
+  return dlpd_k2q_correlate(A, packed, out, CT, nb, L, 0, k2_nsplit_override(), st, 1, pmap, nmasked);
 }
 
 // Slabs that K1 stored transposed (dlpd_zfft_oriented, the per-channel K1 of ligands with fewer than 8 channels): every

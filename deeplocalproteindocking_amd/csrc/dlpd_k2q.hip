@@ -190,7 +190,7 @@ template <int ES> struct Q4 {
 //   contiguous half-kilobytes per (slab, p) -- instead of the natural [kz][kx][ky]
 template <int N, bool PACKED> __global__ void __launch_bounds__(640)
 k_xy_corr_q4(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __restrict__ out,
-             int CT, int nb, int nsplit, long long rec_bstride) {
+             int CT, int nb, int nsplit, long long rec_bstride, const unsigned char* __restrict__ pmap, int nmasked) {
   constexpr int L = N / 2, H = N / 2, NZ = N / 2 + 1;
   constexpr int RS = H + 4, HR = H + 4, SUB = HR * RS;   // 84 x 84: rows / columns 80..82 take the blocks-of-21 intermediates
   constexpr int NT = 640, W = NT / 64;
@@ -227,11 +227,22 @@ k_xy_corr_q4(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __r
   // use the same dealing: their (row, column) are a shift, a mask and an immediate)
   static_assert(L / 2 == 8 * NP, "row = 8 lanes x NP float4");
   float4 apref[NP];
+  // PENCIL MAP (round 6; pmap != null, channels c < nmasked): pmap[b][x cell][y cell] = 0 says that pencil (x, y) of rotation
+  // b's rotated ligand is all zero (dlpd_rotated_occupancy) -- K1 did not write it (dlpd_zfft_channels_last_occ, skip_empty) and
+  // it is NOT read here: the pair is the zero it stands for.  A float4 is two neighbouring y of one row: one cell.
+  constexpr int NC = (L + 3) / 4;
+  const bool by_map = pmap != nullptr && c < nmasked;          // (block-uniform)
   auto fetch_A = [&](int b) {
     const int srow = 8 * wave + (lane >> 3);
     const float4* a4 = reinterpret_cast<const float4*>(A + (((size_t)b * CT + c) * NZ + kz) * L * L + (size_t)srow * L) + (lane & 7);
+    if (by_map) {
+      const unsigned char* pm = pmap + ((size_t)b * NC + (srow >> 2)) * NC + ((lane & 7) >> 1);      // y cell = ((lane & 7) + 8 k) / 2
 #pragma unroll
-    for (int k = 0; k < NP; k++) apref[k] = DLPD_LOAD_STREAM(a4 + 8 * k);
+      for (int k = 0; k < NP; k++) apref[k] = pm[4 * k] ? DLPD_LOAD_STREAM(a4 + 8 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NP; k++) apref[k] = DLPD_LOAD_STREAM(a4 + 8 * k);
+    }
   };
   // H_0[u][v..v+1], H_0[u][v+H..] wait for H_1: NPR of the NP pairs in registers, the others parked in the LDS the
   // sub-slabs leave free (with all 40 registers held the column phase of p = 1 spills)
@@ -406,7 +417,7 @@ DLPD_HD int k2s4_column(int wave, int pidx) {
 }
 template <int N, bool PACKED> __global__ void __launch_bounds__(320)
 k_xy_corr_s4(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __restrict__ out,
-             int CT, int nb, int nsplit, long long rec_bstride) {
+             int CT, int nb, int nsplit, long long rec_bstride, const unsigned char* __restrict__ pmap, int nmasked) {
   constexpr int L = N / 2, NZ = N / 2 + 1, RS = N + 4, HR = N + 4;
   constexpr int NT = 320, W = NT / 64;
   static_assert(N == 80 && 16 * W == N && 8 * W == L, "five waves: 8 input rows, 16 columns and 16 output rows each");
@@ -436,11 +447,17 @@ k_xy_corr_s4(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __r
   const typename Q4<RS>::Rot rot_c = Q4<RS>::rot_of(t);
 
   float4 apref[NPI];
+  constexpr int NC = (L + 3) / 4;                       // pencil map (k_xy_corr_q4): pmap[b][x cell][y cell]
+  const bool by_map = pmap != nullptr && c < nmasked;
   auto fetch_A = [&](int b) {
     const float4* a4 = reinterpret_cast<const float4*>(A + (((size_t)b * CT + c) * NZ + kz) * L * L + (size_t)wave * 8 * L);
 #pragma unroll
     for (int k = 0; k < NPI; k++)
-      if (lane + 64 * k < NIN) apref[k] = DLPD_LOAD_STREAM(a4 + lane + 64 * k);
+      if (lane + 64 * k < NIN) {
+        const int f = lane + 64 * k, x = 8 * wave + f / (L / 2), yc = (f % (L / 2)) >> 1;
+        const bool live = !by_map || pmap[((size_t)b * NC + (x >> 2)) * NC + yc];
+        apref[k] = live ? DLPD_LOAD_STREAM(a4 + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
   };
   fetch_A(b_beg);
   DLPD_LDS_BARRIER();                                  // twiddle table visible
@@ -568,14 +585,14 @@ int dlpd_k2q_pack_receptor(const cplx* rec, void* packed, int CT, int L, hipStre
 }
 
 template <bool PACKED> static int k2q_launch(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, int L, long long rbs,
-                                             int nsplit, hipStream_t st) {
+                                             int nsplit, hipStream_t st, const unsigned char* pmap = nullptr, int nmasked = 0) {
   if (L == 40) {
     constexpr int N = 80, NZ = N / 2 + 1, RS = N + 4;
     const size_t shmem = (size_t)(RS * RS + N) * sizeof(cplx);
     int rc = dlpd_set_max_dyn_shared((const void*)k_xy_corr_s4<N, PACKED>, shmem);
     if (rc) return rc;
     const int slabs8 = ((NZ * CT + 7) / 8) * 8;
-    DLPD_LAUNCH((k_xy_corr_s4<N, PACKED>), dim3(slabs8 * nsplit), dim3(320), shmem, st, A, rec, out, CT, nb, nsplit, rbs);
+    DLPD_LAUNCH((k_xy_corr_s4<N, PACKED>), dim3(slabs8 * nsplit), dim3(320), shmem, st, A, rec, out, CT, nb, nsplit, rbs, pmap, nmasked);
     return dlpd_check_launch();
   }
   if (L != 80) return DLPD_ERR_UNSUPPORTED;
@@ -584,15 +601,16 @@ template <bool PACKED> static int k2q_launch(const cplx* A, const cplx* rec, cpl
   int rc = dlpd_set_max_dyn_shared((const void*)k_xy_corr_q4<N, PACKED>, shmem);
   if (rc) return rc;
   const int slabs8 = ((NZ * CT + 7) / 8) * 8;
-  DLPD_LAUNCH((k_xy_corr_q4<N, PACKED>), dim3(slabs8 * nsplit), dim3(640), shmem, st, A, rec, out, CT, nb, nsplit, rbs);
+  DLPD_LAUNCH((k_xy_corr_q4<N, PACKED>), dim3(slabs8 * nsplit), dim3(640), shmem, st, A, rec, out, CT, nb, nsplit, rbs, pmap, nmasked);
   return dlpd_check_launch();
 }
 
 // packed: rec is dlpd_k2q_pack_receptor's output (one receptor shared by the batch)
 int dlpd_k2q_correlate(const cplx* A, const cplx* rec, cplx* out, int CT, int nb, int L, long long rbs, int nsplit_override,
-                       hipStream_t st, int packed) {
+                       hipStream_t st, int packed, const unsigned char* pmap, int nmasked) {
   int nsplit = nb >= 8 ? 2 : 1;
   if (nsplit_override > 0) nsplit = nsplit_override;
-  if (packed) return rbs ? DLPD_ERR_ARG : k2q_launch<true>(A, rec, out, CT, nb, L, 0, nsplit, st);
+  if (pmap && !packed) return DLPD_ERR_UNSUPPORTED;
+  if (packed) return rbs ? DLPD_ERR_ARG : k2q_launch<true>(A, rec, out, CT, nb, L, 0, nsplit, st, pmap, nmasked);
   return k2q_launch<false>(A, rec, out, CT, nb, L, rbs, nsplit, st);
 }

@@ -221,7 +221,8 @@ class DockingEngine:
         # representation) gets per-rotation occupancy maps, and the channels-last K1 skips what they mark empty -- same
         # spectra.  None: decided per ligand in set_ligand (on below SPARSE_K1_MAX_FILL of the cells occupied); True / False force it.
         self.sparse_k1_wanted = sparse_k1
-        self.sparse_k1 = self.sparse_k1_coarse = False
+        self.sparse_k1 = self.sparse_k1_coarse = self.k2_pencil_map = self.k2_pencil_map_coarse = False
+        self._k2_by_map = {False: False, True: False}
         self.lig_fill = self.lig_fill_coarse = None
         self.window = None
         if self.extent:
@@ -303,6 +304,7 @@ class DockingEngine:
                 "k2_packed_receptor": {"fine": self.recP is not None, "coarse": self.recP1 is not None},
                 "embedded_extent": self.extent or None,
                 "k1_occupancy_maps": {"fine": bool(self.sparse_k1), "coarse": bool(self.sparse_k1_coarse),
+                                      "k2_pencil_map": {"fine": bool(self.k2_pencil_map), "coarse": bool(self.k2_pencil_map_coarse)},
                                       "ligand_cells_occupied": {"fine": self.lig_fill, "coarse": self.lig_fill_coarse}},
                 "rotation": {"center": self.center, "scale": self.rot_scale, "axis_order": self.rot_axis_order,
                              "transpose": self.rot_transpose},
@@ -366,7 +368,13 @@ class DockingEngine:
         """Stage K2 of the fine or the coarse grid on what K1 left in its wsA; tr: the slab orientation K1 used."""
         wsA, rec, recP, wsB, CT, L = ((self.wsA1, self.recF1, self.recP1, self.wsB1, self.C1, self.L1) if coarse else
                                       (self.wsA, self.recF, self.recP, self.wsB, self.CT, self.L))
-        if recP is not None and not tr:
+        if self._k2_by_map[bool(coarse)]:
+            # K1 left the pencils of empty blocks unwritten: K2 takes them as zeros by the map (score channels only)
+            assert recP is not None and not tr
+            self._k2_by_map[bool(coarse)] = False
+            self.lib.call("dlpd_xy_correlate_packed_occ", _ptr(wsA), _ptr(recP), _ptr(wsB), nb, CT, L,
+                          _ptr(self.pen_rot1 if coarse else self.pen_rot), self.C1 if coarse else self.C, st)
+        elif recP is not None and not tr:
             self.lib.call("dlpd_xy_correlate_packed", _ptr(wsA), _ptr(recP), _ptr(wsB), nb, CT, L, st)
         else:
             if rec is None:          # (packed-receptor boxes drop the natural-layout spectrum: keep_receptor_spectrum=True keeps it)
@@ -388,6 +396,7 @@ class DockingEngine:
         self.sparse_k1 = bool(self.sparse_k1_wanted) or self.lig_fill < self.SPARSE_K1_MAX_FILL
         if self.sparse_k1 and not hasattr(self, "occ_rot"):
             self.occ_rot = torch.empty(self.batch, nc, nc, nc, dtype=torch.uint8, device=self.device)
+            self.pen_rot = torch.empty(self.batch, nc, nc, dtype=torch.uint8, device=self.device)
         if self.C1:
             nc1 = (self.L1 + 3) // 4
             self.occ_src1 = ops.tile_occupancy(self.lig1.unsqueeze(0), lib=self.lib)
@@ -395,19 +404,27 @@ class DockingEngine:
             self.sparse_k1_coarse = bool(self.sparse_k1_wanted) or self.lig_fill_coarse < self.SPARSE_K1_MAX_FILL
             if self.sparse_k1_coarse and not hasattr(self, "occ_rot1"):
                 self.occ_rot1 = torch.empty(self.batch, nc1, nc1, nc1, dtype=torch.uint8, device=self.device)
+                self.pen_rot1 = torch.empty(self.batch, nc1, nc1, dtype=torch.uint8, device=self.device)
+        # Where K2 reads the packed receptor (boxes 80 / 40) it can go by a per-rotation PENCIL map: K1 then does not write
+        # the blocks without an occupied cell and K2 does not read the pencils the map marks empty (same spectra, same lists)
+        self.k2_pencil_map = bool(self.sparse_k1 and self.recP is not None and self.lib.call("dlpd_pencil_map_supported", self.L))
+        self.k2_pencil_map_coarse = bool(self.C1 and self.sparse_k1_coarse and self.recP1 is not None and
+                                         self.lib.call("dlpd_pencil_map_supported", self.L1))
 
     def _k1_channels_last(self, coarse, R, nb, st):
         """Rotation + z transform of the score channels from the channels-last copy, by occupancy maps where the ligand is sparse."""
         call = self.lib.call
         if coarse:
             cl, wsA, C, CT, L, c0, ext, sparse = self.ligcl1, self.wsA1, self.C1, self.C1, self.L1, self.center1, self.extent1, self.sparse_k1_coarse
-            occ_src, occ_rot = (self.occ_src1, self.occ_rot1) if sparse else (None, None)
+            occ_src, occ_rot, pen, skip = (self.occ_src1, self.occ_rot1, self.pen_rot1, self.k2_pencil_map_coarse) if sparse else (None,) * 4
         else:
             cl, wsA, C, CT, L, c0, ext, sparse = self.ligcl, self.wsA, self.C, self.CT, self.L, self.center, self.extent, self.sparse_k1
-            occ_src, occ_rot = (self.occ_src, self.occ_rot) if sparse else (None, None)
+            occ_src, occ_rot, pen, skip = (self.occ_src, self.occ_rot, self.pen_rot, self.k2_pencil_map) if sparse else (None,) * 4
+        self._k2_by_map[bool(coarse)] = False
         if sparse and self._k1_form_at(L) in (0, 1):
-            call("dlpd_rotated_occupancy", _ptr(occ_src), _ptr(R), _ptr(occ_rot), nb, L, c0, st)
-            call("dlpd_zfft_channels_last_occ", _ptr(cl), _ptr(R), _ptr(occ_rot), _ptr(wsA), nb, C, CT, 0, L, c0, ext, st)
+            call("dlpd_rotated_occupancy", _ptr(occ_src), _ptr(R), _ptr(occ_rot), _ptr(pen) if skip else 0, nb, L, c0, st)
+            call("dlpd_zfft_channels_last_occ", _ptr(cl), _ptr(R), _ptr(occ_rot), _ptr(wsA), nb, C, CT, 0, L, c0, ext, int(skip), st)
+            self._k2_by_map[bool(coarse)] = bool(skip)        # this launch's K2 must go by the pencil map (wsA holds unwritten pencils)
         else:
             call("dlpd_zfft_channels_last_form", _ptr(cl), _ptr(R), _ptr(wsA), nb, C, CT, 0, L, c0, ext, self._k1_form_at(L), st)
 

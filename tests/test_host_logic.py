@@ -22,7 +22,7 @@ def built_lib():
 
 def test_library_exports_every_declared_symbol(built_lib):
     header = open(os.path.join(ROOT, "include", "dlpd.h")).read()
-    assert "dlpd_debug_" not in header                            # test hooks live in their own header ...
+    assert not re.search(r"\bdlpd_debug_[a-z0-9_]+\s*\(", header)   # test hooks are declared in their own header ...
     debug = open(os.path.join(ROOT, "include", "dlpd_debug.h")).read()
     names = set(re.findall(r"\b(dlpd_[a-z0-9_]+)\s*\(", header)) | set(re.findall(r"\b(dlpd_debug_[a-z0-9_]+)\s*\(", debug))
     assert len(names) >= 15
@@ -266,9 +266,17 @@ def test_bench_reads_the_dominant_kernels_traffic_from_a_counter_pass(tmp_path, 
     import sys
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     args = bench.parse_args()
+    # K2<128>: the raw read count is taken apart by load shape (scripts/micro/fetch_size_shapes.hip: A rows tallied at 0.500 of
+    # their bytes, the receptor's 64-byte runs at 0.727) -- a canned 4 GB raw count at config 2's sizes
+    A, rec = 16 * 49 * 65 * 64 * 64 * 8.0, 49 * 65 * 128 * 128 * 8.0
+    reads, refetch = bench.k2_natural_read_bytes(0.5 * A + 0.727 * 3.0 * rec, 16, 49, 64)
+    assert abs(reads - (A + 3.0 * rec)) < 1.0 and abs(refetch - 3.0) < 1e-9
     traffic, src = bench.live_pmc_traffic(args, "k2_xy_corr", 128)
-    assert traffic == (2.0 * 1000.0 + 3000.0) * 1024.0 and "measured in this run" in src
-    assert "raw FETCH_SIZE 1024000 bytes x 2" in src and "raw WRITE_SIZE 3072000 bytes" in src      # auditable
+    assert traffic == A + 3000.0 * 1024.0 and "measured in this run" in src and "0.727" in src     # (1000 KB raw < the A rows' share)
+    # every other stage: x 2 (whole 128-byte lines tallied at 64 bytes)
+    traffic, src = bench.live_pmc_traffic(args, "k3_zifft_filter", 128)
+    assert traffic == (2.0 * 55555.0 + 55555.0) * 1024.0 and "measured in this run" in src
+    assert "raw FETCH_SIZE %d bytes x 2" % (55555 * 1024) in src and "raw WRITE_SIZE %d bytes" % (55555 * 1024) in src      # auditable
     assert bench.live_pmc_traffic(args, "topk_select", 128) == (None, None)
     # K3's wide configurations read 64-byte runs (8-row tiles): their FETCH_SIZE is taken at face value
     assert bench.fetch_scale("k3_zifft_filter", 160, 24) == 2.0 and bench.fetch_scale("k3_zifft_filter", 160, 32) == 1.0

@@ -977,7 +977,7 @@ def _k1_occupancy_checks(lib, device, L, C, nb, lo, hi, seed=17, scale=1.0):
     occ_src = ops.tile_occupancy(vol.unsqueeze(0), lib=lib)
     assert occ_src.shape == (1, nc, nc, nc) and 0 < int(occ_src.sum()) < occ_src.numel() // 2
     occ = torch.full((nb, nc, nc, nc), 255, dtype=torch.uint8, device=device)
-    lib.call("dlpd_rotated_occupancy", _ptr(occ_src), _ptr(R), _ptr(occ), nb, L, c0, st)
+    lib.call("dlpd_rotated_occupancy", _ptr(occ_src), _ptr(R), _ptr(occ), 0, nb, L, c0, st)
     assert int((occ > 1).sum()) == 0 and 0 < int(occ.sum()) < occ.numel()
     rot = torch.empty(nb, C, L, L, L, device=device)
     lib.call("dlpd_rotate_trilinear", _ptr(vol), _ptr(R), _ptr(rot), nb, C, L, 0, c0, st)
@@ -987,7 +987,7 @@ def _k1_occupancy_checks(lib, device, L, C, nb, lo, hi, seed=17, scale=1.0):
     want = torch.full((nb * CT * NZ * L * L * 2,), 7.0, device=device)
     got = torch.full_like(want, float("nan"))
     lib.call("dlpd_zfft_channels_last_ext", _ptr(cl), _ptr(R), _ptr(want), nb, C, CT, 0, L, c0, 0, st)
-    lib.call("dlpd_zfft_channels_last_occ", _ptr(cl), _ptr(R), _ptr(occ), _ptr(got), nb, C, CT, 0, L, c0, 0, st)
+    lib.call("dlpd_zfft_channels_last_occ", _ptr(cl), _ptr(R), _ptr(occ), _ptr(got), nb, C, CT, 0, L, c0, 0, 0, st)
     want, got = want.view(nb, CT, NZ, L, L, 2), got.view(nb, CT, NZ, L, L, 2)
     assert torch.equal(got[:, :C], want[:, :C]) and bool(torch.isnan(got[:, C]).all())
     return float(occ.float().mean())
@@ -1029,3 +1029,58 @@ def test_engine_search_with_k1_occupancy_maps_gives_the_same_list_emulated(emu):
     eng2.set_receptor(rec, recf, rec1)
     eng2.set_ligand(rec, ligf, rec1)                                 # ... and on an undecided one: no maps
     assert eng2.switches()["k1_occupancy_maps"]["fine"] is False and eng2.lig_fill == 1.0
+
+
+def _pencil_map_checks(lib, device, L, C, nb, lo, hi, seed=29):
+    """K1 that does not WRITE its empty blocks (dlpd_zfft_channels_last_occ, skip_empty) + K2 going by the per-rotation pencil
+    map (dlpd_xy_correlate_packed_occ; the packed-receptor boxes 80 / 40) against K1 + K2 on everything: the same K2 output
+    bit for bit, with the workspace between them full of NaNs wherever nothing was written; the clash channel behind the
+    masked channels is dense and read as it is."""
+    from deeplocalproteindocking_amd import ops
+    if lib is None:
+        from deeplocalproteindocking_amd._lib import get_lib
+        lib = get_lib()
+    assert lib.call("dlpd_pencil_map_supported", L) == 1 and lib.call("dlpd_pencil_map_supported", 64) == 0
+    g = torch.Generator().manual_seed(seed)
+    N, NZ, CT, nc = 2 * L, L + 1, C + 1, (L + 3) // 4
+    lig = torch.zeros(C, L, L, L)
+    lig[:, lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] = torch.randn(C, hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2], generator=g)
+    forb = torch.rand(nb, L, L, L, generator=g)                    # the clash channel: dense, per rotation (as from re-projected atoms)
+    rec = torch.randn(CT, L, L, L, generator=g) * 0.1
+    lig, forb, rec = lig.to(device), forb.to(device), rec.to(device)
+    ang = np.random.RandomState(seed).uniform(-np.pi, np.pi, size=(nb, 3))
+    R = torch.from_numpy(orc.euler_to_matrix(ang[:, 0], np.abs(ang[:, 1]), ang[:, 2])).float().contiguous().to(device)
+    st = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0
+    c0 = L / 2.0
+    cl = torch.empty(lib.call("dlpd_channels_last_floats", C, L), device=device)
+    lib.call("dlpd_make_channels_last", _ptr(lig), _ptr(cl), C, L, st)
+    spec = torch.empty(CT * NZ * N * N * 2, device=device)
+    scratch = torch.empty(CT * NZ * L * L * 2, device=device)
+    lib.call("dlpd_rfft3d_padded", _ptr(rec), _ptr(spec), _ptr(scratch), CT, L, 1.0 / N ** 3, st)
+    packed = torch.empty(lib.call("dlpd_receptor_packed_floats", CT, L), device=device)
+    lib.call("dlpd_receptor_pack", _ptr(spec), _ptr(packed), CT, L, st)
+    occ_src = ops.tile_occupancy(lig.unsqueeze(0), lib=lib)
+    occ = torch.full((nb, nc, nc, nc), 255, dtype=torch.uint8, device=device)
+    pen = torch.full((nb, nc, nc), 255, dtype=torch.uint8, device=device)
+    lib.call("dlpd_rotated_occupancy", _ptr(occ_src), _ptr(R), _ptr(occ), _ptr(pen), nb, L, c0, st)
+    assert torch.equal(pen.bool(), occ.bool().any(dim=3)) and 0 < int(pen.bool().sum()) < pen.numel()
+    wsA_d = torch.zeros(nb * CT * NZ * L * L * 2, device=device)
+    wsA_s = torch.full_like(wsA_d, float("nan"))
+    lib.call("dlpd_zfft_channels_last_ext", _ptr(cl), _ptr(R), _ptr(wsA_d), nb, C, CT, 0, L, c0, 0, st)
+    lib.call("dlpd_zfft_channels_last_occ", _ptr(cl), _ptr(R), _ptr(occ), _ptr(wsA_s), nb, C, CT, 0, L, c0, 0, 1, st)
+    for w in (wsA_d, wsA_s):
+        lib.call("dlpd_zfft_into", _ptr(forb), 0, _ptr(w), nb, 1, CT, C, L, L ** 3, 0, 0.0, st)
+    A_d, A_s = wsA_d.view(nb, CT, NZ, L, L, 2), wsA_s.view(nb, CT, NZ, L, L, 2)
+    assert bool(torch.isnan(A_s[:, :C]).any()) and not bool(torch.isnan(A_s[:, C]).any())      # blocks really left unwritten
+    written = ~torch.isnan(A_s)
+    assert torch.equal(A_s[written], A_d[written]) and bool((A_d[~written] == 0).all())
+    wsB_d = torch.empty(nb * CT * NZ * N * N * 2, device=device)
+    wsB_s = torch.full_like(wsB_d, float("nan"))
+    lib.call("dlpd_xy_correlate_packed", _ptr(wsA_d), _ptr(packed), _ptr(wsB_d), nb, CT, L, st)
+    lib.call("dlpd_xy_correlate_packed_occ", _ptr(wsA_s), _ptr(packed), _ptr(wsB_s), nb, CT, L, _ptr(pen), C, st)
+    assert torch.equal(wsB_d, wsB_s) and not bool(torch.isnan(wsB_s).any()) and float(wsB_d.abs().max()) > 0
+
+
+@pytest.mark.parametrize("L,C,nb,lo,hi", [(40, 2, 2, (22, 3, 14), (31, 12, 26)), (80, 1, 1, (30, 41, 22), (44, 58, 35))])
+def test_k2_by_the_pencil_map_reads_no_unwritten_pencil_emulated(emu, L, C, nb, lo, hi):
+    _pencil_map_checks(emu, "cpu", L, C, nb, lo, hi)
