@@ -465,6 +465,55 @@ def test_k1_by_occupancy_maps_gives_the_same_spectra(dev, L, C, lo, hi):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("L,C,lo,hi", [(80, 16, (30, 41, 22), (52, 62, 45)), (40, 32, (22, 3, 14), (31, 12, 26))])
+def test_k2_by_the_pencil_map_reads_no_unwritten_pencil(dev, L, C, lo, hi):
+    """Round 6: K1 leaves the blocks without an occupied cell UNWRITTEN and K2 (boxes 80 / 40, 16 rotations per launch) goes by
+    the pencil map -- the same K2 output bit for bit although the workspace between them is NaN wherever nothing was written."""
+    from test_kernels_emu import _pencil_map_checks
+    _pencil_map_checks(None, dev, L, C, 16, lo, hi)
+
+
+@pytest.mark.gpu
+def test_search_of_a_protein_shaped_pair_is_the_same_with_and_without_occupancy_maps(dev):
+    """The reference's real shapes [16 @ 80^3, 32 @ 40^3] with blob-shaped ligand volumes: the engine picks K1 by occupancy
+    maps + K2 by pencil maps on its own; the ranked list of 48 rotations equals the list of the dense kernels entry for
+    entry, with the K1 -> K2 workspaces refilled with NaNs before every launch."""
+    from deeplocalproteindocking_amd.engine import DockingEngine
+    g = torch.Generator().manual_seed(31)
+    L, C, C1, H = 80, 16, 32, 24
+    blob = lambda c, l, a, b: torch.nn.functional.pad(torch.randn(c, b - a, b - a, b - a, generator=g) * 0.3, (a, l - b) * 3)
+    rec, lig = blob(C, L, 18, 60), blob(C, L, 26, 52)
+    rec1, lig1 = blob(C1, 40, 7, 32), blob(C1, 40, 10, 28)
+    recf, ligf = blob(1, L, 22, 56)[0].abs(), blob(1, L, 30, 48)[0].abs()
+    W1, b1 = torch.randn(H, C + C1, generator=g) * 0.3, torch.randn(H, generator=g) * 0.1
+    W2, b2 = torch.randn(1, H, generator=g), torch.zeros(1)
+    b2 = b2 - (W2 @ torch.relu(b1).reshape(-1, 1)).reshape(-1)            # a pose without contact scores 0
+    R = torch.from_numpy(_rots(48, seed=12)).float()
+    lists = {}
+    for mode in (None, False):
+        eng = DockingEngine(L, C, W1, b1, W2, b2, clip=5.0, threshold_clash=200.0, max_conf=2000, batch=16, device=dev, coarse_channels=C1,
+                            sparse_k1=mode)
+        eng.set_receptor(rec, recf, rec1)
+        eng.set_ligand(lig, ligf, lig1)
+        sw = eng.switches()["k1_occupancy_maps"]
+        assert sw["fine"] == sw["coarse"] == (mode is None) and sw["k2_pencil_map"] == {"fine": mode is None, "coarse": mode is None}
+        eng.reset_top()
+        Rd = R.to(dev).contiguous()
+        ids = torch.arange(48, dtype=torch.int32, device=dev)
+        for beg in range(0, 48, 16):
+            if mode is None:
+                torch.cuda.synchronize()
+                eng.wsA.fill_(float("nan"))
+                eng.wsA1.fill_(float("nan"))
+            eng.step(Rd[beg:beg + 16], ids[beg:beg + 16])
+        lists[mode] = eng.top_list()
+        del eng
+        torch.cuda.empty_cache()
+    assert lists[None] == lists[False] and len(lists[None]) == 2000
+    assert all(t[4] == t[4] for t in lists[None]) and min(t[4] for t in lists[None]) < 0        # no NaN; real (negative) scores
+
+
+@pytest.mark.gpu
 def test_unwritten_activations_stand_for_the_same_tensors(dev):
     """Round 6 (Docker.dockE3's representation, Docker.py:163-167): convolution / pooling layers that neither compute nor
     WRITE their empty tiles and never read an empty cell, and the engine's K1 for given volumes going by the map
