@@ -31,7 +31,7 @@ SIGNATURES = {
     "dlpd_rotate_trilinear": (_i, [_p, _p, _p, _i, _i, _i, _ll, _f, _p]),
     "dlpd_zfft": (_i, [_p, _p, _p, _i, _i, _i, _ll, _i, _f, _p]),
     "dlpd_zfft_into": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _ll, _i, _f, _p]),
-    "dlpd_zfft_volumes_occ": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _ll, _p]),
+    "dlpd_zfft_volumes_occ": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _ll, _i, _p]),
     "dlpd_project_atoms": (_i, [_p, _p, _p, _p, _f, _f, _f, _p, _i, _i, _i, _i, _f, _i, _p]),
     "dlpd_project_atoms_ext": (_i, [_p, _p, _p, _p, _f, _f, _f, _p, _i, _i, _i, _i, _f, _i, _f, _i, _f, _f, _p]),
     "dlpd_rfft3d_padded": (_i, [_p, _p, _p, _i, _i, _f, _p]),

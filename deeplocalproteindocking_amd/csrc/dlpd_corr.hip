@@ -167,7 +167,7 @@ extern "C" int dlpd_debug_read_stamps_k1(unsigned long long* host16) {
 template <int N> __global__ void __launch_bounds__((N / 4) * FftPlan<N>::T)
 k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* __restrict__ A,
               int CT, int nb, long long vol_bstride, int do_rotate, float c0, int CT_out, int c_base,
-              int transposed, const float4* __restrict__ quads, int ext, const unsigned char* __restrict__ occ) {
+              int transposed, const float4* __restrict__ quads, int ext, const unsigned char* __restrict__ occ, int skip_empty) {
   constexpr int L = N / 2, NZ = N / 2 + 1, RS = N + 1, NP = L / 2;
   constexpr int T = FftPlan<N>::T, R1 = FftPlan<N>::R1, R2 = FftPlan<N>::R2;
   constexpr int NT = NP * T;
@@ -239,6 +239,7 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
         if (ob[i]) occ_any = 1;                                // (plain store of the same value by whoever finds one)
       __syncthreads();
       if (!occ_any) {                                          // (block-uniform)
+        if (skip_empty) return;                                // the consumer goes by the pencil map (dlpd_xy_correlate_packed_occ)
         cplx* a = A + ((size_t)b * CT_out + c_base + c) * NZ * L * L + (size_t)x * L;
         for (int s = tid; s < NP * NZ; s += NT)
           DLPD_STORE_STREAM(reinterpret_cast<float4*>(a + (size_t)(s / NP) * L * L + 2 * (s % NP)), make_float4(0.f, 0.f, 0.f, 0.f));
@@ -1304,12 +1305,12 @@ template <int HP> static int launch_filter_vec(const float* conv0, int C0, long 
 template <int N> static int launch_k1(const float* vol, const float* R, cplx* A, int CT, int nb, long long vbs,
                                       int do_rotate, float c0, hipStream_t st, int CT_out = 0, int c_base = 0,
                                       int transposed = 0, const float4* quads = nullptr, int ext = 0,
-                                      const unsigned char* occ = nullptr) {
+                                      const unsigned char* occ = nullptr, int skip_empty = 0) {
   constexpr int L = N / 2;
   const int groups = ((CT * nb + 7) / 8) * 8;
   dim3 grid(groups * L), block((N / 4) * FftPlan<N>::T);
   DLPD_LAUNCH((k_rotate_zfft<N>), grid, block, 0, st, vol, R, A, CT, nb, vbs, do_rotate, c0,
-              CT_out > 0 ? CT_out : CT, c_base, transposed ? 1 : 0, quads, (ext > 0 && ext < L) ? ext : L, occ);
+              CT_out > 0 ? CT_out : CT, c_base, transposed ? 1 : 0, quads, (ext > 0 && ext < L) ? ext : L, occ, skip_empty);
   return dlpd_check_launch();
 }
 
@@ -1467,15 +1468,15 @@ int dlpd_zfft_oriented_ext(const float* vol, const float* R, void* wsA, int nb, 
 
 // given volumes (no rotation) with their occupancy maps: occ (nb, ceil(L/4)^3) bytes, one map per batch entry (all CT channels)
 int dlpd_zfft_volumes_occ(const float* vol, const unsigned char* occ, void* wsA, int nb, int CT, int CT_out, int c_base, int L,
-                          long long vol_bstride, void* stream) {
+                          long long vol_bstride, int skip_empty, void* stream) {
   if (!vol || !occ || !wsA || nb <= 0 || CT <= 0 || c_base < 0 || c_base + CT > CT_out) return DLPD_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   cplx* A = (cplx*)wsA;
   switch (L) {
-    case 32: return launch_k1<64>(vol, nullptr, A, CT, nb, vol_bstride, 0, 0.f, st, CT_out, c_base, 0, nullptr, 0, occ);
-    case 40: return launch_k1<80>(vol, nullptr, A, CT, nb, vol_bstride, 0, 0.f, st, CT_out, c_base, 0, nullptr, 0, occ);
-    case 64: return launch_k1<128>(vol, nullptr, A, CT, nb, vol_bstride, 0, 0.f, st, CT_out, c_base, 0, nullptr, 0, occ);
-    case 80: return launch_k1<160>(vol, nullptr, A, CT, nb, vol_bstride, 0, 0.f, st, CT_out, c_base, 0, nullptr, 0, occ);
+    case 32: return launch_k1<64>(vol, nullptr, A, CT, nb, vol_bstride, 0, 0.f, st, CT_out, c_base, 0, nullptr, 0, occ, skip_empty);
+    case 40: return launch_k1<80>(vol, nullptr, A, CT, nb, vol_bstride, 0, 0.f, st, CT_out, c_base, 0, nullptr, 0, occ, skip_empty);
+    case 64: return launch_k1<128>(vol, nullptr, A, CT, nb, vol_bstride, 0, 0.f, st, CT_out, c_base, 0, nullptr, 0, occ, skip_empty);
+    case 80: return launch_k1<160>(vol, nullptr, A, CT, nb, vol_bstride, 0, 0.f, st, CT_out, c_base, 0, nullptr, 0, occ, skip_empty);
     default: return DLPD_ERR_UNSUPPORTED;
   }
 }

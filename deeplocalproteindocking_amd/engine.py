@@ -368,12 +368,15 @@ class DockingEngine:
         """Stage K2 of the fine or the coarse grid on what K1 left in its wsA; tr: the slab orientation K1 used."""
         wsA, rec, recP, wsB, CT, L = ((self.wsA1, self.recF1, self.recP1, self.wsB1, self.C1, self.L1) if coarse else
                                       (self.wsA, self.recF, self.recP, self.wsB, self.CT, self.L))
-        if self._k2_by_map[bool(coarse)]:
-            # K1 left the pencils of empty blocks unwritten: K2 takes them as zeros by the map (score channels only)
+        by_map = self._k2_by_map[bool(coarse)]
+        if by_map is not False:
+            # K1 left the pencils of empty blocks unwritten: K2 takes them as zeros by the map (score channels only).  The map
+            # is the engine's own (rotation path: True) or the one made from the batch's volumes (a tensor)
             assert recP is not None and not tr
             self._k2_by_map[bool(coarse)] = False
-            self.lib.call("dlpd_xy_correlate_packed_occ", _ptr(wsA), _ptr(recP), _ptr(wsB), nb, CT, L,
-                          _ptr(self.pen_rot1 if coarse else self.pen_rot), self.C1 if coarse else self.C, st)
+            pen = by_map if torch.is_tensor(by_map) else (self.pen_rot1 if coarse else self.pen_rot)
+            self.lib.call("dlpd_xy_correlate_packed_occ", _ptr(wsA), _ptr(recP), _ptr(wsB), nb, CT, L, _ptr(pen),
+                          self.C1 if coarse else self.C, st)
         elif recP is not None and not tr:
             self.lib.call("dlpd_xy_correlate_packed", _ptr(wsA), _ptr(recP), _ptr(wsB), nb, CT, L, st)
         else:
@@ -576,7 +579,14 @@ class DockingEngine:
             L1 = self.L1
             vc = f32c(vc).reshape(nb, self.C1, L1, L1, L1)
             if occ1 is not None:
-                call("dlpd_zfft_volumes_occ", _ptr(vc), _ptr(occ1), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1, self.C1 * L1 ** 3, st)
+                # (boxes whose K2 reads the packed receptor: empty x-planes are not written, K2 goes by the maps' OR over z)
+                skip1 = self.recP1 is not None and bool(self.lib.call("dlpd_pencil_map_supported", L1))
+                if skip1:
+                    nc1 = (L1 + 3) // 4
+                    self.pen_vol1 = occ1.reshape(nb, nc1, nc1, nc1).amax(dim=3).contiguous()
+                call("dlpd_zfft_volumes_occ", _ptr(vc), _ptr(occ1), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1, self.C1 * L1 ** 3,
+                     int(skip1), st)
+                self._k2_by_map[True] = self.pen_vol1 if skip1 else False
             else:
                 call("dlpd_zfft", _ptr(vc), 0, _ptr(self.wsA1), nb, self.C1, L1, self.C1 * L1 ** 3, 0, 0.0, st)
             self._k2(True, nb, 0, st)
@@ -584,7 +594,12 @@ class DockingEngine:
             mark("coarse")
         vl = f32c(vl).reshape(nb, self.C, L, L, L)
         if occ0 is not None:
-            call("dlpd_zfft_volumes_occ", _ptr(vl), _ptr(occ0), _ptr(self.wsA), nb, self.C, self.CT, 0, L, self.C * L ** 3, st)
+            skip0 = self.recP is not None and bool(self.lib.call("dlpd_pencil_map_supported", L))
+            if skip0:
+                nc0 = (L + 3) // 4
+                self.pen_vol = occ0.reshape(nb, nc0, nc0, nc0).amax(dim=3).contiguous()
+            call("dlpd_zfft_volumes_occ", _ptr(vl), _ptr(occ0), _ptr(self.wsA), nb, self.C, self.CT, 0, L, self.C * L ** 3, int(skip0), st)
+            self._k2_by_map[False] = self.pen_vol if skip0 else False
         else:
             call("dlpd_zfft_into", _ptr(vl), 0, _ptr(self.wsA), nb, self.C, self.CT, 0, L, self.C * L ** 3, 0, 0.0, st)
         if self.has_clash:

@@ -81,9 +81,10 @@ int dlpd_zfft_into(const float* vol, const float* R, void* wsA, int nb, int CT, 
  * occupancy maps: occ (nb, ceil(L/4)^3) bytes, one map per batch entry for all its CT channels, non-zero where the 4 x 4 x 4
  * cell holds a non-zero value (the maps dlpd_conv3d_split_sparse / dlpd_maxpool3d_5s2_sparse hand on).  Voxels of empty
  * cells are taken as zero and NOT read (unwritten activations), x-planes without an occupied cell are written as zeros
- * without a transform.  Same spectra as dlpd_zfft_into on the dense tensor. */
+ * without a transform -- or, with skip_empty != 0, not written at all: for a consumer that goes by the pencil map (the maps'
+ * OR over z; dlpd_xy_correlate_packed_occ).  Same spectra as dlpd_zfft_into on the dense tensor. */
 int dlpd_zfft_volumes_occ(const float* vol, const unsigned char* occ, void* wsA, int nb, int CT, int CT_out, int c_base, int L,
-                          long long vol_bstride, void* stream);
+                          long long vol_bstride, int skip_empty, void* stream);
 
 /* Slab orientation (speed only, results identical).  With transposed = 1 every rotation of the call is
  * processed with the roles of x and y exchanged and its slabs are stored as [kz][y][x]: the caller groups the

@@ -34,7 +34,7 @@ for f in ("soak_full_search_6deg", "soak_full_search_4deg", "soak_config4"):
         print(f, "FAILED", e)
 for f in ("bench_default", "bench_cpu32", "bench_real", "bench_real_protein", "bench_real_protein_k1_occupancy_off", "bench_c48l80", "bench_config1", "bench_two_ranks_one_gpu"):
     try:
-        d = json.load(open("$OUT/%s.json" % f)); print(f, round(d["ms_per_step"], 3), "%.3e" % d["value"], {k: round(v["ms_per_launch"], 3) for k, v in d["stages"].items()})
+        d = json.loads([l for l in open("$OUT/%s.json" % f) if l.startswith("{")][-1]); print(f, round(d["ms_per_step"], 3), "%.3e" % d["value"], {k: round(v["ms_per_launch"], 3) for k, v in d["stages"].items()})
     except Exception as e:
         print(f, "FAILED", e)
 d = json.load(open("$OUT/bench_default.json"))

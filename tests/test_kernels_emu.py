@@ -938,7 +938,7 @@ def _unwritten_chain_checks(lib, device, D=21, lo=9, hi=15, B=1):
     A_u = torch.full((B, C + 1, NZ, L, L, 2), float("nan"), device=device)
     st = torch.cuda.current_stream(device).cuda_stream if str(device) != "cpu" else 0
     call("dlpd_zfft_into", d1.data_ptr(), 0, A_d.data_ptr(), B, C, C + 1, 0, L, C * L ** 3, 0, 0.0, st)
-    call("dlpd_zfft_volumes_occ", u1.data_ptr(), n1.data_ptr(), A_u.data_ptr(), B, C, C + 1, 0, L, C * L ** 3, st)
+    call("dlpd_zfft_volumes_occ", u1.data_ptr(), n1.data_ptr(), A_u.data_ptr(), B, C, C + 1, 0, L, C * L ** 3, 0, st)
     assert torch.equal(A_d[:, :C], A_u[:, :C]) and torch.isnan(A_u[:, C]).all()      # (the other channel is not touched)
     assert int(n1.sum()) < n1.numel() // 2                          # ... with most of the box empty
     # misuse is refused: unwritten needs the maps
