@@ -53,6 +53,7 @@ SIGNATURES = {
     "dlpd_rotated_occupancy": (_i, [_p, _p, _p, _p, _i, _i, _f, _p]),
     "dlpd_zfft_channels_last_occ": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
     "dlpd_pencil_map_supported": (_i, [_i]),
+    "dlpd_pencil_bits": (_i, [_p, _p, _i, _i, _p]),
     "dlpd_xy_correlate_packed_occ": (_i, [_p, _p, _p, _i, _i, _i, _p, _i, _p]),
     "dlpd_xy_correlate_oriented": (_i, [_p, _p, _p, _i, _i, _i, _ll, _i, _p]),
     "dlpd_score_rotations_oriented": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _f, _i, _i, _f, _f,

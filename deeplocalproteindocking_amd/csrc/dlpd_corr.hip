@@ -452,8 +452,7 @@ template <int N> static int launch_k1_cl(const float4* cl, const float* R, cplx*
 // occ_src (one map for all channels of the stored ligand, dlpd_conv3d_tile_occupancy), all their products are zero.
 // Same sample map as k1cl_sample_rows (p = c0 + M (voxel - c0), M columns r0..r2 | r3..r5 | r6..r8).
 __global__ void __launch_bounds__(256) k_rotated_occupancy(const unsigned char* __restrict__ occ_src, const float* __restrict__ R,
-                                                           unsigned char* __restrict__ occ_out, unsigned char* __restrict__ pencil_out,
-                                                           int nb, int L, float c0) {
+                                                           unsigned char* __restrict__ occ_out, int nb, int L, float c0) {
   const int nc = (L + 3) / 4, nc3 = nc * nc * nc;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb * nc3; i += gridDim.x * blockDim.x) {
     const int b = i / nc3, cell = i % nc3, cz = cell % nc, cy = (cell / nc) % nc, cx = cell / (nc * nc);
@@ -475,9 +474,20 @@ __global__ void __launch_bounds__(256) k_rotated_occupancy(const unsigned char* 
       for (int sy = lo[1]; sy <= hi[1]; sy++)
         for (int sz = lo[2]; sz <= hi[2]; sz++) any |= occ_src[(sx * nc + sy) * nc + sz] != 0;
     occ_out[i] = any ? 1 : 0;
-    // pencil map (zeroed by the host): (x cell, y cell) holds an occupied z cell -- plain stores of the same value
-    if (any && pencil_out) pencil_out[((size_t)b * nc + cx) * nc + cy] = 1;
   }
+}
+// pencil map of nb cell maps: word [b][x cell] has bit (y cell) set where some z cell of that column is occupied
+__global__ void __launch_bounds__(256) k_pencil_bits(const unsigned char* __restrict__ occ, unsigned* __restrict__ bits, int nb, int nc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nb * nc) return;
+  const unsigned char* o = occ + (size_t)i * nc * nc;
+  unsigned w = 0;
+  for (int cy = 0; cy < nc; cy++) {
+    bool any = false;
+    for (int cz = 0; cz < nc; cz++) any |= o[cy * nc + cz] != 0;
+    w |= any ? (1u << cy) : 0u;
+  }
+  bits[i] = w;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1553,13 +1563,21 @@ int dlpd_zfft_channels_last_form(const float* cl, const float* R, void* wsA, int
 
 // occ_src (ceil(L/4)^3 bytes: the stored ligand's cells, all channels) -> occ_out (nb maps): the cells of each ROTATED volume
 // that can hold a non-zero sample (conservative); R as K1 takes it
-int dlpd_rotated_occupancy(const unsigned char* occ_src, const float* R, unsigned char* occ_out, unsigned char* pencil_out, int nb,
+int dlpd_rotated_occupancy(const unsigned char* occ_src, const float* R, unsigned char* occ_out, unsigned* pencil_out, int nb,
                            int L, float center, void* stream) {
-  if (!occ_src || !R || !occ_out || nb <= 0 || L <= 0) return DLPD_ERR_ARG;
+  if (!occ_src || !R || !occ_out || nb <= 0 || L <= 0 || L > 128) return DLPD_ERR_ARG;
   const int nc = (L + 3) / 4, total = nb * nc * nc * nc;
-  if (pencil_out && hipMemsetAsync(pencil_out, 0, (size_t)nb * nc * nc, (hipStream_t)stream) != hipSuccess) return DLPD_ERR_LAUNCH;
   DLPD_LAUNCH(k_rotated_occupancy, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, occ_src, R, occ_out,
-              pencil_out, nb, L, center);
+              nb, L, center);
+  if (pencil_out)
+    DLPD_LAUNCH(k_pencil_bits, dim3((unsigned)((nb * nc + 255) / 256)), dim3(256), 0, (hipStream_t)stream, occ_out, pencil_out, nb, nc);
+  return dlpd_check_launch();
+}
+// the pencil words of nb GIVEN cell maps (the volumes path: the plugin's own maps)
+int dlpd_pencil_bits(const unsigned char* occ, unsigned* pencil_out, int nb, int L, void* stream) {
+  if (!occ || !pencil_out || nb <= 0 || L <= 0 || L > 128) return DLPD_ERR_ARG;
+  const int nc = (L + 3) / 4;
+  DLPD_LAUNCH(k_pencil_bits, dim3((unsigned)((nb * nc + 255) / 256)), dim3(256), 0, (hipStream_t)stream, occ, pencil_out, nb, nc);
   return dlpd_check_launch();
 }
 // 1 where dlpd_xy_correlate_packed_occ exists: the packed-receptor boxes (80, 40)
@@ -1638,10 +1656,10 @@ int dlpd_xy_correlate_packed(const void* wsA, const void* rec_packed, void* wsB,
 // ... going by a per-rotation pencil map (dlpd_rotated_occupancy's second output) for channels [0, nmasked): pencils the map
 // marks empty are not read from wsA (K1 with skip_empty did not write them); the packed-receptor boxes only
 int dlpd_xy_correlate_packed_occ(const void* wsA, const void* rec_packed, void* wsB, int nb, int CT, int L,
-                                 const unsigned char* pencil_map, int nmasked, void* stream) {
+                                 const unsigned* pencil_map, int nmasked, void* stream) {
   if (!wsA || !rec_packed || !wsB || !pencil_map || nb <= 0 || CT <= 0 || nmasked < 0 || nmasked > CT) return DLPD_ERR_ARG;
-  return dlpd_k2_correlate_packed((const cplx*)wsA, (const cplx*)rec_packed, (cplx*)wsB, CT, nb, L, (hipStream_t)stream, pencil_map,
-                                  nmasked);
+  return dlpd_k2_correlate_packed((const cplx*)wsA, (const cplx*)rec_packed, (cplx*)wsB, CT, nb, L, (hipStream_t)stream,
+                                  (const unsigned char*)pencil_map, nmasked);
 }
 
 // wsB -> real correlation volumes out (nb, CT, N^3), optional clamp

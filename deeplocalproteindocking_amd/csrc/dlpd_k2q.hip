@@ -227,7 +227,7 @@ k_xy_corr_q4(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __r
   // use the same dealing: their (row, column) are a shift, a mask and an immediate)
   static_assert(L / 2 == 8 * NP, "row = 8 lanes x NP float4");
   float4 apref[NP];
-  // PENCIL MAP (round 6; pmap != null, channels c < nmasked): pmap[b][x cell][y cell] = 0 says that pencil (x, y) of rotation
+  // PENCIL MAP (round 6; pmap != null, channels c < nmasked): bit (y cell) of the 32-bit word pmap[b][x cell] = 0 says that pencil (x, y) of rotation
   // b's rotated ligand is all zero (dlpd_rotated_occupancy) -- K1 did not write it (dlpd_zfft_channels_last_occ, skip_empty) and
   // it is NOT read here: the pair is the zero it stands for.  A float4 is two neighbouring y of one row: one cell.
   constexpr int NC = (L + 3) / 4;
@@ -236,9 +236,13 @@ k_xy_corr_q4(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __r
     const int srow = 8 * wave + (lane >> 3);
     const float4* a4 = reinterpret_cast<const float4*>(A + (((size_t)b * CT + c) * NZ + kz) * L * L + (size_t)srow * L) + (lane & 7);
     if (by_map) {
-      const unsigned char* pm = pmap + ((size_t)b * NC + (srow >> 2)) * NC + ((lane & 7) >> 1);      // y cell = ((lane & 7) + 8 k) / 2
+      // one 32-bit word per (rotation, x cell): bit = y cell.  The wave's 8 rows are x cells 2w (lanes 0-31) and 2w + 1: two
+      // words at a wave-uniform address (scalar loads: no vector load waits for a vector load)
+      const unsigned* pw = reinterpret_cast<const unsigned*>(pmap) + (size_t)b * NC + 2 * DLPD_UNIFORM(wave);
+      const unsigned m0 = pw[0], m1 = pw[1];
+      const unsigned m = ((lane & 32) ? m1 : m0) >> ((lane & 7) >> 1);                               // y cell = ((lane & 7) + 8 k) / 2
 #pragma unroll
-      for (int k = 0; k < NP; k++) apref[k] = pm[4 * k] ? DLPD_LOAD_STREAM(a4 + 8 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 0; k < NP; k++) apref[k] = ((m >> (4 * k)) & 1u) ? DLPD_LOAD_STREAM(a4 + 8 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
 #pragma unroll
       for (int k = 0; k < NP; k++) apref[k] = DLPD_LOAD_STREAM(a4 + 8 * k);
@@ -451,11 +455,17 @@ k_xy_corr_s4(const cplx* __restrict__ A, const cplx* __restrict__ rec, cplx* __r
   const bool by_map = pmap != nullptr && c < nmasked;
   auto fetch_A = [&](int b) {
     const float4* a4 = reinterpret_cast<const float4*>(A + (((size_t)b * CT + c) * NZ + kz) * L * L + (size_t)wave * 8 * L);
+    unsigned m0 = ~0u, m1 = ~0u;                         // bit (y cell) of word pmap[b][x cell]; the wave's rows are x cells 2w, 2w + 1
+    if (by_map) {
+      const unsigned* pw = reinterpret_cast<const unsigned*>(pmap) + (size_t)b * NC + 2 * DLPD_UNIFORM(wave);
+      m0 = pw[0];
+      m1 = pw[1];
+    }
 #pragma unroll
     for (int k = 0; k < NPI; k++)
       if (lane + 64 * k < NIN) {
-        const int f = lane + 64 * k, x = 8 * wave + f / (L / 2), yc = (f % (L / 2)) >> 1;
-        const bool live = !by_map || pmap[((size_t)b * NC + (x >> 2)) * NC + yc];
+        const int f = lane + 64 * k, r = f / (L / 2), yc = (f % (L / 2)) >> 1;
+        const bool live = (((r & 4) ? m1 : m0) >> yc) & 1u;
         apref[k] = live ? DLPD_LOAD_STREAM(a4 + f) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
   };

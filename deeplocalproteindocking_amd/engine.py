@@ -399,7 +399,7 @@ class DockingEngine:
         self.sparse_k1 = bool(self.sparse_k1_wanted) or self.lig_fill < self.SPARSE_K1_MAX_FILL
         if self.sparse_k1 and not hasattr(self, "occ_rot"):
             self.occ_rot = torch.empty(self.batch, nc, nc, nc, dtype=torch.uint8, device=self.device)
-            self.pen_rot = torch.empty(self.batch, nc, nc, dtype=torch.uint8, device=self.device)
+            self.pen_rot = torch.empty(self.batch, nc, dtype=torch.int32, device=self.device)
         if self.C1:
             nc1 = (self.L1 + 3) // 4
             self.occ_src1 = ops.tile_occupancy(self.lig1.unsqueeze(0), lib=self.lib)
@@ -407,7 +407,7 @@ class DockingEngine:
             self.sparse_k1_coarse = bool(self.sparse_k1_wanted) or self.lig_fill_coarse < self.SPARSE_K1_MAX_FILL
             if self.sparse_k1_coarse and not hasattr(self, "occ_rot1"):
                 self.occ_rot1 = torch.empty(self.batch, nc1, nc1, nc1, dtype=torch.uint8, device=self.device)
-                self.pen_rot1 = torch.empty(self.batch, nc1, nc1, dtype=torch.uint8, device=self.device)
+                self.pen_rot1 = torch.empty(self.batch, nc1, dtype=torch.int32, device=self.device)
         # Where K2 reads the packed receptor (boxes 80 / 40) it can go by a per-rotation PENCIL map: K1 then does not write
         # the blocks without an occupied cell and K2 does not read the pencils the map marks empty (same spectra, same lists)
         self.k2_pencil_map = bool(self.sparse_k1 and self.recP is not None and self.lib.call("dlpd_pencil_map_supported", self.L))
@@ -582,8 +582,8 @@ class DockingEngine:
                 # (boxes whose K2 reads the packed receptor: empty x-planes are not written, K2 goes by the maps' OR over z)
                 skip1 = self.recP1 is not None and bool(self.lib.call("dlpd_pencil_map_supported", L1))
                 if skip1:
-                    nc1 = (L1 + 3) // 4
-                    self.pen_vol1 = occ1.reshape(nb, nc1, nc1, nc1).amax(dim=3).contiguous()
+                    self.pen_vol1 = torch.empty(nb, (L1 + 3) // 4, dtype=torch.int32, device=self.device)
+                    call("dlpd_pencil_bits", _ptr(occ1), _ptr(self.pen_vol1), nb, L1, st)
                 call("dlpd_zfft_volumes_occ", _ptr(vc), _ptr(occ1), _ptr(self.wsA1), nb, self.C1, self.C1, 0, L1, self.C1 * L1 ** 3,
                      int(skip1), st)
                 self._k2_by_map[True] = self.pen_vol1 if skip1 else False
@@ -596,8 +596,8 @@ class DockingEngine:
         if occ0 is not None:
             skip0 = self.recP is not None and bool(self.lib.call("dlpd_pencil_map_supported", L))
             if skip0:
-                nc0 = (L + 3) // 4
-                self.pen_vol = occ0.reshape(nb, nc0, nc0, nc0).amax(dim=3).contiguous()
+                self.pen_vol = torch.empty(nb, (L + 3) // 4, dtype=torch.int32, device=self.device)
+                call("dlpd_pencil_bits", _ptr(occ0), _ptr(self.pen_vol), nb, L, st)
             call("dlpd_zfft_volumes_occ", _ptr(vl), _ptr(occ0), _ptr(self.wsA), nb, self.C, self.CT, 0, L, self.C * L ** 3, int(skip0), st)
             self._k2_by_map[False] = self.pen_vol if skip0 else False
         else:

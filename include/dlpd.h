@@ -140,17 +140,19 @@ int dlpd_zfft_channels_last_form(const float* cl, const float* R, void* wsA, int
  * trilinear sample of that 4 x 4 x 4 cell of the rotated volume is certainly zero); R are the matrices K1 samples with.
  * dlpd_zfft_channels_last_occ is dlpd_zfft_channels_last_ext that skips the loads of samples in empty cells and the
  * transform of blocks without an occupied cell (their zeros are written).  Same spectra.
- * pencil_out (may be null; nb x ceil(L/4)^2 bytes, [x cell][y cell]): non-zero where some z cell of that column is marked.
+ * pencil_out (may be null; nb x ceil(L/4) 32-bit words, [rotation][x cell]): bit (y cell) set where some z cell of that column
+ * is marked; dlpd_pencil_bits makes the same words from nb given cell maps (the plugin's own, dlpd_zfft_volumes_occ).
  * skip_empty != 0: blocks without an occupied cell write NOTHING -- for a consumer that goes by the pencil map and never reads
  * those pencils: dlpd_xy_correlate_packed_occ (boxes with a packed receptor: dlpd_pencil_map_supported(L)), which takes the
  * pencils the map marks empty as zeros for channels [0, nmasked) (the clash channel behind them is read as it is). */
-int dlpd_rotated_occupancy(const unsigned char* occ_src, const float* R, unsigned char* occ_out, unsigned char* pencil_out, int nb,
+int dlpd_rotated_occupancy(const unsigned char* occ_src, const float* R, unsigned char* occ_out, unsigned* pencil_out, int nb,
                            int L, float center, void* stream);
+int dlpd_pencil_bits(const unsigned char* occ, unsigned* pencil_out, int nb, int L, void* stream);
 int dlpd_zfft_channels_last_occ(const float* cl, const float* R, const unsigned char* occ, void* wsA, int nb, int C, int CT_out,
                                 int c_base, int L, float center, int extent, int skip_empty, void* stream);
 int dlpd_pencil_map_supported(int L);
 int dlpd_xy_correlate_packed_occ(const void* wsA, const void* rec_packed, void* wsB, int nb, int CT, int L,
-                                 const unsigned char* pencil_map, int nmasked, void* stream);
+                                 const unsigned* pencil_map, int nmasked, void* stream);
 
 /* CoordsRotate + CoordsTranslate + TypedCoords2Volume (+ channel sum) of src/Docker/Docker.py:204,
  * 208,221-224 in one kernel: p' = R_b p + shift, density exp(-|r - p'|^2 / 2) on the 5^3 voxels

@@ -1061,9 +1061,13 @@ def _pencil_map_checks(lib, device, L, C, nb, lo, hi, seed=29):
     lib.call("dlpd_receptor_pack", _ptr(spec), _ptr(packed), CT, L, st)
     occ_src = ops.tile_occupancy(lig.unsqueeze(0), lib=lib)
     occ = torch.full((nb, nc, nc, nc), 255, dtype=torch.uint8, device=device)
-    pen = torch.full((nb, nc, nc), 255, dtype=torch.uint8, device=device)
+    pen = torch.full((nb, nc), -1, dtype=torch.int32, device=device)
     lib.call("dlpd_rotated_occupancy", _ptr(occ_src), _ptr(R), _ptr(occ), _ptr(pen), nb, L, c0, st)
-    assert torch.equal(pen.bool(), occ.bool().any(dim=3)) and 0 < int(pen.bool().sum()) < pen.numel()
+    want_bits = (occ.bool().any(dim=3).to(torch.int64) << torch.arange(nc, device=occ.device)).sum(dim=2).to(torch.int32)
+    assert torch.equal(pen, want_bits) and 0 < int(occ.bool().any(dim=3).sum()) < nb * nc * nc
+    pen2 = torch.full_like(pen, -1)
+    lib.call("dlpd_pencil_bits", _ptr(occ), _ptr(pen2), nb, L, st)                 # (the same words from given maps)
+    assert torch.equal(pen2, pen)
     wsA_d = torch.zeros(nb * CT * NZ * L * L * 2, device=device)
     wsA_s = torch.full_like(wsA_d, float("nan"))
     lib.call("dlpd_zfft_channels_last_ext", _ptr(cl), _ptr(R), _ptr(wsA_d), nb, C, CT, 0, L, c0, 0, st)
