@@ -882,13 +882,15 @@ class Docker:
         # (``outputs_with_maps``).  Not with an embedded box: the copy into the larger box reads every voxel.
         import contextlib
         rep = getattr(self.docking_model, "representation", None)
-        with_maps = (not Lc) and bool(getattr(rep, "supports_unwritten_outputs", False)) and self.unwritten_activations
+        # (clip_mode "input" clamps every voxel of the batch's volumes: maps are not combined with it)
+        maps_ok = (not Lc) and eng._in_clip is None
+        with_maps = maps_ok and bool(getattr(rep, "supports_unwritten_outputs", False)) and self.unwritten_activations
         for bid in batches:
             with (rep.outputs_with_maps() if with_maps else contextlib.nullcontext()):
                 ligand, ligand_volumes = represent(bid)
             bid_dev = torch.as_tensor(bid, dtype=torch.int32).to(dev)
             occ = None
-            if not Lc:
+            if maps_ok:
                 o0 = getattr(ligand_volumes[0], "dlpd_occupancy", None)
                 o1 = getattr(ligand_volumes[1], "dlpd_occupancy", None) if eng.C1 else None
                 occ = (o0, o1) if (o0 is not None or o1 is not None) else None
