@@ -15,6 +15,29 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """The CPU suite (-m "not gpu": oracle, host logic, emulated kernels, gloo ranks) is 160 independent, single-threaded
+    tests: run it on four pytest-xdist workers unless the caller chose otherwise (-n ..., or DLPD_TEST_WORKERS=0) -- 5 minutes
+    instead of 17.  The GPU suite is NEVER parallelised here: its tests share one device, its timings and its memory."""
+    if os.environ.get("PYTEST_XDIST_WORKER") or os.environ.get("DLPD_TEST_WORKERS") == "0":
+        return None
+    opt = config.option
+    if (getattr(opt, "markexpr", "") or "").strip() != "not gpu" or getattr(opt, "collectonly", False):
+        return None
+    if not hasattr(opt, "numprocesses") or opt.numprocesses not in (None, 0) or getattr(opt, "dist", "no") != "no":
+        return None                                    # (xdist absent, or the caller passed -n / --dist)
+    try:
+        n = int(os.environ.get("DLPD_TEST_WORKERS", "4"))
+    except ValueError:
+        n = 4
+    n = max(1, min(n, _usable_cores() // 2 or 1))
+    if n > 1:
+        opt.numprocesses = n
+        opt.dist = "load"                              # (what -n implies; xdist's own hook fills in the rest)
+    return None
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np
