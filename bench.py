@@ -904,8 +904,9 @@ def e3_measurement(dev, nb, nsteps=6):
         nbat = 4 * nsteps
         batches = [list(range(nb))] * nbat
 
-        def represent(bid):
-            l = be.project(lc, ln, lo, L, res, dev, R=Rb, shift=dk.box_center)
+        def represent(bid):                          # (as Docker.dockE3's own closure)
+            l = be.project(lc, ln, lo, L, res, dev, R=Rb, shift=dk.box_center, cells=bool(getattr(dk, "_project_cells", False)))
+            l.dlpd_type_sum = be.project(lc, ln, lo, L, res, dev, R=Rb, shift=dk.box_center, sum_types=True)[:, 0]
             return l, model.representation(l)
 
         def docker_loop():

@@ -825,7 +825,13 @@ class Docker:
             def represent(bid):
                 """rotate + translate + project in one kernel (Docker.py:163-165), then the plugin (Docker.py:166-167)"""
                 Rb = self.rot.R[bid].to(device=dev, dtype=torch.float32).contiguous()
-                ligand = be.project(lc, ln, lo, L, self.resolution, dev, R=Rb, shift=self.box_center)
+                # (_project_cells: set by _dockE3_fused when the plugin and the engine go by occupancy maps -- the projection
+                #  then writes only the cells the atoms reach)
+                ligand = be.project(lc, ln, lo, L, self.resolution, dev, R=Rb, shift=self.box_center,
+                                    cells=bool(getattr(self, "_project_cells", False)))
+                # the forbidden volume = the sum over the atom types (Docker.py:169): projected once more with the types summed in
+                # the accumulator (33 MB; exact) instead of a pass over the eleven volumes
+                ligand.dlpd_type_sum = be.project(lc, ln, lo, L, self.resolution, dev, R=Rb, shift=self.box_center, sum_types=True)[:, 0]
                 return ligand, model.representation(ligand)
 
             batches = [ids[beg:beg + nbatch] for beg in range(0, len(ids), nbatch)]
@@ -864,7 +870,8 @@ class Docker:
         ebuf = {}
 
         def volumes_of(ligand, ligand_volumes, nb, slot):
-            vols = (ligand_volumes[0], ligand.sum(dim=1), ligand_volumes[1] if eng.C1 else None)
+            forb = getattr(ligand, "dlpd_type_sum", None)
+            vols = (ligand_volumes[0], forb if forb is not None else ligand.sum(dim=1), ligand_volumes[1] if eng.C1 else None)
             if Lc:
                 # the batch's volumes into the corner of buffers that were zeroed ONCE (not three allocations and zero
                 # fills per batch); two sets when the plugin runs ahead of the engine
@@ -885,9 +892,16 @@ class Docker:
         # (clip_mode "input" clamps every voxel of the batch's volumes: maps are not combined with it)
         maps_ok = (not Lc) and eng._in_clip is None
         with_maps = maps_ok and bool(getattr(rep, "supports_unwritten_outputs", False)) and self.unwritten_activations
+        from deeplocalproteindocking_amd import ops as _ops
+        cells_ok = with_maps and bool(getattr(rep, "use_tile_occupancy", False)) and bool(getattr(rep, "use_hip_conv", False)) and \
+            _ops.CONV_PRECISION == "split_bf16" and self.device.type == "cuda"
         for bid in batches:
-            with (rep.outputs_with_maps() if with_maps else contextlib.nullcontext()):
-                ligand, ligand_volumes = represent(bid)
+            self._project_cells = cells_ok
+            try:
+                with (rep.outputs_with_maps() if with_maps else contextlib.nullcontext()):
+                    ligand, ligand_volumes = represent(bid)
+            finally:
+                self._project_cells = False
             bid_dev = torch.as_tensor(bid, dtype=torch.int32).to(dev)
             occ = None
             if maps_ok:

@@ -174,7 +174,16 @@ class E3MultiResRepr4x4(Module):
 
     def forward(self, volume):
         uw = self._unwritten
-        vol1, occ1 = self._run(self.conv1, volume, None, True, unwritten=uw)
+        # an input that comes with its map (CoordsBackend.project(cells=True)): the first layer takes the map instead of
+        # making one, and -- the input being unwritten outside its cells -- must go by it
+        occ0 = getattr(volume, "dlpd_occupancy", None)
+        from deeplocalproteindocking_amd import ops
+        if getattr(volume, "dlpd_unwritten", False) and not (uw and self.use_hip_conv and self.use_tile_occupancy and
+                                                              ops.CONV_PRECISION == "split_bf16" and
+                                                              _hip_inference(volume, self.hip_lib)):
+            raise RuntimeError("dlpd: a cell-wise projected volume (unwritten outside its occupied cells) can only enter the plugin "
+                               "inside outputs_with_maps() on the tile-occupancy kernels")
+        vol1, occ1 = self._run(self.conv1, volume, occ0, True, unwritten=uw)
         vol2, occ2 = self._run(self.conv2, vol1, occ1, True, unwritten=uw and occ1 is not None)
         if occ1 is not None:                       # (tile-occupancy path: the maps travel with the volumes)
             vol1.dlpd_occupancy = occ1

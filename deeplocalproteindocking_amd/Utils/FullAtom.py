@@ -216,9 +216,12 @@ class CoordsBackend:
                 offsets.to(device=device, dtype=torch.int32).contiguous())
 
     def project(self, coords, num_atoms_of_type, offsets, box_size, resolution, device, R=None, shift=None,
-                sum_types=False, lib=None):
+                sum_types=False, lib=None, cells=False):
         """coords (B or 1, 3*Nmax); R (nb,3,3) f32 device -> one volume set per rotation of the
-        SAME atoms (B must be 1 then).  Returns (nb, 11 or 1, L, L, L) float32 on ``device``."""
+        SAME atoms (B must be 1 then).  Returns (nb, 11 or 1, L, L, L) float32 on ``device``.
+        cells (all types only): the CELL-WISE projection -- only the 4 x 4 x 4 cells the atoms' windows reach are cleared,
+        accumulated and converted; the result carries their map (``.dlpd_occupancy``, uint8 (nb, ceil(L/4)^3)) and is NOT
+        WRITTEN elsewhere (``.dlpd_unwritten``): for consumers that go by the map (the E3 plugin inside outputs_with_maps)."""
         device = torch.device(device)
         lib = lib or self.lib or get_lib()
         ready = (coords.device == device and coords.dtype == torch.float32 and
@@ -235,6 +238,16 @@ class CoordsBackend:
         sx, sy, sz = (0.0, 0.0, 0.0) if shift is None else [float(v) for v in torch.as_tensor(shift).reshape(-1)[:3]]
         nch = 1 if sum_types else NUM_ATOM_TYPES
         out = torch.empty(nb, nch, box_size, box_size, box_size, dtype=torch.float32, device=device)
+        if cells:
+            if sum_types:
+                raise RuntimeError("dlpd: the cell-wise projection keeps the atom types apart (sum_types=False)")
+            nc = (box_size + 3) // 4
+            occ = torch.empty(nb, nc, nc, nc, dtype=torch.uint8, device=device)
+            lib.call("dlpd_project_atoms_cells", _ptr(c), _ptr(nt), _ptr(of), _ptr(R), sx, sy, sz, _ptr(out), _ptr(occ), nb, stride,
+                     NUM_ATOM_TYPES, box_size, float(resolution), float(self.splat["sigma"]), int(self.splat["window"]),
+                     float(self.splat["voxel_offset"]), float(self.splat["norm"]), _stream(device))
+            out.dlpd_occupancy, out.dlpd_unwritten = occ, True
+            return out
         lib.call("dlpd_project_atoms_ext", _ptr(c), _ptr(nt), _ptr(of), _ptr(R), sx, sy, sz, _ptr(out), nb, stride,
                  NUM_ATOM_TYPES, box_size, float(resolution), int(sum_types), float(self.splat["sigma"]),
                  int(self.splat["window"]), float(self.splat["voxel_offset"]), float(self.splat["norm"]), _stream(device))

@@ -34,6 +34,7 @@ SIGNATURES = {
     "dlpd_zfft_volumes_occ": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _ll, _i, _p]),
     "dlpd_project_atoms": (_i, [_p, _p, _p, _p, _f, _f, _f, _p, _i, _i, _i, _i, _f, _i, _p]),
     "dlpd_project_atoms_ext": (_i, [_p, _p, _p, _p, _f, _f, _f, _p, _i, _i, _i, _i, _f, _i, _f, _i, _f, _f, _p]),
+    "dlpd_project_atoms_cells": (_i, [_p, _p, _p, _p, _f, _f, _f, _p, _p, _i, _i, _i, _i, _f, _f, _i, _f, _f, _p]),
     "dlpd_rfft3d_padded": (_i, [_p, _p, _p, _i, _i, _f, _p]),
     "dlpd_xy_correlate": (_i, [_p, _p, _p, _i, _i, _i, _ll, _p]),
     "dlpd_receptor_packed_floats": (_ll, [_i, _i]),

@@ -80,7 +80,91 @@ __global__ void __launch_bounds__(256) k_splat_to_float(unsigned* __restrict__ a
   }
 }
 
+// ---- the same projection CELL-WISE (round 6): a protein fills a few per cent of its box, and Docker.dockE3 projects sixteen
+// poses per batch (Docker.py:163-165) -- clearing, converting and then scanning (sum over types, tile occupancy) 360 MB that
+// are almost all zero cost more than everything the atoms touch.  Here the 4 x 4 x 4 cells an atom's window can reach are
+// marked first; only marked cells are cleared, accumulated into and converted; the rest of `out` is NOT WRITTEN and `occ` (the
+// maps of dlpd_conv3d_tile_occupancy: one byte per cell, all types) says which is which -- for consumers that go by the map
+// (dlpd_conv3d_split_sparse with unwritten != 0).  Same accumulation, same conversion: the same values where the map is set.
+__global__ void __launch_bounds__(256)
+k_mark_atom_cells(const float* __restrict__ coords, const int* __restrict__ ntype, const int* __restrict__ offs,
+                  const float* __restrict__ R, float sx, float sy, float sz, unsigned char* __restrict__ occ, int B, int stride_atoms,
+                  int T, int L, float res, int d, float voff) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = gid / stride_atoms, a = gid % stride_atoms;
+  if (b >= B) return;
+  bool typed = false;
+  for (int t = 0; t < T; t++) {
+    const int o = offs[b * T + t];
+    typed |= (a >= o && a < o + ntype[b * T + t]);
+  }
+  if (!typed) return;
+  const float* p = coords + ((size_t)b * stride_atoms + a) * 3;
+  float x = p[0], y = p[1], z = p[2];
+  if (R) {                                              // (the same expressions as k_project_atoms: the same voxel indices)
+    const float* r = R + (size_t)b * 9;
+    const float rx = r[0] * x + r[1] * y + r[2] * z;
+    const float ry = r[3] * x + r[4] * y + r[5] * z;
+    const float rz = r[6] * x + r[7] * y + r[8] * z;
+    x = rx; y = ry; z = rz;
+  }
+  x += sx; y += sy; z += sz;
+  const int ci = (int)floorf(x / res - voff), cj = (int)floorf(y / res - voff), ck = (int)floorf(z / res - voff);
+  const int nc = (L + 3) / 4;
+  const int i0 = max(ci - d, 0) >> 2, i1 = min(ci + d, L - 1) >> 2, j0 = max(cj - d, 0) >> 2, j1 = min(cj + d, L - 1) >> 2;
+  const int k0 = max(ck - d, 0) >> 2, k1 = min(ck + d, L - 1) >> 2;
+  if (ci + d < 0 || cj + d < 0 || ck + d < 0 || ci - d >= L || cj - d >= L || ck - d >= L) return;   // window outside the box
+  for (int i = i0; i <= i1; i++)
+    for (int j = j0; j <= j1; j++)
+      for (int k = k0; k <= k1; k++) occ[(((size_t)b * nc + i) * nc + j) * nc + k] = 1;     // (plain stores of the same value)
+}
+
+// one thread per voxel of every cell: MODE 0 clears the marked cells' accumulators, MODE 1 converts them to float
+template <int MODE> __global__ void __launch_bounds__(256)
+k_marked_cells(const unsigned char* __restrict__ occ, unsigned* __restrict__ acc, int B, int T, int L) {
+  const int nc = (L + 3) / 4;
+  const size_t total = (size_t)B * nc * nc * nc * 64;
+  const size_t L3 = (size_t)L * L * L;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t cell = i >> 6;
+    if (!occ[cell]) continue;
+    const int v = (int)(i & 63), cz = (int)(cell % nc), cy = (int)((cell / nc) % nc), cx = (int)((cell / ((size_t)nc * nc)) % nc);
+    const int b = (int)(cell / ((size_t)nc * nc * nc));
+    const int x = 4 * cx + (v >> 4), y = 4 * cy + ((v >> 2) & 3), z = 4 * cz + (v & 3);
+    if (x >= L || y >= L || z >= L) continue;
+    unsigned* a = acc + (size_t)b * T * L3 + ((size_t)x * L + y) * L + z;
+    for (int t = 0; t < T; t++) {
+      if (MODE == 0) a[(size_t)t * L3] = 0u;
+      else reinterpret_cast<float*>(a)[(size_t)t * L3] = (float)a[(size_t)t * L3] * (1.0f / DLPD_SPLAT_SCALE);
+    }
+  }
+}
+
 extern "C" {
+
+int dlpd_project_atoms_cells(const float* coords, const int* num_atoms_of_type, const int* offsets, const float* R,
+                             float shift_x, float shift_y, float shift_z, float* out, unsigned char* occ, int B, int stride_atoms,
+                             int ntypes, int L, float resolution, float sigma, int window, float voxel_offset, float norm,
+                             void* stream) {
+  if (!coords || !num_atoms_of_type || !offsets || !out || !occ || B <= 0 || stride_atoms <= 0 || ntypes <= 0 || L <= 0 ||
+      resolution <= 0.f || !(sigma > 0.f) || window < 0 || window > DLPD_SPLAT_MAX_WINDOW || !(norm > 0.f) || norm > 64.f)
+    return DLPD_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int nc = (L + 3) / 4;
+  const size_t ncell = (size_t)B * nc * nc * nc;
+  if (hipMemsetAsync(occ, 0, ncell, st) != hipSuccess) return DLPD_ERR_LAUNCH;
+  const int total = B * stride_atoms;
+  DLPD_LAUNCH(k_mark_atom_cells, dim3((total + 255) / 256), dim3(256), 0, st, coords, num_atoms_of_type, offsets, R, shift_x, shift_y,
+              shift_z, occ, B, stride_atoms, ntypes, L, resolution, window, voxel_offset);
+  size_t nblk = (ncell * 64 + 255) / 256;
+  if (nblk > 32768) nblk = 32768;
+  DLPD_LAUNCH(k_marked_cells<0>, dim3((unsigned)nblk), dim3(256), 0, st, occ, reinterpret_cast<unsigned*>(out), B, ntypes, L);
+  DLPD_LAUNCH(k_project_atoms, dim3((total + 255) / 256), dim3(256), 0, st, coords, num_atoms_of_type, offsets, R,
+              shift_x, shift_y, shift_z, reinterpret_cast<unsigned*>(out), B, stride_atoms, ntypes, L, resolution, 0,
+              0.5f / (sigma * sigma), window, voxel_offset, norm);
+  DLPD_LAUNCH(k_marked_cells<1>, dim3((unsigned)nblk), dim3(256), 0, st, occ, reinterpret_cast<unsigned*>(out), B, ntypes, L);
+  return dlpd_check_launch();
+}
 
 // Clears `out`, accumulates the densities in fixed point, converts to float: bit-reproducible.
 int dlpd_project_atoms_ext(const float* coords, const int* num_atoms_of_type, const int* offsets, const float* R,

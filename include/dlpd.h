@@ -170,6 +170,14 @@ int dlpd_project_atoms_ext(const float* coords, const int* num_atoms_of_type, co
                            float shift_x, float shift_y, float shift_z, float* out, int B, int stride_atoms,
                            int ntypes, int L, float resolution, int sum_types, float sigma, int window,
                            float voxel_offset, float norm, void* stream);
+/* The same projection (all types, no sum) CELL-WISE, for consumers that go by occupancy maps (Docker.dockE3's per-batch
+ * projection, Docker.py:163-165, in front of dlpd_conv3d_split_sparse(unwritten != 0)): only the 4 x 4 x 4 cells an atom's
+ * window reaches are cleared, accumulated into and converted; occ (B, ceil(L/4)^3 bytes, written in full) marks them; out
+ * (B, ntypes, L^3) holds the same values as dlpd_project_atoms_ext in marked cells and is NOT WRITTEN elsewhere. */
+int dlpd_project_atoms_cells(const float* coords, const int* num_atoms_of_type, const int* offsets, const float* R,
+                             float shift_x, float shift_y, float shift_z, float* out, unsigned char* occ, int B, int stride_atoms,
+                             int ntypes, int L, float resolution, float sigma, int window, float voxel_offset, float norm,
+                             void* stream);
 
 /* Zero-padded 3-D R2C spectrum (receptor side of VolumeConvolution, DockingModels.py:71):
  * spec (nvol, NZ, N, N) = scale * rfftn(pad(vol)).  wsA: nvol*NZ*L*L complex64 scratch. */

@@ -842,3 +842,43 @@ def test_a_prepared_pair_overwritten_in_its_engine_slot_refuses_to_dock(tmp_path
     third = dk.prepare(pa, pb, "SE3", slot=0)                  # and the other slot is independent
     dk.dockSE3(pa, pb, 2, prepared=third)
     assert len(dk.top_list) == 20
+
+
+def _cellwise_projection_checks(be, device, L=24, res=1.25):
+    """CoordsBackend.project(cells=True) (dlpd_project_atoms_cells: only the cells the atoms' windows reach are cleared,
+    accumulated and converted) against the dense projection: the same values wherever the map is set, zeros in the dense
+    volume everywhere else, a map that covers every non-zero cell, and nothing written outside it (NaN-filled buffer)."""
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="dlpd_cells_")
+    _, coords, counts, offs = _typed(__import__("pathlib").Path(tmp), 10, seed=3)
+    centre = torch.full((1, 3), L * res / 2.0, dtype=torch.double)
+    R = torch.from_numpy(orc.euler_to_matrix([0.4, -2.0, 1.3], [1.0, 0.3, 2.2], [-0.7, 1.9, 0.2])).float()
+    dense = be.project(coords, counts, offs, L, res, device, R=R, shift=centre)
+    orig = torch.empty
+
+    def nan_empty(*a, **kw):
+        t = orig(*a, **kw)
+        return t.fill_(float("nan")) if t.is_floating_point() else t
+    torch.empty = nan_empty
+    try:
+        sparse = be.project(coords, counts, offs, L, res, device, R=R, shift=centre, cells=True)
+    finally:
+        torch.empty = orig
+    occ = sparse.dlpd_occupancy
+    nc = (L + 3) // 4
+    assert sparse.dlpd_unwritten and occ.shape == (3, nc, nc, nc) and 0 < int(occ.sum()) < occ.numel()
+    live = occ.bool().repeat_interleave(4, 1).repeat_interleave(4, 2).repeat_interleave(4, 3)[:, None, :L, :L, :L].expand_as(dense)
+    assert torch.equal(sparse[live], dense[live]) and bool((dense[~live] == 0).all()) and bool(torch.isnan(sparse[~live]).all())
+    with pytest.raises(RuntimeError, match="sum_types"):
+        be.project(coords, counts, offs, L, res, device, R=R, shift=centre, cells=True, sum_types=True)
+
+
+def test_cellwise_projection_equals_the_dense_one_where_its_map_is_set_emulated(emu):
+    _cellwise_projection_checks(CoordsBackend(lib=emu), "cpu")
+
+
+@pytest.mark.gpu
+def test_cellwise_projection_equals_the_dense_one_where_its_map_is_set_on_gpu():
+    import __graft_entry__ as entry
+    entry.build()
+    _cellwise_projection_checks(CoordsBackend(), torch.device("cuda:0"), L=80)
