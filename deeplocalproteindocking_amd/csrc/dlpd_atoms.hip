@@ -27,13 +27,16 @@
 
 // coords (B, 3*stride_atoms) f32 [x0 y0 z0 x1 ...] ordered by atom type; ntype (B, T) counts,
 // offs (B, T) first atom of each type.  p' = R_b p + shift (R row-major, may be null).
-// out (B, T, L^3), or (B, 1, L^3) when sum_types != 0.  One thread per (b, atom).
+// out (B, T, L^3), or (B, 1, L^3) when sum_types != 0.  One thread per (b, atom, x-plane of its window): 2d + 1 threads share
+// an atom (round 6: one thread per atom left 56 blocks of 125 serial atomics each -- 80-110 us per call, and Docker.dockSE3
+// makes one per batch, Docker.dockE3 two); every voxel gets the same contribution, integer adds commute: the same bits.
 __global__ void __launch_bounds__(256)
 k_project_atoms(const float* __restrict__ coords, const int* __restrict__ ntype, const int* __restrict__ offs,
                 const float* __restrict__ R, float sx, float sy, float sz, unsigned* __restrict__ out, int B,
                 int stride_atoms, int T, int L, float res, int sum_types, float inv2s2, int d, float voff, float norm) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int b = gid / stride_atoms, a = gid % stride_atoms;
+  const int nw = 2 * d + 1, wi = gid % nw, ga = gid / nw;
+  const int b = ga / stride_atoms, a = ga % stride_atoms;
   if (b >= B) return;
   int ty = -1;
   for (int t = 0; t < T; t++) {
@@ -55,8 +58,9 @@ k_project_atoms(const float* __restrict__ coords, const int* __restrict__ ntype,
   const int ci = (int)floorf(x / res - voff), cj = (int)floorf(y / res - voff), ck = (int)floorf(z / res - voff);
   const int ch = sum_types ? 0 : ty, nch = sum_types ? 1 : T;
   unsigned* vol = out + ((size_t)b * nch + ch) * L * L * L;
-  for (int i = ci - d; i <= ci + d; i++) {
-    if (i < 0 || i >= L) continue;
+  {
+    const int i = ci - d + wi;                          // this thread's plane of the window
+    if (i < 0 || i >= L) return;
     const float dx = x - (i + voff) * res;
     for (int j = cj - d; j <= cj + d; j++) {
       if (j < 0 || j >= L) continue;
@@ -154,12 +158,13 @@ int dlpd_project_atoms_cells(const float* coords, const int* num_atoms_of_type, 
   const size_t ncell = (size_t)B * nc * nc * nc;
   if (hipMemsetAsync(occ, 0, ncell, st) != hipSuccess) return DLPD_ERR_LAUNCH;
   const int total = B * stride_atoms;
+  const int total_w = total * (2 * window + 1);          // k_project_atoms: one thread per (atom, window plane)
   DLPD_LAUNCH(k_mark_atom_cells, dim3((total + 255) / 256), dim3(256), 0, st, coords, num_atoms_of_type, offsets, R, shift_x, shift_y,
               shift_z, occ, B, stride_atoms, ntypes, L, resolution, window, voxel_offset);
   size_t nblk = (ncell * 64 + 255) / 256;
   if (nblk > 32768) nblk = 32768;
   DLPD_LAUNCH(k_marked_cells<0>, dim3((unsigned)nblk), dim3(256), 0, st, occ, reinterpret_cast<unsigned*>(out), B, ntypes, L);
-  DLPD_LAUNCH(k_project_atoms, dim3((total + 255) / 256), dim3(256), 0, st, coords, num_atoms_of_type, offsets, R,
+  DLPD_LAUNCH(k_project_atoms, dim3((total_w + 255) / 256), dim3(256), 0, st, coords, num_atoms_of_type, offsets, R,
               shift_x, shift_y, shift_z, reinterpret_cast<unsigned*>(out), B, stride_atoms, ntypes, L, resolution, 0,
               0.5f / (sigma * sigma), window, voxel_offset, norm);
   DLPD_LAUNCH(k_marked_cells<1>, dim3((unsigned)nblk), dim3(256), 0, st, occ, reinterpret_cast<unsigned*>(out), B, ntypes, L);
@@ -177,7 +182,7 @@ int dlpd_project_atoms_ext(const float* coords, const int* num_atoms_of_type, co
   hipStream_t st = (hipStream_t)stream;
   const size_t bytes = (size_t)B * (sum_types ? 1 : ntypes) * L * L * L * sizeof(float);
   if (hipMemsetAsync(out, 0, bytes, st) != hipSuccess) return DLPD_ERR_LAUNCH;
-  const int total = B * stride_atoms;
+  const int total = B * stride_atoms * (2 * window + 1);      // one thread per (atom, window plane)
   DLPD_LAUNCH(k_project_atoms, dim3((total + 255) / 256), dim3(256), 0, st, coords, num_atoms_of_type, offsets, R,
               shift_x, shift_y, shift_z, reinterpret_cast<unsigned*>(out), B, stride_atoms, ntypes, L, resolution, sum_types,
               0.5f / (sigma * sigma), window, voxel_offset, norm);
