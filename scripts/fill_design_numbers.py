@@ -99,5 +99,21 @@ text = open(path).read()
 for k, v in rep.items():
     text = text.replace("@@%s@@" % k, v)
 left = re.findall(r"@@[A-Z0-9]+@@", text)
-open(path, "w").write(text.replace("r06_z_", tag + "_"))
+# a DESIGN.md that was filled before: rewrite the second cell of the section-0 rows by their (stable) first cells
+ROWS = {"| BASELINE config 2 (48 ch": "HEADLINE", "| stages of that step": "STAGES", "| what bounds the dominant kernel K2": "K2BOUND",
+        "| complete searches": "SOAK", "| CPU baseline": "CPU", "| reference's real shapes": "REAL", "| the same shapes with PROTEIN-SHAPED": "REALPROTEIN",
+        "| config 5's literal": "OTHER", "| `dockE3` at box 80": "E3", "| two ranks on the one GPU": "TWORANKS", "| suites": "SUITES"}
+out = []
+for line in text.split("\n"):
+    for start, key in ROWS.items():
+        if line.startswith(start):
+            cells = line.split(" | ")
+            if len(cells) >= 3:
+                cells[1] = rep[key]
+                line = " | ".join(cells)
+            break
+    out.append(line)
+text = "\n".join(out)
+text = re.sub(r"r06_[a-z]+_(?=[a-z0-9_{},*]+\.(json|txt|log))", tag + "_", text) if tag != "r06_z" else text
+open(path, "w").write(text.replace("r06_z_", tag + "_") if tag != "r06_z" else text)
 print("filled", sorted(rep), "left", left)
