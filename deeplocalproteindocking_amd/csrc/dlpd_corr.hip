@@ -476,18 +476,17 @@ __global__ void __launch_bounds__(256) k_rotated_occupancy(const unsigned char* 
     occ_out[i] = any ? 1 : 0;
   }
 }
-// pencil map of nb cell maps: word [b][x cell] has bit (y cell) set where some z cell of that column is occupied
+// pencil map of nb cell maps: word [b][x cell] has bit (y cell) set where some z cell of that column is occupied.
+// One wave per word: lane = y cell (nc <= 32) ORs its column's z cells, a ballot makes the word.
 __global__ void __launch_bounds__(256) k_pencil_bits(const unsigned char* __restrict__ occ, unsigned* __restrict__ bits, int nb, int nc) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nb * nc) return;
-  const unsigned char* o = occ + (size_t)i * nc * nc;
-  unsigned w = 0;
-  for (int cy = 0; cy < nc; cy++) {
-    bool any = false;
-    for (int cz = 0; cz < nc; cz++) any |= o[cy * nc + cz] != 0;
-    w |= any ? (1u << cy) : 0u;
+  const int lane = threadIdx.x & 63, i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;      // word index (wave-uniform)
+  bool any = false;
+  if (i < nb * nc && lane < nc) {
+    const unsigned char* o = occ + ((size_t)i * nc + lane) * nc;
+    for (int cz = 0; cz < nc; cz++) any |= o[cz] != 0;
   }
-  bits[i] = w;
+  const unsigned long long m = __ballot(any);
+  if (i < nb * nc && lane == 0) bits[i] = (unsigned)m;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1570,14 +1569,14 @@ int dlpd_rotated_occupancy(const unsigned char* occ_src, const float* R, unsigne
   DLPD_LAUNCH(k_rotated_occupancy, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, occ_src, R, occ_out,
               nb, L, center);
   if (pencil_out)
-    DLPD_LAUNCH(k_pencil_bits, dim3((unsigned)((nb * nc + 255) / 256)), dim3(256), 0, (hipStream_t)stream, occ_out, pencil_out, nb, nc);
+    DLPD_LAUNCH(k_pencil_bits, dim3((unsigned)((nb * nc + 3) / 4)), dim3(256), 0, (hipStream_t)stream, occ_out, pencil_out, nb, nc);
   return dlpd_check_launch();
 }
 // the pencil words of nb GIVEN cell maps (the volumes path: the plugin's own maps)
 int dlpd_pencil_bits(const unsigned char* occ, unsigned* pencil_out, int nb, int L, void* stream) {
   if (!occ || !pencil_out || nb <= 0 || L <= 0 || L > 128) return DLPD_ERR_ARG;
   const int nc = (L + 3) / 4;
-  DLPD_LAUNCH(k_pencil_bits, dim3((unsigned)((nb * nc + 255) / 256)), dim3(256), 0, (hipStream_t)stream, occ, pencil_out, nb, nc);
+  DLPD_LAUNCH(k_pencil_bits, dim3((unsigned)((nb * nc + 3) / 4)), dim3(256), 0, (hipStream_t)stream, occ, pencil_out, nb, nc);
   return dlpd_check_launch();
 }
 // 1 where dlpd_xy_correlate_packed_occ exists: the packed-receptor boxes (80, 40)

@@ -219,7 +219,8 @@ class DockingEngine:
         self.prefilter = bool(prefilter)
         # Search-side sparsity (round 6): a ligand whose channels are zero in most 4^3 cells of its box (any real protein's
         # representation) gets per-rotation occupancy maps, and the channels-last K1 skips what they mark empty -- same
-        # spectra.  None: decided per ligand in set_ligand (on below SPARSE_K1_MAX_FILL of the cells occupied); True / False force it.
+        # spectra.  None: decided per ligand and grid in set_ligand (on where the ligand's cells, dilated by one, stay below
+        # SPARSE_K1_MAX_FILL of the box); True / False force it.
         self.sparse_k1_wanted = sparse_k1
         self.sparse_k1 = self.sparse_k1_coarse = self.k2_pencil_map = self.k2_pencil_map_coarse = False
         self._k2_by_map = {False: False, True: False}
@@ -394,9 +395,15 @@ class DockingEngine:
         if not self.use_cl or self.sparse_k1_wanted is False:
             return
         nc = (self.L + 3) // 4
+
+        def reach(occ):
+            """Fraction of the cells a ROTATED copy can mark: the per-rotation maps are conservative by about one cell per
+            side, so the decision goes by the ligand's cells dilated by one (a 60 %-full coarse grid marks everything)."""
+            o = occ.to(torch.float32).reshape(1, 1, *occ.shape[-3:])
+            return float(torch.nn.functional.max_pool3d(o, kernel_size=3, stride=1, padding=1).mean())
         self.occ_src = ops.tile_occupancy(self.lig[: self.C].unsqueeze(0), lib=self.lib)
         self.lig_fill = float(self.occ_src.float().mean())
-        self.sparse_k1 = bool(self.sparse_k1_wanted) or self.lig_fill < self.SPARSE_K1_MAX_FILL
+        self.sparse_k1 = bool(self.sparse_k1_wanted) or reach(self.occ_src) < self.SPARSE_K1_MAX_FILL
         if self.sparse_k1 and not hasattr(self, "occ_rot"):
             self.occ_rot = torch.empty(self.batch, nc, nc, nc, dtype=torch.uint8, device=self.device)
             self.pen_rot = torch.empty(self.batch, nc, dtype=torch.int32, device=self.device)
@@ -404,7 +411,7 @@ class DockingEngine:
             nc1 = (self.L1 + 3) // 4
             self.occ_src1 = ops.tile_occupancy(self.lig1.unsqueeze(0), lib=self.lib)
             self.lig_fill_coarse = float(self.occ_src1.float().mean())
-            self.sparse_k1_coarse = bool(self.sparse_k1_wanted) or self.lig_fill_coarse < self.SPARSE_K1_MAX_FILL
+            self.sparse_k1_coarse = bool(self.sparse_k1_wanted) or reach(self.occ_src1) < self.SPARSE_K1_MAX_FILL
             if self.sparse_k1_coarse and not hasattr(self, "occ_rot1"):
                 self.occ_rot1 = torch.empty(self.batch, nc1, nc1, nc1, dtype=torch.uint8, device=self.device)
                 self.pen_rot1 = torch.empty(self.batch, nc1, dtype=torch.int32, device=self.device)
