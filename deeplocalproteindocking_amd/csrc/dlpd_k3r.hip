@@ -122,6 +122,26 @@ extern "C" int dlpd_debug_read_stamps_k3r(unsigned long long* host32) {
 // pair m = msl ^ k3r_pair_swz(k).  The swizzle (8 pairs per bin only) makes the 16-byte reads of the first pass --
 // lane = 8*pencil + t reads bin t + 8r of its pencil -- bank-conflict free: a ds_read_b128 is served in groups of 16
 // lanes {0-3,12-15,20-27}, ..., and 8k + m alone puts lanes t, t+2 of one pencil on the same 16-byte column.
+// WHERE K3's LDS BANK CONFLICTS COME FROM (round 6; SQ_LDS_BANK_CONFLICT = 15 % of its LDS-active cycles): every access the
+// source writes is conflict free by the bank model, but the compiler turns the two special-cased first-pass reads of a
+// pencil (bins 0 and N/2: `dc ? (x, z) : (x - w, y + z)`) into ds_read2_b32 pairs -- x, z for every lane, y, w under the branch
+// of the general case -- and the 32-lane groups of ds_read2_b32 put four lanes on a bank where the 16-lane groups of the
+// ds_read_b128 it replaces are conflict free by the pair swizzle: 4 instructions x 12 extra cycles = 48 per channel and
+// tile, which IS the counter (3.85e7 per launch / 16,384 tiles / 49 channels).  DLPD_K3R_DC_OPAQUE = 1 keeps the two loads
+// whole (16 ds_read_b128, no ds_read2_b32, conflict counter at zero, 143 instead of 163 registers) -- and measured SLOWER,
+// same box, alternating libraries, twice: K3 1.750 / 1.762 against 1.710 / 1.713 ms with a volatile keep-alive, 1.752 / 1.744
+// against 1.707 / 1.706 with a plain one (EXPERIMENTS.md R6): the kernel is vector-issue bound and the conflicts sit in its
+// slack.  Default 0: the compiler's form stays.
+#ifndef DLPD_K3R_DC_OPAQUE
+#define DLPD_K3R_DC_OPAQUE 0
+#endif
+// all four components of a loaded float4 needed at ONE point (a plain, non-volatile asm: a data dependence, no ordering
+// against the kernel's other inline assembly)
+#if defined(DLPD_CPU_EMU)
+#define DLPD_K3R_KEEP4(q) ((void)0)
+#else
+#define DLPD_K3R_KEEP4(q) asm("" : "+v"((q).x), "+v"((q).y), "+v"((q).z), "+v"((q).w))
+#endif
 template <int NPAIR> DLPD_HD int k3r_pair_swz(int k) { return NPAIR == 8 ? ((k & 2) << 1) : 0; }
 
 // first pass of the inverse z transform of one pencil (thread t of 8): inputs from the raw channel `rj`, radix-R1
@@ -138,6 +158,8 @@ template <int N, int NPAIR> DLPD_D void k3r_first_pass_load(typename K3rFirst<N>
     float4 q[RH];
 #pragma unroll
     for (int r = 0; r < RH; r++) q[r] = lo[NPAIR * 8 * r];
+    // (DLPD_K3R_DC_OPAQUE, above: keeps the special-cased bin's load ONE 16-byte read; measured slower, off)
+    if (DLPD_K3R_DC_OPAQUE) DLPD_K3R_KEEP4(q[0]);
 #pragma unroll
     for (int r = 0; r < RH; r++) {
       // k = 0: the purely real bin of both rows
@@ -149,6 +171,7 @@ template <int N, int NPAIR> DLPD_D void k3r_first_pass_load(typename K3rFirst<N>
     float4 q[RH];
 #pragma unroll
     for (int s = 0; s < RH; s++) q[s] = *(hi - NPAIR * 8 * s);
+    if (DLPD_K3R_DC_OPAQUE) DLPD_K3R_KEEP4(q[0]);
 #pragma unroll
     for (int s = 0; s < RH; s++) {
       // k = N/2: purely real as well
