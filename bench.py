@@ -64,7 +64,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="rotations per step")
+    ap.add_argument("--batch", type=int, default=32, help="rotations per step = per launch (Docker.launch_batch: 32 since round 6, 16 before)")
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--channels", type=int, default=None, help="override the workload's channel count")
     ap.add_argument("--box", type=int, default=None, help="override the workload's box size")
@@ -695,7 +695,8 @@ def run_rank(args):
             "config": {"workload": "%s, %d-degree SOI-sized rotation set (%d rotations, %s), max_conf=%d" %
                                    (wl["desc"] if (args.channels, args.box) == (None, None) else
                                     "synthetic %d-channel %d^3 pair" % (C, L), angle, nrot_total, rot_src, K),
-                       "rotations_per_step": nb, "rotations_timed_per_gpu": args.steps * nb,
+                       "rotations_per_step": nb, "ms_per_16_rotations": ms_step * 16.0 / nb,
+                       "rotations_timed_per_gpu": args.steps * nb,
                        "timed_steps": "batches spread evenly over the rank's whole %d-batch visiting sequence "
                                       "(all four search groups)" % shard_batches,
                        "translations_per_rotation": N ** 3, "sharding": "rotations interleaved over %d rank(s)" % world,
@@ -805,7 +806,8 @@ def short_measurement(name, args, dev, R_all, nb, nsteps=24):
     sw = eng.switches()
     del eng
     torch.cuda.empty_cache()
-    return {"workload": wl["desc"], "kernel_switches": sw, "steps": nsteps, "ms_per_step": ms, "rot_per_s": rps,
+    return {"workload": wl["desc"], "kernel_switches": sw, "steps": nsteps, "rotations_per_step": nb, "ms_per_step": ms,
+            "ms_per_16_rotations": ms * 16.0 / nb, "rot_per_s": rps,
             "value": rps * N ** 3, "unit": "pose scores/s",
             "stages": {k: {"ms_per_launch": v, "alg_GBps": (alg[k] / (v * 1e-3) / 1e9 if k in alg else None),
                            "frac_of_peak": (alg[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS if k in alg else None)}
@@ -921,7 +923,8 @@ def e3_measurement(dev, nb, nsteps=6):
                "rotations_per_launch": nb, "ms_projection": ms_proj, "ms_representation": ms_repr, "ms_engine": ms_eng,
                # the headline is ONE designated measurement: Docker's own batch loop (Docker._dockE3_fused); the hand-written
                # serial loop of the same three calls is reported beside it, not mixed in
-               "ms_per_launch": ms_all, "ms_per_launch_serial": ms_serial, "ms_per_launch_docker_loop": ms_all,
+               "ms_per_launch": ms_all, "ms_per_16_rotations": ms_all * 16.0 / nb, "ms_per_launch_serial": ms_serial,
+               "ms_per_launch_docker_loop": ms_all,
                "tile_occupancy": bool(getattr(repr_, "use_tile_occupancy", False)),
                "unwritten_activations": with_maps,
                "ms_representation_writing_every_voxel": ms_repr_written,

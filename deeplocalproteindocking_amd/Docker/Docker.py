@@ -14,7 +14,7 @@ What differs underneath:
     lives on the device until the pair is finished;
   * the caller's ``batch_size`` does NOT size the launches: the ranked list is independent of how
     the rotations are batched (merge key (score, rotation, pick); tested), so ``dockSE3`` /
-    ``dockE3`` always score ``launch_batch`` (16) rotations per launch -- the receptor slab in K2 is
+    ``dockE3`` always score ``launch_batch`` (32) rotations per launch -- the receptor slab in K2 is
     amortised over the launch batch, and ``batch_size=2`` of local_test.py:69,71 would cost 8x the
     launches;
   * the scoring call ``docking_model(receptor_volumes, ligand_volumes_rotated)`` (Docker.py:229) is
@@ -121,7 +121,7 @@ def all_gather_top_entries(entries, K, world_size, process_group=None, device="c
     return DeviceTopList.merge_entries(parts, K)
 
 
-LAUNCH_BATCH = 16      # rotations per launch of the fused pipeline
+LAUNCH_BATCH = 32      # rotations per launch of the fused pipeline (16 through round 5: EXPERIMENTS.md R6)
 
 
 class PreparedPair(object):
@@ -369,7 +369,7 @@ class Docker:
         return self.conventions.pivot(L, self.box_size)
 
     def release_engine(self):
-        """Drop the cached fused engine and its device workspaces (several GB at box 80: wsB for 16 rotations,
+        """Drop the cached fused engine and its device workspaces (several GB at box 80: wsB for 32 rotations,
         double-buffered score volumes).  The next ``dock*`` call builds a new one."""
         for _, eng in self._engine_pool.values():
             eng.finish()

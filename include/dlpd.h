@@ -15,7 +15,7 @@
  *   once per pair    dlpd_rfft3d_padded        receptor spectrum            (DockingModels.py:71, hoisted out of the loop)
  *                    dlpd_receptor_pack        ... in K2's read order       (boxes 80 / 40 only)
  *                    dlpd_make_channels_last   ligand copy K1 gathers from
- *   per 16 rotations dlpd_zfft_channels_last   K1: rotation + z transform  (Docker.py:218)
+ *   per launch       dlpd_zfft_channels_last   K1: rotation + z transform  (Docker.py:218)
  *                    dlpd_project_atoms + dlpd_zfft_into   clash channel from rotated atoms (Docker.py:221-224)
  *                    dlpd_xy_correlate_packed / dlpd_xy_correlate   K2     (DockingModels.py:70-71, Docker.py:225)
  *                    dlpd_zifft_filter_cand    K3: z inverse + clip + MLP + clash mask + candidates (DockingModels.py:74-83, Docker.py:226-232)

@@ -17,13 +17,15 @@ def load(name):
 
 
 d = load("bench_default.json")
-st = {k: v["ms_per_launch"] for k, v in d["stages"].items()}
+NB = d["config"]["rotations_per_step"]
+SC = 16.0 / NB                       # every ms figure below is per 16 rotations (comparable with rounds 1-5), whatever the launch batch
+st = {k: v["ms_per_launch"] * SC for k, v in d["stages"].items()}
 rl = d["rooflines"]
 sec = d["roofline"]["secondary"]
 sus = d.get("sustained") or {}
 rep = {}
-rep["HEADLINE"] = "**%.2fe9 pose scores/s, %.2f ms per 16 rotations** (%d rotations/s)%s" % (
-    d["value"] / 1e9, d["ms_per_step"], round(d["rot_per_s"]),
+rep["HEADLINE"] = "**%.2fe9 pose scores/s, %.2f ms per 16 rotations** (launches of %d: %.2f ms per step; %d rotations/s)%s" % (
+    d["value"] / 1e9, d["ms_per_step"] * SC, NB, d["ms_per_step"], round(d["rot_per_s"]),
     ("; `sustained` %.2fe9 over %d consecutive batches" % (sus["value"] / 1e9, sus.get("steps", 0)) if sus.get("value") else ""))
 rep["STAGES"] = "K1 %.2f (%.2f), **K2 %.2f (%.2f; dominant)**, K3 %.2f (%.2f); top-K %.2f + %.2f on a side stream" % (
     st["k1_rotate_zfft"], rl["k1_rotate_zfft"]["frac"], st["k2_xy_corr"], rl["k2_xy_corr"]["frac"], st["k3_zifft_filter"],
@@ -49,34 +51,38 @@ rep["CPU"] = ("%.2fe6 pose scores/s on %d cores (16 rotations, the driver defaul
 
 def line(name):
     x = load(name)
-    s = {k: v["ms_per_launch"] for k, v in x["stages"].items()}
+    sc = 16.0 / x["config"]["rotations_per_step"]
+    s = {k: v["ms_per_launch"] * sc for k, v in x["stages"].items()}
+    x["ms16"] = x["ms_per_step"] * sc
     return x, s
 
 
 x, s = line("bench_real.json")
 rep["REAL"] = "**%.2fe10 pose scores/s, %.2f ms per 16 rotations** (%d rotations/s): coarse %.2f, K1 %.2f, K2 %.2f, K3 %.2f" % (
-    x["value"] / 1e10, x["ms_per_step"], round(x["rot_per_s"]), s["coarse"], s["k1_rotate_zfft"], s["k2_xy_corr"], s["k3_zifft_filter"])
+    x["value"] / 1e10, x["ms16"], round(x["rot_per_s"]), s["coarse"], s["k1_rotate_zfft"], s["k2_xy_corr"], s["k3_zifft_filter"])
 x, s = line("bench_real_protein.json")
 y, t = line("bench_real_protein_k1_occupancy_off.json")
 sw = x["config"]["kernel_switches"]["k1_occupancy_maps"]
 rep["REALPROTEIN"] = ("**%.2f ms per 16 rotations (%d rotations/s) with K1 by occupancy maps + K2 by pencil maps, %.2f without**: K1 %.2f "
                       "against %.2f, coarse %.2f, K2 %.2f, K3 %.2f; %.0f %% of the ligand's fine cells and %.0f %% of its coarse cells "
-                      "occupied" % (x["ms_per_step"], round(x["rot_per_s"]), y["ms_per_step"], s["k1_rotate_zfft"], t["k1_rotate_zfft"],
+                      "occupied" % (x["ms16"], round(x["rot_per_s"]), y["ms16"], s["k1_rotate_zfft"], t["k1_rotate_zfft"],
                                     s["coarse"], s["k2_xy_corr"], s["k3_zifft_filter"], 100 * sw["ligand_cells_occupied"]["fine"],
                                     100 * sw["ligand_cells_occupied"]["coarse"]))
 x, s = line("bench_c48l80.json")
 y, t = line("bench_config1.json")
 rep["OTHER"] = "%.2fe9 pose scores/s, %.2f ms (K1 %.2f, K2 %.2f, K3 %.2f); config 1: %.2fe10 (launch-bound: %.2f ms per 16 rotations)" % (
-    x["value"] / 1e9, x["ms_per_step"], s["k1_rotate_zfft"], s["k2_xy_corr"], s["k3_zifft_filter"], y["value"] / 1e10, y["ms_per_step"])
+    x["value"] / 1e9, x["ms16"], s["k1_rotate_zfft"], s["k2_xy_corr"], s["k3_zifft_filter"], y["value"] / 1e10, y["ms16"])
 c4 = json.load(open(P("soak_config4.json")))
 secs = [t_["seconds"] for run in c4["runs"] for t_ in run]
 rps = [t_["rot_per_s"] for run in c4["runs"] for t_ in run]
 rep["CONFIG4"] = "%.1f–%.1f s per target = %d–%d rotations/s" % (min(secs), max(secs), round(min(rps)), round(max(rps)))
 e3 = d["e3"]
-rep["E3"] = ("**%.2f ms per 16 rotations = %d rotations/s** (projection %.2f + representation %.2f + engine %.2f; representation writing "
-             "every voxel %.2f, computing every tile %.2f; round 5: 9.5–9.75 ms)" % (
-                 e3["ms_per_launch"], round(e3["rot_per_s"]), e3["ms_projection"], e3["ms_representation"], e3["ms_engine"],
-                 e3["ms_representation_writing_every_voxel"], e3["ms_representation_computing_every_tile"]))
+E3S = 16.0 / e3["rotations_per_launch"]
+rep["E3"] = ("**%.2f ms per 16 rotations = %d rotations/s** (launches of %d; per 16: projection %.2f + representation %.2f + engine %.2f; "
+             "representation writing every voxel %.2f, computing every tile %.2f; round 5: 9.5–9.75 ms)" % (
+                 e3["ms_per_launch"] * E3S, round(e3["rot_per_s"]), e3["rotations_per_launch"], e3["ms_projection"] * E3S,
+                 e3["ms_representation"] * E3S, e3["ms_engine"] * E3S, e3["ms_representation_writing_every_voxel"] * E3S,
+                 e3["ms_representation_computing_every_tile"] * E3S))
 tw = load("bench_two_ranks_one_gpu.json")
 rep["TWORANKS"] = "%.2fe9 aggregate, `gather_check` hash equal to the one-rank line's (`%s…`)%s" % (
     tw["value"] / 1e9, tw["gather_check"]["list_sha256"][:8],
@@ -92,8 +98,8 @@ rr = x["rooflines"]
 rep["K2Q"] = "K2<160> %.2f ms = %.2f of 8 TB/s at the real shapes" % (s["k2_xy_corr"], rr["k2_xy_corr"]["frac"])
 rep["K3"] = "%.2f ms = %.2f (N = 128); %.2f ms = %.2f at the real shapes" % (st["k3_zifft_filter"], rl["k3_zifft_filter"]["frac"], s["k3_zifft_filter"],
                                                                             rr["k3_zifft_filter"]["frac"])
-rep["CONV"] = "the nine layers of `E3MultiResRepr4x4(8)` at box 80, batch 16: %.2f ms on the occupied tiles (%.2f computing every tile)" % (
-    e3["ms_representation"], e3["ms_representation_computing_every_tile"])
+rep["CONV"] = "the nine layers of `E3MultiResRepr4x4(8)` at box 80, per 16 poses: %.2f ms on the occupied tiles (%.2f computing every tile)" % (
+    e3["ms_representation"] * E3S, e3["ms_representation_computing_every_tile"] * E3S)
 path = os.path.join(ROOT, "DESIGN.md")
 text = open(path).read()
 for k, v in rep.items():

@@ -22,8 +22,8 @@ bash scripts/profile_gpu.sh ${TAG}_rp --workload real_protein > /dev/null 2>&1; 
 bash scripts/gpu_r06_e3prof.sh ${TAG} > /dev/null 2>&1
 (timeout 120 scripts/micro/coresidency_repro 300 0; timeout 200 scripts/micro/coresidency_repro 300 1) > $OUT/coresidency_repro.log 2>&1
 bash scripts/micro/fetch_size_shapes.sh $OUT/fetch_shapes > $OUT/fetch_size_shapes.txt 2>&1; rm -rf $OUT/fetch_shapes
-timeout 600 python scripts/soak_full_search.py --angle_inc 6 --runs 16,12 --out $OUT/soak_full_search_6deg.json > /dev/null 2>&1
-timeout 900 python scripts/soak_full_search.py --angle_inc 4 --runs 16 --out $OUT/soak_full_search_4deg.json > /dev/null 2>&1
+timeout 600 python scripts/soak_full_search.py --angle_inc 6 --runs 32,16,12 --out $OUT/soak_full_search_6deg.json > /dev/null 2>&1
+timeout 900 python scripts/soak_full_search.py --angle_inc 4 --runs 32 --out $OUT/soak_full_search_4deg.json > /dev/null 2>&1
 timeout 900 python scripts/soak_config4.py --out $OUT/soak_config4.json > $OUT/soak_config4.log 2>&1
 head -c 700 $OUT/summary.txt; python - <<PY
 import json

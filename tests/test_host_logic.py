@@ -186,7 +186,7 @@ def test_docker_interface_surface():
     # no coords_backend argument (the reference's constructor has none): the build's own is created on first use
     from deeplocalproteindocking_amd.Utils.FullAtom import CoordsBackend
     assert dk.coords_backend is None and isinstance(dk._need_backend(), CoordsBackend)
-    assert dk.launch_batch == 16                                # launches are not sized by the caller's batch_size
+    assert dk.launch_batch == 32                                # launches are not sized by the caller's batch_size
     assert dk.box_length == 5.0 and dk.shard(10).tolist() == list(range(10))
     dk.rank, dk.world_size = 1, 4
     assert dk.shard(10).tolist() == [1, 5, 9]
@@ -272,7 +272,8 @@ def test_bench_reads_the_dominant_kernels_traffic_from_a_counter_pass(tmp_path, 
     reads, refetch = bench.k2_natural_read_bytes(0.5 * A + 0.727 * 3.0 * rec, 16, 49, 64)
     assert abs(reads - (A + 3.0 * rec)) < 1.0 and abs(refetch - 3.0) < 1e-9
     traffic, src = bench.live_pmc_traffic(args, "k2_xy_corr", 128)
-    assert traffic == A + 3000.0 * 1024.0 and "measured in this run" in src and "0.727" in src     # (1000 KB raw < the A rows' share)
+    A_launch = A * args.batch / 16.0                              # (the default launch holds args.batch rotations)
+    assert traffic == A_launch + 3000.0 * 1024.0 and "measured in this run" in src and "0.727" in src     # (1000 KB raw < the A rows' share)
     # every other stage: x 2 (whole 128-byte lines tallied at 64 bytes)
     traffic, src = bench.live_pmc_traffic(args, "k3_zifft_filter", 128)
     assert traffic == (2.0 * 55555.0 + 55555.0) * 1024.0 and "measured in this run" in src

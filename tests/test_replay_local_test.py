@@ -59,7 +59,7 @@ def test_reference_driver_replay_dockSE3_and_dockE3(tmp_path):
     make_benchmark(root)
     rep, stdout = _replay(root, "logA", extra_args=["-rewrite", "1"])
     t = rep["targets"][0]
-    assert "Processing 1SYN" in stdout and t["path"] == "fused" and t["launch_batch"] == 16 and t["rotations"] == 1854
+    assert "Processing 1SYN" in stdout and t["path"] == "fused" and t["launch_batch"] == 32 and t["rotations"] == 1854
     dat = os.path.join(rep["test_dir"], "1SYN.dat")
     lines = open(dat).read().strip().split("\n")
     assert len(lines) == 2000 and all(len(l.split("\t")) == 13 for l in lines)
@@ -71,7 +71,7 @@ def test_reference_driver_replay_dockSE3_and_dockE3(tmp_path):
     t2 = rep2["targets"][0]
     assert t2["launch_batch"] == 2
     assert open(os.path.join(rep2["test_dir"], "1SYN.dat")).read() == open(dat).read()
-    print("dockSE3 via the reference's calls (batch_size=2): %.0f rot/s at launch batch 16, %.0f rot/s if the "
+    print("dockSE3 via the reference's calls (batch_size=2): %.0f rot/s at launch batch 32, %.0f rot/s if the "
           "launches were sized by the caller (2)" % (t["rot_per_s"], t2["rot_per_s"]))
     # resume rule (local_test.py:65 with rewrite=0): the finished target is skipped
     rep3, stdout3 = _replay(root, "logA", extra_args=["-rewrite", "0"])
