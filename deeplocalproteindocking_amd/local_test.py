@@ -162,7 +162,7 @@ def parse_args(argv=None):
     ap.add_argument("-rewrite", default=0, help="Rewrite previous output", type=int)
     # this build's extras (all optional)
     ap.add_argument("-seed", default=None, type=int, help="fixes the random receptor rotation")
-    ap.add_argument("-init_weights", default=0, type=int, help="write a randomly initialised checkpoint first if none exists")
+    ap.add_argument("-init_weights", default=0, type=int, help="write a randomly initialised checkpoint first if none exists (with -seed: the same one every time)")
     ap.add_argument("-report", default=0, type=int, help="print one JSON line with timings (rank 0)")
     ap.add_argument("-prefetch", default=1, type=int, help="prepare the next target while the current one is searched")
     ap.add_argument("-backend", default="nccl", choices=("nccl", "gloo"), help="collective backend (nccl = RCCL)")
@@ -214,6 +214,8 @@ def main(argv=None):
         os.makedirs(test_dir, exist_ok=True)
 
     stream_test = get_benchmark_stream(data_dir, struct_folder="Matched", subset=subset_name, debug=False)
+    if args.init_weights and args.seed is not None:
+        torch.manual_seed(args.seed)                    # the checkpoint -init_weights writes is then the same in every run
     protein_model, conformations_filter = select_model(args)
     docking_model = GlobalDockingModel(representation=protein_model, filter=conformations_filter,
                                        normalize=False, rotate_ligand=False, exclude_clashes=True,
