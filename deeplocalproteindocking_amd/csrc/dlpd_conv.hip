@@ -561,81 +561,124 @@ template <int KS, int COUT> static int launch_conv_split(const float* X, const f
 // without reading them; occ_out: the cells of the OUTPUT grid that hold a non-zero value (zeroed by the host; any channel).
 #define DLPD_MP_OX 4
 #define DLPD_MP_OZ 20
-__global__ void __launch_bounds__(256) k_maxpool3d_5s2_tiled(const float* __restrict__ x, float* __restrict__ y, int D, int Do,
+// Round 6, second form: a block walks CPB channels of its (volume, tile) -- the channels of a batch entry share one map and
+// one geometry, so the occupancy test, the cells of the region and every thread's staging offsets (21 of them: where in the
+// volume, "outside" or "empty cell") are made ONCE and a channel costs 21 loads and LDS stores per thread; the first form
+// (a block per channel) spent its time on that index arithmetic: 0.39-0.44 ms per batch of 16 at box 80.
+template <int CPB> __global__ void __launch_bounds__(256) k_maxpool3d_5s2_tiled(const float* __restrict__ x, float* __restrict__ y, int D, int Do,
                                                              int nzt, int C, const unsigned char* __restrict__ occ_in,
                                                              unsigned char* __restrict__ occ_out, int unwritten) {
   constexpr int OX = DLPD_MP_OX, OZ = DLPD_MP_OZ, IX = 2 * OX + 3, IZ = 2 * OZ + 3;
-  __shared__ float in[IX * IX * IZ];             // 20.8 KB
+  constexpr int NIN = IX * IX * IZ, NST = (NIN + 255) / 256;
+  __shared__ float in[NIN];                      // 20.8 KB
   __shared__ float m1[IX * IX * OZ];             // max over z
   __shared__ float m2[IX * OX * OZ];             // ... and y
-  __shared__ int flag[8];
+  __shared__ int flag[1], oflag[8];              // "some input cell is occupied"; the output cells that hold a non-zero value
+  // the occupancy cells of the block's input region (at most 4 x 4 x 12)
+  constexpr int CX = (IX + 2) / 4 + 1, CZ = (IZ + 2) / 4 + 1;
+  __shared__ unsigned char cell[CX * CX * CZ];
   const int tid = threadIdx.x;
-  const int vol = blockIdx.z / nzt, zt = blockIdx.z % nzt, b = vol / C;
+  const int ncg = (C + CPB - 1) / CPB;           // channel groups of a batch entry
+  const int zt = blockIdx.z % nzt, cg = (blockIdx.z / nzt) % ncg, b = blockIdx.z / (nzt * ncg);
+  const int c0 = cg * CPB, nch = (C - c0 < CPB) ? C - c0 : CPB;
   const int ox0 = blockIdx.x * OX, oy0 = blockIdx.y * OX, oz0 = zt * OZ;
   const int ix0 = 2 * ox0 - 2, iy0 = 2 * oy0 - 2, iz0 = 2 * oz0 - 2;
-  const float* src = x + (size_t)vol * D * D * D;
-  float* dst = y + (size_t)vol * Do * Do * Do;
+  const size_t D3 = (size_t)D * D * D, Do3 = (size_t)Do * Do * Do;
+  const float* src = x + ((size_t)b * C + c0) * D3;
+  float* dst = y + ((size_t)b * C + c0) * Do3;
+  const int nc = (D + 3) / 4;
+  const int cx0 = (ix0 < 0 ? 0 : ix0) >> 2, cy0 = (iy0 < 0 ? 0 : iy0) >> 2, cz0 = (iz0 < 0 ? 0 : iz0) >> 2;
   bool empty = false;
   if (occ_in) {                                  // (block-uniform) the occupancy cells the input region touches
-    const int nc = (D + 3) / 4;
-    const int cx0 = (ix0 < 0 ? 0 : ix0) >> 2, cy0 = (iy0 < 0 ? 0 : iy0) >> 2, cz0 = (iz0 < 0 ? 0 : iz0) >> 2;
     const int cx1 = (ix0 + IX - 1 >= D ? D - 1 : ix0 + IX - 1) >> 2, cy1 = (iy0 + IX - 1 >= D ? D - 1 : iy0 + IX - 1) >> 2;
     const int cz1 = (iz0 + IZ - 1 >= D ? D - 1 : iz0 + IZ - 1) >> 2;
     const int nx = cx1 - cx0 + 1, ny = cy1 - cy0 + 1, nz = cz1 - cz0 + 1;
     if (tid == 0) flag[0] = 0;
     __syncthreads();
     for (int i = tid; i < nx * ny * nz; i += 256) {
-      const int cz = cz0 + i % nz, cy = cy0 + (i / nz) % ny, cx = cx0 + i / (nz * ny);
-      if (occ_in[(((size_t)b * nc + cx) * nc + cy) * nc + cz]) flag[0] = 1;
+      const int cz = i % nz, cy = (i / nz) % ny, cx = i / (nz * ny);
+      const unsigned char o = occ_in[(((size_t)b * nc + cx0 + cx) * nc + cy0 + cy) * nc + cz0 + cz];
+      cell[(cx * CX + cy) * CZ + cz] = o;
+      if (o) flag[0] = 1;
     }
     __syncthreads();
     empty = flag[0] == 0;
   }
   if (empty && unwritten) return;                // unwritten activations (k_conv3d_bf16x3): the map says it all
   if (empty) {
-    for (int i = tid; i < OX * OX * OZ; i += 256) {
-      const int oz = oz0 + i % OZ, oy = oy0 + (i / OZ) % OX, ox = ox0 + i / (OZ * OX);
-      if (ox < Do && oy < Do && oz < Do) dst[((size_t)ox * Do + oy) * Do + oz] = 0.f;
-    }
+    for (int c = 0; c < nch; c++)
+      for (int i = tid; i < OX * OX * OZ; i += 256) {
+        const int oz = oz0 + i % OZ, oy = oy0 + (i / OZ) % OX, ox = ox0 + i / (OZ * OX);
+        if (ox < Do && oy < Do && oz < Do) dst[c * Do3 + ((size_t)ox * Do + oy) * Do + oz] = 0.f;
+      }
     return;
   }
-  for (int i = tid; i < IX * IX * IZ; i += 256) {
-    const int zz = i % IZ, yy = (i / IZ) % IX, xx = i / (IZ * IX);
-    const int gx = ix0 + xx, gy = iy0 + yy, gz = iz0 + zz;
-    const bool ok = gx >= 0 && gx < D && gy >= 0 && gy < D && gz >= 0 && gz < D;
-    // (unwritten activations: a voxel of an empty cell is the zero its map stands for and is not read)
-    const int nc = (D + 3) / 4;
-    const bool zero = ok && unwritten && occ_in && !occ_in[(((size_t)b * nc + (gx >> 2)) * nc + (gy >> 2)) * nc + (gz >> 2)];
-    in[i] = zero ? 0.f : (ok ? src[((size_t)gx * D + gy) * D + gz] : -INFINITY);
+  // where each of this thread's staged voxels comes from: an offset into the volume, -1 = outside (torch pads with -inf),
+  // -2 = a voxel of an empty cell under unwritten activations (the zero its map stands for; not read)
+  int off[NST];
+  {
+    const bool by_map = unwritten && occ_in;
+#pragma unroll
+    for (int k = 0; k < NST; k++) {
+      const int i = tid + 256 * k;
+      const int zz = i % IZ, yy = (i / IZ) % IX, xx = i / (IZ * IX);
+      const int gx = ix0 + xx, gy = iy0 + yy, gz = iz0 + zz;
+      const bool ok = i < NIN && gx >= 0 && gx < D && gy >= 0 && gy < D && gz >= 0 && gz < D;
+      int o = ok ? (gx * D + gy) * D + gz : -1;
+      if (ok && by_map && !cell[(((gx >> 2) - cx0) * CX + (gy >> 2) - cy0) * CZ + (gz >> 2) - cz0]) o = -2;
+      off[k] = o;
+    }
   }
+  if (tid < 8) oflag[tid] = 0;
   __syncthreads();
-  for (int i = tid; i < IX * IX * OZ; i += 256) {
-    const int oz = i % OZ, r = i / OZ;
-    const float* p = in + r * IZ + 2 * oz;
-    m1[i] = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), p[4]);
-  }
-  __syncthreads();
-  for (int i = tid; i < IX * OX * OZ; i += 256) {
-    const int oz = i % OZ, oy = (i / OZ) % OX, xx = i / (OZ * OX);
-    const float* p = m1 + (xx * IX + 2 * oy) * OZ + oz;
-    m2[i] = fmaxf(fmaxf(fmaxf(p[0], p[OZ]), fmaxf(p[2 * OZ], p[3 * OZ])), p[4 * OZ]);
-  }
-  __syncthreads();
-  if (tid < 8) flag[tid] = 0;
-  __syncthreads();
-  for (int i = tid; i < OX * OX * OZ; i += 256) {
-    const int oz = i % OZ, oy = (i / OZ) % OX, ox = i / (OZ * OX);
-    const float* p = m2 + ((2 * ox) * OX + oy) * OZ + oz;
-    const float v = fmaxf(fmaxf(fmaxf(p[0], p[OX * OZ]), fmaxf(p[2 * OX * OZ], p[3 * OX * OZ])), p[4 * OX * OZ]);
-    if (ox0 + ox < Do && oy0 + oy < Do && oz0 + oz < Do) {
-      dst[((size_t)(ox0 + ox) * Do + oy0 + oy) * Do + oz0 + oz] = v;
-      if (occ_out && v != 0.f) flag[oz >> 2] = 1;              // (OZ = 20: five 4-voxel cells, aligned: oz0 is a multiple of 20)
+  for (int c = 0; c < nch; c++) {
+    // (no barrier between channels: the next one's staging writes `in`, last read two barriers ago)
+    const float* sc = src + c * D3;
+#pragma unroll
+    for (int k = 0; k < NST; k++) {
+      const int i = tid + 256 * k;
+      const float v = off[k] >= 0 ? sc[off[k]] : (off[k] == -1 ? -INFINITY : 0.f);
+      if (i < NIN) in[i] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < (IX * IX * OZ + 255) / 256; k++) {
+      const int i = tid + 256 * k;
+      if (i < IX * IX * OZ) {
+        const int oz = i % OZ, r = i / OZ;
+        const float* p = in + r * IZ + 2 * oz;
+        m1[i] = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), p[4]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < (IX * OX * OZ + 255) / 256; k++) {
+      const int i = tid + 256 * k;
+      if (i < IX * OX * OZ) {
+        const int oz = i % OZ, oy = (i / OZ) % OX, xx = i / (OZ * OX);
+        const float* p = m1 + (xx * IX + 2 * oy) * OZ + oz;
+        m2[i] = fmaxf(fmaxf(fmaxf(p[0], p[OZ]), fmaxf(p[2 * OZ], p[3 * OZ])), p[4 * OZ]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < (OX * OX * OZ + 255) / 256; k++) {
+      const int i = tid + 256 * k;
+      if (i < OX * OX * OZ) {
+        const int oz = i % OZ, oy = (i / OZ) % OX, ox = i / (OZ * OX);
+        const float* p = m2 + ((2 * ox) * OX + oy) * OZ + oz;
+        const float v = fmaxf(fmaxf(fmaxf(p[0], p[OX * OZ]), fmaxf(p[2 * OX * OZ], p[3 * OX * OZ])), p[4 * OX * OZ]);
+        if (ox0 + ox < Do && oy0 + oy < Do && oz0 + oz < Do) {
+          dst[c * Do3 + ((size_t)(ox0 + ox) * Do + oy0 + oy) * Do + oz0 + oz] = v;
+          if (occ_out && v != 0.f) oflag[oz >> 2] = 1;            // (OZ = 20: five 4-voxel cells, aligned: oz0 is a multiple of 20)
+        }
+      }
     }
   }
   if (occ_out) {
     __syncthreads();
     const int nco = (Do + 3) / 4;
-    if (tid < OZ / 4 && (oz0 >> 2) + tid < nco && flag[tid])
+    if (tid < OZ / 4 && (oz0 >> 2) + tid < nco && oflag[tid])
       occ_out[(((size_t)b * nco + blockIdx.x) * nco + blockIdx.y) * nco + (oz0 >> 2) + tid] = 1;
   }
 }
@@ -651,13 +694,17 @@ int dlpd_maxpool3d_5s2_sparse(const float* x, float* y, const unsigned char* occ
   const int Do = (D + 4 - 5) / 2 + 1;
   const int nzt = (Do + DLPD_MP_OZ - 1) / DLPD_MP_OZ, nxy = (Do + DLPD_MP_OX - 1) / DLPD_MP_OX;
   if (occ_out && hipMemsetAsync(occ_out, 0, dlpd_conv3d_tile_occupancy_bytes(B, Do), st) != hipSuccess) return DLPD_ERR_LAUNCH;
-  // a grid's z extent holds 65,535 blocks: more (volume, z tile) pairs than that go in several launches of whole map volumes
-  const int per = 65535 / (C * nzt);                            // batch entries (C volumes each) per launch
+  // a block takes up to 8 channels of one batch entry (one map, one geometry: k_maxpool3d_5s2_tiled); a grid's z extent holds
+  // 65,535 blocks: more (entry, channel group, z tile) triples than that go in several launches of whole batch entries
+  constexpr int CPB = 8;
+  const int ncg = (C + CPB - 1) / CPB;
+  const int per = 65535 / (ncg * nzt);                          // batch entries per launch
   if (per < 1) return DLPD_ERR_UNSUPPORTED;
   const size_t D3 = (size_t)D * D * D, Do3 = (size_t)Do * Do * Do;
+  if (D3 * (size_t)(C < CPB ? C : CPB) > 0x7fffffffu) return DLPD_ERR_UNSUPPORTED;     // (32-bit offsets inside a volume)
   for (int b0 = 0; b0 < B; b0 += per) {
     const int nbl = (B - b0 < per) ? B - b0 : per;
-    DLPD_LAUNCH(k_maxpool3d_5s2_tiled, dim3(nxy, nxy, nbl * C * nzt), dim3(256), 0, st, x + (size_t)b0 * C * D3, y + (size_t)b0 * C * Do3,
+    DLPD_LAUNCH((k_maxpool3d_5s2_tiled<CPB>), dim3(nxy, nxy, nbl * ncg * nzt), dim3(256), 0, st, x + (size_t)b0 * C * D3, y + (size_t)b0 * C * Do3,
                 D, Do, nzt, C, occ_in ? occ_in + dlpd_conv3d_tile_occupancy_bytes(b0, D) : nullptr,
                 occ_out ? occ_out + dlpd_conv3d_tile_occupancy_bytes(b0, Do) : nullptr, unwritten);
     int rc = dlpd_check_launch();
@@ -669,6 +716,9 @@ int dlpd_maxpool3d_5s2_sparse(const float* x, float* y, const unsigned char* occ
 int dlpd_maxpool3d_5s2(const float* x, float* y, int nvol, int D, void* stream) {
   if (!x || !y || nvol <= 0 || D < 1) return DLPD_ERR_ARG;
   const int Do = (D + 4 - 5) / 2 + 1;
+  // (no maps: the volumes are channels of ONE entry to the kernel -- a block then amortises its index arithmetic over eight of them)
+  if ((size_t)((nvol + 7) / 8) * ((Do + DLPD_MP_OZ - 1) / DLPD_MP_OZ) <= 65535)
+    return dlpd_maxpool3d_5s2_sparse(x, y, nullptr, nullptr, 1, nvol, D, 0, stream);
   return dlpd_maxpool3d_5s2_sparse(x, y, nullptr, nullptr, nvol, 1, D, 0, stream);      // (chunked launches for many volumes)
 }
 

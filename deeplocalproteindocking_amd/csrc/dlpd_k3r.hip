@@ -135,6 +135,14 @@ extern "C" int dlpd_debug_read_stamps_k3r(unsigned long long* host32) {
 #ifndef DLPD_K3R_DC_OPAQUE
 #define DLPD_K3R_DC_OPAQUE 0
 #endif
+// TIMING PROBE, wrong results (round 6; EXPERIMENTS.md R6 "first layer on the f32 matrix core"): 1 = the first layer's
+// multiply-adds reduced to one hidden unit and no candidates emitted -- what K3 takes when that layer costs nothing: 3.11
+// against 3.66 ms per 32 rotations at N = 128 (the transform waves alone set 85 % of the kernel's time), which bounds what
+// moving the layer to v_mfma_f32_16x16x4_f32 (a k-ascending fmaf chain, bit for bit: scripts/micro/mfma_f32_order.hip) could
+// give; not built
+#ifndef DLPD_K3R_PROBE
+#define DLPD_K3R_PROBE 0
+#endif
 // all four components of a loaded float4 needed at ONE point (a plain, non-volatile asm: a data dependence, no ordering
 // against the kernel's other inline assembly)
 #if defined(DLPD_CPU_EMU)
@@ -579,7 +587,7 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
               v0 = DLPD_CLAMP(v0, clampv);
               v1 = DLPD_CLAMP(v1, clampv);
 #pragma unroll
-              for (int j = 0; j < HP; j++) {
+              for (int j = 0; j < (DLPD_K3R_PROBE == 1 ? 1 : HP); j++) {
                 h[2 * e][j] = fmaf(wcur[j], v0, h[2 * e][j]);
                 h[2 * e + 1][j] = fmaf(wcur[j], v1, h[2 * e + 1][j]);
               }
@@ -618,7 +626,7 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
               for (int j = 0; j < HP; j++) acc = fmaf(W2[j], fmaxf(h[2 * e + u][j], 0.f), acc);
               if (has_clash) acc = acc * ((nrm[2 * e + u] < thr) ? 1.0f : 0.0f);
               (out + (((size_t)b * N + xo) * N + y0) * N)[(unsigned)((2 * m + u) * N + zz)] = acc;
-              if (cd.keys && cand_tau) k3_emit(cd, cand_tau, b, (unsigned)((xo * N + y0 + 2 * m + u) * N + zz), acc);
+              if (!DLPD_K3R_PROBE && cd.keys && cand_tau) k3_emit(cd, cand_tau, b, (unsigned)((xo * N + y0 + 2 * m + u) * N + zz), acc);
             }
           }
         }
