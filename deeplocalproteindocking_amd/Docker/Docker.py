@@ -214,6 +214,9 @@ class Docker:
         # dockE3 on the fused engine: a plugin with occupancy maps does not write the tiles it skips (the engine goes by the
         # maps); False: every voxel of the batch's volumes is written (same lists; DLPD_UNWRITTEN_ACTIVATIONS=0)
         self.unwritten_activations = os.environ.get("DLPD_UNWRITTEN_ACTIVATIONS", "1") != "0"
+        # the search side's occupancy maps (DockingEngine(sparse_k1=)): None = decided per ligand; DLPD_K1_OCCUPANCY=0 / 1 forces
+        # the dense / the map kernels for whole programs (A/B runs: the lists are the same either way)
+        self.k1_occupancy = {"0": False, "1": True}.get(os.environ.get("DLPD_K1_OCCUPANCY", ""))
         self._top = None            # DeviceTopList behind update_top()
         self.top_list = []
         self.engine = None
@@ -482,7 +485,7 @@ class Docker:
                                 center=self.rotation_pivot(Lp), coarse_center=self.rotation_pivot(Lp // 2),
                                 extent=(Lp if Lp < L else None), rotation_scale=cv.scale(Lp),
                                 coarse_rotation_scale=cv.scale(Lp // 2), rotation_axis_order=cv.rotation_axis_order,
-                                clip_mode=cv.clip_mode, rotation_transpose=cv.rotation_transpose)
+                                clip_mode=cv.clip_mode, rotation_transpose=cv.rotation_transpose, sparse_k1=self.k1_occupancy)
             self._engine_pool[slot] = (key, eng)
         else:
             eng.finish()

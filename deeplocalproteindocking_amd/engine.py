@@ -6,8 +6,6 @@ volumes, clash correlation + threshold, GlobalDockingModel.forward, mask multipl
 for a single-resolution representation, without any host synchronisation inside the loop.
 torch is plumbing only (memory + streams); all arithmetic is in libdlpd.so.
 """
-import os
-
 import numpy as np
 import torch
 
@@ -223,8 +221,6 @@ class DockingEngine:
         # representation) gets per-rotation occupancy maps, and the channels-last K1 skips what they mark empty -- same
         # spectra.  None: decided per ligand and grid in set_ligand (on where the ligand's cells, dilated by one, stay below
         # SPARSE_K1_MAX_FILL of the box); True / False force it.
-        if sparse_k1 is None and os.environ.get("DLPD_K1_OCCUPANCY") in ("0", "1"):
-            sparse_k1 = os.environ["DLPD_K1_OCCUPANCY"] == "1"       # (A/B switch for whole programs: 0 = the dense kernels)
         self.sparse_k1_wanted = sparse_k1
         self.sparse_k1 = self.sparse_k1_coarse = self.k2_pencil_map = self.k2_pencil_map_coarse = False
         self._k2_by_map = {False: False, True: False}
