@@ -20,7 +20,6 @@ SIGNATURES = {
     "dlpd_version": (_i, []),
     "dlpd_source_hash": (ctypes.c_char_p, []),
     "dlpd_debug_poison_lds": (_i, [_i]),
-    "dlpd_debug_k3_matrix_filter": (_i, [_i]),
     "dlpd_debug_poison_selfcheck": (_i, [_p, _p]),
     "dlpd_grid_supported": (_i, [_i]),
     "dlpd_orientation_supported": (_i, [_i]),

@@ -135,14 +135,14 @@ extern "C" int dlpd_debug_read_stamps_k3r(unsigned long long* host32) {
 #ifndef DLPD_K3R_DC_OPAQUE
 #define DLPD_K3R_DC_OPAQUE 0
 #endif
-// TIMING PROBE, wrong results (round 6; EXPERIMENTS.md R6 "first layer on the f32 matrix core"): 1 = the first layer's
-// multiply-adds reduced to one hidden unit and no candidates emitted -- what K3 takes when that layer costs nothing: 3.11
-// against 3.66 ms per 32 rotations at N = 128 (the transform waves alone set 85 % of the kernel's time), which bounds what
-// moving the layer to v_mfma_f32_16x16x4_f32 (a k-ascending fmaf chain, bit for bit: scripts/micro/mfma_f32_order.hip) could
-// give; not built
-#ifndef DLPD_K3R_PROBE
-#define DLPD_K3R_PROBE 0
-#endif
+// ROUND 6, the first filter layer and the matrix core (EXPERIMENTS.md R6; the code: git show 7504e3b).  With the layer's
+// multiply-adds reduced to one hidden unit (a timing probe, wrong results) K3<128, 24> takes 3.11 instead of 3.66 ms per 32
+// rotations: the transform waves alone set 85 % of the kernel's time.  The layer as chains of v_mfma_f32_16x16x4_f32 -- a
+// k-ascending fmaf chain bit for bit (scripts/micro/mfma_f32_order.hip), so the SAME scores and list hash -- was built (filter
+// wave = one row pair, lane (k, n) = channel k of the group at 16 z, hidden units 16..23 of both rows in one tile through a
+// v_permlane32_swap of the B registers, the second layer as matrix chains as well, 162 registers) and measured 4.78 against
+// 3.61 ms: the f32 matrix pipe has the vector rate, 24 hidden units pad a second tile, and 512 fully paced matrix
+// instructions per wave and tile are a longer filter phase than 2,700 packed FMAs.  Removed.
 // all four components of a loaded float4 needed at ONE point (a plain, non-volatile asm: a data dependence, no ordering
 // against the kernel's other inline assembly)
 #if defined(DLPD_CPU_EMU)
@@ -256,157 +256,12 @@ template <int N> DLPD_D void k3r_second_pass(cplx* S, int rowoff, int t, const c
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// FILTER ROLE ON THE F32 MATRIX CORE (round 6; N = 128, hidden width <= 24, one resolution).  v_mfma_f32_16x16x4_f32 returns
-// fma(a3, b3, fma(a2, b2, fma(a1, b1, fma(a0, b0, C)))) bit for bit, denormals kept (scripts/micro/mfma_f32_order.hip on an
-// MI355X: 100 % of 153,600 outputs) -- the chain over the channels the vector form of this role computes, four channels
-// (= one group of the four transform waves) per instruction.  Same products, same order: the scores are the same bits.
-//   * filter wave w owns row pair w of the tile (rows 2w, 2w + 1; 128 z each): 16 voxel tiles of 16 z.  Lane (q, n) = (l >> 4,
-//     l & 15) holds, of one 8-byte pencil read, channel q of the group at z = 16 zt + n for both rows (B operands of the two).
-//   * hidden units 0..15: accumulator tile T0[row][zt], matrix row r <-> hidden unit 4 (r & 3) + (r >> 2) (see the epilogue).
-//   * hidden units 16..23 would half-fill a second 16-row tile: instead ONE tile T1[zt] carries them for both rows of the
-//     pair -- matrix rows 0..7 for row 2w, rows 8..15 for row 2w + 1 -- with two channels per instruction: B = channels
-//     (0, 1) of row 2w in k = 0, 1 and of row 2w + 1 in k = 2, 3 (one v_permlane32_swap of the two rows' B registers gives this
-//     operand and the one for channels (2, 3)); A holds the weights where (matrix row, k) belong to the same row and 0.0
-//     elsewhere: fma(0, b, acc) = acc, so each accumulator still sees its channels in ascending order and nothing else.
-//     96 accumulators per lane, as in the vector form; 32 matrix instructions per group where that one issues 192 packed FMAs.
-//   * second layer: out = b2 + sum_j W2[j] relu(h_j), j ascending, as a chain of matrix instructions too -- step i takes
-//     accumulator element i (matrix rows 4 k + i, k = lane group) as its B operand, so the row <-> hidden unit maps above
-//     are the ones that make step i, k visit j = 4 i + k (T0) and j = 16 + 2 i + k (T1, k < 2 per row): no cross-lane sums.
-// Measured: EXPERIMENTS.md R6.
-template <int N, int HP, int TY, int M> struct K3rMxOk {
-  static constexpr bool value = (N == 128) && (HP == 24) && (TY == 16) && (M == 8);
-};
-template <int N, int HP, int F, int M, int TY>
-DLPD_D void k3r_filter_role_mx(const cplx* S, float* __restrict__ out, int CT, int C, int has_clash, int G,
-                               const float* __restrict__ W1t, const float* __restrict__ b1, const float* __restrict__ W2, float b2,
-                               float clampv, float thr, int t_beg, int t_end, int plane, int fwave, int lane, K3Cand cd,
-                               unsigned cand_tau) {
-  constexpr int RS = N + 8, NPAIR = TY / 2, NYT = N / TY, NZT = N / 16;
-  static_assert(M == NPAIR && F == 4 && HP == 24, "one filter wave per row pair, groups of <= 4 channels, 16 + 8 hidden units");
-  const int xo = plane % N, b = plane / N;
-  dlpd_acc4 t0[2][NZT], t1[NZT];
-  float nrm[NZT];
-  // (two nested loops where the vector form walks (tile, group) steps in one: the accumulators are initialised in front of
-  // the group loop -- as a branch inside one loop their 96 registers met copies of themselves at the join: 56 of them spilled)
-#pragma unroll 1
-  for (int t = t_beg; t < t_end; t++) {
-    const int y0 = (t - plane * NYT) * TY;
-    // the lane index re-enters every tile, group and epilogue as an opaque value (as in the vector form): the addresses and
-    // masks derived from it -- weight and bias pointers, the eight swizzled pencil offsets -- are recomputed where they are
-    // used, a few vector instructions, instead of being hoisted out of the loops and spilled (98 registers' worth)
-    int ln = lane;
-    DLPD_OPAQUE_V(ln);
-    {
-      const int q = ln >> 4;
-      if (cd.keys && !cand_tau && fwave == 0 && ln == 0) cd.count[cd.nb + b] = 1u;
-      // accumulator element i of lane (q, n) is matrix row 4 q + i
-      const dlpd_acc4 i0 = dlpd_acc4_make(b1[q], b1[4 + q], b1[8 + q], b1[12 + q]);
-      const dlpd_acc4 i1 = dlpd_acc4_make(b1[16 + (q & 1)], b1[18 + (q & 1)], b1[20 + (q & 1)], b1[22 + (q & 1)]);
-#pragma unroll
-      for (int zt = 0; zt < NZT; zt++) {
-        t0[0][zt] = i0;
-        t0[1][zt] = i0;
-        t1[zt] = i1;
-        nrm[zt] = 0.f;
-      }
-    }
-#pragma unroll 1
-    for (int cbase = 0; cbase < CT; cbase += G) {
-    int lg = lane;
-    DLPD_OPAQUE_V(lg);
-    const int q = lg >> 4, n = lg & 15;
-    // A operands, lane (matrix row n, k = q): first layer T0 row n <-> hidden 4 (n & 3) + (n >> 2); T1 row n <-> hidden
-    // 16 + 2 (n & 3) + ((n & 7) >> 2), live where row and k belong to the same row of the pair
-    const int hid0 = 4 * (n & 3) + (n >> 2), hid1 = 16 + 2 * (n & 3) + ((n & 7) >> 2);
-    const bool live1 = (n < 8) == (q < 2);
-    // this lane's pencil reads: channel slot q, row pair fwave, z = 16 zt + n
-    const cplx* pv = S + (q * NPAIR + fwave) * RS;
-    const int gn = (CT - cbase) < G ? (CT - cbase) : G;
-    DLPD_LDS_BARRIER();                        // B1: all pencils of the group transformed
-    // score channels of this group; the clash channel (index C, always last) is peeled off
-    const int gs = (cbase + gn <= C) ? gn : (C - cbase > 0 ? C - cbase : 0);
-    cplx vals[NZT];
-    const bool mine = q < gs;
-    // this group's weights: requested here, used behind the barrier
-    const float a0 = mine ? W1t[(size_t)(cbase + q) * HP + hid0] : 0.f;
-    const float a1a = (live1 && (q & 1) < gs) ? W1t[(size_t)(cbase + (q & 1)) * HP + hid1] : 0.f;
-    const float a1b = (live1 && 2 + (q & 1) < gs) ? W1t[(size_t)(cbase + 2 + (q & 1)) * HP + hid1] : 0.f;
-#pragma unroll
-    for (int zt = 0; zt < NZT; zt++) vals[zt] = pv[pencil_out_pos<N>(16 * zt + n)];
-    if (has_clash && cbase + gn > C) {
-      const cplx* pc = S + ((C - cbase) * NPAIR + fwave) * RS;
-#pragma unroll
-      for (int zt = 0; zt < NZT; zt++) {
-        const cplx v = pc[pencil_out_pos<N>(16 * zt + n)];
-        nrm[zt] = q < 2 ? v.x : v.y;
-      }
-    }
-    DLPD_LDS_BARRIER();                        // B2: values held in registers, pencils free for the next group
-    if (gs > 0) {
-      // (T1 takes two dependent instructions per z tile: the second one is issued one tile later)
-      float yprev = 0.f;
-#pragma unroll
-      for (int zt = 0; zt < NZT; zt++) {
-        // (a slot beyond the group holds a pencil nobody transformed: its value must not meet even a zero weight)
-        const float vx = mine ? DLPD_CLAMP(vals[zt].x, clampv) : 0.f, vy = mine ? DLPD_CLAMP(vals[zt].y, clampv) : 0.f;
-        float xs, ys;
-        dlpd_swap32(vx, vy, xs, ys);
-        t0[0][zt] = DLPD_MFMA_16x16x4(a0, vx, t0[0][zt]);
-        t0[1][zt] = DLPD_MFMA_16x16x4(a0, vy, t0[1][zt]);
-        t1[zt] = DLPD_MFMA_16x16x4(a1a, xs, t1[zt]);
-        if (zt > 0) t1[zt - 1] = DLPD_MFMA_16x16x4(a1b, yprev, t1[zt - 1]);
-        yprev = ys;
-        DLPD_SCHED_FENCE();
-      }
-      t1[NZT - 1] = DLPD_MFMA_16x16x4(a1b, yprev, t1[NZT - 1]);
-    }
-    }                                          // groups
-    {
-      int le = lane;
-      DLPD_OPAQUE_V(le);
-      const int q = le >> 4, n = le & 15;
-      const bool live1 = (n < 8) == (q < 2);
-      float* orow = out + ((((size_t)b * N + xo) * N + y0 + 2 * fwave + (q >> 1)) * N) + n;
-      // second layer, lane (any row, k = q): step i multiplies hidden 4 i + q (T0) / 16 + 2 i + (q & 1) (T1, where live)
-      float w2a[4], w2b[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        w2a[i] = W2[4 * i + q];
-        w2b[i] = live1 ? W2[16 + 2 * i + (q & 1)] : 0.f;
-      }
-#pragma unroll
-      for (int zt = 0; zt < NZT; zt++) {
-        dlpd_acc4 d0 = dlpd_acc4_make(b2, b2, b2, b2), d1 = d0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          d0 = DLPD_MFMA_16x16x4(w2a[i], fmaxf(dlpd_acc4_get(t0[0][zt], i), 0.f), d0);
-          d1 = DLPD_MFMA_16x16x4(w2a[i], fmaxf(dlpd_acc4_get(t0[1][zt], i), 0.f), d1);
-        }
-        // every matrix row of d0 / d1 holds the row's partial sum; T1's rows 0..7 continue row 2w's, rows 8..15 row 2w + 1's
-        const float c0 = q < 2 ? dlpd_acc4_get(d0, 0) : dlpd_acc4_get(d1, 0);
-        dlpd_acc4 d = dlpd_acc4_make(c0, c0, c0, c0);
-#pragma unroll
-        for (int i = 0; i < 4; i++) d = DLPD_MFMA_16x16x4(w2b[i], fmaxf(dlpd_acc4_get(t1[zt], i), 0.f), d);
-        float acc = dlpd_acc4_get(d, 0);       // matrix row 4 q: lane groups 0, 1 row 2w, groups 2, 3 row 2w + 1
-        if (has_clash) acc = acc * ((nrm[zt] < thr) ? 1.0f : 0.0f);
-        if ((q & 1) == 0) {
-          orow[16 * zt] = acc;
-          if (!DLPD_K3R_PROBE && cd.keys && cand_tau)
-            k3_emit(cd, cand_tau, b, (unsigned)((xo * N + y0 + 2 * fwave + (q >> 1)) * N + 16 * zt + n), acc);
-        }
-        DLPD_SCHED_FENCE();
-      }
-    }
-  }
-}
-
 //   Bw   (nb, CT, NZ, N, N) complex [kz][x'][y']
 //   MODE 1: V (nb, N,N,N) = mask * (W2 . relu(W1 . clamp(corr) + b1) + b2); score channels [0,C), clash channel C
 //           if has_clash (mask = corr_C < thr); aux: HP first-layer pre-activation planes on the coarse grid (or none)
 //   MODE 2: out (nb, HP, N,N,N) = b1 + W1rows^T clamp(corr): the coarse resolution's half of the first layer
 //   W1t  (C, HP) transposed + zero padded, b1 (HP), W2 (HP);  G channels per group (<= F * CPW)
-template <int N, int HP, int MODE, bool MX = false> __global__ void __launch_bounds__(64 * (K3rCfg<N, (HP > K3rWideAbove<N>::value)>::F + K3rCfg<N, (HP > K3rWideAbove<N>::value)>::M))
+template <int N, int HP, int MODE> __global__ void __launch_bounds__(64 * (K3rCfg<N, (HP > K3rWideAbove<N>::value)>::F + K3rCfg<N, (HP > K3rWideAbove<N>::value)>::M))
 k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, int C, int has_clash, int G,
                   const float* __restrict__ W1t, const float* __restrict__ b1, const float* __restrict__ W2,
                   float b2, int has_clip, float clip, float thr, K3Aux aux, int ntiles, int tpb, K3Cand cd) {
@@ -574,10 +429,6 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
       DLPD_STAMP(4);
       if (last_group) { cbase = 0; t++; } else cbase += G;
     }
-  } else if constexpr (MX) {
-    // ================= filter waves, first and second layer on the f32 matrix core =================
-    k3r_filter_role_mx<N, HP, F, M, TY>(S, out, CT, C, has_clash, G, W1t, b1, W2, b2, clampv, thr, t_beg, t_end, plane, fwave, lane, cd,
-                                        cand_tau);
   } else {
     // ================= filter waves =================
     float nrm[EPT * 2];
@@ -736,7 +587,7 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
               v0 = DLPD_CLAMP(v0, clampv);
               v1 = DLPD_CLAMP(v1, clampv);
 #pragma unroll
-              for (int j = 0; j < (DLPD_K3R_PROBE == 1 ? 1 : HP); j++) {
+              for (int j = 0; j < HP; j++) {
                 h[2 * e][j] = fmaf(wcur[j], v0, h[2 * e][j]);
                 h[2 * e + 1][j] = fmaf(wcur[j], v1, h[2 * e + 1][j]);
               }
@@ -775,7 +626,7 @@ k_zifft_filter_rs(const cplx* __restrict__ Bw, float* __restrict__ out, int CT, 
               for (int j = 0; j < HP; j++) acc = fmaf(W2[j], fmaxf(h[2 * e + u][j], 0.f), acc);
               if (has_clash) acc = acc * ((nrm[2 * e + u] < thr) ? 1.0f : 0.0f);
               (out + (((size_t)b * N + xo) * N + y0) * N)[(unsigned)((2 * m + u) * N + zz)] = acc;
-              if (!DLPD_K3R_PROBE && cd.keys && cand_tau) k3_emit(cd, cand_tau, b, (unsigned)((xo * N + y0 + 2 * m + u) * N + zz), acc);
+              if (cd.keys && cand_tau) k3_emit(cd, cand_tau, b, (unsigned)((xo * N + y0 + 2 * m + u) * N + zz), acc);
             }
           }
         }
@@ -806,18 +657,7 @@ static int k3r_group(int CT, int maxg, bool balanced) {
 #ifndef DLPD_K3R_TPB_DIV
 #define DLPD_K3R_TPB_DIV 1                   // tiles per block = (y-tiles of an x' plane) / DIV
 #endif
-// the filter role's form where both exist (k3r_filter_role_mx): 1 = matrix core, 0 = vector FMAs; same bits
-#ifndef DLPD_K3R_MX
-#define DLPD_K3R_MX 1
-#endif
-static int g_k3r_mx = DLPD_K3R_MX;
-extern "C" int dlpd_debug_k3_matrix_filter(int on) {
-  const int was = g_k3r_mx;
-  if (on == 0 || on == 1) g_k3r_mx = on;
-  return was;
-}
-
-template <int N, int HP, int MODE, bool MX = false> static int launch_k3r(const cplx* Bw, float* out, int CT, int C, int has_clash, int nb,
+template <int N, int HP, int MODE> static int launch_k3r(const cplx* Bw, float* out, int CT, int C, int has_clash, int nb,
                                                          const float* W1t, const float* b1, const float* W2, float b2,
                                                          int has_clip, float clip, float thr, hipStream_t st, K3Aux aux,
                                                          K3Cand cd) {
@@ -825,11 +665,11 @@ template <int N, int HP, int MODE, bool MX = false> static int launch_k3r(const 
   constexpr int RS = N + 8, NZ = N / 2 + 1, NPAIR = Cfg::TY / 2, CPW = 8 / NPAIR;
   constexpr int RAWC = (Cfg::PBUF == 2) ? NZ * NPAIR : ((NZ * NPAIR + 63) / 64) * 64;
   const size_t shmem = (size_t)(Cfg::PBUF * Cfg::F * 8 * RS + N) * sizeof(cplx) + (size_t)Cfg::RAWBUF * Cfg::F * CPW * RAWC * 16;
-  int rc = dlpd_set_max_dyn_shared((const void*)k_zifft_filter_rs<N, HP, MODE, MX>, shmem);
+  int rc = dlpd_set_max_dyn_shared((const void*)k_zifft_filter_rs<N, HP, MODE>, shmem);
   if (rc) return rc;
   const int G = k3r_group(CT, Cfg::F * CPW, true);
   const int ntiles = (N / Cfg::TY) * N * nb, tpb = (N / Cfg::TY) / DLPD_K3R_TPB_DIV;
-  DLPD_LAUNCH((k_zifft_filter_rs<N, HP, MODE, MX>), dim3((ntiles + tpb - 1) / tpb), dim3(64 * (Cfg::F + Cfg::M)), shmem, st, Bw,
+  DLPD_LAUNCH((k_zifft_filter_rs<N, HP, MODE>), dim3((ntiles + tpb - 1) / tpb), dim3(64 * (Cfg::F + Cfg::M)), shmem, st, Bw,
               out, CT, C, has_clash, G, W1t, b1, W2, b2, has_clip, clip, thr, aux, ntiles, tpb, cd);
   return dlpd_check_launch();
 }
@@ -850,12 +690,7 @@ template <int N, int MODE> static int k3r_dispatch(int HP, const cplx* Bw, float
     case 4: return launch_k3r<N, 4, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
     case 8: return launch_k3r<N, 8, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
     case 16: return launch_k3r<N, 16, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
-    case 24:
-      if constexpr (N == 128 && MODE == 1) {
-        if (g_k3r_mx && aux.C == 0)
-          return launch_k3r<N, 24, MODE, true>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
-      }
-      return launch_k3r<N, 24, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
+    case 24: return launch_k3r<N, 24, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
     case 32: return launch_k3r<N, 32, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
     case 48: return launch_k3r<N, 48, MODE>(Bw, out, CT, C, has_clash, nb, W1t, b1, W2, b2, has_clip, clip, thr, st, aux, cd);
     default: return DLPD_ERR_UNSUPPORTED;

@@ -194,12 +194,6 @@ __device__ __forceinline__ dlpd_acc4 dlpd_acc4_zero() { dlpd_acc4 z = {0.f, 0.f,
 __device__ __forceinline__ float dlpd_acc4_get(dlpd_acc4 v, int j) { return v[j]; }
 __device__ __forceinline__ dlpd_acc4 dlpd_acc4_make(float a, float b, float c, float d) { dlpd_acc4 z = {a, b, c, d}; return z; }
 #define DLPD_MFMA_16x16x4(a, b, acc) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (acc), 0, 0, 0)
-// v_permlane32_swap: x = (a of lanes 0-31 | b of lanes 0-31), y = (a of lanes 32-63 | b of lanes 32-63), each as (lanes 0-31 | 32-63)
-__device__ __forceinline__ void dlpd_swap32(float a, float b, float& x, float& y) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  x = __uint_as_float(r[0]);
-  y = __uint_as_float(r[1]);
-}
 // bf16-input matrix core: D(16x16) += A(16x32) * B(32x16), f32 accumulate.  A fragment is 8 consecutive k values
 // (16 bytes, passed as a float4): lane l holds A[l&15][8*(l>>4) + j] and B[8*(l>>4) + j][l&15], j = 0..7; D as 16x16x4.
 typedef __bf16 dlpd_bf16x8 __attribute__((ext_vector_type(8)));

@@ -14,11 +14,6 @@ int dlpd_debug_poison_lds(int on);
  * (0 .. 1000), -1 on a launch error.  counter8: 8 bytes of device memory. */
 int dlpd_debug_poison_selfcheck(void* counter8, void* stream);
 
-/* K3 at box 64 with a hidden width <= 24 and one resolution has two forms of its filter role with the same bits (csrc/dlpd_k3r.hip:
- * k3r_filter_role_mx on the f32 matrix core -- the default -- and the vector FMAs); on = 1 / 0 selects, anything else only
- * asks; returns the previous setting.  The tests compare the two bit for bit. */
-int dlpd_debug_k3_matrix_filter(int on);
-
 #ifdef __cplusplus
 }
 #endif

@@ -277,13 +277,6 @@ static inline dlpd_acc4 dlpd_emu_mfma_16x16x4(float a, float b, dlpd_acc4 acc) {
   return acc;
 }
 #define DLPD_MFMA_16x16x4(a, b, acc) dlpd_emu_mfma_16x16x4((a), (b), (acc))
-// v_permlane32_swap as a wave collective: x = (a of lanes 0-31 | b of lanes 0-31), y = (a of lanes 32-63 | b of lanes 32-63)
-static inline void dlpd_swap32(float a, float b, float& x, float& y) {
-  const int l = emu::S().cur % 64;
-  const float ao = __shfl_xor(a, 32), bo = __shfl_xor(b, 32);
-  x = l < 32 ? a : bo;
-  y = l < 32 ? ao : b;
-}
 // bf16 MFMA 16x16x32 as a wave collective: lane l holds A[l&15][8*(l>>4) + j] / B[8*(l>>4) + j][l&15] (8 bf16 = 16 bytes each);
 // exact products, summed in double and rounded once (the hardware's internal order is not specified; tests use tolerances)
 static inline unsigned dlpd_f2bf(float x) {
