@@ -182,7 +182,8 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
   const int grp = (bid & 7) + 8 * (jj / L);
   if (grp >= CT * nb) return;
   const int c = grp % CT, b = grp / CT;
-  init_twiddles<N>(tw, tid, NT);
+  // (given volumes with maps: the twiddles are made behind the plane's occupancy test -- half of dockE3's planes leave there)
+  if (do_rotate || !occ) init_twiddles<N>(tw, tid, NT);
   // Slab orientation.  When the source z axis lies closer to the output x axis than to the output y axis,
   // the gather of an x-plane is perpendicular to the contiguous direction of memory (every lane its own
   // cache line).  The caller groups such rotations into launches with transposed = 1: they are processed
@@ -193,6 +194,7 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
   (void)lane; (void)wave;
   DLPD_STAMP_DECL;
   const int x = jj % L;
+  bool pencil_live = true;                     // (this thread's pencil pair p = tid % NP, see the transform passes)
   {
   const float* v = vol + (size_t)b * vol_bstride + (size_t)c * L * L * L;
   float* Sf = reinterpret_cast<float*>(S);
@@ -231,12 +233,21 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
     // activations nobody wrote them); a plane whose cells are all empty goes out as zeros without a transform
     constexpr int NC = (L + 3) / 4;
     const unsigned char* ob = occ ? occ + ((size_t)b * NC + (x >> 2)) * NC * NC : nullptr;
+    // the plane's cells in LDS (round 6, second form: the staging loop looked every voxel's cell up in global memory, a byte
+    // load in front of every float load), and per y cell whether ANY of its z cells is occupied: with skip_empty the pencil
+    // pairs of the other y cells are neither transformed nor written -- the consumer's pencil map (dlpd_pencil_bits of the
+    // same occupancy map) does not mark them
+    __shared__ unsigned char ocell[NC * NC];
+    __shared__ int occ_any, yany[NC];
     if (ob) {
-      __shared__ int occ_any;
       if (tid == 0) occ_any = 0;
+      if (tid < NC) yany[tid] = 0;
       __syncthreads();
-      for (int i = tid; i < NC * NC; i += NT)
-        if (ob[i]) occ_any = 1;                                // (plain store of the same value by whoever finds one)
+      for (int i = tid; i < NC * NC; i += NT) {
+        const unsigned char o = ob[i];
+        ocell[i] = o;
+        if (o) { occ_any = 1; yany[i / NC] = 1; }              // (plain stores of the same value by whoever finds one)
+      }
       __syncthreads();
       if (!occ_any) {                                          // (block-uniform)
         if (skip_empty) return;                                // the consumer goes by the pencil map (dlpd_xy_correlate_packed_occ)
@@ -245,13 +256,15 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
           DLPD_STORE_STREAM(reinterpret_cast<float4*>(a + (size_t)(s / NP) * L * L + 2 * (s % NP)), make_float4(0.f, 0.f, 0.f, 0.f));
         return;
       }
+      init_twiddles<N>(tw, tid, NT);
     }
     for (int s = tid; s < L * L; s += NT) {
       const int y = s / L, z = s % L;
       // transposed: this block is the plane y_orig = x, its in-plane index runs over x_orig
-      const bool zero = ob && !ob[(y >> 2) * NC + (z >> 2)];
+      const bool zero = ob && !ocell[(y >> 2) * NC + (z >> 2)];
       Sf[((y >> 1) * RS + z) * 2 + (y & 1)] = zero ? 0.f : (tr_flag ? v[((size_t)y * L + x) * L + z] : v[((size_t)x * L + y) * L + z]);
     }
+    pencil_live = !(ob && skip_empty) || yany[(tid % NP) >> 1];
   }
   DLPD_STAMP(0);
   __syncthreads();
@@ -259,16 +272,16 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
   const int p = tid % NP, t = tid / NP;
   {
     FftPass<N, R1, 1, -1, T, L> ps;
-    ps.load(S + p * RS, 1, t, tw);
+    if (pencil_live) ps.load(S + p * RS, 1, t, tw);
     __syncthreads();
-    ps.store(S + p * RS, 1, t);
+    if (pencil_live) ps.store(S + p * RS, 1, t);
     __syncthreads();
   }
   {
     FftPass<N, R2, R1, -1, T> ps;
-    ps.load(S + p * RS, 1, t, tw);
+    if (pencil_live) ps.load(S + p * RS, 1, t, tw);
     __syncthreads();
-    ps.store(S + p * RS, 1, t);
+    if (pencil_live) ps.store(S + p * RS, 1, t);
     __syncthreads();
   }
   DLPD_STAMP(2);
@@ -276,6 +289,7 @@ k_rotate_zfft(const float* __restrict__ vol, const float* __restrict__ R, cplx* 
   cplx* a = A + ((size_t)b * CT_out + c_base + c) * NZ * L * L + (size_t)x * L;
   for (int s = tid; s < NP * NZ; s += NT) {
     const int m = s % NP, k = s / NP;
+    if (!pencil_live) continue;                // (NT is a multiple of NP: m = tid % NP = p in every round)
     const cplx zk = S[m * RS + k];
     const cplx zn = S[m * RS + ((N - k) % N)];
     // even row: (Z[k] + conj(Z[N-k]))/2 ; odd row: (Z[k] - conj(Z[N-k]))/(2i)
