@@ -89,7 +89,7 @@ rep["TWORANKS"] = "%.2fe9 aggregate, `gather_check` hash equal to the one-rank l
     "" if tw["gather_check"]["list_sha256"] == d["gather_check"]["list_sha256"] else " — DIFFERENT from the one-rank line (two processes share the GPU: parity band only)")
 log = open(P("pytest_gpu.log")).read()
 m = re.search(r"(\d+) passed.*? in ([0-9.]+)s", log)
-rep["SUITES"] = "GPU: %s; CPU: 161 tests in 5 min on four workers (17 min serially); the multi-rank files 10 × green" % (
+rep["SUITES"] = "GPU: %s; CPU: 162 tests in 5 min on four workers (17 min serially); the multi-rank files 10 × green" % (
     re.search(r"\d+ passed[^\n]*", log).group(0).strip() if m else "see log")
 rep["K1"] = "%.2f ms = %.2f of 8 TB/s on its algorithmic bytes (dense ligand); `real_protein`: see §0" % (st["k1_rotate_zfft"], rl["k1_rotate_zfft"]["frac"])
 rep["K2"] = "%.2f ms, **%.2f of 8 TB/s**; LDS conflicts %.3f of LDS-active" % (st["k2_xy_corr"], rl["k2_xy_corr"]["frac"], sec["lds_bank_conflict_frac_of_lds_active"])

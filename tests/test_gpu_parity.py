@@ -448,7 +448,7 @@ def test_conv3d_tile_occupancy_skips_empty_tiles_with_the_same_bits(dev, cin, cm
     _sparse_conv_checks(None, dev, cin, cmid, cout, ks, D, lo, hi, B=3)
 
 
-@pytest.mark.parametrize("C,D,lo,hi", [(16, 80, 22, 50), (5, 37, 0, 9), (32, 40, 30, 40)])
+@pytest.mark.parametrize("C,D,lo,hi", [(16, 80, 22, 50), (5, 37, 0, 9), (32, 40, 30, 40), (12, 37, 3, 20)])
 def test_maxpool_tiled_with_occupancy_equals_torch(dev, C, D, lo, hi):
     """The E3 plugin's pooling on the tiled kernel (separable maximum through LDS), with and without occupancy maps, at the
     plugin's sizes and an odd one: torch's values exactly, and the map it hands on equals the map of its output."""

@@ -859,7 +859,7 @@ def _sparse_pool_checks(lib, device, C, D, lo, hi, B=1):
     assert torch.equal(y2, y0) and torch.equal(occ2, occ1)
 
 
-@pytest.mark.parametrize("C,D,lo,hi", [(3, 13, 1, 5), (2, 40, 22, 31)])
+@pytest.mark.parametrize("C,D,lo,hi", [(3, 13, 1, 5), (2, 40, 22, 31), (11, 9, 1, 5)])        # 11 channels: a group of 8 and one of 3
 def test_maxpool_tiled_with_occupancy_equals_torch(emu, C, D, lo, hi):
     _sparse_pool_checks(emu, "cpu", C, D, lo, hi)
 
