@@ -696,7 +696,10 @@ int dlpd_maxpool3d_5s2_sparse(const float* x, float* y, const unsigned char* occ
   if (occ_out && hipMemsetAsync(occ_out, 0, dlpd_conv3d_tile_occupancy_bytes(B, Do), st) != hipSuccess) return DLPD_ERR_LAUNCH;
   // a block takes up to 8 channels of one batch entry (one map, one geometry: k_maxpool3d_5s2_tiled); a grid's z extent holds
   // 65,535 blocks: more (entry, channel group, z tile) triples than that go in several launches of whole batch entries
-  constexpr int CPB = 8;
+#ifndef DLPD_POOL_CPB
+#define DLPD_POOL_CPB 8
+#endif
+  constexpr int CPB = DLPD_POOL_CPB;
   const int ncg = (C + CPB - 1) / CPB;
   const int per = 65535 / (ncg * nzt);                          // batch entries per launch
   if (per < 1) return DLPD_ERR_UNSUPPORTED;
@@ -716,8 +719,8 @@ int dlpd_maxpool3d_5s2_sparse(const float* x, float* y, const unsigned char* occ
 int dlpd_maxpool3d_5s2(const float* x, float* y, int nvol, int D, void* stream) {
   if (!x || !y || nvol <= 0 || D < 1) return DLPD_ERR_ARG;
   const int Do = (D + 4 - 5) / 2 + 1;
-  // (no maps: the volumes are channels of ONE entry to the kernel -- a block then amortises its index arithmetic over eight of them)
-  if ((size_t)((nvol + 7) / 8) * ((Do + DLPD_MP_OZ - 1) / DLPD_MP_OZ) <= 65535)
+  // (no maps: the volumes are channels of ONE entry to the kernel -- a block then amortises its index arithmetic over DLPD_POOL_CPB of them)
+  if ((size_t)((nvol + DLPD_POOL_CPB - 1) / DLPD_POOL_CPB) * ((Do + DLPD_MP_OZ - 1) / DLPD_MP_OZ) <= 65535)
     return dlpd_maxpool3d_5s2_sparse(x, y, nullptr, nullptr, 1, nvol, D, 0, stream);
   return dlpd_maxpool3d_5s2_sparse(x, y, nullptr, nullptr, nvol, 1, D, 0, stream);      // (chunked launches for many volumes)
 }
