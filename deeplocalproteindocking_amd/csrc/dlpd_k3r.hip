@@ -141,8 +141,9 @@ extern "C" int dlpd_debug_read_stamps_k3r(unsigned long long* host32) {
 // k-ascending fmaf chain bit for bit (scripts/micro/mfma_f32_order.hip), so the SAME scores and list hash -- was built (filter
 // wave = one row pair, lane (k, n) = channel k of the group at 16 z, hidden units 16..23 of both rows in one tile through a
 // v_permlane32_swap of the B registers, the second layer as matrix chains as well, 162 registers) and measured 4.78 against
-// 3.61 ms: the f32 matrix pipe has the vector rate, 24 hidden units pad a second tile, and 512 fully paced matrix
-// instructions per wave and tile are a longer filter phase than 2,700 packed FMAs.  Removed.
+// 3.61 ms (4.57 with every operand of the role in an LDS table).  Why: scripts/micro/mfma_f32_rate.hip -- beside a stream of
+// f32-input matrix instructions a vector wave on the same SIMD issues one packed FMA per 22 cycles instead of one per 5: the
+// f32 matrix work does not run BESIDE the transform waves' vector work, it displaces it.  Removed.
 // all four components of a loaded float4 needed at ONE point (a plain, non-volatile asm: a data dependence, no ordering
 // against the kernel's other inline assembly)
 #if defined(DLPD_CPU_EMU)
