@@ -690,6 +690,9 @@ def run_rank(args):
             "metric": metric, "value": poses / elapsed, "unit": "pose scores/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # a step = one launch of config.rotations_per_step rotations (32 since round 6, 16 before): the figure comparable with
+            # rounds 1-5's ms_per_step is this one
+            "ms_per_16_rotations": ms_step * 16.0 / nb,
             **({"same_device_note": "ranks share one GPU: co-resident kernels of different processes can perturb low bits of a few scores "
                                     "on this hardware (parity band only; INTEGRATION.md)"} if (args.same_device and world > 1) else {}),
             "config": {"workload": "%s, %d-degree SOI-sized rotation set (%d rotations, %s), max_conf=%d" %
